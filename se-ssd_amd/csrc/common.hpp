@@ -1,0 +1,103 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels of the SE-SSD hot path.
+// Wave width is 64 on CDNA4; every wave-level idiom below is written for that.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SESSD_WAVE 64
+
+// Every C-ABI entry point returns 0 on success or a hipError_t / negative
+// argument-error code; nothing in this library calls exit() (the reference's
+// iou3d.cpp:13-21 printf+exit behaviour is deliberately not reproduced).
+#define SESSD_OK 0
+#define SESSD_EINVAL (-1)
+#define SESSD_EWORKSPACE (-2)
+
+#define SESSD_CHECK_LAUNCH()                          \
+  do {                                                \
+    hipError_t e__ = hipGetLastError();               \
+    if (e__ != hipSuccess) return (int)e__;           \
+  } while (0)
+
+#define SESSD_TRY(expr)                               \
+  do {                                                \
+    hipError_t e__ = (expr);                          \
+    if (e__ != hipSuccess) return (int)e__;           \
+  } while (0)
+
+static inline __host__ __device__ int sessd_divup(int a, int b) { return (a + b - 1) / b; }
+static inline __host__ __device__ size_t sessd_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- open-addressing hash: linear cell key -> row ------------------------
+// EMPTY key is 0x7F7F7F7F so that one hipMemsetAsync(0x7F) clears keys,
+// values and the voxelizer's per-entry index lists in a single pass.
+#define SESSD_HASH_EMPTY 0x7F7F7F7Fu
+#define SESSD_SENT 0x7F7F7F7F  // "no index" sentinel for int lists (same byte pattern)
+
+static __device__ __forceinline__ uint32_t sessd_hash_u32(uint32_t k) {
+  k ^= k >> 16;
+  k *= 0x7feb352du;
+  k ^= k >> 15;
+  k *= 0x846ca68bu;
+  k ^= k >> 16;
+  return k;
+}
+
+// Insert-or-find. Returns the slot that holds `key`.
+static __device__ __forceinline__ uint32_t sessd_hash_insert(uint32_t* keys, uint32_t mask, uint32_t key) {
+  uint32_t slot = sessd_hash_u32(key) & mask;
+  while (true) {
+    uint32_t prev = atomicCAS(&keys[slot], SESSD_HASH_EMPTY, key);
+    if (prev == SESSD_HASH_EMPTY || prev == key) return slot;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// Lookup. Returns value or -1.
+static __device__ __forceinline__ int sessd_hash_find(const uint32_t* __restrict__ keys,
+                                                      const int* __restrict__ vals, uint32_t mask,
+                                                      uint32_t key) {
+  uint32_t slot = sessd_hash_u32(key) & mask;
+  while (true) {
+    uint32_t k = keys[slot];
+    if (k == key) {
+      int v = vals[slot];
+      return v == SESSD_SENT ? -1 : v;
+    }
+    if (k == SESSD_HASH_EMPTY) return -1;
+    slot = (slot + 1) & mask;
+  }
+}
+
+// ---- wave / block reductions ----------------------------------------------
+static __device__ __forceinline__ int sessd_wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Exclusive scan of one int per thread across a block of NT threads (NT % 64 == 0,
+// NT <= 1024). `smem` must hold NT/64 ints. Returns the exclusive prefix; *total
+// receives the block sum.
+template <int NT>
+static __device__ __forceinline__ int sessd_block_exscan(int v, int* smem, int* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) smem[wid] = incl;
+  __syncthreads();
+  int wbase = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    int s = smem[w];
+    if (w < wid) wbase += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return wbase + incl - v;
+}
