@@ -1,0 +1,67 @@
+/* libsessd_hip.so -- C ABI of the MI355X (gfx950) SE-SSD inference hot path.
+ *
+ * Plain C: raw DEVICE pointers, sizes and a hipStream_t (passed as void*). No torch types.
+ * Every function returns 0 on success, a negative SESSD_E* code for argument errors, or a
+ * positive hipError_t. Nothing here synchronises the host, allocates device memory, prints or
+ * exits: workspaces are caller-provided (size queries below) and results stay on the device,
+ * so a whole frame can be enqueued (or captured in a hipGraph) without a host round trip.
+ *
+ * Each entry point cites the reference interface it replaces (paths relative to the
+ * Vegeta2020/SE-SSD tree). INTEGRATION.md shows the ctypes binding a maintainer would add.
+ */
+#ifndef SESSD_HIP_H
+#define SESSD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SESSD_OK 0
+#define SESSD_EINVAL (-1)
+#define SESSD_EWORKSPACE (-2)
+
+typedef void* sessd_stream_t; /* hipStream_t */
+
+const char* sessd_version(void);
+
+/* ------------------------------------------------------------------ voxelizer (a1-a3)
+ * replaces det3d/ops/point_cloud/point_cloud_ops_v2.py:120-194 points_to_voxel (numba, CPU),
+ *          det3d/core/input/voxel_generator.py:24-32 VoxelGenerator.generate,
+ *          det3d/models/readers/voxel_encoder.py:215-220 VoxelFeatureExtractorV3.forward (mean_feat).
+ * Bit-exact with the reference's serial first-come-first-served loop, including the `break`
+ * at max_voxels and the <= max_points_per_voxel rule. The hash (keys/vals) afterwards maps
+ * cell -> output row and is reused as the level-0 site index of SpMiddleFHD. */
+uint32_t sessd_hash_capacity(int max_items);
+int sessd_hash_clear(uint32_t* keys, int32_t* vals, uint32_t capacity, sessd_stream_t stream);
+size_t sessd_voxelize_workspace_bytes(uint32_t hash_capacity, int max_points_in_frame, int max_points_per_voxel,
+                                      int max_voxels);
+int sessd_voxelize_frame(const float* points, int num_points, int ndim, const float* range6, const float* voxel_size3,
+                         const int32_t* grid3, int max_points_per_voxel, int max_voxels, int batch_index,
+                         uint32_t* hash_keys, int32_t* hash_vals, uint32_t hash_capacity, float* voxels, int32_t* coors,
+                         int coors_stride, int32_t* num_points_per_voxel, float* mean_feat, int32_t* prefix,
+                         void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+int sessd_vfe_mean(const float* voxels, const int32_t* num_points, const int32_t* num_voxels_dev, int num_voxels_host,
+                   int max_points_per_voxel, int ndim, int num_features, float* out, sessd_stream_t stream);
+
+/* ------------------------------------------------------------------ iou3d_cuda operators (a15)
+ * replace det3d/core/iou3d/src/iou3d.cpp:24-115 (boxes_overlap_bev_gpu, boxes_aligned_overlap_bev_gpu,
+ * boxes_iou_bev_gpu, boxes_iou3d_gpu) and :117-262 (nms_gpu, nms_3d_gpu, nms_normal_gpu).
+ * mode for pairwise: 0 overlap area (N,5)x(M,5) | 1 BEV IoU (N,5)x(M,5) | 2 3-D IoU (N,7)x(M,7).
+ * Boxes are [x1,y1,x2,y2,ry] or [x1,y1,z1,x2,y2,z2,ry]; out is (N,M) row-major float32.
+ * NMS: boxes already sorted by descending score; keep (device int64[N]) and num_keep (device
+ * int32) are produced ON THE DEVICE (the reference reduces the bitmask on the host). */
+int sessd_boxes_pairwise(int mode, const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* out,
+                         sessd_stream_t stream);
+int sessd_boxes_aligned_overlap_bev(const float* boxes_a, const float* boxes_b, int num, float* out,
+                                    sessd_stream_t stream);
+size_t sessd_nms_workspace_bytes(int num_boxes);
+int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, long long* keep, int32_t* num_keep,
+                     void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SESSD_HIP_H */

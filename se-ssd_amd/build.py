@@ -18,6 +18,9 @@ ARCH = "gfx950"
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC]
+# Geometry / index kernels must round like the reference's scalar CPU code: no FMA contraction.
+# The MFMA / FMA-chain kernels (sparse and dense convolutions) contract freely.
+CONTRACT_FAST = {"dense_conv.hip", "sparse_conv.hip"}
 
 
 def _newer(src_list, target):
@@ -41,7 +44,8 @@ def build(verbose=True, force=False):
         obj = os.path.join(OBJDIR, s[:-4] + ".o")
         objs.append(obj)
         if force or _newer([src] + hdrs, obj):
-            jobs.append([HIPCC] + FLAGS + ["-c", src, "-o", obj])
+            extra = [] if s in CONTRACT_FAST else ["-ffp-contract=off"]
+            jobs.append([HIPCC] + FLAGS + extra + ["-c", src, "-o", obj])
 
     def run(cmd):
         if verbose:

@@ -1,0 +1,52 @@
+"""ctypes loader of the gfx950 C-ABI library (include/sessd_hip.h).
+
+The product path has no CPU fallback: if libsessd_hip.so is missing or a symbol is absent this
+module raises at import time, and every op raises on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsessd_hip.so")
+
+vp, i32, u32, f32, sz, i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t, C.c_longlong
+
+# name -> (restype, argtypes). Kept in step with include/sessd_hip.h (tests/test_abi.py checks it).
+SIGNATURES = {
+    "sessd_version": (C.c_char_p, []),
+    "sessd_hash_capacity": (u32, [i32]),
+    "sessd_hash_clear": (i32, [vp, vp, u32, vp]),
+    "sessd_voxelize_workspace_bytes": (sz, [u32, i32, i32, i32]),
+    "sessd_voxelize_frame": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, u32, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "sessd_vfe_mean": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
+    "sessd_boxes_pairwise": (i32, [i32, vp, i32, vp, i32, vp, vp]),
+    "sessd_boxes_aligned_overlap_bev": (i32, [vp, vp, i32, vp, vp]),
+    "sessd_nms_workspace_bytes": (sz, [i32]),
+    "sessd_nms_sorted": (i32, [i32, vp, i32, f32, vp, vp, vp, sz, vp]),
+}
+
+
+class SessdError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libsessd_hip.so not built (%s). Run `python se-ssd_amd/build.py` (hipcc --offload-arch=gfx950); "
+            "there is no CPU fallback for the product path." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "workspace too small"}.get(rc, "hipError_t %d" % rc)
+        raise SessdError("%s failed: %s" % (what, kind))

@@ -1,0 +1,138 @@
+"""Thin torch-facing wrappers over the C ABI: one function per entry point of include/sessd_hip.h.
+
+torch is plumbing only (device memory + the current HIP stream). Inputs must be contiguous CUDA
+tensors of the stated dtype; nothing here copies to the host or synchronises.
+"""
+import torch
+
+from ._lib import lib, check
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _req(t, dtype, name):
+    if not t.is_cuda:
+        raise ValueError("%s must be a CUDA (HIP) tensor: the SE-SSD hot path has no CPU fallback" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+_ws_cache = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """A cached per-(device, stream, tag) byte workspace, grown on demand (never shrinks)."""
+    key = (device.index, _stream(), tag)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+# ------------------------------------------------------------------ voxelizer
+class VoxelHash:
+    """Open-addressing cell -> row hash shared by a batch of frames (and by SpMiddleFHD level 0)."""
+
+    def __init__(self, max_items, device):
+        self.capacity = int(lib.sessd_hash_capacity(int(max_items)))
+        self.keys = torch.empty(self.capacity, dtype=torch.int32, device=device)
+        self.vals = torch.empty(self.capacity, dtype=torch.int32, device=device)
+
+    def clear(self):
+        check(lib.sessd_hash_clear(self.keys.data_ptr(), self.vals.data_ptr(), self.capacity, _stream()), "hash_clear")
+
+
+def voxelize_batch(points_list, voxel_size, coors_range, max_points, max_voxels, with_batch_index=True,
+                   want_mean=True):
+    """points_list: list of (P_b, ndim) float32 CUDA tensors. Returns a dict of device tensors:
+    voxels (cap,max_points,ndim), coors (cap,4|3) int32, num_points (cap,), mean (cap,ndim) or None,
+    prefix (B+1,) int32 (prefix[b]..prefix[b+1] = rows of frame b; prefix[B] = total), hash.
+    cap = B*max_voxels; rows beyond prefix[B] are unspecified."""
+    B = len(points_list)
+    dev = points_list[0].device
+    ndim = points_list[0].shape[1]
+    vs = torch.tensor(voxel_size, dtype=torch.float32)
+    cr = torch.tensor(coors_range, dtype=torch.float32)
+    grid = torch.round((cr[3:] - cr[:3]) / vs).to(torch.int32)  # voxel_generator.py:15-16 (float32 math)
+    cap = B * max_voxels
+    maxp = max(int(p.shape[0]) for p in points_list)
+    h = VoxelHash(maxp * B if B > 1 else maxp, dev)
+    h.clear()
+    voxels = torch.empty((cap, max_points, ndim), dtype=torch.float32, device=dev)
+    cs = 4 if with_batch_index else 3
+    coors = torch.empty((cap, cs), dtype=torch.int32, device=dev)
+    nump = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, ndim), dtype=torch.float32, device=dev) if want_mean else None
+    prefix = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
+    need = lib.sessd_voxelize_workspace_bytes(h.capacity, maxp, max_points, max_voxels)
+    ws = workspace(need, dev, "voxelize")
+    range_h, vs_h, grid_h = cr.contiguous(), vs.contiguous(), grid.contiguous()
+    for b, pts in enumerate(points_list):
+        _req(pts, torch.float32, "points")
+        check(lib.sessd_voxelize_frame(pts.data_ptr(), pts.shape[0], ndim, range_h.data_ptr(), vs_h.data_ptr(),
+                                       grid_h.data_ptr(), max_points, max_voxels, b, h.keys.data_ptr(),
+                                       h.vals.data_ptr(), h.capacity, voxels.data_ptr(), coors.data_ptr(), cs,
+                                       nump.data_ptr(), _p(mean), prefix.data_ptr(), ws.data_ptr(), ws.numel(),
+                                       _stream()), "voxelize_frame")
+    return dict(voxels=voxels, coors=coors, num_points=nump, mean=mean, prefix=prefix, hash=h, grid=grid)
+
+
+def vfe_mean(voxels, num_points, num_features=4, num_voxels_dev=None):
+    _req(voxels, torch.float32, "voxels")
+    _req(num_points, torch.int32, "num_points")
+    M, MP, ndim = voxels.shape
+    out = torch.empty((M, num_features), dtype=torch.float32, device=voxels.device)
+    check(lib.sessd_vfe_mean(voxels.data_ptr(), num_points.data_ptr(), _p(num_voxels_dev), M, MP, ndim, num_features,
+                             out.data_ptr(), _stream()), "vfe_mean")
+    return out
+
+
+# ------------------------------------------------------------------ iou3d operators
+def boxes_pairwise(mode, a, b, out=None):
+    w = 7 if mode == 2 else 5
+    _req(a, torch.float32, "boxes_a")
+    _req(b, torch.float32, "boxes_b")
+    if a.dim() != 2 or b.dim() != 2 or a.shape[1] != w or b.shape[1] != w:
+        raise ValueError("boxes must be (N,%d)" % w)
+    if out is None:
+        out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=a.device)
+    else:
+        _req(out, torch.float32, "out")
+    check(lib.sessd_boxes_pairwise(mode, a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), _stream()),
+          "boxes_pairwise")
+    return out
+
+
+def boxes_aligned_overlap_bev(a, b, out=None):
+    _req(a, torch.float32, "boxes_a")
+    _req(b, torch.float32, "boxes_b")
+    if a.shape != b.shape or a.shape[1] != 5:
+        raise ValueError("aligned boxes must both be (N,5)")
+    if out is None:
+        out = torch.empty((a.shape[0],), dtype=torch.float32, device=a.device)
+    check(lib.sessd_boxes_aligned_overlap_bev(a.data_ptr(), b.data_ptr(), a.shape[0], out.data_ptr(), _stream()),
+          "boxes_aligned_overlap_bev")
+    return out
+
+
+def nms_sorted(mode, boxes, thresh):
+    """boxes sorted by descending score. Returns (keep int64[N] device, num_keep int32[1] device)."""
+    _req(boxes, torch.float32, "boxes")
+    n = boxes.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    need = lib.sessd_nms_workspace_bytes(n)
+    ws = workspace(need, boxes.device, "nms")
+    check(lib.sessd_nms_sorted(mode, boxes.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr(),
+                               ws.data_ptr(), ws.numel(), _stream()), "nms_sorted")
+    return keep, num
