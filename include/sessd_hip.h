@@ -61,6 +61,36 @@ size_t sessd_nms_workspace_bytes(int num_boxes);
 int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, long long* keep, int32_t* num_keep,
                      void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 
+/* ------------------------------------------------------------------ sparse 3-D convolution (a4-a8)
+ * replace the third-party spconv calls of det3d/models/backbones/scn.py:106-148,179-187:
+ * SparseConvTensor / SubMConv3d / SparseConv3d rulebooks (spconv.ops.get_indice_pairs), the
+ * convolution itself (spconv indice_conv), BatchNorm1d(eval)+ReLU on .features, and .dense().
+ * Sites are (N,4) int32 [b,z,y,x]; live counts stay on the device (n_*_dev), arrays are sized by
+ * capacity. A rulebook is output-stationary: nbr[k][o] = input row (or -1), k = (kz*KY+ky)*KX+kx,
+ * stored [kernel_volume][n_out_cap]; tile_mask[o/16] has bit k set when any of the 16 sites of the
+ * tile has a neighbour through offset k. */
+int sessd_sparse_hash_build(const int32_t* indices, const int32_t* n_dev, int n_cap, const int32_t* dims3,
+                            uint32_t* keys, int32_t* vals, uint32_t capacity, sessd_stream_t stream);
+size_t sessd_sparse_downsample_workspace_bytes(int n_in_cap, int kernel_volume, uint32_t out_hash_capacity);
+int sessd_sparse_downsample_sites(const int32_t* in_indices, const int32_t* n_in_dev, int n_in_cap,
+                                  const int32_t* ksize3, const int32_t* stride3, const int32_t* pad3,
+                                  const int32_t* out_dims3, uint32_t* out_keys, int32_t* out_vals,
+                                  uint32_t out_capacity, int32_t* out_indices, int n_out_cap, int32_t* n_out_dev,
+                                  int32_t* err_flag, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+int sessd_sparse_rulebook(const int32_t* out_indices, const int32_t* n_out_dev, int n_out_cap, const int32_t* ksize3,
+                          const int32_t* stride3, const int32_t* pad3, const uint32_t* in_keys, const int32_t* in_vals,
+                          uint32_t in_capacity, const int32_t* in_dims3, int32_t* nbr, uint32_t* tile_mask,
+                          sessd_stream_t stream);
+/* weight (kernel_volume, cin, cout) row-major == spconv's [kz,ky,kx,Cin,Cout] flattened -> MFMA fragment order */
+int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, int cout, float* packed,
+                             sessd_stream_t stream);
+/* out[o] = act((sum_k W[k]^T in[nbr[k][o]]) * scale + shift); scale/shift = folded eval BatchNorm1d (may be NULL).
+ * dense_out != NULL: scatter into the pre-zeroed BEV tensor (B, cout*D, H, W), dense_dims3 = (D,H,W). */
+int sessd_sparse_conv(const float* in_feat, int cin, const int32_t* nbr, const uint32_t* tile_mask, int kernel_volume,
+                      const int32_t* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
+                      const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
+                      float* dense_out, const int32_t* dense_dims3, sessd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

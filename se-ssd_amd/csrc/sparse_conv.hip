@@ -1,0 +1,189 @@
+// Sparse 3-D convolution (SubMConv3d / SparseConv3d) + folded BatchNorm1d + ReLU on gfx950.
+// Replaces spconv's indice_conv (per-offset gather -> cuBLAS mm -> scatter-add) as called from
+//   det3d/models/backbones/scn.py:106-148,183 (SpMiddleFHD.middle_conv) and the BN/ReLU modules
+//   that SparseSequential applies to .features; optionally the `.dense()` of scn.py:184-187.
+//
+// Output-stationary implicit GEMM on the exact-f32 matrix cores: one wave owns a tile of 16 output
+// sites x all Cout channels and walks the kernel offsets. For an offset with at least one neighbour
+// in the tile (wave-uniform test on the rulebook's tile bitmask) it does
+//     acc[16 x Cout] += A[16 x Cin] * W[k][Cin x Cout]      v_mfma_f32_16x16x4_f32
+// A is gathered straight into registers: lane (i, kq) = (lane&15, lane>>4) reads the CONTIGUOUS
+// quarter row in[nbr[k][i]][kq*Cin/4 .. +Cin/4) with 16-byte loads (four lanes cover one feature
+// row = whole cache lines; no LDS round trip is needed because MFMA step s may use any K order,
+// here cin = kq*Cin/4 + s). W is pre-packed in exactly that fragment order so B operands are
+// coalesced 16-byte loads that stay L2/L1 resident (<= 442 KB per layer). Results are bit-for-bit
+// an fmaf chain in (offset, cin) order; every output row is written once, fused with
+// y = max(0, acc*scale + shift). HBM traffic ~ features in (once per neighbour hit, L2-absorbed)
+// + features out once + 4*27 B/site of rulebook.
+#include "common.hpp"
+
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+template <int CIN, int COUT, bool DENSE_OUT>
+__global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restrict__ in_feat,
+                                                           const int* __restrict__ nbr,
+                                                           const uint32_t* __restrict__ tile_mask, int kv,
+                                                           const int* __restrict__ n_dev, int n_cap,
+                                                           const float* __restrict__ wpk,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int relu,
+                                                           float* __restrict__ out_feat,
+                                                           const int* __restrict__ out_indices,
+                                                           float* __restrict__ dense_out, int dD, int dH, int dW) {
+  constexpr int STEPS = CIN / 4;          // MFMA k-steps per offset
+  constexpr int NTILE = COUT / 16;        // 16-wide cout tiles
+  constexpr int G = STEPS < 4 ? STEPS : 4;  // floats per vector load
+  constexpr int SG = STEPS / G;
+  const int lane = threadIdx.x & 63;
+  const int tile = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int n = min(n_dev[0], n_cap);
+  if (tile * 16 >= n) return;
+  const int i = lane & 15, kq = lane >> 4;
+  const uint32_t tmask = tile_mask[tile];
+
+  f32x4 acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int k = 0; k < kv; ++k) {
+    if (!((tmask >> k) & 1u)) continue;  // wave-uniform skip of empty (tile, offset)
+    const int row = nbr[(size_t)k * n_cap + tile * 16 + i];
+    float a[STEPS];
+    if (row >= 0) {
+      const float* src = in_feat + (size_t)row * CIN + kq * STEPS;
+      if (G == 4) {
+#pragma unroll
+        for (int g = 0; g < SG; ++g) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * g);
+          a[4 * g] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) a[s] = src[s];
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) a[s] = 0.f;
+    }
+    const float* wk = wpk + (size_t)k * NTILE * STEPS * 64;
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      float b[STEPS];
+      if (G == 4) {
+#pragma unroll
+        for (int g = 0; g < SG; ++g) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(wk + ((size_t)(t * SG + g) * 64 + lane) * 4);
+          b[4 * g] = v.x; b[4 * g + 1] = v.y; b[4 * g + 2] = v.z; b[4 * g + 3] = v.w;
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) b[s] = wk[((size_t)(t * SG) * 64 + lane) * G + s];
+      }
+#pragma unroll
+      for (int s = 0; s < STEPS; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc[t], 0, 0, 0);
+    }
+  }
+
+  // C/D layout: column (cout) = lane & 15, rows (sites) = (lane >> 4) * 4 + r
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int co = t * 16 + i;
+    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int site = tile * 16 + kq * 4 + r;
+      if (site >= n) continue;
+      float v = fmaf(acc[t][r], sc, sh);
+      if (relu) v = fmaxf(v, 0.f);
+      if (DENSE_OUT) {
+        // .dense() + view(N, C*D, H, W): channel = c*D + z  (scn.py:184-187)
+        const int4 c = *reinterpret_cast<const int4*>(out_indices + (size_t)site * 4);
+        dense_out[(((size_t)c.x * COUT + co) * dD + c.y) * dH * dW + (size_t)c.z * dW + c.w] = v;
+      } else {
+        out_feat[(size_t)site * COUT + co] = v;
+      }
+    }
+  }
+}
+
+// W (kv, cin, cout) row-major [the flattened spconv layout (kz,ky,kx,Cin,Cout)] -> fragment order
+//   wpk[(((k*NTILE + t)*SG + g)*64 + lane)*G + e] = W[k][ (lane>>4)*STEPS + g*G + e ][ t*16 + (lane&15) ]
+__global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin, int cout, float* __restrict__ wpk) {
+  const int steps = cin / 4, ntile = cout / 16, G = steps < 4 ? steps : 4, SG = steps / G;
+  const size_t total = (size_t)kv * cin * cout;
+  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int e = idx % G;
+  size_t r = idx / G;
+  int lane = r % 64; r /= 64;
+  int g = r % SG; r /= SG;
+  int t = r % ntile;
+  int k = (int)(r / ntile);
+  int ci = (lane >> 4) * steps + g * G + e, co = t * 16 + (lane & 15);
+  wpk[idx] = w[((size_t)k * cin + ci) * cout + co];
+}
+
+template <int CIN, int COUT>
+int launch(bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
+           int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
+           const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
+  const int tiles = sessd_divup(n_cap, 16);
+  dim3 grid(sessd_divup(tiles, 4)), block(256);
+  if (dense)
+    hipLaunchKernelGGL((sparse_conv_kernel<CIN, COUT, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv, n_dev,
+                       n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2]);
+  else
+    hipLaunchKernelGGL((sparse_conv_kernel<CIN, COUT, false>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv, n_dev,
+                       n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, int cout, float* packed,
+                             hipStream_t stream) {
+  if (cin % 4 || cout % 16 || kernel_volume <= 0) return SESSD_EINVAL;
+  const int steps = cin / 4;
+  if (steps > 4 && steps % 4) return SESSD_EINVAL;
+  size_t total = (size_t)kernel_volume * cin * cout;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, weight,
+                     kernel_volume, cin, cout, packed);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// out[o] = act( (sum_k W[k]^T in[nbr[k][o]]) * scale + shift ). If dense_out != NULL the result is
+// scattered instead into the dense BEV tensor (B, cout*D, H, W) with dense_dims3 = (D,H,W) (pre-zeroed
+// by the caller) and out_feat may be NULL.
+int sessd_sparse_conv(const float* in_feat, int cin, const int* nbr, const uint32_t* tile_mask, int kernel_volume,
+                      const int* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
+                      const float* shift, int relu, float* out_feat, int cout, const int* out_indices,
+                      float* dense_out, const int* dense_dims3, hipStream_t stream) {
+  if (n_out_cap <= 0 || kernel_volume <= 0 || kernel_volume > 32) return SESSD_EINVAL;
+  const bool dense = dense_out != nullptr;
+  if (dense && (!out_indices || !dense_dims3)) return SESSD_EINVAL;
+  if (!dense && !out_feat) return SESSD_EINVAL;
+#define SESSD_SC(CI, CO)                                                                                              \
+  if (cin == CI && cout == CO)                                                                                        \
+    return launch<CI, CO>(dense, in_feat, nbr, tile_mask, kernel_volume, n_out_dev, n_out_cap, packed_weight, scale,  \
+                          shift, relu, out_feat, out_indices, dense_out, dense_dims3, stream);
+  SESSD_SC(4, 16)
+  SESSD_SC(16, 16)
+  SESSD_SC(16, 32)
+  SESSD_SC(32, 32)
+  SESSD_SC(32, 64)
+  SESSD_SC(64, 64)
+  SESSD_SC(8, 16)
+  SESSD_SC(16, 64)
+  SESSD_SC(64, 128)
+  SESSD_SC(128, 128)
+#undef SESSD_SC
+  return SESSD_EINVAL;  // channel pair not instantiated
+}
+
+}  // extern "C"

@@ -136,3 +136,97 @@ def nms_sorted(mode, boxes, thresh):
     check(lib.sessd_nms_sorted(mode, boxes.data_ptr(), n, float(thresh), keep.data_ptr(), num.data_ptr(),
                                ws.data_ptr(), ws.numel(), _stream()), "nms_sorted")
     return keep, num
+
+
+# ------------------------------------------------------------------ sparse 3-D convolution
+def _i3(v):
+    v = [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
+    return torch.tensor(v, dtype=torch.int32)
+
+
+class SiteHash:
+    """cell -> row hash of one resolution level. dims = (D,H,W) used for the linear key."""
+
+    def __init__(self, capacity, dims, device, keys=None, vals=None):
+        self.capacity = int(capacity)
+        self.dims = [int(d) for d in dims]
+        self.keys = keys if keys is not None else torch.empty(self.capacity, dtype=torch.int32, device=device)
+        self.vals = vals if vals is not None else torch.empty(self.capacity, dtype=torch.int32, device=device)
+        self._dims_t = _i3(self.dims)
+
+
+def sparse_hash_build(indices, n_dev, dims):
+    _req(indices, torch.int32, "indices")
+    n_cap = indices.shape[0]
+    h = SiteHash(lib.sessd_hash_capacity(max(n_cap, 1)), dims, indices.device)
+    check(lib.sessd_hash_clear(h.keys.data_ptr(), h.vals.data_ptr(), h.capacity, _stream()), "hash_clear")
+    check(lib.sessd_sparse_hash_build(indices.data_ptr(), _p(n_dev), n_cap, h._dims_t.data_ptr(), h.keys.data_ptr(),
+                                      h.vals.data_ptr(), h.capacity, _stream()), "sparse_hash_build")
+    return h
+
+
+def sparse_downsample_sites(in_indices, n_in_dev, ksize, stride, pad, out_dims, n_out_cap, err_flag=None):
+    """Output sites of a strided sparse conv. Returns (out_indices (cap,4), n_out_dev (1,), out_hash, err_flag)."""
+    _req(in_indices, torch.int32, "in_indices")
+    dev = in_indices.device
+    n_in_cap = in_indices.shape[0]
+    ks, st, pd, od = _i3(ksize), _i3(stride), _i3(pad), _i3(out_dims)
+    kv = int(ks.prod())
+    h = SiteHash(lib.sessd_hash_capacity(n_out_cap), out_dims, dev)
+    out_idx = torch.empty((n_out_cap, 4), dtype=torch.int32, device=dev)
+    n_out = torch.zeros((1,), dtype=torch.int32, device=dev)
+    if err_flag is None:
+        err_flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+    need = lib.sessd_sparse_downsample_workspace_bytes(n_in_cap, kv, h.capacity)
+    ws = workspace(need, dev, "downsample")
+    check(lib.sessd_sparse_downsample_sites(in_indices.data_ptr(), n_in_dev.data_ptr(), n_in_cap, ks.data_ptr(),
+                                            st.data_ptr(), pd.data_ptr(), od.data_ptr(), h.keys.data_ptr(),
+                                            h.vals.data_ptr(), h.capacity, out_idx.data_ptr(), n_out_cap,
+                                            n_out.data_ptr(), err_flag.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "sparse_downsample_sites")
+    return out_idx, n_out, h, err_flag
+
+
+def sparse_rulebook(out_indices, n_out_dev, ksize, stride, pad, in_hash):
+    """nbr (kv, n_out_cap) int32 and tile_mask (ceil(cap/16),) for a conv whose input level is in_hash."""
+    _req(out_indices, torch.int32, "out_indices")
+    dev = out_indices.device
+    cap = out_indices.shape[0]
+    ks, st, pd = _i3(ksize), _i3(stride), _i3(pad)
+    kv = int(ks.prod())
+    nbr = torch.empty((kv, cap), dtype=torch.int32, device=dev)
+    tmask = torch.empty(((cap + 15) // 16,), dtype=torch.int32, device=dev)
+    check(lib.sessd_sparse_rulebook(out_indices.data_ptr(), n_out_dev.data_ptr(), cap, ks.data_ptr(), st.data_ptr(),
+                                    pd.data_ptr(), in_hash.keys.data_ptr(), in_hash.vals.data_ptr(), in_hash.capacity,
+                                    in_hash._dims_t.data_ptr(), nbr.data_ptr(), tmask.data_ptr(), _stream()),
+          "sparse_rulebook")
+    return nbr, tmask
+
+
+def sparse_pack_weight(weight):
+    """weight (kz,ky,kx,Cin,Cout) (spconv v1 layout) on the device -> packed MFMA-fragment order."""
+    w = weight.detach().to(torch.float32).contiguous()
+    if not w.is_cuda:
+        raise ValueError("weight must be on the HIP device")
+    cin, cout = w.shape[-2], w.shape[-1]
+    kv = w.numel() // (cin * cout)
+    out = torch.empty_like(w).view(-1)
+    check(lib.sessd_sparse_pack_weight(w.data_ptr(), kv, cin, cout, out.data_ptr(), _stream()), "sparse_pack_weight")
+    return out
+
+
+def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, scale=None, shift=None, relu=True,
+                out=None, dense_out=None, out_indices=None, dense_dims=None):
+    _req(in_feat, torch.float32, "in_feat")
+    kv, cap = nbr.shape
+    dd = None
+    if dense_out is None:
+        if out is None:
+            out = torch.empty((cap, cout), dtype=torch.float32, device=in_feat.device)
+    else:
+        dd = _i3(dense_dims)
+    check(lib.sessd_sparse_conv(in_feat.data_ptr(), cin, nbr.data_ptr(), tile_mask.data_ptr(), kv, n_out_dev.data_ptr(),
+                                cap, packed_weight.data_ptr(), _p(scale), _p(shift), 1 if relu else 0, _p(out), cout,
+                                _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), _stream()),
+          "sparse_conv")
+    return out if dense_out is None else dense_out

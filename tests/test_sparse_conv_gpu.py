@@ -1,0 +1,114 @@
+"""HIP sparse convolution vs the CPU oracle (oracle/sparse_conv.py, spconv-v1 semantics restated).
+
+Index work is exact: the output SITE SET and every rulebook entry must match (row order is an
+implementation choice -- compared as sets / through the dense tensor). Features are float32 sums in
+a different order than the oracle's gather-mm-scatter: tolerance 1e-4 relative to the layer's scale."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import sparse_conv as osc
+from sessd_hip import ops, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_sites(rng, B, shape, n):
+    s = set()
+    while len(s) < n:
+        s.add((rng.randint(B), rng.randint(shape[0]), rng.randint(shape[1]), rng.randint(shape[2])))
+    idx = np.array(sorted(s), np.int32)
+    rng.shuffle(idx)
+    return idx
+
+
+def _pad_rows(a, cap):
+    out = np.zeros((cap,) + a.shape[1:], a.dtype)
+    out[:a.shape[0]] = a
+    return out
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 16), (16, 16), (32, 32), (64, 64), (16, 32), (32, 64)])
+@pytest.mark.parametrize("ks,st,pd,subm", [(3, 1, 0, True), (3, 2, 1, False), (3, 2, [0, 1, 1], False), ((3, 1, 1), (2, 1, 1), 0, False)])
+def test_single_layer(dev, cin, cout, ks, st, pd, subm):
+    rng = np.random.RandomState(cin * 7 + cout)
+    B, shape, n = 2, [11, 40, 36], 1500
+    idx = _random_sites(rng, B, shape, n)
+    cap = 2048
+    feat = torch.randn(n, cin, generator=torch.Generator().manual_seed(1))
+    k3 = osc._triple(ks)
+    w = torch.randn(*k3, cin, cout, generator=torch.Generator().manual_seed(2)) * 0.2
+    scale = torch.rand(cout) + 0.5
+    shift = torch.randn(cout) * 0.1
+    want, oidx, oshape, rb = osc.sparse_conv(feat, idx, shape, w, ks, st, pd, subm)
+    want = torch.relu(want * scale + shift)
+
+    d_idx = torch.from_numpy(_pad_rows(idx, cap)).to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    d_feat = torch.from_numpy(_pad_rows(feat.numpy(), cap)).to(dev)
+    in_hash = ops.sparse_hash_build(d_idx, n_dev, shape)
+    if subm:
+        out_idx, n_out, p3 = d_idx, n_dev, [k // 2 for k in k3]
+        nbr, tm = ops.sparse_rulebook(out_idx, n_out, ks, 1, p3, in_hash)
+    else:
+        out_idx, n_out, out_hash, err = ops.sparse_downsample_sites(d_idx, n_dev, ks, st, pd, oshape, 4096)
+        assert int(err.item()) == 0
+        nbr, tm = ops.sparse_rulebook(out_idx, n_out, ks, st, pd, in_hash)
+    m = int(n_out.item())
+    assert m == oidx.shape[0]
+    got_idx = out_idx[:m].cpu().numpy()
+    # identical site sets
+    key = lambda a: set(map(tuple, a.tolist()))
+    assert key(got_idx) == key(oidx)
+    wpk = ops.sparse_pack_weight(w.to(dev))
+    out = ops.sparse_conv(d_feat, nbr, tm, n_out, wpk, cin, cout, scale.to(dev), shift.to(dev), True)
+    got = out[:m].cpu()
+    # align rows through the coordinates
+    lut = {tuple(c): r for r, c in enumerate(oidx.tolist())}
+    perm = np.array([lut[tuple(c)] for c in got_idx.tolist()])
+    ref = want[perm]
+    tol = 1e-4 * max(1.0, float(ref.abs().max()))
+    assert float((got - ref).abs().max()) < tol
+    # rulebook entries: number of (in,out) pairs per offset must equal the oracle's
+    nb = nbr[:, :m].cpu().numpy()
+    for k, (ri, ro) in enumerate(rb[2]):
+        assert int((nb[k] >= 0).sum()) == len(ri)
+
+
+def test_dense_scatter_and_overflow_flag(dev):
+    rng = np.random.RandomState(3)
+    B, shape, n = 2, [5, 24, 20], 700
+    idx = _random_sites(rng, B, shape, n)
+    cap = 1024
+    feat = torch.randn(n, 64)
+    w = torch.randn(3, 1, 1, 64, 64) * 0.1
+    want, oidx, oshape, rb = osc.sparse_conv(feat, idx, shape, w, (3, 1, 1), (2, 1, 1), 0, False)
+    wd = osc.dense(torch.relu(want), oidx, oshape, B)
+    wd = wd.view(B, 64 * oshape[0], oshape[1], oshape[2])
+    d_idx = torch.from_numpy(_pad_rows(idx, cap)).to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    d_feat = torch.from_numpy(_pad_rows(feat.numpy(), cap)).to(dev)
+    in_hash = ops.sparse_hash_build(d_idx, n_dev, shape)
+    out_idx, n_out, out_hash, err = ops.sparse_downsample_sites(d_idx, n_dev, (3, 1, 1), (2, 1, 1), 0, oshape, 2048)
+    nbr, tm = ops.sparse_rulebook(out_idx, n_out, (3, 1, 1), (2, 1, 1), 0, in_hash)
+    dense = torch.zeros((B, 64 * oshape[0], oshape[1], oshape[2]), device=dev)
+    ops.sparse_conv(d_feat, nbr, tm, n_out, ops.sparse_pack_weight(w.to(dev)), 64, 64, None, None, True,
+                    dense_out=dense, out_indices=out_idx, dense_dims=oshape)
+    assert float((dense.cpu() - wd).abs().max()) < 1e-4 * max(1.0, float(wd.abs().max()))
+    # capacity overflow is flagged, never silent
+    _, n_small, _, err2 = ops.sparse_downsample_sites(d_idx, n_dev, (3, 1, 1), (2, 1, 1), 0, oshape, 64)
+    assert int(err2.item()) == 1 and int(n_small.item()) == 64
+
+
+def test_empty_input(dev):
+    cap = 256
+    d_idx = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    n_dev = torch.zeros((1,), dtype=torch.int32, device=dev)
+    h = ops.sparse_hash_build(d_idx, n_dev, [11, 40, 36])
+    out_idx, n_out, out_hash, err = ops.sparse_downsample_sites(d_idx, n_dev, 3, 2, 1, [6, 20, 18], 256)
+    assert int(n_out.item()) == 0 and int(err.item()) == 0
+    nbr, tm = ops.sparse_rulebook(out_idx, n_out, 3, 2, 1, h)
+    out = ops.sparse_conv(torch.zeros(cap, 16, device=dev), nbr, tm, n_out,
+                          ops.sparse_pack_weight(torch.zeros(3, 3, 3, 16, 32, device=dev)), 16, 32)
+    torch.cuda.synchronize()
