@@ -91,6 +91,26 @@ int sessd_sparse_conv(const float* in_feat, int cin, const int32_t* nbr, const u
                       const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
                       float* dense_out, const int32_t* dense_dims3, sessd_stream_t stream);
 
+/* ------------------------------------------------------------------ dense BEV neck + heads (a9-a10)
+ * replace the ATen/cuDNN conv2d, conv_transpose2d, batch_norm, relu, softmax calls made by
+ * det3d/models/necks/rpn_v1.py:220-235 (SSFA.forward; RPN.forward :107-116 uses the same layers) and
+ * det3d/models/bbox_heads/mg_head_sessd.py:217-230 (Head.forward, four 1x1 convs).
+ * Activations are NCHW float32. One launcher covers 3x3 s1, 3x3 s2, 1x1 and the four output-parity
+ * classes of ConvTranspose2d(3, stride 2, padding 1, output_padding 1):
+ *   input pixel = (y*in_mul + taps_dy[t], x*in_mul + taps_dx[t]), (y,x) in [0,tile_h) x [0,tile_w)
+ *   output pixel = (y*out_mul + out_py, x*out_mul + out_px)
+ *   out = act(conv * scale[c] + shift[c]) (+ residual)
+ * wpk: packed weights [cin/2][ntaps][2][cout_pad], cout_pad = roundup(cout,32), element
+ *   wpk[kp][t][h][co] = W[co][2*kp+h][tap t]. tile_cfg 0..5 selects the wave/workgroup tiling. */
+int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, const float* wpk, int ntaps,
+                      const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out, int cout,
+                      int hout, int wout, int out_mul, int out_py, int out_px, const float* scale, const float* shift,
+                      int relu, const float* residual, int tile_cfg, sessd_stream_t stream);
+/* rpn_v1.py:227-233: softmax over the two 1-channel weight maps and the weighted sum of x0, x1 */
+int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
+                    float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,
+                    float* out, sessd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,241 @@
+// Dense 2-D BEV convolutions of the SSFA neck and the MultiGroupHead 1x1 heads on gfx950.
+// Replaces the cuDNN/MIOpen conv2d / conv_transpose2d + BatchNorm2d + ReLU chain of
+//   det3d/models/necks/rpn_v1.py:135-210,220-235 (SSFA) and the four 1x1 convs of
+//   det3d/models/bbox_heads/mg_head_sessd.py:202-230 (Head.forward).
+//
+// Direct-to-register implicit GEMM on the exact-f32 matrix cores (v_mfma_f32_32x32x2_f32):
+//     D[cout][pixel] += W[cout][k] * X[k][pixel],   k = (cin pair, tap)
+// A operand (weights): lane (i, h) = (lane&31, lane>>5) holds Wp[kp][tap][h][m0+i]  -- the packed
+//     weight layout makes this two 128-byte rows per wave, L2-resident (<= 2.4 MB per layer).
+// B operand (activations, NCHW): lane (j, h) holds X[2*kp+h][pixel p0+j shifted by the tap] -- 32
+//     CONSECUTIVE pixels of one channel plane = one 128-byte line per half wave. Because the f32
+//     MFMA issues only every 64 cycles per SIMD, operands go global/L2/L1 -> VGPR directly:
+//     no LDS staging, no barriers; the 9 taps of a 3x3 window re-hit the same lines in L1.
+// D (32 couts x 32 pixels per MFMA tile): lane holds pixel j and 16 couts -> every store is two
+//     full 128-byte lines; epilogue fuses the folded BatchNorm (scale, shift), ReLU and an optional
+//     residual add (deconv_block_0(x) + x_trans_0, rpn_v1.py:225).
+// One kernel covers conv 3x3 s1, 3x3 s2, 1x1 and the 4 output-parity classes of the 3x3 s2
+// transposed conv through (taps, in_mul, out_mul, out_py, out_px):
+//     input pixel = (y*in_mul + dy[t], x*in_mul + dx[t]),  output pixel = (y*out_mul + py, x*out_mul + px)
+// Numerics: bit-for-bit an fmaf chain over (cin pair, tap, cin parity) -- exact float32.
+#include "common.hpp"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+struct ConvArgs {
+  const float* in;     // (B, cin, hin, win)
+  const float* wpk;    // [cin/2][ntaps][2][cout_pad]
+  float* out;          // (B, cout, hout, wout)
+  const float* scale;  // [cout] or null
+  const float* shift;  // [cout] or null
+  const float* residual;  // same shape as out, or null (added after the activation)
+  int cin, hin, win;
+  int cout, cout_pad, hout, wout;
+  int ht, wt;          // tile-space extent
+  int in_mul, out_mul, out_py, out_px;
+  int relu;
+  int dy[9], dx[9];
+};
+
+// wave tile: (CT*32 couts) x (PT*32 pixels); workgroup = 4 waves arranged WC x WP
+template <int NTAPS, int CT, int PT, int WC, int WP>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
+  static_assert(WC * WP == 4, "four waves per workgroup");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int wc = wave % WC, wp = wave / WC;
+  const int npix = A.ht * A.wt;
+  const int p_base = (blockIdx.x * WP + wp) * (PT * 32);
+  const int m_base = (blockIdx.y * WC + wc) * (CT * 32);
+  if (p_base >= npix || m_base >= A.cout_pad) return;
+  const int b = blockIdx.z;
+  const size_t in_plane = (size_t)A.hin * A.win;
+  const float* in = A.in + (size_t)b * A.cin * in_plane + (size_t)h * in_plane;
+
+  // per-lane pixel geometry: offset of every tap (clamped to a valid address) + validity bits
+  int off[PT][NTAPS];
+  unsigned vmask[PT];
+#pragma unroll
+  for (int q = 0; q < PT; ++q) {
+    const int p = p_base + q * 32 + j;
+    const bool live = p < npix;
+    const int y = live ? p / A.wt : 0, x = live ? p - (p / A.wt) * A.wt : 0;
+    vmask[q] = 0;
+#pragma unroll
+    for (int t = 0; t < NTAPS; ++t) {
+      const int iy = y * A.in_mul + A.dy[t], ix = x * A.in_mul + A.dx[t];
+      const bool ok = live && iy >= 0 && iy < A.hin && ix >= 0 && ix < A.win;
+      off[q][t] = ok ? iy * A.win + ix : 0;
+      vmask[q] |= (ok ? 1u : 0u) << t;
+    }
+  }
+
+  f32x16 acc[CT][PT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int q = 0; q < PT; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
+
+  const int KP = A.cin >> 1;
+  const size_t wstep = (size_t)NTAPS * 2 * A.cout_pad;  // floats per cin pair
+  const float* wl = A.wpk + (size_t)h * A.cout_pad + m_base + j;
+
+  float wa[2][NTAPS][CT], xb[2][NTAPS][PT];
+
+#define SESSD_LOAD(SET, KPI)                                                         \
+  {                                                                                  \
+    const float* wk = wl + (size_t)(KPI)*wstep;                                      \
+    const float* xk = in + (size_t)(KPI)*2 * in_plane;                               \
+    _Pragma("unroll") for (int t = 0; t < NTAPS; ++t) {                              \
+      _Pragma("unroll") for (int c = 0; c < CT; ++c) wa[SET][t][c] = wk[(size_t)t * 2 * A.cout_pad + c * 32]; \
+      _Pragma("unroll") for (int q = 0; q < PT; ++q) {                               \
+        float v = xk[off[q][t]];                                                     \
+        xb[SET][t][q] = ((vmask[q] >> t) & 1u) ? v : 0.f;                            \
+      }                                                                              \
+    }                                                                                \
+  }
+#define SESSD_MMA(SET)                                                               \
+  {                                                                                  \
+    _Pragma("unroll") for (int t = 0; t < NTAPS; ++t)                                \
+      _Pragma("unroll") for (int c = 0; c < CT; ++c)                                 \
+        _Pragma("unroll") for (int q = 0; q < PT; ++q)                               \
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[SET][t][c], xb[SET][t][q], acc[c][q], 0, 0, 0); \
+  }
+
+  SESSD_LOAD(0, 0)
+  int kp = 0;
+  for (; kp + 2 <= KP; kp += 2) {
+    SESSD_LOAD(1, kp + 1)
+    SESSD_MMA(0)
+    if (kp + 2 < KP) SESSD_LOAD(0, kp + 2)
+    SESSD_MMA(1)
+  }
+  if (kp < KP) SESSD_MMA(0)  // odd KP tail (set 0 holds kp)
+#undef SESSD_LOAD
+#undef SESSD_MMA
+
+  // epilogue. D layout (32x32): column = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*h (cout)
+  const size_t out_plane = (size_t)A.hout * A.wout;
+  float* outb = A.out + (size_t)b * A.cout * out_plane;
+  const float* resb = A.residual ? A.residual + (size_t)b * A.cout * out_plane : nullptr;
+#pragma unroll
+  for (int q = 0; q < PT; ++q) {
+    const int p = p_base + q * 32 + j;
+    if (p >= npix) continue;
+    const int y = p / A.wt, x = p - y * A.wt;
+    const size_t opix = (size_t)(y * A.out_mul + A.out_py) * A.wout + (x * A.out_mul + A.out_px);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = m_base + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co >= A.cout) continue;
+        float v = acc[c][q][r];
+        const float sc = A.scale ? A.scale[co] : 1.f, sh = A.shift ? A.shift[co] : 0.f;
+        v = fmaf(v, sc, sh);
+        if (A.relu) v = fmaxf(v, 0.f);
+        if (resb) v += resb[(size_t)co * out_plane + opix];
+        outb[(size_t)co * out_plane + opix] = v;
+      }
+    }
+  }
+}
+
+// SSFA tail (rpn_v1.py:227-233): w0 = BN(conv1x1(x0)), w1 = BN(conv1x1(x1)) (128 -> 1 channel, no ReLU),
+// (s0, s1) = softmax(w0, w1), out = x0*s0 + x1*s1. One thread per pixel, channel loop reads are
+// coalesced across pixels (NCHW planes). Two passes over x0/x1 rows that stay in L2.
+__global__ __launch_bounds__(256) void ssfa_fuse_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                         const float* __restrict__ w0, const float* __restrict__ w1,
+                                                         float s0, float t0, float s1, float t1, int C, int npix,
+                                                         float* __restrict__ out) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (p >= npix) return;
+  const size_t base = (size_t)b * C * npix + p;
+  float a0 = 0.f, a1 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    a0 = fmaf(x0[base + (size_t)c * npix], w0[c], a0);
+    a1 = fmaf(x1[base + (size_t)c * npix], w1[c], a1);
+  }
+  a0 = fmaf(a0, s0, t0);
+  a1 = fmaf(a1, s1, t1);
+  const float m = fmaxf(a0, a1);
+  const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+  const float inv = 1.f / (e0 + e1);
+  const float p0 = e0 * inv, p1 = e1 * inv;
+  for (int c = 0; c < C; ++c) {
+    const size_t o = base + (size_t)c * npix;
+    out[o] = x0[o] * p0 + x1[o] * p1;
+  }
+}
+
+template <int NTAPS, int CT, int PT, int WC, int WP>
+int launch_conv(const ConvArgs& A, int batch, hipStream_t stream) {
+  const int npix = A.ht * A.wt;
+  dim3 grid(sessd_divup(npix, WP * PT * 32), sessd_divup(A.cout_pad, WC * CT * 32), batch);
+  hipLaunchKernelGGL((conv2d_mfma_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+template <int NTAPS>
+int dispatch_tile(const ConvArgs& A, int batch, int tile_cfg, hipStream_t stream) {
+  switch (tile_cfg) {
+    case 0: return launch_conv<NTAPS, 2, 2, 2, 2>(A, batch, stream);  // wave 64c x 64p, WG 128c x 128p
+    case 1: return launch_conv<NTAPS, 2, 1, 2, 2>(A, batch, stream);  // wave 64c x 32p, WG 128c x 64p
+    case 2: return launch_conv<NTAPS, 1, 2, 4, 1>(A, batch, stream);  // wave 32c x 64p, WG 128c x 64p
+    case 3: return launch_conv<NTAPS, 1, 1, 4, 1>(A, batch, stream);  // wave 32c x 32p, WG 128c x 32p
+    case 4: return launch_conv<NTAPS, 1, 1, 1, 4>(A, batch, stream);  // wave 32c x 32p, WG 32c x 128p (small cout)
+    case 5: return launch_conv<NTAPS, 2, 1, 4, 1>(A, batch, stream);  // wave 64c x 32p, WG 256c x 32p
+    default: return SESSD_EINVAL;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// Generic conv launcher. taps_dy/taps_dx: host int[ntaps] input offsets; wpk packed [cin/2][ntaps][2][cout_pad]
+// (cout_pad = cout rounded up to 32, padding columns zero). tile_cfg selects the wave/workgroup tiling (0..5).
+int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, const float* wpk, int ntaps,
+                      const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out, int cout,
+                      int hout, int wout, int out_mul, int out_py, int out_px, const float* scale, const float* shift,
+                      int relu, const float* residual, int tile_cfg, hipStream_t stream) {
+  if (cin % 2 || ntaps < 1 || ntaps > 9 || batch < 1 || cout < 1) return SESSD_EINVAL;
+  ConvArgs A;
+  A.in = in; A.wpk = wpk; A.out = out; A.scale = scale; A.shift = shift; A.residual = residual;
+  A.cin = cin; A.hin = hin; A.win = win;
+  A.cout = cout; A.cout_pad = sessd_divup(cout, 32) * 32; A.hout = hout; A.wout = wout;
+  A.ht = tile_h; A.wt = tile_w;
+  A.in_mul = in_mul; A.out_mul = out_mul; A.out_py = out_py; A.out_px = out_px;
+  A.relu = relu;
+  for (int t = 0; t < 9; ++t) {
+    A.dy[t] = t < ntaps ? taps_dy[t] : 0;
+    A.dx[t] = t < ntaps ? taps_dx[t] : 0;
+  }
+  switch (ntaps) {
+    case 1: return dispatch_tile<1>(A, batch, tile_cfg, stream);
+    case 2: return dispatch_tile<2>(A, batch, tile_cfg, stream);
+    case 4: return dispatch_tile<4>(A, batch, tile_cfg, stream);
+    case 9: return dispatch_tile<9>(A, batch, tile_cfg, stream);
+    default: return SESSD_EINVAL;
+  }
+}
+
+// SSFA fusion tail: x0, x1, out are (B, C, H, W); w0, w1 the (C,) 1x1 conv weights; (s, t) the folded
+// single-channel BatchNorm of each weight branch.
+int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
+                    float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,
+                    float* out, hipStream_t stream) {
+  if (batch < 1 || channels < 1 || num_pixels < 1) return SESSD_EINVAL;
+  hipLaunchKernelGGL(ssfa_fuse_kernel, dim3(sessd_divup(num_pixels, 256), batch), dim3(256), 0, stream, x0, x1, w0, w1,
+                     bn_scale0, bn_shift0, bn_scale1, bn_shift1, channels, num_pixels, out);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+}  // extern "C"

@@ -230,3 +230,103 @@ def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, sc
                                 _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), _stream()),
           "sparse_conv")
     return out if dense_out is None else dense_out
+
+
+# ------------------------------------------------------------------ dense BEV convolutions
+class PackedConv:
+    """A conv layer lowered to one or more sessd_conv2d_mfma launches (weights in MFMA fragment order)."""
+
+    def __init__(self, launches, cin, cout, kind, stride):
+        self.launches = launches  # list of dict(wpk, dy, dx, in_mul, out_mul, py, px, ntaps)
+        self.cin, self.cout, self.kind, self.stride = cin, cout, kind, stride
+
+
+def _pack_taps(w_co_ci_t, cout):
+    """w (cout, cin, ntaps) -> [cin/2][ntaps][2][cout_pad] contiguous on the same device."""
+    co, ci, nt = w_co_ci_t.shape
+    cp = (co + 31) // 32 * 32
+    w = torch.zeros((ci // 2, nt, 2, cp), dtype=torch.float32, device=w_co_ci_t.device)
+    w[:, :, :, :co] = w_co_ci_t.permute(1, 2, 0).reshape(ci // 2, 2, nt, co).permute(0, 2, 1, 3)
+    return w.contiguous()
+
+
+def pack_conv2d(weight, stride=1, padding=None):
+    """nn.Conv2d weight (Cout,Cin,k,k), k in {1,3}; padding k//2 (the only form SSFA / Head use)."""
+    w = weight.detach().to(torch.float32)
+    co, ci, kh, kw = w.shape
+    assert kh == kw and kh in (1, 3) and ci % 2 == 0
+    pad = kh // 2 if padding is None else padding
+    assert pad == kh // 2
+    dy = [ky - pad for ky in range(kh) for kx in range(kw)]
+    dx = [kx - pad for ky in range(kh) for kx in range(kw)]
+    wpk = _pack_taps(w.reshape(co, ci, kh * kw), co)
+    la = dict(wpk=wpk, dy=torch.tensor(dy, dtype=torch.int32), dx=torch.tensor(dx, dtype=torch.int32), in_mul=stride,
+              out_mul=1, py=0, px=0, ntaps=kh * kw)
+    return PackedConv([la], ci, co, "conv", stride)
+
+
+def pack_deconv2d_s2(weight):
+    """nn.ConvTranspose2d(Cin,Cout,3,stride=2,padding=1,output_padding=1) weight (Cin,Cout,3,3):
+    four output-parity classes; out(2y+py, 2x+px) = sum over taps of in(y+ey, x+ex) W[:, :, ky, kx]
+    with (k, e) = (1, 0) for even parity and (0, +1), (2, 0) for odd parity (oy = 2*iy - 1 + ky)."""
+    w = weight.detach().to(torch.float32)
+    ci, co, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and ci % 2 == 0
+    sel = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}
+    launches = []
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = [(ky, ey, kx, ex) for (ky, ey) in sel[py] for (kx, ex) in sel[px]]
+            wt = torch.stack([w[:, :, ky, kx] for (ky, ey, kx, ex) in taps], -1)  # (ci, co, nt)
+            wpk = _pack_taps(wt.permute(1, 0, 2).contiguous(), co)
+            launches.append(dict(wpk=wpk, dy=torch.tensor([t[1] for t in taps], dtype=torch.int32),
+                                 dx=torch.tensor([t[3] for t in taps], dtype=torch.int32), in_mul=1, out_mul=2, py=py,
+                                 px=px, ntaps=len(taps)))
+    return PackedConv(launches, ci, co, "deconv", 2)
+
+
+def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, tile_cfg=None):
+    """x (B,Cin,H,W) NCHW float32 on the device. Returns (B,Cout,Ho,Wo)."""
+    _req(x, torch.float32, "x")
+    B, ci, H, W = x.shape
+    assert ci == pc.cin
+    if pc.kind == "conv":
+        Ho, Wo = (H + pc.stride - 1) // pc.stride, (W + pc.stride - 1) // pc.stride
+        th, tw = Ho, Wo
+    else:
+        Ho, Wo = 2 * H, 2 * W
+        th, tw = H, W
+    if out is None:
+        out = torch.empty((B, pc.cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    for la in pc.launches:
+        cfg = tile_cfg
+        if cfg is None:
+            cfg = default_tile_cfg(pc.cout, th * tw, la["ntaps"])
+        check(lib.sessd_conv2d_mfma(x.data_ptr(), B, ci, H, W, la["wpk"].data_ptr(), la["ntaps"], la["dy"].data_ptr(),
+                                    la["dx"].data_ptr(), la["in_mul"], th, tw, out.data_ptr(), pc.cout, Ho, Wo,
+                                    la["out_mul"], la["py"], la["px"], _p(scale), _p(shift), 1 if relu else 0,
+                                    _p(residual), cfg, _stream()), "conv2d_mfma")
+    return out
+
+
+_TILE_CFG_OVERRIDE = {}
+
+
+def default_tile_cfg(cout, npix, ntaps):
+    key = (cout, npix, ntaps)
+    if key in _TILE_CFG_OVERRIDE:
+        return _TILE_CFG_OVERRIDE[key]
+    if cout <= 32:
+        return 4
+    return 1
+
+
+def ssfa_fuse(x0, x1, w0, w1, s0, t0, s1, t1, out=None):
+    _req(x0, torch.float32, "x0")
+    _req(x1, torch.float32, "x1")
+    B, C, H, W = x0.shape
+    if out is None:
+        out = torch.empty_like(x0)
+    check(lib.sessd_ssfa_fuse(x0.data_ptr(), x1.data_ptr(), w0.data_ptr(), w1.data_ptr(), float(s0), float(t0),
+                              float(s1), float(t1), B, C, H * W, out.data_ptr(), _stream()), "ssfa_fuse")
+    return out

@@ -1,0 +1,106 @@
+"""HIP f32-MFMA BEV convolutions vs torch CPU float32 (the same ops the reference's SSFA / Head call).
+Tolerance: float32 sums of K <= 2304 products in a different order: 2e-4 * max|ref| absolute."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sessd_hip import ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(got, ref, rel=2e-4):
+    tol = rel * max(1.0, float(ref.abs().max()))
+    err = float((got - ref).abs().max())
+    assert err < tol, (err, tol)
+
+
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 5])
+@pytest.mark.parametrize("cin,cout,k,stride,H,W", [(128, 128, 3, 1, 24, 40), (128, 256, 3, 2, 24, 40), (256, 256, 3, 1, 12, 20),
+                                                   (128, 128, 1, 1, 24, 40), (6, 32, 3, 1, 7, 9)])
+def test_conv2d(dev, cfg, cin, cout, k, stride, H, W):
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x = torch.randn(2, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.05
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    ref = torch.relu(F.conv2d(x, w, stride=stride, padding=k // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    pc = ops.pack_conv2d(w.to(dev), stride)
+    got = ops.conv2d(x.to(dev), pc, scale.to(dev), shift.to(dev), True, tile_cfg=cfg).cpu()
+    assert got.shape == ref.shape
+    _close(got, ref)
+
+
+@pytest.mark.parametrize("cfg", [1, 3])
+def test_deconv_s2_with_residual(dev, cfg):
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 256, 10, 12, generator=g)
+    w = torch.randn(256, 128, 3, 3, generator=g) * 0.05
+    scale = torch.rand(128, generator=g) + 0.5
+    shift = torch.randn(128, generator=g) * 0.1
+    res = torch.randn(2, 128, 20, 24, generator=g)
+    ref = torch.relu(F.conv_transpose2d(x, w, stride=2, padding=1, output_padding=1) * scale.view(1, -1, 1, 1)
+                     + shift.view(1, -1, 1, 1)) + res
+    pc = ops.pack_deconv2d_s2(w.to(dev))
+    got = ops.conv2d(x.to(dev), pc, scale.to(dev), shift.to(dev), True, residual=res.to(dev), tile_cfg=cfg).cpu()
+    _close(got, ref)
+
+
+def test_head_conv_cout22_bias_no_relu(dev):
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 128, 16, 24, generator=g)
+    w = torch.randn(22, 128, 1, 1, generator=g) * 0.1
+    b = torch.randn(22, generator=g)
+    ref = F.conv2d(x, w, b)
+    got = ops.conv2d(x.to(dev), ops.pack_conv2d(w.to(dev)), None, b.to(dev), False).cpu()
+    _close(got, ref)
+
+
+def test_transpose_detecting_identity(dev):
+    """A = I style check with an asymmetric operand: 1x1 conv with a permutation-like weight."""
+    cin = cout = 64
+    w = torch.zeros(cout, cin, 1, 1)
+    for o in range(cout):
+        w[o, (o * 7 + 3) % cin, 0, 0] = 1.0 + o
+    x = torch.arange(cin * 8 * 8, dtype=torch.float32).view(1, cin, 8, 8) * 1e-3
+    ref = F.conv2d(x, w)
+    got = ops.conv2d(x.to(dev), ops.pack_conv2d(w.to(dev)), None, None, False).cpu()
+    assert torch.equal(got, ref)
+
+
+def test_ssfa_fuse(dev):
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(2, 128, 10, 12, generator=g)
+    x1 = torch.randn(2, 128, 10, 12, generator=g)
+    w0 = torch.randn(128, generator=g) * 0.1
+    w1 = torch.randn(128, generator=g) * 0.1
+    s0, t0, s1, t1 = 1.3, -0.2, 0.7, 0.1
+    a0 = (x0 * w0.view(1, -1, 1, 1)).sum(1, keepdim=True) * s0 + t0
+    a1 = (x1 * w1.view(1, -1, 1, 1)).sum(1, keepdim=True) * s1 + t1
+    sm = torch.softmax(torch.cat([a0, a1], 1), 1)
+    ref = x0 * sm[:, 0:1] + x1 * sm[:, 1:]
+    got = ops.ssfa_fuse(x0.to(dev), x1.to(dev), w0.to(dev), w1.to(dev), s0, t0, s1, t1).cpu()
+    _close(got, ref, 1e-5)
+
+
+def test_full_size_layer_bench(dev):
+    """KITTI-size 3x3 128->128 @200x176: correctness on a strided sample + a timing printout per tile cfg."""
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 128, 200, 176, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) * 0.03
+    ref = F.conv2d(x, w, padding=1)
+    xd = x.to(dev)
+    pc = ops.pack_conv2d(w.to(dev))
+    for cfg in (0, 1, 2, 3):
+        out = ops.conv2d(xd, pc, None, None, False, tile_cfg=cfg)
+        torch.cuda.synchronize()
+        _close(out.cpu(), ref)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            ops.conv2d(xd, pc, None, None, False, out=out, tile_cfg=cfg)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        print("conv3x3 128->128 @200x176 cfg %d: %.3f ms  %.1f TFLOP/s" % (cfg, ms, 10.38e9 / ms / 1e9))
