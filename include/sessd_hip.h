@@ -111,6 +111,24 @@ int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const flo
                     float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,
                     float* out, sessd_stream_t stream);
 
+/* ------------------------------------------------------------------ predict / post-processing (a11-a14)
+ * replaces det3d/models/bbox_heads/mg_head_sessd.py:893-1057 (MultiGroupHead.predict / get_task_detections),
+ * det3d/core/bbox/box_torch_ops.py:81-147 (second_box_decode) and :527-548 (rotate_nms), the CPU NMS of
+ * det3d/ops/nms/nms_cpu.py:40-51 + nms_cpu.h:72-168 and the numba frustum test geometry.py:215-277.
+ * head: (B,22,H*W) planar float32 -- ch 0..13 box codes (7 per anchor), 14..15 cls, 16..19 dir, 20..21 iou;
+ * anchors (A,7) shared (anchors_per_frame = 0) or (B,A,7), A = 2*H*W; frustum (B,1,6,4,3) float64 or NULL.
+ * Outputs (device): out_box (B,post,7), out_score (B,post), out_label (B,post) int32, out_count (B,). */
+size_t sessd_predict_workspace_bytes(int batch, int num_anchors, int pre_max_size, int post_max_size);
+int sessd_predict(const float* head, int batch, int num_pixels, const float* anchors, int anchors_per_frame,
+                  const double* frustum, float score_thresh, int pre_max_size, int post_max_size, float nms_iou_thresh,
+                  const float* post_center_range6, float direction_offset, float* out_box, float* out_score,
+                  int32_t* out_label, int32_t* out_count, void* workspace, size_t workspace_bytes,
+                  sessd_stream_t stream);
+/* box_torch_ops.rotate_nms after its topk: dets (N,5) [x,y,w,l,r] sorted by descending score -> keep int32[post] */
+size_t sessd_rotate_nms_workspace_bytes(int num_boxes);
+int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float iou_thresh, int post_max_size, int32_t* keep,
+                            int32_t* num_keep, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

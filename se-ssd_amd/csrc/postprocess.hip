@@ -1,0 +1,444 @@
+// MultiGroupHead.predict on the device, end to end, with no host round trip:
+//   det3d/models/bbox_heads/mg_head_sessd.py:893-943 (predict) and :945-1057 (get_task_detections)
+//   det3d/core/bbox/box_torch_ops.py:81-147 (second_box_decode), :527-548 (rotate_nms: topk, keep[:post])
+//   det3d/ops/nms/nms_cpu.py:40-51 + det3d/ops/nms/nms_cpu.h:72-168 (rotate_nms_cc, CPU/boost in the reference)
+//   det3d/core/bbox/geometry.py:215-277 (frustum test), mg_head_sessd.py:1035-1045 (direction fix, range mask)
+// The reference leaves the GPU three times per frame here (boolean-mask indexing, NMS on the CPU,
+// frustum test in numba). Pipeline of this file, all on one stream:
+//   K1 score_filter   1 thread / BEV location: sigmoid(cls) >= thresh -> 64-bit key (~score | anchor) appended
+//                     with a wave-aggregated atomic (order does not matter: the key is a total order)
+//   K2 topk_decode    1 workgroup / frame: running top-`pre_max` by bitonic sort in LDS (2048 keys at a time),
+//                     then decode ONLY the survivors (box, rectified score, direction label, BEV corners, AABB)
+//   K3 rnms_mask      64x64 suppression bitmask tiles: AABB prefilter (float32, iou_jit eps=0) then convex
+//                     polygon clipping in float64; suppress when IoU >= thresh
+//   K4 nms_reduce     one wave / frame, greedy, stops at post_max (iou3d.hip: sessd_nms_reduce_kernel)
+//   K5 finalize       frustum (float64 planes), direction fix, centre-range mask, ordered compaction
+// Head tensor layout consumed here: planar (B, 22, H*W): ch 0..13 box codes (anchor-major, 7 each),
+// 14..15 cls, 16..19 dir (2 per anchor), 20..21 iou; anchor id = pixel*2 + a (mg_head_sessd.py:409-481).
+#include "geom.hpp"
+
+namespace {
+
+constexpr int APL = 2;        // anchors per location
+constexpr int HEAD_CH = 22;
+constexpr int SORT_N = 2048;  // keys sorted per pass in LDS
+constexpr int SORT_NT = 1024;
+
+struct PostCfg {
+  int num_pix;         // H*W
+  float score_thresh;  // 0.3
+  int pre_max, post_max;
+  float nms_thresh;
+  float range[6];      // post_center_range
+  float dir_offset;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void score_filter_kernel(const float* __restrict__ head, PostCfg C,
+                                                            unsigned long long* __restrict__ keys, int key_cap,
+                                                            int* __restrict__ count) {
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y;
+  if (pix >= C.num_pix) return;
+  const float* hb = head + (size_t)b * HEAD_CH * C.num_pix;
+#pragma unroll
+  for (int a = 0; a < APL; ++a) {
+    const float s = sigmoidf_(hb[(size_t)(14 + a) * C.num_pix + pix]);
+    if (s >= C.score_thresh) {
+      // IoU rectification (mg_head_sessd.py:971-972): s *= ((iou + 1) * 0.5)^4
+      const float r = (hb[(size_t)(20 + a) * C.num_pix + pix] + 1.0f) * 0.5f;
+      const float sc = s * (r * r * r * r);
+      const unsigned aid = (unsigned)(pix * APL + a);
+      const unsigned long long key = ((unsigned long long)(~__float_as_uint(sc)) << 32) | aid;
+      const int slot = atomicAdd(&count[b], 1);
+      if (slot < key_cap) keys[(size_t)b * key_cap + slot] = key;
+    }
+  }
+}
+
+__device__ __forceinline__ void bitonic_sort_lds(unsigned long long* s, int n) {
+  for (int k = 2; k <= n; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = threadIdx.x; t < (n >> 1); t += SORT_NT) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool up = (lo & k) == 0;
+        const unsigned long long a = s[lo], b = s[hi];
+        if ((a > b) == up) { s[lo] = b; s[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Outputs per frame (stride pre_max): cand_box (7), cand_score, cand_dir, corners (8), standup (4), n_top
+__global__ __launch_bounds__(SORT_NT) void topk_decode_kernel(const float* __restrict__ head,
+                                                               const float* __restrict__ anchors, int anchors_per_frame,
+                                                               PostCfg C, const unsigned long long* __restrict__ keys,
+                                                               int key_cap, const int* __restrict__ count,
+                                                               float* __restrict__ cand_box, float* __restrict__ cand_score,
+                                                               int* __restrict__ cand_dir, float* __restrict__ corners,
+                                                               float* __restrict__ standup, int* __restrict__ n_top) {
+  __shared__ unsigned long long s[SORT_N];
+  const int b = blockIdx.x;
+  const int n = min(count[b], key_cap);
+  const unsigned long long* kb = keys + (size_t)b * key_cap;
+  int T = 0, pos = 0;
+  while (pos < n) {
+    const int take = min(n - pos, SORT_N - T);
+    int npad = 64;
+    while (npad < T + take) npad <<= 1;
+    for (int t = threadIdx.x; t < npad - T; t += SORT_NT) s[T + t] = t < take ? kb[pos + t] : ~0ull;
+    __syncthreads();
+    bitonic_sort_lds(s, npad);
+    T = min(T + take, C.pre_max);
+    pos += take;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_top[b] = T;
+  const float* hb = head + (size_t)b * HEAD_CH * C.num_pix;
+  for (int k = threadIdx.x; k < T; k += SORT_NT) {
+    const unsigned long long key = s[k];
+    const unsigned aid = (unsigned)(key & 0xFFFFFFFFull);
+    const float sc = __uint_as_float(~(unsigned)(key >> 32));
+    const int pix = aid / APL, a = aid % APL;
+    const float* an = anchors + ((size_t)(anchors_per_frame ? (size_t)b * anchors_per_frame : 0) + aid) * 7;
+    float t[7];
+#pragma unroll
+    for (int q = 0; q < 7; ++q) t[q] = hb[(size_t)(a * 7 + q) * C.num_pix + pix];
+    // second_box_decode (box_torch_ops.py:112-146)
+    const float xa = an[0], ya = an[1], za = an[2], wa = an[3], la = an[4], ha = an[5], ra = an[6];
+    const float diag = sqrtf(la * la + wa * wa);
+    float bx[7];
+    bx[0] = t[0] * diag + xa;
+    bx[1] = t[1] * diag + ya;
+    bx[2] = t[2] * ha + za;
+    bx[3] = expf(t[3]) * wa;
+    bx[4] = expf(t[4]) * la;
+    bx[5] = expf(t[5]) * ha;
+    bx[6] = t[6] + ra;
+    const size_t o = (size_t)b * C.pre_max + k;
+#pragma unroll
+    for (int q = 0; q < 7; ++q) cand_box[o * 7 + q] = bx[q];
+    cand_score[o] = sc;
+    const float d0 = hb[(size_t)(16 + a * 2) * C.num_pix + pix], d1 = hb[(size_t)(17 + a * 2) * C.num_pix + pix];
+    cand_dir[o] = d1 > d0 ? 1 : 0;  // torch.max: first maximum on ties
+    // boxes_for_nms = box[:, [0,1,3,4,6]] -> corners (box_np_ops.py:512-532) and stand-up box
+    const float det[5] = {bx[0], bx[1], bx[3], bx[4], bx[6]};
+    float c8[8];
+    sessd_box2d_corners(det, c8);
+    float x0 = c8[0], y0 = c8[1], x1 = c8[0], y1 = c8[1];
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+      x0 = fminf(x0, c8[2 * q]); x1 = fmaxf(x1, c8[2 * q]);
+      y0 = fminf(y0, c8[2 * q + 1]); y1 = fmaxf(y1, c8[2 * q + 1]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) corners[o * 8 + q] = c8[q];
+    standup[o * 4 + 0] = x0; standup[o * 4 + 1] = y0; standup[o * 4 + 2] = x1; standup[o * 4 + 3] = y1;
+  }
+}
+
+__device__ __forceinline__ bool rnms_suppresses(const float* ci, const float* si, const float* cj, const float* sj,
+                                                float thresh) {
+  // iou_jit(eps=0) prefilter (box_np_ops.py:1007-1045), float32
+  const float iw = fminf(si[2], sj[2]) - fmaxf(si[0], sj[0]);
+  if (!(iw > 0.f)) return false;
+  const float ih = fminf(si[3], sj[3]) - fmaxf(si[1], sj[1]);
+  if (!(ih > 0.f)) return false;
+  const float ua = (si[2] - si[0]) * (si[3] - si[1]) + (sj[2] - sj[0]) * (sj[3] - sj[1]) - iw * ih;
+  const float siou = iw * ih / ua;
+  if (siou <= 0.f) return false;
+  const double inter = sessd_quad_clip_area(ci, cj);
+  if (inter <= 0) return false;
+  double px[4], py[4], qx[4], qy[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { px[q] = ci[2 * q]; py[q] = ci[2 * q + 1]; qx[q] = cj[2 * q]; qy[q] = cj[2 * q + 1]; }
+  const double uni = fabs(sessd_poly_area2(px, py, 4)) * 0.5 + fabs(sessd_poly_area2(qx, qy, 4)) * 0.5 - inter;
+  const double ov = uni > 0 ? inter / uni : 0.0;
+  return ov >= (double)thresh;
+}
+
+__global__ __launch_bounds__(64) void rnms_mask_kernel(const int* __restrict__ n_top, int pre_max, float thresh,
+                                                        const float* __restrict__ corners, const float* __restrict__ standup,
+                                                        unsigned long long* __restrict__ mask, int words) {
+  const int b = blockIdx.z, rblk = blockIdx.y, cblk = blockIdx.x;
+  const int n = n_top[b];
+  if (cblk < rblk || rblk * 64 >= n || cblk * 64 >= n) return;
+  __shared__ float cc[64][8];
+  __shared__ float cs[64][4];
+  const int t = threadIdx.x;
+  const float* cb = corners + (size_t)b * pre_max * 8;
+  const float* sb = standup + (size_t)b * pre_max * 4;
+  const int ncol = min(n - cblk * 64, 64);
+  if (t < ncol) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cc[t][q] = cb[(size_t)(cblk * 64 + t) * 8 + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) cs[t][q] = sb[(size_t)(cblk * 64 + t) * 4 + q];
+  }
+  __syncthreads();
+  const int i = rblk * 64 + t;
+  if (i >= n) return;
+  float ci[8], si[4];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) ci[q] = cb[(size_t)i * 8 + q];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) si[q] = sb[(size_t)i * 4 + q];
+  unsigned long long bits = 0;
+  const int start = rblk == cblk ? t + 1 : 0;
+  for (int k = start; k < ncol; ++k)
+    if (rnms_suppresses(ci, si, cc[k], cs[k], thresh)) bits |= 1ull << k;
+  mask[((size_t)b * pre_max + i) * words + cblk] = bits;
+}
+
+// frustum: (B,1,6,4,3) float64 surfaces (or null). One wave per frame.
+__global__ __launch_bounds__(64) void finalize_kernel(PostCfg C, const int* __restrict__ keep, const int* __restrict__ n_keep,
+                                                       const float* __restrict__ cand_box, const float* __restrict__ cand_score,
+                                                       const int* __restrict__ cand_dir, const double* __restrict__ frustum,
+                                                       float* __restrict__ out_box, float* __restrict__ out_score,
+                                                       int* __restrict__ out_label, int* __restrict__ out_count) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nk = min(n_keep[b], C.post_max);
+  double nx[6], ny[6], nz[6], nd[6];
+  if (frustum) {
+    const double* f = frustum + (size_t)b * 72;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const double* s = f + k * 12;
+      const double ax = s[0] - s[3], ay = s[1] - s[4], az = s[2] - s[5];
+      const double bx = s[3] - s[6], by = s[4] - s[7], bz = s[5] - s[8];
+      nx[k] = ay * bz - az * by;
+      ny[k] = az * bx - ax * bz;
+      nz[k] = ax * by - ay * bx;
+      nd[k] = -s[0] * nx[k] - s[1] * ny[k] - s[2] * nz[k];
+    }
+  }
+  int written = 0;
+  for (int base = 0; base < nk; base += 64) {
+    const int k = base + lane;
+    bool ok = k < nk;
+    float bx[7] = {0, 0, 0, 0, 0, 0, 0};
+    float sc = 0.f;
+    if (ok) {
+      const size_t o = (size_t)b * C.pre_max + keep[(size_t)b * C.post_max + k];
+#pragma unroll
+      for (int q = 0; q < 7; ++q) bx[q] = cand_box[o * 7 + q];
+      sc = cand_score[o];
+      if (frustum) {
+#pragma unroll
+        for (int p = 0; p < 6; ++p) {
+          const double sign = (double)bx[0] * nx[p] + (double)bx[1] * ny[p] + (double)bx[2] * nz[p] + nd[p];
+          if (sign >= 0) ok = false;
+        }
+      }
+      const bool opp = ((bx[6] - C.dir_offset) > 0.f) != (cand_dir[o] == 1);
+      if (opp) bx[6] += 3.14159265358979323846f;
+      ok = ok && bx[0] >= C.range[0] && bx[1] >= C.range[1] && bx[2] >= C.range[2] && bx[0] <= C.range[3] &&
+           bx[1] <= C.range[4] && bx[2] <= C.range[5];
+    }
+    const unsigned long long bal = __ballot(ok);
+    if (ok) {
+      const int dst = written + __popcll(bal & ((1ull << lane) - 1ull));
+      const size_t o = (size_t)b * C.post_max + dst;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) out_box[o * 7 + q] = bx[q];
+      out_score[o] = sc;
+      out_label[o] = 0;
+    }
+    written += __popcll(bal);
+  }
+  if (lane == 0) out_count[b] = written;
+}
+
+struct PostWs {
+  unsigned long long* keys;
+  int* count;
+  float* cand_box;
+  float* cand_score;
+  int* cand_dir;
+  float* corners;
+  float* standup;
+  int* n_top;
+  unsigned long long* mask;
+  int* keep;
+  int* n_keep;
+};
+
+size_t post_ws_layout(int batch, int num_anchors, int pre_max, int post_max, PostWs* w, char* base) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = sessd_align(off + bytes, 256);
+    return o;
+  };
+  const int words = sessd_divup(pre_max, 64);
+  size_t o_keys = take((size_t)batch * num_anchors * 8);
+  size_t o_count = take((size_t)batch * 4);
+  size_t o_box = take((size_t)batch * pre_max * 7 * 4);
+  size_t o_score = take((size_t)batch * pre_max * 4);
+  size_t o_dir = take((size_t)batch * pre_max * 4);
+  size_t o_cor = take((size_t)batch * pre_max * 8 * 4);
+  size_t o_su = take((size_t)batch * pre_max * 4 * 4);
+  size_t o_nt = take((size_t)batch * 4);
+  size_t o_mask = take((size_t)batch * pre_max * words * 8);
+  size_t o_keep = take((size_t)batch * post_max * 4);
+  size_t o_nk = take((size_t)batch * 4);
+  if (w) {
+    w->keys = (unsigned long long*)(base + o_keys);
+    w->count = (int*)(base + o_count);
+    w->cand_box = (float*)(base + o_box);
+    w->cand_score = (float*)(base + o_score);
+    w->cand_dir = (int*)(base + o_dir);
+    w->corners = (float*)(base + o_cor);
+    w->standup = (float*)(base + o_su);
+    w->n_top = (int*)(base + o_nt);
+    w->mask = (unsigned long long*)(base + o_mask);
+    w->keep = (int*)(base + o_keep);
+    w->n_keep = (int*)(base + o_nk);
+  }
+  return off;
+}
+
+// batched variant of the greedy reduction (one wave per frame)
+__global__ __launch_bounds__(64) void nms_reduce_batch_kernel(const int* __restrict__ n_top, int pre_max,
+                                                               const unsigned long long* __restrict__ mask, int words,
+                                                               int post_max, int* __restrict__ keep, int* __restrict__ n_keep) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int n = min(n_top[b], pre_max);
+  const unsigned long long* mb = mask + (size_t)b * pre_max * words;
+  int* kb = keep + (size_t)b * post_max;
+  const int cb = sessd_divup(n, 64);
+  unsigned long long removed = 0;  // lane w owns word w (pre_max <= 4096)
+  int nk = 0;
+  for (int blk = 0; blk < cb && nk < post_max; ++blk) {
+    const int row = blk * 64 + lane;
+    unsigned long long diag = row < n ? mb[(size_t)row * words + blk] : 0ull;
+    unsigned long long rem = __shfl(removed, blk, 64);
+    unsigned long long kept = 0;
+    const int lim = min(64, n - blk * 64);
+    for (int bb = 0; bb < lim; ++bb) {
+      const unsigned long long d = __shfl(diag, bb, 64);
+      if (!((rem >> bb) & 1ull) && nk < post_max) {
+        kept |= 1ull << bb;
+        if (lane == 0) kb[nk] = blk * 64 + bb;
+        ++nk;
+        rem |= d;
+      }
+    }
+    if (nk >= post_max) break;
+    for (int bb = 0; bb < lim; ++bb) {
+      if (!((kept >> bb) & 1ull)) continue;
+      if (lane > blk && lane < cb) removed |= mb[(size_t)(blk * 64 + bb) * words + lane];
+    }
+  }
+  if (lane == 0) n_keep[b] = nk;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sessd_predict_workspace_bytes(int batch, int num_anchors, int pre_max_size, int post_max_size) {
+  return post_ws_layout(batch, num_anchors, pre_max_size, post_max_size, nullptr, nullptr);
+}
+
+// head (B,22,H*W) planar, anchors (A,7) shared by all frames (anchors_per_frame = 0) or (B,A,7),
+// frustum (B,1,6,4,3) float64 or NULL. Outputs: out_box (B,post,7), out_score (B,post), out_label (B,post) int32,
+// out_count (B,) -- rows [0,out_count[b]) are the detections of frame b in NMS order.
+int sessd_predict(const float* head, int batch, int num_pixels, const float* anchors, int anchors_per_frame,
+                  const double* frustum, float score_thresh, int pre_max_size, int post_max_size, float nms_iou_thresh,
+                  const float* post_center_range6, float direction_offset, float* out_box, float* out_score,
+                  int* out_label, int* out_count, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (batch < 1 || num_pixels < 1 || pre_max_size < 1 || pre_max_size > 4096 || post_max_size < 1) return SESSD_EINVAL;
+  if (pre_max_size > SORT_N - 64) return SESSD_EINVAL;  // running top-k keeps pre_max + a fresh chunk in 2048 slots
+  const int A = num_pixels * APL;
+  PostWs w;
+  if (post_ws_layout(batch, A, pre_max_size, post_max_size, &w, (char*)workspace) > workspace_bytes)
+    return SESSD_EWORKSPACE;
+  PostCfg C;
+  C.num_pix = num_pixels;
+  C.score_thresh = score_thresh;
+  C.pre_max = pre_max_size;
+  C.post_max = post_max_size;
+  C.nms_thresh = nms_iou_thresh;
+  for (int i = 0; i < 6; ++i) C.range[i] = post_center_range6[i];
+  C.dir_offset = direction_offset;
+  SESSD_TRY(hipMemsetAsync(w.count, 0, (size_t)batch * 4, stream));
+  hipLaunchKernelGGL(score_filter_kernel, dim3(sessd_divup(num_pixels, 256), batch), dim3(256), 0, stream, head, C,
+                     w.keys, A, w.count);
+  SESSD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(topk_decode_kernel, dim3(batch), dim3(SORT_NT), 0, stream, head, anchors, anchors_per_frame, C,
+                     w.keys, A, w.count, w.cand_box, w.cand_score, w.cand_dir, w.corners, w.standup, w.n_top);
+  SESSD_CHECK_LAUNCH();
+  const int words = sessd_divup(pre_max_size, 64);
+  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, words, batch), dim3(64), 0, stream, w.n_top, pre_max_size,
+                     nms_iou_thresh, w.corners, w.standup, w.mask, words);
+  SESSD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nms_reduce_batch_kernel, dim3(batch), dim3(64), 0, stream, w.n_top, pre_max_size, w.mask, words,
+                     post_max_size, w.keep, w.n_keep);
+  SESSD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(finalize_kernel, dim3(batch), dim3(64), 0, stream, C, w.keep, w.n_keep, w.cand_box, w.cand_score,
+                     w.cand_dir, frustum, out_box, out_score, out_label, out_count);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// Stand-alone rotated NMS with the predict-path semantics (box_torch_ops.rotate_nms after its topk):
+// dets (N,5) [x,y,w,l,r] sorted by descending score. keep (device int32[post_max]), num_keep (device int).
+size_t sessd_rotate_nms_workspace_bytes(int num_boxes) {
+  const int words = sessd_divup(num_boxes > 0 ? num_boxes : 1, 64);
+  return sessd_align((size_t)num_boxes * 12 * 4, 256) + sessd_align((size_t)num_boxes * words * 8, 256) + 512;
+}
+
+}  // extern "C"
+
+namespace {
+__global__ __launch_bounds__(256) void rnms_prep_kernel(const float* __restrict__ dets, int n, float* __restrict__ corners,
+                                                         float* __restrict__ standup) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float c8[8];
+  sessd_box2d_corners(dets + (size_t)i * 5, c8);
+  float x0 = c8[0], y0 = c8[1], x1 = c8[0], y1 = c8[1];
+#pragma unroll
+  for (int q = 1; q < 4; ++q) {
+    x0 = fminf(x0, c8[2 * q]); x1 = fmaxf(x1, c8[2 * q]);
+    y0 = fminf(y0, c8[2 * q + 1]); y1 = fmaxf(y1, c8[2 * q + 1]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) corners[(size_t)i * 8 + q] = c8[q];
+  standup[(size_t)i * 4 + 0] = x0; standup[(size_t)i * 4 + 1] = y0; standup[(size_t)i * 4 + 2] = x1; standup[(size_t)i * 4 + 3] = y1;
+}
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+}  // namespace
+
+extern "C" int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float iou_thresh, int post_max_size, int* keep,
+                                       int* num_keep, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (num_boxes < 0 || num_boxes > 4096 || post_max_size < 1) return SESSD_EINVAL;
+  if (workspace_bytes < sessd_rotate_nms_workspace_bytes(num_boxes)) return SESSD_EWORKSPACE;
+  if (num_boxes == 0) {
+    SESSD_TRY(hipMemsetAsync(num_keep, 0, 4, stream));
+    return SESSD_OK;
+  }
+  char* base = (char*)workspace;
+  float* corners = (float*)base;
+  float* standup = corners + (size_t)num_boxes * 8;
+  size_t off = sessd_align((size_t)num_boxes * 12 * 4, 256);
+  const int words = sessd_divup(num_boxes, 64);
+  unsigned long long* mask = (unsigned long long*)(base + off);
+  off += sessd_align((size_t)num_boxes * words * 8, 256);
+  int* n_top = (int*)(base + off);
+  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, stream, n_top, num_boxes);
+  hipLaunchKernelGGL(rnms_prep_kernel, dim3(sessd_divup(num_boxes, 256)), dim3(256), 0, stream, dets, num_boxes, corners,
+                     standup);
+  SESSD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, words, 1), dim3(64), 0, stream, n_top, num_boxes, iou_thresh, corners,
+                     standup, mask, words);
+  SESSD_CHECK_LAUNCH();
+  hipLaunchKernelGGL(nms_reduce_batch_kernel, dim3(1), dim3(64), 0, stream, n_top, num_boxes, mask, words, post_max_size,
+                     keep, num_keep);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}

@@ -330,3 +330,48 @@ def ssfa_fuse(x0, x1, w0, w1, s0, t0, s1, t1, out=None):
     check(lib.sessd_ssfa_fuse(x0.data_ptr(), x1.data_ptr(), w0.data_ptr(), w1.data_ptr(), float(s0), float(t0),
                               float(s1), float(t1), B, C, H * W, out.data_ptr(), _stream()), "ssfa_fuse")
     return out
+
+
+# ------------------------------------------------------------------ predict / post-processing
+def predict(head, anchors, frustum=None, score_thresh=0.3, pre_max=1000, post_max=100, nms_thresh=0.01,
+            post_center_range=(0, -40.0, -5.0, 70.4, 40.0, 5.0), direction_offset=0.0, out=None):
+    """head (B,22,P) planar float32; anchors (A,7) or (B,A,7); frustum (B,1,6,4,3) float64 or None.
+    Returns dict(box (B,post,7), score (B,post), label (B,post) int32, count (B,) int32), all on the device."""
+    _req(head, torch.float32, "head")
+    _req(anchors, torch.float32, "anchors")
+    B, ch, P = head.shape
+    assert ch == 22
+    per_frame = 0
+    if anchors.dim() == 3:
+        per_frame = anchors.shape[1]
+        assert anchors.shape[0] == B
+    assert anchors.shape[-2] == 2 * P and anchors.shape[-1] == 7
+    if frustum is not None:
+        _req(frustum, torch.float64, "frustum")
+        assert frustum.numel() == B * 72
+    dev = head.device
+    if out is None:
+        out = dict(box=torch.empty((B, post_max, 7), dtype=torch.float32, device=dev),
+                   score=torch.empty((B, post_max), dtype=torch.float32, device=dev),
+                   label=torch.empty((B, post_max), dtype=torch.int32, device=dev),
+                   count=torch.empty((B,), dtype=torch.int32, device=dev))
+    need = lib.sessd_predict_workspace_bytes(B, 2 * P, pre_max, post_max)
+    ws = workspace(need, dev, "predict")
+    rng = torch.tensor(post_center_range, dtype=torch.float32)
+    check(lib.sessd_predict(head.data_ptr(), B, P, anchors.data_ptr(), per_frame, _p(frustum), float(score_thresh),
+                            pre_max, post_max, float(nms_thresh), rng.data_ptr(), float(direction_offset),
+                            out["box"].data_ptr(), out["score"].data_ptr(), out["label"].data_ptr(),
+                            out["count"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "predict")
+    return out
+
+
+def rotate_nms_sorted(dets, thresh, post_max):
+    """dets (N,5) [x,y,w,l,r] sorted by descending score -> (keep int32[post_max], num int32[1]) on the device."""
+    _req(dets, torch.float32, "dets")
+    n = dets.shape[0]
+    keep = torch.empty((post_max,), dtype=torch.int32, device=dets.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    ws = workspace(lib.sessd_rotate_nms_workspace_bytes(n), dets.device, "rnms")
+    check(lib.sessd_rotate_nms_sorted(dets.data_ptr(), n, float(thresh), int(post_max), keep.data_ptr(), num.data_ptr(),
+                                      ws.data_ptr(), ws.numel(), _stream()), "rotate_nms_sorted")
+    return keep, num

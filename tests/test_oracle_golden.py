@@ -64,3 +64,28 @@ def test_quad_iou_agrees_with_iou3d_reference_algorithm():
             # iou3d rotates corners by +angle (x' = x cos + y sin ...) exactly like rotation_2d.
             worst = max(worst, abs(oracle.quad_iou(c[i], c[j]) - float(ref[i, j])))
     assert worst < 5e-5, worst
+
+
+def test_postprocess_oracle_vs_reference_helpers(golden_dir):
+    """anchors, frustum surfaces, frustum test and box decode of oracle/postprocess.py vs the reference's own functions."""
+    from oracle import postprocess as pp
+    g = np.load(os.path.join(golden_dir, "nms_helpers_ref.npz"))
+    anchors = pp.create_anchors_3d_range().reshape(-1, 7)
+    assert np.array_equal(anchors[g["anchors_sample_idx"]], g["anchors_sample"])
+    assert np.allclose(anchors.sum(0), g["anchors_sum"], rtol=1e-6)
+    cal = synth.kitti_calib()
+    fr = pp.get_valid_frustum(cal["rect"], cal["Trv2c"], cal["P2"], cal["image_shape"])
+    assert fr.shape == (1, 6, 4, 3) and np.allclose(fr, g["frustum"], rtol=1e-9, atol=1e-9)
+    assert np.array_equal(pp.points_in_frustum(g["frustum_pts"], g["frustum"]), g["frustum_inside"].reshape(-1))
+    d = np.load(os.path.join(golden_dir, "decode_ref.npz"))
+    dec = pp.second_box_decode(d["enc"], d["anchors"])
+    assert np.allclose(dec, d["dec"], rtol=2e-6, atol=2e-6)
+
+
+def test_standup_iou_prefilter_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "nms_helpers_ref.npz"))
+    su = g["standup"]
+    # the oracle's prefilter (iou_jit eps=0 > 0) decision on every pair
+    iw = np.minimum(su[:, None, 2], su[None, :, 2]) - np.maximum(su[:, None, 0], su[None, :, 0])
+    ih = np.minimum(su[:, None, 3], su[None, :, 3]) - np.maximum(su[:, None, 1], su[None, :, 1])
+    assert np.array_equal((iw > 0) & (ih > 0), g["standup_iou"] > 0)
