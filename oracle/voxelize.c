@@ -31,9 +31,17 @@ int oracle_points_to_voxel(const float *points, int N, int ndim, const float *vo
     grid[j] = (int32_t)rintf(g);
   }
   size_t cells = (size_t)grid[0] * grid[1] * grid[2];
-  int32_t *map = (int32_t *)malloc(cells * sizeof(int32_t));
-  if (!map) return -1;
-  memset(map, 0xFF, cells * sizeof(int32_t)); /* -1 == empty */
+  /* like the reference's module-global COOR_TO_VOXELIDX2 (line 6): allocated once, kept all-empty between
+   * calls by resetting only the touched cells (lines 58-61) */
+  static int32_t *map = NULL;
+  static size_t map_cells = 0;
+  if (map_cells != cells) {
+    free(map);
+    map = (int32_t *)malloc(cells * sizeof(int32_t));
+    if (!map) { map_cells = 0; return -1; }
+    memset(map, 0xFF, cells * sizeof(int32_t)); /* -1 == empty */
+    map_cells = cells;
+  }
   memset(voxels, 0, (size_t)max_voxels * max_points * ndim * sizeof(float));
   memset(coors, 0, (size_t)max_voxels * 3 * sizeof(int32_t));
   memset(num_points_per_voxel, 0, (size_t)max_voxels * sizeof(int32_t));
@@ -71,7 +79,8 @@ int oracle_points_to_voxel(const float *points, int N, int ndim, const float *vo
       num_points_per_voxel[voxelidx] += 1;
     }
   }
-  free(map);
+  for (int v = 0; v < voxel_num; ++v)
+    map[((size_t)coors[v * 3] * grid[1] + coors[v * 3 + 1]) * grid[0] + coors[v * 3 + 2]] = -1;
   return voxel_num;
 }
 

@@ -1,0 +1,76 @@
+"""mirrors det3d/core/bbox/box_torch_ops.py: second_box_encode/decode (:26-147), nms (:505-524), rotate_nms (:527-548).
+
+rotate_nms keeps the reference signature but never leaves the device: topk on the HIP device, rotated NMS by
+libsessd_hip.so (sessd_rotate_nms_sorted), one tiny read of the kept count at the end (the reference does a
+D2H + CPU boost NMS + H2D here)."""
+import torch
+
+from sessd_hip import ops
+
+
+def second_box_encode(boxes, anchors, encode_angle_to_vector=False, smooth_dim=False, norm_velo=False):
+    xa, ya, za, wa, la, ha, ra = torch.split(anchors, 1, dim=-1)
+    xg, yg, zg, wg, lg, hg, rg = torch.split(boxes, 1, dim=-1)
+    diagonal = torch.sqrt(la ** 2 + wa ** 2)
+    xt, yt, zt = (xg - xa) / diagonal, (yg - ya) / diagonal, (zg - za) / ha
+    if smooth_dim:
+        lt, wt, ht = lg / la - 1, wg / wa - 1, hg / ha - 1
+    else:
+        lt, wt, ht = torch.log(lg / la), torch.log(wg / wa), torch.log(hg / ha)
+    if encode_angle_to_vector:
+        return torch.cat([xt, yt, zt, wt, lt, ht, torch.cos(rg) - torch.cos(ra), torch.sin(rg) - torch.sin(ra)], dim=-1)
+    return torch.cat([xt, yt, zt, wt, lt, ht, rg - ra], dim=-1)
+
+
+def second_box_decode(box_encodings, anchors, encode_angle_to_vector=False, bin_loss=False, smooth_dim=False,
+                      norm_velo=False):
+    """box decode for VoxelNet in lidar: boxes/anchors [...,7] x,y,z,w,l,h,r."""
+    xa, ya, za, wa, la, ha, ra = torch.split(anchors, 1, dim=-1)
+    if encode_angle_to_vector:
+        xt, yt, zt, wt, lt, ht, rtx, rty = torch.split(box_encodings, 1, dim=-1)
+    else:
+        xt, yt, zt, wt, lt, ht, rt = torch.split(box_encodings, 1, dim=-1)
+    diagonal = torch.sqrt(la ** 2 + wa ** 2)
+    xg, yg, zg = xt * diagonal + xa, yt * diagonal + ya, zt * ha + za
+    if smooth_dim:
+        lg, wg, hg = (lt + 1) * la, (wt + 1) * wa, (ht + 1) * ha
+    else:
+        lg, wg, hg = torch.exp(lt) * la, torch.exp(wt) * wa, torch.exp(ht) * ha
+    if encode_angle_to_vector:
+        rg = torch.atan2(rty + torch.sin(ra), rtx + torch.cos(ra))
+    else:
+        rg = rt + ra
+    return torch.cat([xg, yg, zg, wg, lg, hg, rg], dim=-1)
+
+
+def rotate_nms(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5):
+    """rbboxes (K,5) [x,y,w,l,r], scores (K,) -> LongTensor of kept indices into the input (<= post_max_size)."""
+    if rbboxes.shape[0] == 0:
+        return torch.zeros([0]).long().to(rbboxes.device)
+    if pre_max_size is not None:
+        k = min(scores.shape[0], pre_max_size)
+        scores, indices = torch.topk(scores, k=k)
+        rbboxes = rbboxes[indices]
+    else:
+        scores, indices = torch.sort(scores, descending=True)
+        rbboxes = rbboxes[indices]
+    post = int(post_max_size) if post_max_size is not None else int(rbboxes.shape[0])
+    keep, num = ops.rotate_nms_sorted(rbboxes.float().contiguous(), iou_threshold, post)
+    keep = keep[: int(num.item())].long()
+    if keep.shape[0] == 0:
+        return torch.zeros([0]).long().to(rbboxes.device)
+    return indices[keep]
+
+
+def nms(bboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5):
+    """axis-aligned NMS (box_torch_ops.py:505-524); boxes (K,4) [x1,y1,x2,y2]. Uses the iou3d 'normal' bitmask NMS."""
+    if bboxes.shape[0] == 0:
+        return torch.zeros([0]).long().to(bboxes.device)
+    k = scores.shape[0] if pre_max_size is None else min(scores.shape[0], pre_max_size)
+    scores, indices = torch.topk(scores, k=k)
+    b5 = torch.cat([bboxes[indices].float(), torch.zeros((k, 1), device=bboxes.device)], 1).contiguous()
+    keep, num = ops.nms_sorted(2, b5, iou_threshold)
+    keep = keep[: int(num.item())]
+    if post_max_size is not None:
+        keep = keep[:post_max_size]
+    return indices[keep]

@@ -1,0 +1,50 @@
+"""mirrors det3d/models/backbones/scn.py:92-189 (SpMiddleFHD): same module tree => same state_dict keys
+(`middle_conv.{0,3,...,39}.weight` in spconv's [kz,ky,kx,Cin,Cout] layout, BatchNorm1d at {1,4,...})."""
+import numpy as np
+import spconv
+import torch
+from spconv import SparseConv3d, SubMConv3d
+from torch import nn
+
+from ..registry import BACKBONES
+from ..utils import build_norm_layer
+
+
+@BACKBONES.register_module
+class SpMiddleFHD(nn.Module):
+    def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleFHD", **kwargs):
+        super().__init__()
+        self.name = name
+        self.dcn = None
+        self.zero_init_residual = False
+        if norm_cfg is None:
+            norm_cfg = dict(type="BN1d", eps=1e-3, momentum=0.01)
+        bn = lambda c: build_norm_layer(norm_cfg, c)[1]
+        self.middle_conv = spconv.SparseSequential(
+            SubMConv3d(num_input_features, 16, 3, bias=False, indice_key="subm0"), bn(16), nn.ReLU(),
+            SubMConv3d(16, 16, 3, bias=False, indice_key="subm0"), bn(16), nn.ReLU(),
+            SparseConv3d(16, 32, 3, 2, padding=1, bias=False), bn(32), nn.ReLU(),
+            SubMConv3d(32, 32, 3, indice_key="subm1", bias=False), bn(32), nn.ReLU(),
+            SubMConv3d(32, 32, 3, indice_key="subm1", bias=False), bn(32), nn.ReLU(),
+            SparseConv3d(32, 64, 3, 2, padding=1, bias=False), bn(64), nn.ReLU(),
+            SubMConv3d(64, 64, 3, indice_key="subm2", bias=False), bn(64), nn.ReLU(),
+            SubMConv3d(64, 64, 3, indice_key="subm2", bias=False), bn(64), nn.ReLU(),
+            SubMConv3d(64, 64, 3, indice_key="subm2", bias=False), bn(64), nn.ReLU(),
+            SparseConv3d(64, 64, 3, 2, padding=[0, 1, 1], bias=False), bn(64), nn.ReLU(),
+            SubMConv3d(64, 64, 3, indice_key="subm3", bias=False), bn(64), nn.ReLU(),
+            SubMConv3d(64, 64, 3, indice_key="subm3", bias=False), bn(64), nn.ReLU(),
+            SubMConv3d(64, 64, 3, indice_key="subm3", bias=False), bn(64), nn.ReLU(),
+            SparseConv3d(64, 64, (3, 1, 1), (2, 1, 1), bias=False), bn(64), nn.ReLU(),
+        )
+
+    def init_weights(self, pretrained=None):
+        pass
+
+    def forward(self, voxel_features, coors, batch_size, input_shape):
+        sparse_shape = np.array([int(v) for v in input_shape[::-1]]) + [1, 0, 0]
+        coors = coors.int()
+        ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape, batch_size)
+        ret = self.middle_conv(ret)
+        ret = ret.dense()
+        N, C, D, H, W = ret.shape
+        return ret.view(N, C * D, H, W)

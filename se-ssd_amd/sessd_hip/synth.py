@@ -127,3 +127,88 @@ def boxes7_to_bev7(b):
     b = np.asarray(b, np.float32)
     return np.stack([b[:, 0] - b[:, 3] / 2, b[:, 1] - b[:, 4] / 2, b[:, 2] - b[:, 5] / 2, b[:, 0] + b[:, 3] / 2,
                      b[:, 1] + b[:, 4] / 2, b[:, 2] + b[:, 5] / 2, b[:, 6]], 1).astype(np.float32)
+
+
+def init_synthetic_weights(model, seed=0):
+    """Deterministic non-trivial weights for a det3d-mirror VoxelNet (no checkpoint exists here): kaiming-uniform
+    convolutions, BatchNorm gamma~U(0.5,1.5), beta~U(-0.1,0.1); small box/dir/iou head weights. BatchNorm running
+    statistics and the classification bias are then set by `calibrate_synthetic_model` on one frame, which is what
+    keeps activations O(1) through the 28 layers (as in a trained network)."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                if name.startswith("backbone"):
+                    fan_in = p.shape[-2] * int(np.prod(p.shape[:-2]))
+                elif "deconv" in name:
+                    fan_in = p.shape[0] * p.shape[2] * p.shape[3] / 4.0
+                else:
+                    fan_in = p.shape[1] * int(np.prod(p.shape[2:]))
+                bound = math.sqrt(6.0 / fan_in)
+                p.copy_((torch.rand(p.shape, generator=g) * 2 - 1) * bound)
+        for name, m in model.named_modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                c = m.num_features
+                m.weight.copy_(torch.rand(c, generator=g) + 0.5)
+                m.bias.copy_(torch.rand(c, generator=g) * 0.2 - 0.1)
+                m.running_mean.zero_()
+                m.running_var.fill_(1.0)
+        head = model.bbox_head.tasks[0]
+        head.conv_box.weight.mul_(0.3)
+        head.conv_box.bias.zero_()
+        head.conv_dir.bias.zero_()
+        head.conv_iou.bias.fill_(0.5)
+        head.conv_iou.weight.mul_(0.3)
+        head.conv_cls.bias.zero_()
+    model.eval()
+    return model
+
+
+def calibrate_synthetic_model(model, voxel_features, coors, batch_size, input_shape, pass_fraction=0.007,
+                              sparse_runner=None):
+    """Set every BatchNorm's running mean/var to the statistics of its input on the given frame(s), layer by
+    layer (data-dependent init), then choose the classification bias so that `pass_fraction` of the anchors
+    clear the 0.3 score threshold. Runs on whatever device the model lives on, through the nn modules themselves
+    (spconv-shim sparse convs on the HIP device, torch convs for the dense neck). Test / benchmark set-up only."""
+    import torch
+    import torch.nn.functional as F
+    hooks = []
+
+    def pre(mod, inp):
+        x = inp[0].detach().float()
+        dims = [d for d in range(x.dim()) if d != 1]
+        mod.running_mean.copy_(x.mean(dims))
+        mod.running_var.copy_(x.var(dims, unbiased=False).clamp_min(1e-6))
+
+    for m in model.modules():
+        if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+            hooks.append(m.register_forward_pre_hook(pre))
+    try:
+        with torch.no_grad():
+            run = sparse_runner if sparse_runner is not None else model.backbone
+            x = run(voxel_features, coors, batch_size, input_shape)
+            nk = model.neck
+            x0 = nk.bottom_up_block_0(x)
+            x1 = nk.bottom_up_block_1(x0)
+            t0, t1 = nk.trans_0(x0), nk.trans_1(x1)
+            m0 = nk.deconv_block_0(t1) + t0
+            m1 = nk.deconv_block_1(t1)
+            o0, o1 = nk.conv_0(m0), nk.conv_1(m1)
+            w = torch.softmax(torch.cat([nk.w_0(o0), nk.w_1(o1)], 1), 1)
+            out = o0 * w[:, 0:1] + o1 * w[:, 1:]
+            head = model.bbox_head.tasks[0]
+            head.conv_cls.bias.zero_()
+            logits = F.conv2d(out, head.conv_cls.weight).reshape(-1)
+            q = torch.quantile(logits.float().cpu(), 1.0 - pass_fraction)
+            head.conv_cls.bias.fill_(float(math.log(0.3 / 0.7) - q))
+            # box codes ~N(0, 0.1) and IoU predictions ~N(0.5, 0.15): plausible, well-conditioned boxes
+            for conv, target, bias in ((head.conv_box, 0.1, 0.0), (head.conv_iou, 0.15, 0.5), (head.conv_dir, 1.0, 0.0)):
+                y = F.conv2d(out, conv.weight)
+                conv.weight.mul_(target / float(y.std().clamp_min(1e-6)))
+                conv.bias.fill_(bias)
+    finally:
+        for h in hooks:
+            h.remove()
+    model.eval()
+    return model

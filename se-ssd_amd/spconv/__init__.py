@@ -1,0 +1,166 @@
+"""spconv-v1 compatible module surface (only what det3d/models/backbones/scn.py touches), running on the
+gfx950 HIP kernels of libsessd_hip.so. Mirrors: spconv.SparseConvTensor, SubMConv3d, SparseConv3d,
+SparseSequential, SparseModule (reference call sites scn.py:4,9,24-44,46,106-148,182-184).
+
+This generic path keeps the spconv API contract (`.features` has exactly N rows), which costs one
+device->host read of the site count after every strided conv. The fused engine (sessd_hip.engine) does not."""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from sessd_hip import ops
+
+
+def _t3(v):
+    return [int(v)] * 3 if isinstance(v, (int, np.integer)) else [int(x) for x in v]
+
+
+class SparseConvTensor(object):
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+        self.features = features
+        self.indices = indices.int().contiguous()
+        self.spatial_shape = [int(v) for v in spatial_shape]
+        self.batch_size = int(batch_size)
+        self.indice_dict = {}
+        self.grid = grid
+
+    @property
+    def spatial_size(self):
+        return int(np.prod(self.spatial_shape))
+
+    def find_indice_pair(self, key):
+        return None if key is None else self.indice_dict.get(key)
+
+    def dense(self, channels_first=True):
+        n, c = self.features.shape
+        out = torch.zeros([self.batch_size] + self.spatial_shape + [c], dtype=self.features.dtype, device=self.features.device)
+        i = self.indices.long()
+        out[i[:, 0], i[:, 1], i[:, 2], i[:, 3]] = self.features
+        return out.permute(0, 4, 1, 2, 3).contiguous() if channels_first else out
+
+    def _hash(self):
+        h = self.indice_dict.get("__hash__")
+        if h is None:
+            n = torch.tensor([self.indices.shape[0]], dtype=torch.int32, device=self.indices.device)
+            h = (ops.sparse_hash_build(self.indices, n, self.spatial_shape), n)
+            self.indice_dict["__hash__"] = h
+        return h
+
+
+class SparseModule(nn.Module):
+    pass
+
+
+class SparseConvolution(SparseModule):
+    def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
+                 bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None):
+        super().__init__()
+        assert ndim == 3 and groups == 1 and not transposed and not inverse and _t3(dilation) == [1, 1, 1]
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = _t3(kernel_size), _t3(stride), _t3(padding)
+        self.subm, self.indice_key = subm, indice_key
+        # spconv v1 weight layout: [kz, ky, kx, Cin, Cout]
+        self.weight = nn.Parameter(torch.empty(*self.kernel_size, in_channels, out_channels))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.reset_parameters()
+        self._packed = None
+
+    def reset_parameters(self):
+        fan_in = self.in_channels * int(np.prod(self.kernel_size))
+        bound = math.sqrt(6.0 / ((1 + 5) * fan_in))  # kaiming_uniform(a=sqrt(5))
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+
+    def _wpk(self):
+        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device))
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key, ops.sparse_pack_weight(self.weight))
+        return self._packed[1]
+
+    def forward(self, x):
+        assert isinstance(x, SparseConvTensor)
+        in_hash, n_in = x._hash()
+        if self.subm:
+            cached = x.find_indice_pair(self.indice_key)
+            if cached is None:
+                nbr, tm = ops.sparse_rulebook(x.indices, n_in, self.kernel_size, 1, [k // 2 for k in self.kernel_size], in_hash)
+                cached = (nbr, tm)
+                if self.indice_key is not None:
+                    x.indice_dict[self.indice_key] = cached
+            nbr, tm = cached
+            out = SparseConvTensor(None, x.indices, x.spatial_shape, x.batch_size)
+            out.indice_dict = x.indice_dict
+            n_out = n_in
+        else:
+            oshape = [(d + 2 * p - k) // s + 1 for d, k, s, p in zip(x.spatial_shape, self.kernel_size, self.stride, self.padding)]
+            cells = x.batch_size * int(np.prod(oshape))
+            kv = int(np.prod(self.kernel_size))
+            cap = min(cells, x.indices.shape[0] * min(kv, 8))
+            cap = max(64, (cap + 63) // 64 * 64)
+            oidx, n_out, ohash, err = ops.sparse_downsample_sites(x.indices, n_in, self.kernel_size, self.stride, self.padding, oshape, cap)
+            nbr, tm = ops.sparse_rulebook(oidx, n_out, self.kernel_size, self.stride, self.padding, in_hash)
+            m = int(n_out.item())  # API contract: exact row count (host sync; the fused engine avoids it)
+            if int(err.item()):
+                raise RuntimeError("sparse conv output capacity overflow")
+            oidx, nbr, tm = oidx[:m].contiguous(), nbr[:, :m].contiguous(), tm[:(m + 15) // 16].contiguous()
+            out = SparseConvTensor(None, oidx, oshape, x.batch_size)
+            n_out = torch.tensor([m], dtype=torch.int32, device=oidx.device)
+            out.indice_dict["__hash__"] = (ops.SiteHash(ohash.capacity, oshape, oidx.device, ohash.keys, ohash.vals), n_out)
+        feats = x.features.float().contiguous()
+        out.features = ops.sparse_conv(feats, nbr, tm, n_out, self._wpk(), self.in_channels, self.out_channels, None,
+                                       self.bias, relu=False)
+        return out
+
+
+class SubMConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, True,
+                         indice_key=indice_key)
+
+
+class SparseConv3d(SparseConvolution):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True,
+                 indice_key=None):
+        super().__init__(3, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias,
+                         indice_key=indice_key)
+
+
+class SparseSequential(SparseModule):
+    """nn.Sequential over SparseConvTensor: non-sparse modules are applied to `.features` (spconv v1 behaviour)."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        for idx, module in enumerate(args):
+            self.add_module(str(idx), module)
+        for name, module in kwargs.items():
+            self.add_module(name, module)
+
+    def __getitem__(self, idx):
+        return list(self._modules.values())[idx]
+
+    def __len__(self):
+        return len(self._modules)
+
+    def __iter__(self):
+        return iter(self._modules.values())
+
+    def add(self, module, name=None):
+        self.add_module(str(len(self._modules)) if name is None else name, module)
+
+    def forward(self, input):
+        for k, module in self._modules.items():
+            if isinstance(module, SparseModule):
+                input = module(input)
+            elif isinstance(input, SparseConvTensor):
+                if input.indices.shape[0] != 0:
+                    input.features = module(input.features)
+            else:
+                input = module(input)
+        return input
+
+
+class utils:  # noqa: N801  (namespace placeholder for `from spconv.utils import rbbox_iou` style imports)
+    pass
