@@ -26,6 +26,8 @@ extern "C" {
 typedef void* sessd_stream_t; /* hipStream_t */
 
 const char* sessd_version(void);
+/* 32-bit pattern fill as a kernel launch (graph-safe clear; the library itself never uses hipMemsetAsync) */
+int sessd_fill_u32(void* ptr, uint32_t value, size_t n_words, sessd_stream_t stream);
 
 /* ------------------------------------------------------------------ voxelizer (a1-a3)
  * replaces det3d/ops/point_cloud/point_cloud_ops_v2.py:120-194 points_to_voxel (numba, CPU),
@@ -43,6 +45,8 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
                          uint32_t* hash_keys, int32_t* hash_vals, uint32_t hash_capacity, float* voxels, int32_t* coors,
                          int coors_stride, int32_t* num_points_per_voxel, float* mean_feat, int32_t* prefix,
                          void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+/* (n,4) points -> fixed-capacity staging buffer, tail rows set out of range (dropped by the voxelizer) */
+int sessd_stage_points(const float* points, int num_points, float* dst, int capacity, sessd_stream_t stream);
 int sessd_vfe_mean(const float* voxels, const int32_t* num_points, const int32_t* num_voxels_dev, int num_voxels_host,
                    int max_points_per_voxel, int ndim, int num_features, float* out, sessd_stream_t stream);
 

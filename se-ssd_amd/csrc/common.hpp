@@ -25,6 +25,14 @@
     if (e__ != hipSuccess) return (int)e__;           \
   } while (0)
 
+// kernel-based clear (fill.hip); the library never calls hipMemsetAsync (see fill.hip)
+int sessd_fill_u32_launch(void* p, uint32_t value, size_t n_words, hipStream_t stream);
+#define SESSD_FILL(ptr, value, n_words, stream)                                        \
+  do {                                                                                 \
+    int rc__ = sessd_fill_u32_launch((void*)(ptr), (uint32_t)(value), (size_t)(n_words), stream); \
+    if (rc__ != 0) return rc__;                                                        \
+  } while (0)
+
 static inline __host__ __device__ int sessd_divup(int a, int b) { return (a + b - 1) / b; }
 static inline __host__ __device__ size_t sessd_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -255,7 +255,7 @@ int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, 
   if (num_boxes > 64 * 64 * 4) return SESSD_EINVAL;
   if (workspace_bytes < sessd_nms_workspace_bytes(num_boxes)) return SESSD_EWORKSPACE;
   if (num_boxes == 0) {
-    SESSD_TRY(hipMemsetAsync(num_keep, 0, sizeof(int), stream));
+    SESSD_FILL(num_keep, 0, 1, stream);
     return SESSD_OK;
   }
   unsigned long long* mask = (unsigned long long*)workspace;

@@ -365,7 +365,7 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
   C.nms_thresh = nms_iou_thresh;
   for (int i = 0; i < 6; ++i) C.range[i] = post_center_range6[i];
   C.dir_offset = direction_offset;
-  SESSD_TRY(hipMemsetAsync(w.count, 0, (size_t)batch * 4, stream));
+  SESSD_FILL(w.count, 0, batch, stream);
   hipLaunchKernelGGL(score_filter_kernel, dim3(sessd_divup(num_pixels, 256), batch), dim3(256), 0, stream, head, C,
                      w.keys, A, w.count);
   SESSD_CHECK_LAUNCH();
@@ -419,7 +419,7 @@ extern "C" int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float i
   if (num_boxes < 0 || num_boxes > 4096 || post_max_size < 1) return SESSD_EINVAL;
   if (workspace_bytes < sessd_rotate_nms_workspace_bytes(num_boxes)) return SESSD_EWORKSPACE;
   if (num_boxes == 0) {
-    SESSD_TRY(hipMemsetAsync(num_keep, 0, 4, stream));
+    SESSD_FILL(num_keep, 0, 1, stream);
     return SESSD_OK;
   }
   char* base = (char*)workspace;

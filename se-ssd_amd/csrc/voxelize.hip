@@ -218,6 +218,15 @@ __global__ void vfe_mean_kernel(const float* __restrict__ voxels, const int* __r
   }
 }
 
+// Stage a frame into the engine's fixed-capacity input buffer: rows [0,n) copied, rows [n,cap) set to a
+// far-out-of-range sentinel so the voxelizer drops them (keeps a captured hipGraph valid for any point count).
+__global__ __launch_bounds__(VOX_NT) void stage_points_kernel(const float4* __restrict__ src, int n, float4* __restrict__ dst,
+                                                                int cap) {
+  int i = blockIdx.x * VOX_NT + threadIdx.x;
+  if (i >= cap) return;
+  dst[i] = i < n ? src[i] : make_float4(-1.0e6f, -1.0e6f, -1.0e6f, 0.f);
+}
+
 struct VoxWs {
   int* lists;
   int* ent;
@@ -260,8 +269,8 @@ uint32_t sessd_hash_capacity(int max_items) {
 }
 
 int sessd_hash_clear(uint32_t* keys, int* vals, uint32_t capacity, hipStream_t stream) {
-  SESSD_TRY(hipMemsetAsync(keys, 0x7F, (size_t)capacity * 4, stream));
-  SESSD_TRY(hipMemsetAsync(vals, 0x7F, (size_t)capacity * 4, stream));
+  SESSD_FILL(keys, SESSD_HASH_EMPTY, capacity, stream);
+  SESSD_FILL(vals, SESSD_HASH_EMPTY, capacity, stream);
   return SESSD_OK;
 }
 
@@ -295,8 +304,8 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
   size_t need = vox_ws_layout((int)hash_capacity, num_points, max_points_per_voxel, max_voxels, &w, (char*)workspace);
   if (need > workspace_bytes) return SESSD_EWORKSPACE;
   const int MP = max_points_per_voxel;
-  SESSD_TRY(hipMemsetAsync(w.lists, 0x7F, (size_t)hash_capacity * MP * 4, stream));
-  SESSD_TRY(hipMemsetAsync(w.meta, 0x7F, 4, stream));  // cut = SESSD_SENT
+  SESSD_FILL(w.lists, SESSD_HASH_EMPTY, (size_t)hash_capacity * MP, stream);
+  SESSD_FILL(w.meta, SESSD_HASH_EMPTY, 1, stream);  // cut = SESSD_SENT
   const int nblk = sessd_divup(num_points > 0 ? num_points : 1, VOX_NT);
   if (num_points > 0) {
     hipLaunchKernelGGL(vox_insert_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, points, num_points, ndim, G, key_base,
@@ -319,6 +328,16 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
                        w.entry_of_vid, w.meta, max_voxels, prefix + batch_index, voxels, num_points_per_voxel,
                        mean_feat);
   }
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// points (n,4) float32 -> dst (capacity,4): copy + out-of-range padding, one launch on `stream`.
+int sessd_stage_points(const float* points, int num_points, float* dst, int capacity, hipStream_t stream) {
+  if (num_points < 0 || capacity < num_points) return SESSD_EINVAL;
+  if (capacity == 0) return SESSD_OK;
+  hipLaunchKernelGGL(stage_points_kernel, dim3(sessd_divup(capacity, VOX_NT)), dim3(VOX_NT), 0, stream,
+                     (const float4*)points, num_points, (float4*)dst, capacity);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

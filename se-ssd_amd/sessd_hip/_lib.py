@@ -14,10 +14,12 @@ vp, i32, u32, f32, sz, i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_siz
 # name -> (restype, argtypes). Kept in step with include/sessd_hip.h (tests/test_abi.py checks it).
 SIGNATURES = {
     "sessd_version": (C.c_char_p, []),
+    "sessd_fill_u32": (i32, [vp, u32, sz, vp]),
     "sessd_hash_capacity": (u32, [i32]),
     "sessd_hash_clear": (i32, [vp, vp, u32, vp]),
     "sessd_voxelize_workspace_bytes": (sz, [u32, i32, i32, i32]),
     "sessd_voxelize_frame": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, u32, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "sessd_stage_points": (i32, [vp, i32, vp, i32, vp]),
     "sessd_vfe_mean": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "sessd_boxes_pairwise": (i32, [i32, vp, i32, vp, i32, vp, vp]),
     "sessd_boxes_aligned_overlap_bev": (i32, [vp, vp, i32, vp, vp]),

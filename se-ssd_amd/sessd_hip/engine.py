@@ -185,6 +185,7 @@ class InferenceEngine:
         self.pred_ws = torch.empty(int(lib.sessd_predict_workspace_bytes(B, 2 * H * W, self.pre_max, self.post_max)),
                                    dtype=torch.uint8, device=dev)
         self._ks = {}
+        self._npts = [0] * B
         self.graph = None
         self.tile_cfg = {}
 
@@ -204,9 +205,10 @@ class InferenceEngine:
             n = p.shape[0]
             if n > self.P_cap:
                 raise ValueError("frame has %d points, engine capacity is %d" % (n, self.P_cap))
-            self.points[b, :n].copy_(p, non_blocking=True)
-            if n < self.P_cap:
-                self.points[b, n:].fill_(-1.0e6)
+            if p.dtype != torch.float32 or not p.is_contiguous() or p.shape[1] != 4 or not p.is_cuda:
+                raise ValueError("points must be contiguous (P,4) float32 device tensors")
+            check(lib.sessd_stage_points(p.data_ptr(), n, self.points[b].data_ptr(), self.P_cap,
+                                         torch.cuda.current_stream().cuda_stream), "stage_points")
         if frustum is not None and self.frustum is not None:
             self.frustum.copy_(frustum.reshape(self.frustum.shape), non_blocking=True)
 
@@ -242,8 +244,8 @@ class InferenceEngine:
         s = torch.cuda.current_stream().cuda_stream
         B = self.B
         # ---- voxelize (a1-a3)
-        self.prefix.zero_()
-        self.err.zero_()
+        check(lib.sessd_fill_u32(self.prefix.data_ptr(), 0, B + 1, s), "fill")
+        check(lib.sessd_fill_u32(self.err.data_ptr(), 0, 1, s), "fill")
         self.hash0.clear()
         for b in range(B):
             check(lib.sessd_voxelize_frame(self.points[b].data_ptr(), self.P_cap, 4, self.vrange.data_ptr(),
@@ -279,7 +281,7 @@ class InferenceEngine:
                                                         self.down_ws.numel(), s), "sparse_downsample_sites")
                 self._rulebook(li + 1, lay["ks"], lay["st"], lay["pd"], li, Lo["nbr_down"], Lo["tm_down"], s)
                 if last:
-                    self.bev.zero_()
+                    check(lib.sessd_fill_u32(self.bev.data_ptr(), 0, self.bev.numel(), s), "fill")
                     self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, None, s, dense=True)
                 else:
                     self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, Lo["feat_a"], s)

@@ -105,7 +105,7 @@ def test_module_path_matches_engine(dev, model):
     got = dets[0]
     assert got["metadata"] == dict(token="0")
     assert got["box3d_lidar"].shape[0] == ref["box3d_lidar"].shape[0]
-    assert np.allclose(got["scores"].cpu().numpy(), ref["scores"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(got["scores"].cpu().numpy(), ref["scores"], rtol=2e-3, atol=1e-6)
     if ref["box3d_lidar"].shape[0]:
         gb = got["box3d_lidar"].cpu().numpy()
         assert np.allclose(gb, ref["box3d_lidar"], rtol=1e-3, atol=1e-3)
