@@ -110,6 +110,13 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
                       const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out, int cout,
                       int hout, int wout, int out_mul, int out_py, int out_px, const float* scale, const float* shift,
                       int relu, const float* residual, int tile_cfg, sessd_stream_t stream);
+/* ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
+ * classes (py,px) = (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps: wpk4[c] packed like above, taps_dy4/taps_dx4 are
+ * 4 rows of 4 ints. input (B,cin,hin,win) -> output (B,cout,2*hin,2*win); cin % 8 == 0. */
+int sessd_deconv2d_s2_mfma(const float* in, int batch, int cin, int hin, int win, const float* const* wpk4,
+                           const int* ntaps4, const int* taps_dy4, const int* taps_dx4, float* out, int cout,
+                           const float* scale, const float* shift, int relu, const float* residual, int tile_cfg,
+                           sessd_stream_t stream);
 /* rpn_v1.py:227-233: softmax over the two 1-channel weight maps and the weighted sum of x0, x1 */
 int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
                     float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,

@@ -36,12 +36,18 @@ struct ConvArgs {
   int ht, wt;          // tile-space extent
   int in_mul, out_mul, out_py, out_px;
   int relu;
+  int cgroup;          // cin pairs consumed per k-step (1 for 3x3; >1 batches 1x1 / few-tap convs into "virtual taps")
   int dy[9], dx[9];
+  int dc[9];           // cin-pair displacement of a tap inside its k-step group
+};
+
+struct ConvArgs4 {
+  ConvArgs c[4];
 };
 
 // wave tile: (CT*32 couts) x (PT*32 pixels); workgroup = 4 waves arranged WC x WP
 template <int NTAPS, int CT, int PT, int WC, int WP>
-__global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
+__device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   static_assert(WC * WP == 4, "four waves per workgroup");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
@@ -50,7 +56,6 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
   const int p_base = (blockIdx.x * WP + wp) * (PT * 32);
   const int m_base = (blockIdx.y * WC + wc) * (CT * 32);
   if (p_base >= npix || m_base >= A.cout_pad) return;
-  const int b = blockIdx.z;
   const size_t in_plane = (size_t)A.hin * A.win;
   const float* in = A.in + (size_t)b * A.cin * in_plane + (size_t)h * in_plane;
 
@@ -67,7 +72,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
     for (int t = 0; t < NTAPS; ++t) {
       const int iy = y * A.in_mul + A.dy[t], ix = x * A.in_mul + A.dx[t];
       const bool ok = live && iy >= 0 && iy < A.hin && ix >= 0 && ix < A.win;
-      off[q][t] = ok ? iy * A.win + ix : 0;
+      off[q][t] = (ok ? iy * A.win + ix : 0) + A.dc[t] * 2 * (int)in_plane;
       vmask[q] |= (ok ? 1u : 0u) << t;
     }
   }
@@ -80,7 +85,7 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
 
-  const int KP = A.cin >> 1;
+  const int KP = (A.cin >> 1) / A.cgroup;  // k-steps; the packed weight layout is the same for any cgroup
   const size_t wstep = (size_t)NTAPS * 2 * A.cout_pad;  // floats per cin pair
   const float* wl = A.wpk + (size_t)h * A.cout_pad + m_base + j;
 
@@ -89,32 +94,39 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
 #define SESSD_LOAD(SET, KPI)                                                         \
   {                                                                                  \
     const float* wk = wl + (size_t)(KPI)*wstep;                                      \
-    const float* xk = in + (size_t)(KPI)*2 * in_plane;                               \
+    const float* xk = in + (size_t)(KPI)*2 * A.cgroup * in_plane;                    \
     _Pragma("unroll") for (int t = 0; t < NTAPS; ++t) {                              \
       _Pragma("unroll") for (int c = 0; c < CT; ++c) wa[SET][t][c] = wk[(size_t)t * 2 * A.cout_pad + c * 32]; \
-      _Pragma("unroll") for (int q = 0; q < PT; ++q) {                               \
-        float v = xk[off[q][t]];                                                     \
-        xb[SET][t][q] = ((vmask[q] >> t) & 1u) ? v : 0.f;                            \
-      }                                                                              \
+      _Pragma("unroll") for (int q = 0; q < PT; ++q) xb[SET][t][q] = xk[off[q][t]];  \
     }                                                                                \
   }
 #define SESSD_MMA(SET)                                                               \
   {                                                                                  \
+    /* the out-of-image select happens HERE, at the use, so that the wait for a load sits in front of  \
+       its MFMA and not right behind the load (which would expose the whole memory latency) */     \
     _Pragma("unroll") for (int t = 0; t < NTAPS; ++t)                                \
-      _Pragma("unroll") for (int c = 0; c < CT; ++c)                                 \
-        _Pragma("unroll") for (int q = 0; q < PT; ++q)                               \
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[SET][t][c], xb[SET][t][q], acc[c][q], 0, 0, 0); \
+      _Pragma("unroll") for (int q = 0; q < PT; ++q) {                               \
+        const float xv = ((vmask[q] >> t) & 1u) ? xb[SET][t][q] : 0.f;               \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c)                               \
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[SET][t][c], xv, acc[c][q], 0, 0, 0); \
+      }                                                                              \
   }
 
+  // Two register sets, one cin pair of look-ahead. Every load in the loop is UNCONDITIONAL (the last one is
+  // clamped and unused): a load under a branch makes hipcc's vmcnt bookkeeping conservative at the merge and it
+  // then waits for the loads it has just issued -- the whole memory latency, every iteration.
   SESSD_LOAD(0, 0)
-  int kp = 0;
-  for (; kp + 2 <= KP; kp += 2) {
+  for (int kp = 0; kp + 2 <= KP; kp += 2) {
     SESSD_LOAD(1, kp + 1)
+    __builtin_amdgcn_sched_barrier(0);  // keep "issue next set, then consume current set" in program order
     SESSD_MMA(0)
-    if (kp + 2 < KP) SESSD_LOAD(0, kp + 2)
+    __builtin_amdgcn_sched_barrier(0);
+    SESSD_LOAD(0, min(kp + 2, KP - 1))
+    __builtin_amdgcn_sched_barrier(0);
     SESSD_MMA(1)
+    __builtin_amdgcn_sched_barrier(0);
   }
-  if (kp < KP) SESSD_MMA(0)  // odd KP tail (set 0 holds kp)
+  if (KP & 1) SESSD_MMA(0)  // odd KP tail (set 0 holds KP-1)
 #undef SESSD_LOAD
 #undef SESSD_MMA
 
@@ -143,6 +155,18 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
       }
     }
   }
+}
+
+template <int NTAPS, int CT, int PT, int WC, int WP>
+__global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
+  conv_body<NTAPS, CT, PT, WC, WP>(A, blockIdx.z);
+}
+
+// Up to four convolutions that share shapes but not weights / taps / output phase in ONE launch
+// (the four output-parity classes of the stride-2 transposed conv): blockIdx.z = batch*4 + class.
+template <int NTAPS, int CT, int PT, int WC, int WP>
+__global__ __launch_bounds__(256) void conv2d_mfma4_kernel(ConvArgs4 A4) {
+  conv_body<NTAPS, CT, PT, WC, WP>(A4.c[blockIdx.z & 3], blockIdx.z >> 2);
 }
 
 // SSFA tail (rpn_v1.py:227-233): w0 = BN(conv1x1(x0)), w1 = BN(conv1x1(x1)) (128 -> 1 channel, no ReLU),
@@ -174,25 +198,56 @@ __global__ __launch_bounds__(256) void ssfa_fuse_kernel(const float* __restrict_
 }
 
 template <int NTAPS, int CT, int PT, int WC, int WP>
-int launch_conv(const ConvArgs& A, int batch, hipStream_t stream) {
-  const int npix = A.ht * A.wt;
-  dim3 grid(sessd_divup(npix, WP * PT * 32), sessd_divup(A.cout_pad, WC * CT * 32), batch);
-  hipLaunchKernelGGL((conv2d_mfma_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A);
+int launch_conv(const ConvArgs* A, int nconv, int batch, hipStream_t stream) {
+  const int npix = A[0].ht * A[0].wt;
+  dim3 grid(sessd_divup(npix, WP * PT * 32), sessd_divup(A[0].cout_pad, WC * CT * 32), batch * (nconv > 1 ? 4 : 1));
+  if (nconv == 1) {
+    hipLaunchKernelGGL((conv2d_mfma_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A[0]);
+  } else {
+    ConvArgs4 A4;
+    for (int i = 0; i < 4; ++i) A4.c[i] = A[i];
+    hipLaunchKernelGGL((conv2d_mfma4_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A4);
+  }
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
 
 template <int NTAPS>
-int dispatch_tile(const ConvArgs& A, int batch, int tile_cfg, hipStream_t stream) {
+int dispatch_tile(const ConvArgs* A, int nconv, int batch, int tile_cfg, hipStream_t stream) {
   switch (tile_cfg) {
-    case 0: return launch_conv<NTAPS, 2, 2, 2, 2>(A, batch, stream);  // wave 64c x 64p, WG 128c x 128p
-    case 1: return launch_conv<NTAPS, 2, 1, 2, 2>(A, batch, stream);  // wave 64c x 32p, WG 128c x 64p
-    case 2: return launch_conv<NTAPS, 1, 2, 4, 1>(A, batch, stream);  // wave 32c x 64p, WG 128c x 64p
-    case 3: return launch_conv<NTAPS, 1, 1, 4, 1>(A, batch, stream);  // wave 32c x 32p, WG 128c x 32p
-    case 4: return launch_conv<NTAPS, 1, 1, 1, 4>(A, batch, stream);  // wave 32c x 32p, WG 32c x 128p (small cout)
-    case 5: return launch_conv<NTAPS, 2, 1, 4, 1>(A, batch, stream);  // wave 64c x 32p, WG 256c x 32p
+    case 0: return launch_conv<NTAPS, 2, 2, 2, 2>(A, nconv, batch, stream);  // wave 64c x 64p, WG 128c x 128p
+    case 1: return launch_conv<NTAPS, 2, 1, 2, 2>(A, nconv, batch, stream);  // wave 64c x 32p, WG 128c x 64p
+    case 2: return launch_conv<NTAPS, 1, 2, 4, 1>(A, nconv, batch, stream);  // wave 32c x 64p, WG 128c x 64p
+    case 3: return launch_conv<NTAPS, 1, 1, 4, 1>(A, nconv, batch, stream);  // wave 32c x 32p, WG 128c x 32p
+    case 4: return launch_conv<NTAPS, 1, 1, 1, 4>(A, nconv, batch, stream);  // wave 32c x 32p, WG 32c x 128p (small cout)
+    case 5: return launch_conv<NTAPS, 2, 1, 4, 1>(A, nconv, batch, stream);  // wave 64c x 32p, WG 256c x 32p
     default: return SESSD_EINVAL;
   }
+}
+
+// Fill one ConvArgs; few-tap convolutions are regrouped into NTAPS_eff "virtual taps" (several cin pairs per
+// k-step) so that every k-step issues a full batch of loads ahead of its MFMAs. Returns the effective tap count.
+int fill_args(ConvArgs& A, const float* in, int cin, int hin, int win, const float* wpk, int ntaps, const int* dy,
+              const int* dx, int in_mul, int tile_h, int tile_w, float* out, int cout, int hout, int wout, int out_mul,
+              int py, int px, const float* scale, const float* shift, int relu, const float* residual) {
+  A.in = in; A.wpk = wpk; A.out = out; A.scale = scale; A.shift = shift; A.residual = residual;
+  A.cin = cin; A.hin = hin; A.win = win;
+  A.cout = cout; A.cout_pad = sessd_divup(cout, 32) * 32; A.hout = hout; A.wout = wout;
+  A.ht = tile_h; A.wt = tile_w;
+  A.in_mul = in_mul; A.out_mul = out_mul; A.out_py = py; A.out_px = px;
+  A.relu = relu;
+  int group = 1;
+  const int pairs = cin / 2;
+  if (ntaps == 1 && pairs % 4 == 0) group = 4;
+  else if (ntaps == 2 && pairs % 2 == 0) group = 2;
+  A.cgroup = group;
+  const int eff = ntaps * group;
+  // packed layout [pair][tap][2][cout_pad]: virtual tap v of a group = (pair displacement v / ntaps, tap v % ntaps)
+  for (int v = 0; v < 9; ++v) {
+    const int t = v < eff ? v % ntaps : 0, g = v < eff ? v / ntaps : 0;
+    A.dy[v] = dy[t]; A.dx[v] = dx[t]; A.dc[v] = g;
+  }
+  return eff;
 }
 
 }  // namespace
@@ -207,23 +262,32 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
                       int relu, const float* residual, int tile_cfg, hipStream_t stream) {
   if (cin % 2 || ntaps < 1 || ntaps > 9 || batch < 1 || cout < 1) return SESSD_EINVAL;
   ConvArgs A;
-  A.in = in; A.wpk = wpk; A.out = out; A.scale = scale; A.shift = shift; A.residual = residual;
-  A.cin = cin; A.hin = hin; A.win = win;
-  A.cout = cout; A.cout_pad = sessd_divup(cout, 32) * 32; A.hout = hout; A.wout = wout;
-  A.ht = tile_h; A.wt = tile_w;
-  A.in_mul = in_mul; A.out_mul = out_mul; A.out_py = out_py; A.out_px = out_px;
-  A.relu = relu;
-  for (int t = 0; t < 9; ++t) {
-    A.dy[t] = t < ntaps ? taps_dy[t] : 0;
-    A.dx[t] = t < ntaps ? taps_dx[t] : 0;
-  }
-  switch (ntaps) {
-    case 1: return dispatch_tile<1>(A, batch, tile_cfg, stream);
-    case 2: return dispatch_tile<2>(A, batch, tile_cfg, stream);
-    case 4: return dispatch_tile<4>(A, batch, tile_cfg, stream);
-    case 9: return dispatch_tile<9>(A, batch, tile_cfg, stream);
+  const int eff = fill_args(A, in, cin, hin, win, wpk, ntaps, taps_dy, taps_dx, in_mul, tile_h, tile_w, out, cout, hout,
+                            wout, out_mul, out_py, out_px, scale, shift, relu, residual);
+  switch (eff) {
+    case 1: return dispatch_tile<1>(&A, 1, batch, tile_cfg, stream);
+    case 2: return dispatch_tile<2>(&A, 1, batch, tile_cfg, stream);
+    case 4: return dispatch_tile<4>(&A, 1, batch, tile_cfg, stream);
+    case 9: return dispatch_tile<9>(&A, 1, batch, tile_cfg, stream);
     default: return SESSD_EINVAL;
   }
+}
+
+// ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
+// classes. wpk4[c], ntaps4[c], taps_dy4/taps_dx4 (4 x 4 ints, row c = class c) in class order (py,px) =
+// (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps; input (B,cin,hin,win) -> output (B,cout,2*hin,2*win).
+int sessd_deconv2d_s2_mfma(const float* in, int batch, int cin, int hin, int win, const float* const* wpk4,
+                           const int* ntaps4, const int* taps_dy4, const int* taps_dx4, float* out, int cout,
+                           const float* scale, const float* shift, int relu, const float* residual, int tile_cfg,
+                           hipStream_t stream) {
+  if (cin % 8 || batch < 1 || cout < 1) return SESSD_EINVAL;
+  ConvArgs A[4];
+  for (int c = 0; c < 4; ++c) {
+    const int eff = fill_args(A[c], in, cin, hin, win, wpk4[c], ntaps4[c], taps_dy4 + 4 * c, taps_dx4 + 4 * c, 1, hin, win,
+                              out, cout, 2 * hin, 2 * win, 2, c >> 1, c & 1, scale, shift, relu, residual);
+    if (eff != 4) return SESSD_EINVAL;
+  }
+  return dispatch_tile<4>(A, 4, batch, tile_cfg, stream);
 }
 
 // SSFA fusion tail: x0, x1, out are (B, C, H, W); w0, w1 the (C,) 1x1 conv weights; (s, t) the folded

@@ -210,3 +210,51 @@ static __device__ double sessd_quad_clip_area(const float* P, const float* Q) {
   if (ns < 3) return 0;
   return fabs(sessd_poly_area2(sx, sy, ns)) * 0.5;
 }
+
+// Intersection area of two convex quads WITHOUT any indexed scratch: by Green's theorem the boundary of P n Q is
+// made of the parts of P's edges inside Q and the parts of Q's edges inside P, so
+//     area = 1/2 * sum over those oriented pieces of cross(start, end).
+// Each edge is clipped against the other quad parametrically (Cyrus-Beck, 4 half-planes), everything stays in
+// registers (float64) and is fully unrolled. Both quads are first made counter-clockwise. An edge of Q lying ON an
+// edge of P is counted once (closed test for P's edges, open test for Q's), so duplicate boxes give |P|.
+static __device__ __forceinline__ double sessd_clip_piece(double ax, double ay, double bx, double by, const double* qx,
+                                                          const double* qy, bool strict) {
+  const double dx = bx - ax, dy = by - ay;
+  double t0 = 0.0, t1 = 1.0;
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const double ex = qx[(k + 1) & 3] - qx[k], ey = qy[(k + 1) & 3] - qy[k];
+    const double c = ex * (ay - qy[k]) - ey * (ax - qx[k]);  // >= 0 : a is inside half-plane k
+    const double sl = ex * dy - ey * dx;                      // d/dt of that quantity along a->b
+    if (sl > 0.0) {
+      t0 = fmax(t0, -c / sl);
+    } else if (sl < 0.0) {
+      t1 = fmin(t1, -c / sl);
+    } else {
+      ok = ok && (strict ? c > 0.0 : c >= 0.0);
+    }
+  }
+  if (!ok || !(t0 < t1)) return 0.0;
+  const double sx = ax + t0 * dx, sy = ay + t0 * dy, ex2 = ax + t1 * dx, ey2 = ay + t1 * dy;
+  return sx * ey2 - sy * ex2;
+}
+
+static __device__ double sessd_quad_inter_area_green(const float* P, const float* Q) {
+  double px[4], py[4], qx[4], qy[4];
+  const double ox = P[0], oy = P[1];  // translate: keeps the cross products small
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    px[i] = (double)P[2 * i] - ox; py[i] = (double)P[2 * i + 1] - oy;
+    qx[i] = (double)Q[2 * i] - ox; qy[i] = (double)Q[2 * i + 1] - oy;
+  }
+  if (sessd_poly_area2(px, py, 4) < 0) { double t = px[1]; px[1] = px[3]; px[3] = t; t = py[1]; py[1] = py[3]; py[3] = t; }
+  if (sessd_poly_area2(qx, qy, 4) < 0) { double t = qx[1]; qx[1] = qx[3]; qx[3] = t; t = qy[1]; qy[1] = qy[3]; qy[3] = t; }
+  double a2 = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a2 += sessd_clip_piece(px[i], py[i], px[(i + 1) & 3], py[(i + 1) & 3], qx, qy, false);
+    a2 += sessd_clip_piece(qx[i], qy[i], qx[(i + 1) & 3], qy[(i + 1) & 3], px, py, true);
+  }
+  return a2 > 0 ? 0.5 * a2 : 0.0;
+}

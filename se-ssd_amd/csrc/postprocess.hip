@@ -150,7 +150,7 @@ __device__ __forceinline__ bool rnms_suppresses(const float* ci, const float* si
   const float ua = (si[2] - si[0]) * (si[3] - si[1]) + (sj[2] - sj[0]) * (sj[3] - sj[1]) - iw * ih;
   const float siou = iw * ih / ua;
   if (siou <= 0.f) return false;
-  const double inter = sessd_quad_clip_area(ci, cj);
+  const double inter = sessd_quad_inter_area_green(ci, cj);
   if (inter <= 0) return false;
   double px[4], py[4], qx[4], qy[4];
 #pragma unroll
@@ -160,37 +160,30 @@ __device__ __forceinline__ bool rnms_suppresses(const float* ci, const float* si
   return ov >= (double)thresh;
 }
 
-__global__ __launch_bounds__(64) void rnms_mask_kernel(const int* __restrict__ n_top, int pre_max, float thresh,
-                                                        const float* __restrict__ corners, const float* __restrict__ standup,
-                                                        unsigned long long* __restrict__ mask, int words) {
-  const int b = blockIdx.z, rblk = blockIdx.y, cblk = blockIdx.x;
+// One WAVE per (row i, 64-column word): lane j evaluates the pair (i, cblk*64 + j) and a ballot assembles the
+// suppression word -- 64-way parallel over the expensive polygon clipping instead of one thread per row.
+__global__ __launch_bounds__(256) void rnms_mask_kernel(const int* __restrict__ n_top, int pre_max, float thresh,
+                                                         const float* __restrict__ corners, const float* __restrict__ standup,
+                                                         unsigned long long* __restrict__ mask, int words) {
+  const int b = blockIdx.z, cblk = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
   const int n = n_top[b];
-  if (cblk < rblk || rblk * 64 >= n || cblk * 64 >= n) return;
-  __shared__ float cc[64][8];
-  __shared__ float cs[64][4];
-  const int t = threadIdx.x;
+  if (i >= n || cblk * 64 >= n || cblk < (i >> 6)) return;  // words left of the diagonal are never read
   const float* cb = corners + (size_t)b * pre_max * 8;
   const float* sb = standup + (size_t)b * pre_max * 4;
-  const int ncol = min(n - cblk * 64, 64);
-  if (t < ncol) {
+  const int col = cblk * 64 + lane;
+  bool sup = false;
+  if (col < n && col > i) {
+    float ci[8], si[4], cj[8], sj[4];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) cc[t][q] = cb[(size_t)(cblk * 64 + t) * 8 + q];
+    for (int q = 0; q < 8; ++q) { ci[q] = cb[(size_t)i * 8 + q]; cj[q] = cb[(size_t)col * 8 + q]; }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) cs[t][q] = sb[(size_t)(cblk * 64 + t) * 4 + q];
+    for (int q = 0; q < 4; ++q) { si[q] = sb[(size_t)i * 4 + q]; sj[q] = sb[(size_t)col * 4 + q]; }
+    sup = rnms_suppresses(ci, si, cj, sj, thresh);
   }
-  __syncthreads();
-  const int i = rblk * 64 + t;
-  if (i >= n) return;
-  float ci[8], si[4];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) ci[q] = cb[(size_t)i * 8 + q];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) si[q] = sb[(size_t)i * 4 + q];
-  unsigned long long bits = 0;
-  const int start = rblk == cblk ? t + 1 : 0;
-  for (int k = start; k < ncol; ++k)
-    if (rnms_suppresses(ci, si, cc[k], cs[k], thresh)) bits |= 1ull << k;
-  mask[((size_t)b * pre_max + i) * words + cblk] = bits;
+  const unsigned long long bits = __ballot(sup);
+  if (lane == 0) mask[((size_t)b * pre_max + i) * words + cblk] = bits;
 }
 
 // frustum: (B,1,6,4,3) float64 surfaces (or null). One wave per frame.
@@ -373,8 +366,8 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
                      w.keys, A, w.count, w.cand_box, w.cand_score, w.cand_dir, w.corners, w.standup, w.n_top);
   SESSD_CHECK_LAUNCH();
   const int words = sessd_divup(pre_max_size, 64);
-  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, words, batch), dim3(64), 0, stream, w.n_top, pre_max_size,
-                     nms_iou_thresh, w.corners, w.standup, w.mask, words);
+  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, sessd_divup(pre_max_size, 4), batch), dim3(256), 0, stream, w.n_top,
+                     pre_max_size, nms_iou_thresh, w.corners, w.standup, w.mask, words);
   SESSD_CHECK_LAUNCH();
   hipLaunchKernelGGL(nms_reduce_batch_kernel, dim3(batch), dim3(64), 0, stream, w.n_top, pre_max_size, w.mask, words,
                      post_max_size, w.keep, w.n_keep);
@@ -434,8 +427,8 @@ extern "C" int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float i
   hipLaunchKernelGGL(rnms_prep_kernel, dim3(sessd_divup(num_boxes, 256)), dim3(256), 0, stream, dets, num_boxes, corners,
                      standup);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, words, 1), dim3(64), 0, stream, n_top, num_boxes, iou_thresh, corners,
-                     standup, mask, words);
+  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, sessd_divup(num_boxes, 4), 1), dim3(256), 0, stream, n_top, num_boxes,
+                     iou_thresh, corners, standup, mask, words);
   SESSD_CHECK_LAUNCH();
   hipLaunchKernelGGL(nms_reduce_batch_kernel, dim3(1), dim3(64), 0, stream, n_top, num_boxes, mask, words, post_max_size,
                      keep, num_keep);

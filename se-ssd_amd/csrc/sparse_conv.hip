@@ -47,44 +47,77 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int k = 0; k < kv; ++k) {
-    if (!((tmask >> k) & 1u)) continue;  // wave-uniform skip of empty (tile, offset)
-    const int row = nbr[(size_t)k * n_cap + tile * 16 + i];
-    float a[STEPS];
-    if (row >= 0) {
-      const float* src = in_feat + (size_t)row * CIN + kq * STEPS;
-      if (G == 4) {
-#pragma unroll
-        for (int g = 0; g < SG; ++g) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * g);
-          a[4 * g] = v.x; a[4 * g + 1] = v.y; a[4 * g + 2] = v.z; a[4 * g + 3] = v.w;
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) a[s] = src[s];
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) a[s] = 0.f;
-    }
-    const float* wk = wpk + (size_t)k * NTILE * STEPS * 64;
-#pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-      float b[STEPS];
-      if (G == 4) {
-#pragma unroll
-        for (int g = 0; g < SG; ++g) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(wk + ((size_t)(t * SG + g) * 64 + lane) * 4);
-          b[4 * g] = v.x; b[4 * g + 1] = v.y; b[4 * g + 2] = v.z; b[4 * g + 3] = v.w;
-        }
-      } else {
-#pragma unroll
-        for (int s = 0; s < STEPS; ++s) b[s] = wk[((size_t)(t * SG) * 64 + lane) * G + s];
-      }
-#pragma unroll
-      for (int s = 0; s < STEPS; ++s) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], b[s], acc[t], 0, 0, 0);
+  // Software pipeline over the ACTIVE offsets of this tile (bits of tmask), three stages deep:
+  //   stage 1  neighbour row index of offset i+2        (4-byte load from the rulebook)
+  //   stage 2  A (gathered quarter row) and B (packed weights) of offset i+1 into the other register set
+  //   stage 3  MFMAs of offset i
+  // All loads are unconditional (exhausted lists re-load the last offset, missing neighbours load row 0 and are
+  // zeroed at the use) so that hipcc's vmcnt accounting stays exact and loads stay in flight under the MFMAs.
+  float a[2][STEPS], bw[2][NTILE][STEPS];
+  bool av[2];
+  uint32_t rest = tmask;
+  int remaining = __builtin_popcount(tmask);
+  const int* nb = nbr + tile * 16 + i;
+  int klast = 0;
+#define SESSD_NEXTK() (rest ? (klast = __builtin_ctz(rest), rest &= rest - 1, klast) : klast)
+#define SESSD_LOADAB(SET, K, ROW)                                                                  \
+  {                                                                                                \
+    av[SET] = (ROW) >= 0;                                                                          \
+    const float* src = in_feat + (size_t)((ROW) >= 0 ? (ROW) : 0) * CIN + kq * STEPS;              \
+    const float* wk = wpk + (size_t)(K)*NTILE * STEPS * 64;                                        \
+    if (G == 4) {                                                                                  \
+      _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                             \
+        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * g);                              \
+        a[SET][4 * g] = v.x; a[SET][4 * g + 1] = v.y; a[SET][4 * g + 2] = v.z; a[SET][4 * g + 3] = v.w; \
+      }                                                                                            \
+      _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
+        _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                           \
+          const f32x4 v = *reinterpret_cast<const f32x4*>(wk + ((size_t)(t * SG + g) * 64 + lane) * 4); \
+          bw[SET][t][4 * g] = v.x; bw[SET][t][4 * g + 1] = v.y; bw[SET][t][4 * g + 2] = v.z; bw[SET][t][4 * g + 3] = v.w; \
+        }                                                                                          \
+    } else {                                                                                       \
+      _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) a[SET][s2] = src[s2];                   \
+      _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
+        _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) bw[SET][t][s2] = wk[((size_t)(t * SG) * 64 + lane) * G + s2]; \
+    }                                                                                              \
+  }
+#define SESSD_MMA(SET)                                                                             \
+  {                                                                                                \
+    _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) {                                         \
+      const float av2 = av[SET] ? a[SET][s2] : 0.f;                                                \
+      _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2, bw[SET][t][s2], acc[t], 0, 0, 0);       \
+    }                                                                                              \
+  }
+  if (remaining > 0) {
+    const int kcur = SESSD_NEXTK();
+    int knext = SESSD_NEXTK();
+    int knn = SESSD_NEXTK();
+    const int rcur = nb[(size_t)kcur * n_cap];
+    int rnext = nb[(size_t)knext * n_cap];
+    int rnn = nb[(size_t)knn * n_cap];
+    SESSD_LOADAB(0, kcur, rcur)
+    while (true) {
+      SESSD_LOADAB(1, knext, rnext)
+      const int k3 = SESSD_NEXTK();
+      const int r3 = nb[(size_t)k3 * n_cap];
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_MMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      if (--remaining == 0) break;
+      SESSD_LOADAB(0, knn, rnn)
+      const int k4 = SESSD_NEXTK();
+      const int r4 = nb[(size_t)k4 * n_cap];
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_MMA(1)
+      __builtin_amdgcn_sched_barrier(0);
+      if (--remaining == 0) break;
+      knext = k3; rnext = r3; knn = k4; rnn = r4;
     }
   }
+#undef SESSD_NEXTK
+#undef SESSD_LOADAB
+#undef SESSD_MMA
 
   // C/D layout: column (cout) = lane & 15, rows (sites) = (lane >> 4) * 4 + r
 #pragma unroll

@@ -282,7 +282,17 @@ def pack_deconv2d_s2(weight):
             launches.append(dict(wpk=wpk, dy=torch.tensor([t[1] for t in taps], dtype=torch.int32),
                                  dx=torch.tensor([t[3] for t in taps], dtype=torch.int32), in_mul=1, out_mul=2, py=py,
                                  px=px, ntaps=len(taps)))
-    return PackedConv(launches, ci, co, "deconv", 2)
+    pc = PackedConv(launches, ci, co, "deconv", 2)
+    # host-side argument blocks of the single merged launch (sessd_deconv2d_s2_mfma)
+    import ctypes
+    pc.wpk4 = (ctypes.c_void_p * 4)(*[la["wpk"].data_ptr() for la in launches])
+    pc.ntaps4 = torch.tensor([la["ntaps"] for la in launches], dtype=torch.int32)
+    pc.dy4 = torch.zeros((4, 4), dtype=torch.int32)
+    pc.dx4 = torch.zeros((4, 4), dtype=torch.int32)
+    for c, la in enumerate(launches):
+        pc.dy4[c, :la["ntaps"]] = la["dy"]
+        pc.dx4[c, :la["ntaps"]] = la["dx"]
+    return pc
 
 
 def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, tile_cfg=None):
@@ -298,6 +308,14 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         th, tw = H, W
     if out is None:
         out = torch.empty((B, pc.cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    if pc.kind == "deconv" and ci % 8 == 0:
+        import ctypes
+        cfg = tile_cfg if tile_cfg is not None else default_tile_cfg(pc.cout, th * tw, 4)
+        check(lib.sessd_deconv2d_s2_mfma(x.data_ptr(), B, ci, H, W, ctypes.cast(pc.wpk4, ctypes.c_void_p).value,
+                                         pc.ntaps4.data_ptr(), pc.dy4.data_ptr(), pc.dx4.data_ptr(), out.data_ptr(),
+                                         pc.cout, _p(scale), _p(shift), 1 if relu else 0, _p(residual), cfg, _stream()),
+              "deconv2d_s2_mfma")
+        return out
     for la in pc.launches:
         cfg = tile_cfg
         if cfg is None:
@@ -318,6 +336,8 @@ def default_tile_cfg(cout, npix, ntaps):
         return _TILE_CFG_OVERRIDE[key]
     if cout <= 32:
         return 4
+    if npix * ((cout + 63) // 64) < 64 * 1024 and ntaps != 9:
+        return 3  # few-tap convs on small maps: 32c x 32p wave tiles to fill the 1024 SIMDs
     return 1
 
 
