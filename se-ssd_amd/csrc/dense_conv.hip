@@ -46,6 +46,16 @@ struct ConvArgs4 {
 };
 
 // wave tile: (CT*32 couts) x (PT*32 pixels); workgroup = 4 waves arranged WC x WP
+// Raw buffer resource (V#) over [base, base + bytes): loads whose (voffset + imm) >= bytes return 0 in hardware.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bufload(rsrc_t rsrc, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
+#define SESSD_OOB 0x80000000u  // a lane offset beyond any buffer: the load returns 0 (out-of-image tap)
+
 template <int NTAPS, int CT, int PT, int WC, int WP>
 __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   static_assert(WC * WP == 4, "four waves per workgroup");
@@ -56,26 +66,29 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   const int p_base = (blockIdx.x * WP + wp) * (PT * 32);
   const int m_base = (blockIdx.y * WC + wc) * (CT * 32);
   if (p_base >= npix || m_base >= A.cout_pad) return;
-  const size_t in_plane = (size_t)A.hin * A.win;
-  const float* in = A.in + (size_t)b * A.cin * in_plane + (size_t)h * in_plane;
+  const int in_plane = A.hin * A.win;
 
-  // per-lane pixel geometry: offset of every tap (clamped to a valid address) + validity bits
-  int off[PT][NTAPS];
-  unsigned vmask[PT];
+  // Operands are fetched with BUFFER loads: address = SGPR resource + per-lane 32-bit offset (loop invariant)
+  // + SGPR offset (advanced per k-step by the scalar unit) + immediate. The k-loop therefore issues NO vector
+  // ALU work for addressing -- on gfx950 the f32 MFMA shares the SIMD's f32 lanes with the VALU, so every VALU
+  // instruction in the loop is MFMA time lost (a 64-bit pointer add per load halved the rate of this kernel).
+  // Out-of-image taps get the offset SESSD_OOB: the hardware range check returns 0, no select needed.
+  const rsrc_t xr = make_rsrc(A.in + (size_t)b * A.cin * in_plane, (unsigned)A.cin * in_plane * 4u);
+  const rsrc_t wr = make_rsrc(A.wpk, (unsigned)(A.cin >> 1) * NTAPS / A.cgroup * 2u * A.cout_pad * 4u);
+  unsigned xo[PT][NTAPS];
 #pragma unroll
   for (int q = 0; q < PT; ++q) {
     const int p = p_base + q * 32 + j;
     const bool live = p < npix;
     const int y = live ? p / A.wt : 0, x = live ? p - (p / A.wt) * A.wt : 0;
-    vmask[q] = 0;
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
       const int iy = y * A.in_mul + A.dy[t], ix = x * A.in_mul + A.dx[t];
       const bool ok = live && iy >= 0 && iy < A.hin && ix >= 0 && ix < A.win;
-      off[q][t] = (ok ? iy * A.win + ix : 0) + A.dc[t] * 2 * (int)in_plane;
-      vmask[q] |= (ok ? 1u : 0u) << t;
+      xo[q][t] = ok ? (unsigned)(((h + A.dc[t] * 2) * in_plane + iy * A.win + ix) * 4) : SESSD_OOB;
     }
   }
+  const unsigned wo = (unsigned)((h * A.cout_pad + m_base + j) * 4);
 
   f32x16 acc[CT][PT];
 #pragma unroll
@@ -86,30 +99,26 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
       for (int r = 0; r < 16; ++r) acc[c][q][r] = 0.f;
 
   const int KP = (A.cin >> 1) / A.cgroup;  // k-steps; the packed weight layout is the same for any cgroup
-  const size_t wstep = (size_t)NTAPS * 2 * A.cout_pad;  // floats per cin pair
-  const float* wl = A.wpk + (size_t)h * A.cout_pad + m_base + j;
+  const unsigned wstep = (unsigned)NTAPS * 2u * A.cout_pad * 4u;       // weight bytes per k-step
+  const unsigned wtap = 2u * A.cout_pad * 4u;                          // weight bytes per tap
+  const unsigned xstep = 2u * (unsigned)A.cgroup * (unsigned)in_plane * 4u;  // activation bytes per k-step
 
   float wa[2][NTAPS][CT], xb[2][NTAPS][PT];
 
-#define SESSD_LOAD(SET, KPI)                                                         \
-  {                                                                                  \
-    const float* wk = wl + (size_t)(KPI)*wstep;                                      \
-    const float* xk = in + (size_t)(KPI)*2 * A.cgroup * in_plane;                    \
-    _Pragma("unroll") for (int t = 0; t < NTAPS; ++t) {                              \
-      _Pragma("unroll") for (int c = 0; c < CT; ++c) wa[SET][t][c] = wk[(size_t)t * 2 * A.cout_pad + c * 32]; \
-      _Pragma("unroll") for (int q = 0; q < PT; ++q) xb[SET][t][q] = xk[off[q][t]];  \
-    }                                                                                \
+#define SESSD_LOAD(SET, KPI)                                                                   \
+  {                                                                                            \
+    const unsigned ws = (unsigned)(KPI)*wstep, xs = (unsigned)(KPI)*xstep;                      \
+    _Pragma("unroll") for (int t = 0; t < NTAPS; ++t) {                                        \
+      _Pragma("unroll") for (int c = 0; c < CT; ++c) wa[SET][t][c] = bufload(wr, wo + c * 128u, ws + t * wtap); \
+      _Pragma("unroll") for (int q = 0; q < PT; ++q) xb[SET][t][q] = bufload(xr, xo[q][t], xs); \
+    }                                                                                          \
   }
-#define SESSD_MMA(SET)                                                               \
-  {                                                                                  \
-    /* the out-of-image select happens HERE, at the use, so that the wait for a load sits in front of  \
-       its MFMA and not right behind the load (which would expose the whole memory latency) */     \
-    _Pragma("unroll") for (int t = 0; t < NTAPS; ++t)                                \
-      _Pragma("unroll") for (int q = 0; q < PT; ++q) {                               \
-        const float xv = ((vmask[q] >> t) & 1u) ? xb[SET][t][q] : 0.f;               \
-        _Pragma("unroll") for (int c = 0; c < CT; ++c)                               \
-          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[SET][t][c], xv, acc[c][q], 0, 0, 0); \
-      }                                                                              \
+#define SESSD_MMA(SET)                                                                         \
+  {                                                                                            \
+    _Pragma("unroll") for (int t = 0; t < NTAPS; ++t)                                          \
+      _Pragma("unroll") for (int q = 0; q < PT; ++q)                                           \
+        _Pragma("unroll") for (int c = 0; c < CT; ++c)                                         \
+          acc[c][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[SET][t][c], xb[SET][t][q], acc[c][q], 0, 0, 0); \
   }
 
   // Two register sets, one cin pair of look-ahead. Every load in the loop is UNCONDITIONAL (the last one is
@@ -221,6 +230,9 @@ int dispatch_tile(const ConvArgs* A, int nconv, int batch, int tile_cfg, hipStre
     case 3: return launch_conv<NTAPS, 1, 1, 4, 1>(A, nconv, batch, stream);  // wave 32c x 32p, WG 128c x 32p
     case 4: return launch_conv<NTAPS, 1, 1, 1, 4>(A, nconv, batch, stream);  // wave 32c x 32p, WG 32c x 128p (small cout)
     case 5: return launch_conv<NTAPS, 2, 1, 4, 1>(A, nconv, batch, stream);  // wave 64c x 32p, WG 256c x 32p
+    case 6: return launch_conv<NTAPS, 2, 1, 1, 4>(A, nconv, batch, stream);  // wave 64c x 32p, WG 64c x 128p (weights shared by the 4 waves)
+    case 7: return launch_conv<NTAPS, 2, 2, 1, 4>(A, nconv, batch, stream);  // wave 64c x 64p, WG 64c x 256p
+    case 8: return launch_conv<NTAPS, 4, 1, 1, 4>(A, nconv, batch, stream);  // wave 128c x 32p, WG 128c x 128p
     default: return SESSD_EINVAL;
   }
 }
