@@ -44,7 +44,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads of the baseline (capped by affinity)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU baseline sample")
+    ap.add_argument("--streams", type=int, default=1, help="frames in flight: independent engines on separate HIP streams")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     return ap.parse_args()
 
 
@@ -74,8 +76,11 @@ def main():
     VG = configs.VOXEL_GENERATOR
 
     model = configs.build_synthetic_detector(dev, seed=0, max_voxels=args.max_voxels, num_points=args.points)
-    eng = InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], args.max_voxels,
-                          configs.TEST_CFG, batch_size=1, max_points_per_frame=args.points, device=dev)
+    engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], args.max_voxels,
+                               configs.TEST_CFG, batch_size=1, max_points_per_frame=args.points, device=dev)
+               for _ in range(max(1, args.streams))]
+    streams = [torch.cuda.Stream() for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream()]
+    eng = engines[0]
     # frames of this rank, resident in HBM before the clock starts (rank r takes seeds r*pool ...)
     frames_np = [synth.make_frame(rank * args.pool + i, args.points) for i in range(args.pool)]
     frames = [torch.from_numpy(f).to(dev) for f in frames_np]
@@ -85,16 +90,29 @@ def main():
     torch.cuda.synchronize()
     first = eng.results()[0]
     log("first frame done:", len(first["scores"]), "detections")
+    if not args.no_autotune:
+        rep = eng.autotune()
+        log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
+    for e in engines[1:]:
+        e.tile_cfg = dict(eng.tile_cfg)
+        e.set_points([frames[0]])
+        e.enqueue()
+    torch.cuda.synchronize()
     if not args.eager:
-        eng.capture()
+        for e, st in zip(engines, streams):
+            with torch.cuda.stream(st):
+                e.capture()
+        torch.cuda.synchronize()
         log("graph captured")
 
     def step(i):
-        eng.set_points([frames[i % args.pool]])  # device-to-device copy into the static input buffer
-        if args.eager:
-            eng.enqueue()
-        else:
-            eng.replay()
+        e, st = engines[i % len(engines)], streams[i % len(engines)]
+        with torch.cuda.stream(st):
+            e.set_points([frames[i % args.pool]])  # device-to-device staging into the engine's static input buffer
+            if args.eager:
+                e.enqueue()
+            else:
+                e.replay()
 
     def barrier():
         if world > 1:
@@ -130,6 +148,7 @@ def main():
                                    "voxel grid [1408,1600,40], max_voxels %d, batch 1 (BASELINE.json configs[1]); "
                                    "seeded random weights, BatchNorm calibrated" % (args.points, args.max_voxels),
                        "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps,
+                       "frames_in_flight": len(engines),
                        "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                        "detections_last_frame": dets, "detections_first_frame": int(len(first["scores"]))},
         }
@@ -137,13 +156,14 @@ def main():
         if not args.no_roofline:
             pc, scale, shift = eng.dn.b0[1]
             x, y = eng.t["a"], eng.t["b"]
+            rcfg = eng.tile_cfg.get("b0.1")
             for _ in range(5):
-                ops.conv2d(x, pc, scale, shift, True, None, y)
+                ops.conv2d(x, pc, scale, shift, True, None, y, rcfg)
             n_l = 50
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(n_l):
-                ops.conv2d(x, pc, scale, shift, True, None, y)
+                ops.conv2d(x, pc, scale, shift, True, None, y, rcfg)
             e1.record()
             torch.cuda.synchronize()
             kms = e0.elapsed_time(e1) / n_l

@@ -28,6 +28,10 @@ typedef void* sessd_stream_t; /* hipStream_t */
 const char* sessd_version(void);
 /* 32-bit pattern fill as a kernel launch (graph-safe clear; the library itself never uses hipMemsetAsync) */
 int sessd_fill_u32(void* ptr, uint32_t value, size_t n_words, sessd_stream_t stream);
+/* on != 0: sessd_voxelize_frame / sessd_sparse_downsample_sites stop clearing their scratch (per-cell lists + cut word
+ * at the start of the voxelizer workspace; output hash keys/vals and the first `out_hash_capacity` words of the
+ * downsample workspace) -- the caller fills them with 0x7F7F7F7F itself, e.g. one fill over a contiguous arena. */
+void sessd_set_external_clear(int on);
 
 /* ------------------------------------------------------------------ voxelizer (a1-a3)
  * replaces det3d/ops/point_cloud/point_cloud_ops_v2.py:120-194 points_to_voxel (numba, CPU),

@@ -33,6 +33,13 @@ int sessd_fill_u32_launch(void* p, uint32_t value, size_t n_words, hipStream_t s
     if (rc__ != 0) return rc__;                                                        \
   } while (0)
 
+// scratch clears that an engine may take over with one arena-wide fill (sessd_set_external_clear)
+int sessd_external_clear_enabled();
+#define SESSD_FILL_SCRATCH(ptr, value, n_words, stream)                 \
+  do {                                                                   \
+    if (!sessd_external_clear_enabled()) SESSD_FILL(ptr, value, n_words, stream); \
+  } while (0)
+
 static inline __host__ __device__ int sessd_divup(int a, int b) { return (a + b - 1) / b; }
 static inline __host__ __device__ size_t sessd_align(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

@@ -178,29 +178,44 @@ __global__ __launch_bounds__(256) void conv2d_mfma4_kernel(ConvArgs4 A4) {
   conv_body<NTAPS, CT, PT, WC, WP>(A4.c[blockIdx.z & 3], blockIdx.z >> 2);
 }
 
-// SSFA tail (rpn_v1.py:227-233): w0 = BN(conv1x1(x0)), w1 = BN(conv1x1(x1)) (128 -> 1 channel, no ReLU),
-// (s0, s1) = softmax(w0, w1), out = x0*s0 + x1*s1. One thread per pixel, channel loop reads are
-// coalesced across pixels (NCHW planes). Two passes over x0/x1 rows that stay in L2.
+// SSFA tail (rpn_v1.py:227-233): w0 = BN(conv1x1(x0)), w1 = BN(conv1x1(x1)) (C -> 1 channel, no ReLU),
+// (s0, s1) = softmax(w0, w1), out = x0*s0 + x1*s1. Workgroup = 64 pixels x 4 channel quarters: each thread
+// dots its quarter of the channels (coalesced across the 64 pixels of a wave), the four partial sums meet in
+// LDS, then every thread blends its own quarter -- the second read of x0/x1 hits L2.
 __global__ __launch_bounds__(256) void ssfa_fuse_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                          const float* __restrict__ w0, const float* __restrict__ w1,
                                                          float s0, float t0, float s1, float t1, int C, int npix,
                                                          float* __restrict__ out) {
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float part[2][4][64];
+  const int px = threadIdx.x & 63, cq = threadIdx.x >> 6;
+  const int p = blockIdx.x * 64 + px;
   const int b = blockIdx.y;
-  if (p >= npix) return;
-  const size_t base = (size_t)b * C * npix + p;
+  const int cper = C >> 2, c0 = cq * cper;
+  const bool live = p < npix;
+  const size_t base = (size_t)b * C * npix + (live ? p : 0);
   float a0 = 0.f, a1 = 0.f;
-  for (int c = 0; c < C; ++c) {
-    a0 = fmaf(x0[base + (size_t)c * npix], w0[c], a0);
-    a1 = fmaf(x1[base + (size_t)c * npix], w1[c], a1);
+  if (live) {
+#pragma unroll 8
+    for (int c = c0; c < c0 + cper; ++c) {
+      a0 = fmaf(x0[base + (size_t)c * npix], w0[c], a0);
+      a1 = fmaf(x1[base + (size_t)c * npix], w1[c], a1);
+    }
   }
+  part[0][cq][px] = a0;
+  part[1][cq][px] = a1;
+  __syncthreads();
+  // fixed summation order (quarter 0..3) so the result does not depend on which thread reads it
+  a0 = ((part[0][0][px] + part[0][1][px]) + part[0][2][px]) + part[0][3][px];
+  a1 = ((part[1][0][px] + part[1][1][px]) + part[1][2][px]) + part[1][3][px];
   a0 = fmaf(a0, s0, t0);
   a1 = fmaf(a1, s1, t1);
   const float m = fmaxf(a0, a1);
   const float e0 = expf(a0 - m), e1 = expf(a1 - m);
   const float inv = 1.f / (e0 + e1);
   const float p0 = e0 * inv, p1 = e1 * inv;
-  for (int c = 0; c < C; ++c) {
+  if (!live) return;
+#pragma unroll 8
+  for (int c = c0; c < c0 + cper; ++c) {
     const size_t o = base + (size_t)c * npix;
     out[o] = x0[o] * p0 + x1[o] * p1;
   }
@@ -308,7 +323,8 @@ int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const flo
                     float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,
                     float* out, hipStream_t stream) {
   if (batch < 1 || channels < 1 || num_pixels < 1) return SESSD_EINVAL;
-  hipLaunchKernelGGL(ssfa_fuse_kernel, dim3(sessd_divup(num_pixels, 256), batch), dim3(256), 0, stream, x0, x1, w0, w1,
+  if (channels % 4) return SESSD_EINVAL;
+  hipLaunchKernelGGL(ssfa_fuse_kernel, dim3(sessd_divup(num_pixels, 64), batch), dim3(256), 0, stream, x0, x1, w0, w1,
                      bn_scale0, bn_shift0, bn_scale1, bn_shift1, channels, num_pixels, out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

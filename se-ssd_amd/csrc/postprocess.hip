@@ -245,6 +245,54 @@ __global__ __launch_bounds__(64) void finalize_kernel(PostCfg C, const int* __re
   if (lane == 0) out_count[b] = written;
 }
 
+// Greedy reduction with the WHOLE suppression mask staged in LDS (pre_max*ceil(pre_max/64)*8 B = 128 KB for
+// pre_max 1000; 160 KB LDS per CU): 1024 threads copy it in one coalesced sweep, then one wave walks it at LDS
+// latency instead of one dependent global load per kept row.
+__global__ __launch_bounds__(1024) void nms_reduce_lds_kernel(const int* __restrict__ n_top, int pre_max,
+                                                              const unsigned long long* __restrict__ mask, int words,
+                                                              int post_max, int* __restrict__ keep, int* __restrict__ n_keep) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+  const int b = blockIdx.x;
+  const int n = min(n_top[b], pre_max);
+  const unsigned long long* mb = mask + (size_t)b * pre_max * words;
+  const int cb = sessd_divup(n, 64);
+  // rows r < n, words w in [r/64, cb) are defined (the mask kernel skips the rest): copy only those
+  for (int idx = threadIdx.x; idx < n * words; idx += 1024) {
+    const int r = idx / words, w = idx - r * words;
+    sm[idx] = (w >= (r >> 6) && w < cb) ? mb[idx] : 0ull;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  int* kb = keep + (size_t)b * post_max;
+  unsigned long long removed = 0;  // lane w owns word w
+  int nk = 0;
+  for (int blk = 0; blk < cb && nk < post_max; ++blk) {
+    const int row = blk * 64 + lane;
+    const unsigned long long diag = row < n ? sm[(size_t)row * words + blk] : 0ull;
+    unsigned long long rem = __shfl(removed, blk, 64);
+    unsigned long long kept = 0;
+    const int lim = min(64, n - blk * 64);
+    for (int bb = 0; bb < lim; ++bb) {
+      const unsigned long long d = __shfl(diag, bb, 64);
+      if (!((rem >> bb) & 1ull) && nk < post_max) {
+        kept |= 1ull << bb;
+        if (lane == 0) kb[nk] = blk * 64 + bb;
+        ++nk;
+        rem |= d;
+      }
+    }
+    if (nk >= post_max) break;
+    if (lane > blk && lane < cb) {
+      unsigned long long acc = 0;
+      for (int bb = 0; bb < lim; ++bb)
+        if ((kept >> bb) & 1ull) acc |= sm[(size_t)(blk * 64 + bb) * words + lane];
+      removed |= acc;
+    }
+  }
+  if (lane == 0) n_keep[b] = nk;
+}
+
 struct PostWs {
   unsigned long long* keys;
   int* count;
@@ -369,8 +417,22 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
   hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, sessd_divup(pre_max_size, 4), batch), dim3(256), 0, stream, w.n_top,
                      pre_max_size, nms_iou_thresh, w.corners, w.standup, w.mask, words);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(nms_reduce_batch_kernel, dim3(batch), dim3(64), 0, stream, w.n_top, pre_max_size, w.mask, words,
-                     post_max_size, w.keep, w.n_keep);
+  {
+    const size_t lds = (size_t)pre_max_size * words * 8;
+    if (lds <= 160 * 1024 - 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        SESSD_TRY(hipFuncSetAttribute((const void*)nms_reduce_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      160 * 1024 - 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(nms_reduce_lds_kernel, dim3(batch), dim3(1024), lds, stream, w.n_top, pre_max_size, w.mask, words,
+                         post_max_size, w.keep, w.n_keep);
+    } else {
+      hipLaunchKernelGGL(nms_reduce_batch_kernel, dim3(batch), dim3(64), 0, stream, w.n_top, pre_max_size, w.mask, words,
+                         post_max_size, w.keep, w.n_keep);
+    }
+  }
   SESSD_CHECK_LAUNCH();
   hipLaunchKernelGGL(finalize_kernel, dim3(batch), dim3(64), 0, stream, C, w.keep, w.n_keep, w.cand_box, w.cand_score,
                      w.cand_dir, frustum, out_box, out_score, out_label, out_count);

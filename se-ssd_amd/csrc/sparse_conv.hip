@@ -20,6 +20,18 @@
 namespace {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using i32x4v = __attribute__((ext_vector_type(4))) int;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float bufload1(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ f32x4 bufload4(rsrc_t r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+#define SESSD_OOB 0x80000000u
 
 template <int CIN, int COUT, bool DENSE_OUT>
 __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restrict__ in_feat,
@@ -53,8 +65,12 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   //   stage 3  MFMAs of offset i
   // All loads are unconditional (exhausted lists re-load the last offset, missing neighbours load row 0 and are
   // zeroed at the use) so that hipcc's vmcnt accounting stays exact and loads stay in flight under the MFMAs.
+  // Buffer loads (SGPR resource + 32-bit lane offset + SGPR offset): no 64-bit VALU address arithmetic in the
+  // loop (the f32 MFMA shares the SIMD lanes with the VALU); a missing neighbour gets an out-of-range offset and
+  // the hardware returns zeros for its row.
+  const rsrc_t fr = make_rsrc(in_feat, 0x7FFFFFFFu);
+  const rsrc_t wrs = make_rsrc(wpk, (unsigned)kv * NTILE * STEPS * 64u * 4u);
   float a[2][STEPS], bw[2][NTILE][STEPS];
-  bool av[2];
   uint32_t rest = tmask;
   int remaining = __builtin_popcount(tmask);
   const int* nb = nbr + tile * 16 + i;
@@ -62,32 +78,30 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
 #define SESSD_NEXTK() (rest ? (klast = __builtin_ctz(rest), rest &= rest - 1, klast) : klast)
 #define SESSD_LOADAB(SET, K, ROW)                                                                  \
   {                                                                                                \
-    av[SET] = (ROW) >= 0;                                                                          \
-    const float* src = in_feat + (size_t)((ROW) >= 0 ? (ROW) : 0) * CIN + kq * STEPS;              \
-    const float* wk = wpk + (size_t)(K)*NTILE * STEPS * 64;                                        \
+    const unsigned ao = (ROW) >= 0 ? (unsigned)(((ROW)*CIN + kq * STEPS) * 4) : SESSD_OOB;          \
+    const unsigned ws = (unsigned)(K) * (NTILE * STEPS * 64 * 4);                                  \
     if (G == 4) {                                                                                  \
       _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                             \
-        const f32x4 v = *reinterpret_cast<const f32x4*>(src + 4 * g);                              \
+        const f32x4 v = bufload4(fr, ao + 16u * g, 0);                                             \
         a[SET][4 * g] = v.x; a[SET][4 * g + 1] = v.y; a[SET][4 * g + 2] = v.z; a[SET][4 * g + 3] = v.w; \
       }                                                                                            \
       _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
         _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                           \
-          const f32x4 v = *reinterpret_cast<const f32x4*>(wk + ((size_t)(t * SG + g) * 64 + lane) * 4); \
+          const f32x4 v = bufload4(wrs, (unsigned)lane * 16u + (unsigned)(t * SG + g) * 1024u, ws); \
           bw[SET][t][4 * g] = v.x; bw[SET][t][4 * g + 1] = v.y; bw[SET][t][4 * g + 2] = v.z; bw[SET][t][4 * g + 3] = v.w; \
         }                                                                                          \
     } else {                                                                                       \
-      _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) a[SET][s2] = src[s2];                   \
+      _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) a[SET][s2] = bufload1(fr, ao + 4u * s2, 0); \
       _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
-        _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) bw[SET][t][s2] = wk[((size_t)(t * SG) * 64 + lane) * G + s2]; \
+        _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2)                                       \
+          bw[SET][t][s2] = bufload1(wrs, ((unsigned)(t * SG) * 64u + lane) * (G * 4u) + 4u * s2, ws); \
     }                                                                                              \
   }
 #define SESSD_MMA(SET)                                                                             \
   {                                                                                                \
-    _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) {                                         \
-      const float av2 = av[SET] ? a[SET][s2] : 0.f;                                                \
+    _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2)                                           \
       _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av2, bw[SET][t][s2], acc[t], 0, 0, 0);       \
-    }                                                                                              \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SET][s2], bw[SET][t][s2], acc[t], 0, 0, 0); \
   }
   if (remaining > 0) {
     const int kcur = SESSD_NEXTK();

@@ -252,9 +252,9 @@ int sessd_sparse_downsample_sites(const int* in_indices, const int* n_in_dev, in
   if (down_ws_layout(n_in_cap, kv, out_capacity, &w, (char*)workspace) > workspace_bytes) return SESSD_EWORKSPACE;
   ConvGeom G;
   fill_geom(G, ksize3, stride3, pad3, nullptr, out_dims3);
-  SESSD_FILL(out_keys, SESSD_HASH_EMPTY, out_capacity, stream);
-  SESSD_FILL(out_vals, SESSD_HASH_EMPTY, out_capacity, stream);
-  SESSD_FILL(w.first, SESSD_HASH_EMPTY, out_capacity, stream);
+  SESSD_FILL_SCRATCH(out_keys, SESSD_HASH_EMPTY, out_capacity, stream);
+  SESSD_FILL_SCRATCH(out_vals, SESSD_HASH_EMPTY, out_capacity, stream);
+  SESSD_FILL_SCRATCH(w.first, SESSD_HASH_EMPTY, out_capacity, stream);
   const int total = n_in_cap * kv;
   const int nblk = sessd_divup(total, NT);
   hipLaunchKernelGGL(down_insert_kernel, dim3(nblk), dim3(NT), 0, stream, in_indices, n_in_dev, n_in_cap, kv, G, out_keys,

@@ -304,8 +304,8 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
   size_t need = vox_ws_layout((int)hash_capacity, num_points, max_points_per_voxel, max_voxels, &w, (char*)workspace);
   if (need > workspace_bytes) return SESSD_EWORKSPACE;
   const int MP = max_points_per_voxel;
-  SESSD_FILL(w.lists, SESSD_HASH_EMPTY, (size_t)hash_capacity * MP, stream);
-  SESSD_FILL(w.meta, SESSD_HASH_EMPTY, 1, stream);  // cut = SESSD_SENT
+  SESSD_FILL_SCRATCH(w.lists, SESSD_HASH_EMPTY, (size_t)hash_capacity * MP, stream);
+  SESSD_FILL_SCRATCH(w.meta, SESSD_HASH_EMPTY, 1, stream);  // cut = SESSD_SENT
   const int nblk = sessd_divup(num_points > 0 ? num_points : 1, VOX_NT);
   if (num_points > 0) {
     hipLaunchKernelGGL(vox_insert_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, points, num_points, ndim, G, key_base,

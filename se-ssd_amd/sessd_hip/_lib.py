@@ -15,6 +15,7 @@ vp, i32, u32, f32, sz, i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_siz
 SIGNATURES = {
     "sessd_version": (C.c_char_p, []),
     "sessd_fill_u32": (i32, [vp, u32, sz, vp]),
+    "sessd_set_external_clear": (None, [i32]),
     "sessd_hash_capacity": (u32, [i32]),
     "sessd_hash_clear": (i32, [vp, vp, u32, vp]),
     "sessd_voxelize_workspace_bytes": (sz, [u32, i32, i32, i32]),

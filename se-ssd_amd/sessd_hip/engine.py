@@ -97,7 +97,10 @@ class DensePlan:
 
 class InferenceEngine:
     def __init__(self, model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, batch_size=1,
-                 max_points_per_frame=32768, device=None, growth=2.0, anchors=None, use_frustum=False):
+                 max_points_per_frame=32768, device=None, growth=(1.5, 1.0, 0.75, 0.75), anchors=None,
+                 use_frustum=False):
+        """growth[i]: capacity of sparse level i+1 relative to level i (observed ratios on KITTI-like scans are
+        ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results()."""
         self.dev = torch.device("cuda:0") if device is None else device
         dev = self.dev
         self.B = int(batch_size)
@@ -127,12 +130,16 @@ class InferenceEngine:
         shape = list(self.sparse_shape)
         cap = _round_up(B * self.max_voxels, 64)
         self.levels.append(dict(shape=shape, hash_dims=[gz, gy, gx], cap=cap))
+        if isinstance(growth, (int, float)):
+            growth = (growth,) * 4
+        gi = 0
         for (kind, cin, cout, ks, st, pd, key) in SPMIDDLE_LAYERS:
             if kind == "conv":
                 ks3, st3, pd3 = _t3(ks), _t3(st), _t3(pd)
                 shape = [(d + 2 * p - k) // s + 1 for d, k, s, p in zip(shape, ks3, st3, pd3)]
                 cells = B * shape[0] * shape[1] * shape[2]
-                cap = _round_up(min(int(growth * cap), cells), 64)
+                cap = _round_up(min(int(growth[gi] * cap), cells), 64)
+                gi += 1
                 self.levels.append(dict(shape=shape, hash_dims=shape, cap=cap))
         self.bev_c = 64 * self.levels[-1]["shape"][0]
         self.H, self.W = self.levels[-1]["shape"][1], self.levels[-1]["shape"][2]
@@ -146,11 +153,32 @@ class InferenceEngine:
         self.coors = E(cap0, 4, dt=i32)
         self.nump = E(cap0, dt=i32)
         self.vfeat = E(cap0, 4)
-        self.prefix = torch.zeros((B + 1,), dtype=i32, device=dev)
-        self.hash0 = ops.VoxelHash(self.P_cap * B, dev)
-        self.vox_ws = torch.empty(int(lib.sessd_voxelize_workspace_bytes(self.hash0.capacity, self.P_cap, self.max_points,
-                                                                         self.max_voxels)), dtype=torch.uint8, device=dev)
-        self.err = torch.zeros((1,), dtype=i32, device=dev)
+        # control words cleared to 0 by ONE fill per frame: prefix[B+1] | err
+        self.ctrl = torch.zeros((B + 2,), dtype=i32, device=dev)
+        self.prefix = self.ctrl[:B + 1]
+        self.err = self.ctrl[B + 1:B + 2]
+        # ---- one contiguous arena for everything that must read 0x7F7F7F7F at the start of a frame (hash tables,
+        # per-cell point lists, first-touch words): cleared by ONE fill instead of ~17 small ones
+        cap0h = int(lib.sessd_hash_capacity(self.P_cap * B))
+        vox_bytes = int(lib.sessd_voxelize_workspace_bytes(cap0h, self.P_cap, self.max_points, self.max_voxels))
+        plan, off = [], 0
+
+        def take(nbytes):
+            nonlocal off
+            o = off
+            off = (off + int(nbytes) + 255) // 256 * 256
+            return (o, int(nbytes))
+
+        p_k0, p_v0, p_vox = take(cap0h * 4), take(cap0h * 4), take(vox_bytes)
+        lvl_parts = []
+        for li in range(1, len(self.levels)):
+            hc = int(lib.sessd_hash_capacity(self.levels[li]["cap"]))
+            wsb = int(lib.sessd_sparse_downsample_workspace_bytes(self.levels[li - 1]["cap"], 27, hc))
+            lvl_parts.append((hc, take(hc * 4), take(hc * 4), take(wsb)))
+        self.arena = torch.empty(off, dtype=torch.uint8, device=dev)
+        view_i32 = lambda pr: self.arena[pr[0]:pr[0] + pr[1]].view(torch.int32)
+        self.hash0 = ops.VoxelHash(self.P_cap * B, dev, view_i32(p_k0), view_i32(p_v0))
+        self.vox_ws = self.arena[p_vox[0]:p_vox[0] + p_vox[1]]
         for li, L in enumerate(self.levels):
             c = L["cap"]
             L["nbr_subm"] = E(27, c, dt=i32)
@@ -161,16 +189,13 @@ class InferenceEngine:
                 L["indices"], L["n"] = self.coors, None  # n = prefix[B]
                 L["hash"] = ops.SiteHash(self.hash0.capacity, L["hash_dims"], dev, self.hash0.keys, self.hash0.vals)
             else:
+                hc, pk, pv, pw = lvl_parts[li - 1]
                 L["indices"] = E(c, 4, dt=i32)
                 L["n"] = torch.zeros((1,), dtype=i32, device=dev)
-                L["hash"] = ops.SiteHash(lib.sessd_hash_capacity(c), L["hash_dims"], dev)
+                L["hash"] = ops.SiteHash(hc, L["hash_dims"], dev, view_i32(pk), view_i32(pv))
+                L["down_ws"] = self.arena[pw[0]:pw[0] + pw[1]]
                 L["nbr_down"] = E(27, c, dt=i32)
                 L["tm_down"] = E((c + 15) // 16, dt=i32)
-        ws = 0
-        for li in range(1, len(self.levels)):
-            ws = max(ws, int(lib.sessd_sparse_downsample_workspace_bytes(self.levels[li - 1]["cap"], 27,
-                                                                         self.levels[li]["hash"].capacity)))
-        self.down_ws = torch.empty(ws, dtype=torch.uint8, device=dev)
         self.bev = torch.zeros((B, self.bev_c, H, W), dtype=f32, device=dev)
         self.t = {k: E(B, 128, H, W) for k in ("a", "b", "x0", "tr0", "mid0", "mid1", "o0", "o1", "out")}
         self.h = {k: E(B, 256, H // 2, W // 2) for k in ("a", "b", "x1", "tr1")}
@@ -188,6 +213,8 @@ class InferenceEngine:
         self._npts = [0] * B
         self.graph = None
         self.tile_cfg = {}
+        self.tune_report = {}
+        self._tuning = None
 
     # ------------------------------------------------------------------ helpers
     def _i3(self, v):
@@ -234,9 +261,41 @@ class InferenceEngine:
                                     Lo["indices"].data_ptr() if dense else 0, self.bev.data_ptr() if dense else 0, dd, s),
               "sparse_conv")
 
-    def _conv(self, x, layer, out, relu=True, residual=None):
+    def _conv(self, x, layer, out, relu=True, residual=None, name=None):
         pc, scale, shift = layer
-        return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get((pc.cout, pc.kind, pc.stride)))
+        if self._tuning is not None:
+            self._tuning.append((name, x, layer, out, relu, residual))
+        return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name))
+
+    def autotune(self, candidates=(1, 2, 3, 4, 6), reps=5):
+        """Pick the wave/workgroup tiling of every dense conv launch by timing it on this device (one-off, ~0.1 s).
+        Needs one representative frame already staged with set_points()."""
+        self._tuning = []
+        self.enqueue()
+        torch.cuda.synchronize()
+        todo, self._tuning = self._tuning, None
+        for name, x, layer, out, relu, residual in todo:
+            pc, scale, shift = layer
+            best = (None, 1e30)
+            for cfg in candidates:
+                if pc.cout <= 32 and cfg != 4:
+                    continue
+                for _ in range(2):
+                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg)
+                e1.record()
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) / reps
+                if t < best[1]:
+                    best = (cfg, t)
+            self.tile_cfg[name] = best[0]
+            self.tune_report[name] = best
+        self.enqueue()  # leave every buffer consistent with the chosen configuration
+        torch.cuda.synchronize()
+        return self.tune_report
 
     # ------------------------------------------------------------------ the frame
     def enqueue(self):
@@ -244,9 +303,16 @@ class InferenceEngine:
         s = torch.cuda.current_stream().cuda_stream
         B = self.B
         # ---- voxelize (a1-a3)
-        check(lib.sessd_fill_u32(self.prefix.data_ptr(), 0, B + 1, s), "fill")
-        check(lib.sessd_fill_u32(self.err.data_ptr(), 0, 1, s), "fill")
-        self.hash0.clear()
+        check(lib.sessd_fill_u32(self.ctrl.data_ptr(), 0, B + 2, s), "fill")
+        check(lib.sessd_fill_u32(self.arena.data_ptr(), 0x7F7F7F7F, self.arena.numel() // 4, s), "fill")
+        lib.sessd_set_external_clear(1)  # the arena fill above replaces the per-call scratch clears
+        try:
+            return self._enqueue_body(s)
+        finally:
+            lib.sessd_set_external_clear(0)
+
+    def _enqueue_body(self, s):
+        B = self.B
         for b in range(B):
             check(lib.sessd_voxelize_frame(self.points[b].data_ptr(), self.P_cap, 4, self.vrange.data_ptr(),
                                            self.vsize.data_ptr(), self.grid.data_ptr(), self.max_points, self.max_voxels,
@@ -277,8 +343,8 @@ class InferenceEngine:
                                                         self._i3(lay["pd"]).data_ptr(), self._i3(Lo["shape"]).data_ptr(),
                                                         Lo["hash"].keys.data_ptr(), Lo["hash"].vals.data_ptr(),
                                                         Lo["hash"].capacity, Lo["indices"].data_ptr(), Lo["cap"],
-                                                        Lo["n"].data_ptr(), self.err.data_ptr(), self.down_ws.data_ptr(),
-                                                        self.down_ws.numel(), s), "sparse_downsample_sites")
+                                                        Lo["n"].data_ptr(), self.err.data_ptr(), Lo["down_ws"].data_ptr(),
+                                                        Lo["down_ws"].numel(), s), "sparse_downsample_sites")
                 self._rulebook(li + 1, lay["ks"], lay["st"], lay["pd"], li, Lo["nbr_down"], Lo["tm_down"], s)
                 if last:
                     check(lib.sessd_fill_u32(self.bev.data_ptr(), 0, self.bev.numel(), s), "fill")
@@ -290,21 +356,21 @@ class InferenceEngine:
                 have_subm = False
         # ---- SSFA (a9) rpn_v1.py:220-235
         t, h, d = self.t, self.h, self.dn
-        x = self._conv(self.bev, d.b0[0], t["a"])
-        x = self._conv(x, d.b0[1], t["b"])
-        x0 = self._conv(x, d.b0[2], t["x0"])
-        y = self._conv(x0, d.b1[0], h["a"])
-        y = self._conv(y, d.b1[1], h["b"])
-        x1 = self._conv(y, d.b1[2], h["x1"])
-        tr0 = self._conv(x0, d.trans_0, t["tr0"])
-        tr1 = self._conv(x1, d.trans_1, h["tr1"])
-        mid0 = self._conv(tr1, d.deconv_0, t["mid0"], residual=tr0)
-        mid1 = self._conv(tr1, d.deconv_1, t["mid1"])
-        o0 = self._conv(mid0, d.conv_0, t["o0"])
-        o1 = self._conv(mid1, d.conv_1, t["o1"])
+        x = self._conv(self.bev, d.b0[0], t["a"], name="b0.0")
+        x = self._conv(x, d.b0[1], t["b"], name="b0.1")
+        x0 = self._conv(x, d.b0[2], t["x0"], name="b0.2")
+        y = self._conv(x0, d.b1[0], h["a"], name="b1.0")
+        y = self._conv(y, d.b1[1], h["b"], name="b1.1")
+        x1 = self._conv(y, d.b1[2], h["x1"], name="b1.2")
+        tr0 = self._conv(x0, d.trans_0, t["tr0"], name="trans_0")
+        tr1 = self._conv(x1, d.trans_1, h["tr1"], name="trans_1")
+        mid0 = self._conv(tr1, d.deconv_0, t["mid0"], residual=tr0, name="deconv_0")
+        mid1 = self._conv(tr1, d.deconv_1, t["mid1"], name="deconv_1")
+        o0 = self._conv(mid0, d.conv_0, t["o0"], name="conv_0")
+        o1 = self._conv(mid1, d.conv_1, t["o1"], name="conv_1")
         ops.ssfa_fuse(o0, o1, d.w0, d.w1, *d.wbn, out=t["out"])
         # ---- heads (a10) + predict (a11-a14)
-        ops.conv2d(t["out"], d.head[0], None, d.head[2], False, None, self.head.view(B, 22, self.H, self.W))
+        self._conv(t["out"], d.head, self.head.view(B, 22, self.H, self.W), relu=False, name="head")
         check(lib.sessd_predict(self.head.data_ptr(), B, self.H * self.W, self.anchors.data_ptr(), 0,
                                 0 if self.frustum is None else self.frustum.data_ptr(), self.score_thresh, self.pre_max,
                                 self.post_max, self.nms_thresh, self.post_range.data_ptr(), self.dir_offset,

@@ -43,10 +43,11 @@ def workspace(nbytes, device, tag="default"):
 class VoxelHash:
     """Open-addressing cell -> row hash shared by a batch of frames (and by SpMiddleFHD level 0)."""
 
-    def __init__(self, max_items, device):
+    def __init__(self, max_items, device, keys=None, vals=None):
         self.capacity = int(lib.sessd_hash_capacity(int(max_items)))
-        self.keys = torch.empty(self.capacity, dtype=torch.int32, device=device)
-        self.vals = torch.empty(self.capacity, dtype=torch.int32, device=device)
+        self.keys = keys if keys is not None else torch.empty(self.capacity, dtype=torch.int32, device=device)
+        self.vals = vals if vals is not None else torch.empty(self.capacity, dtype=torch.int32, device=device)
+        assert self.keys.numel() == self.capacity and self.vals.numel() == self.capacity
 
     def clear(self):
         check(lib.sessd_hash_clear(self.keys.data_ptr(), self.vals.data_ptr(), self.capacity, _stream()), "hash_clear")
