@@ -1,0 +1,64 @@
+"""Multi-GPU layer of the inference path: frames shard across ranks, nothing else is exchanged.
+
+Mirrors the reference's data-parallel evaluation (tools/dist_test.py:60-186: DistributedSampler(shuffle=False) +
+all_gather of pickled per-rank detection dicts, det3d/torchie/trainer/utils.py:115-155). One process per GPU over
+torch.distributed (backend "nccl" == RCCL over xGMI on MI355X nodes, "gloo" in the CPU tests). There is no
+data-path collective: the only communication is ONE fixed-size all_gather of (<=100 x 9 float) records per frame
+at the end (instead of padded pickle byte tensors), or none at all when every rank writes its own results."""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(num_frames, rank, world_size):
+    """DistributedSampler(shuffle=False) semantics (det3d/datasets/loader/sampler.py:74-96): the index list is padded
+    by wrapping to a multiple of world_size, rank r takes indices r, r+world, ... Returns (indices, num_padded)."""
+    per = int(math.ceil(num_frames / float(world_size)))
+    total = per * world_size
+    idx = list(range(num_frames))
+    idx += idx[: total - num_frames]
+    return idx[rank:total:world_size], total - num_frames
+
+
+def pack_detections(dets, post_max=100):
+    """list of per-frame dicts(box3d_lidar (n,7), scores (n,), label_preds (n,)) -> (F, post_max, 9) float32 + counts (F,)."""
+    F = len(dets)
+    rec = torch.zeros((F, post_max, 9), dtype=torch.float32)
+    cnt = torch.zeros((F,), dtype=torch.int32)
+    for f, d in enumerate(dets):
+        n = int(len(d["scores"]))
+        cnt[f] = n
+        if n:
+            rec[f, :n, :7] = torch.as_tensor(d["box3d_lidar"], dtype=torch.float32)
+            rec[f, :n, 7] = torch.as_tensor(d["scores"], dtype=torch.float32)
+            rec[f, :n, 8] = torch.as_tensor(d["label_preds"]).to(torch.float32)
+    return rec, cnt
+
+
+def gather_detections(local_dets, num_frames, post_max=100, device=None):
+    """All ranks call this with the detections of THEIR shard (in shard order). Returns, on every rank, the list of
+    `num_frames` per-frame dicts in dataset order (padding duplicates dropped), via one all_gather."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    rank = dist.get_rank() if dist.is_initialized() else 0
+    per = int(math.ceil(num_frames / float(world)))
+    assert len(local_dets) == per, "every rank must process ceil(num_frames/world) frames (padded shard)"
+    rec, cnt = pack_detections(local_dets, post_max)
+    if device is not None:
+        rec, cnt = rec.to(device), cnt.to(device)
+    if world > 1:
+        recs = [torch.empty_like(rec) for _ in range(world)]
+        cnts = [torch.empty_like(cnt) for _ in range(world)]
+        dist.all_gather(recs, rec)
+        dist.all_gather(cnts, cnt)
+    else:
+        recs, cnts = [rec], [cnt]
+    out = [None] * num_frames
+    for r in range(world):
+        idx, _ = shard_indices(num_frames, r, world)
+        for j, f in enumerate(idx):
+            if out[f] is None:
+                n = int(cnts[r][j])
+                a = recs[r][j, :n].cpu()
+                out[f] = dict(box3d_lidar=a[:, :7].numpy(), scores=a[:, 7].numpy(), label_preds=a[:, 8].long().numpy())
+    return out
