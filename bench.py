@@ -95,6 +95,7 @@ def main():
         log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
     for e in engines[1:]:
         e.tile_cfg = dict(eng.tile_cfg)
+        e.sparse_split = dict(eng.sparse_split)
         e.set_points([frames[0]])
         e.enqueue()
     torch.cuda.synchronize()

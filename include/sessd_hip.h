@@ -93,11 +93,12 @@ int sessd_sparse_rulebook(const int32_t* out_indices, const int32_t* n_out_dev, 
 int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, int cout, float* packed,
                              sessd_stream_t stream);
 /* out[o] = act((sum_k W[k]^T in[nbr[k][o]]) * scale + shift); scale/shift = folded eval BatchNorm1d (may be NULL).
- * dense_out != NULL: scatter into the pre-zeroed BEV tensor (B, cout*D, H, W), dense_dims3 = (D,H,W). */
+ * dense_out != NULL: scatter into the pre-zeroed BEV tensor (B, cout*D, H, W), dense_dims3 = (D,H,W).
+ * cout_split: 0 heuristic | 1,2,4 waves per 16-site tile (each computes cout/split channels). */
 int sessd_sparse_conv(const float* in_feat, int cin, const int32_t* nbr, const uint32_t* tile_mask, int kernel_volume,
                       const int32_t* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
                       const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
-                      float* dense_out, const int32_t* dense_dims3, sessd_stream_t stream);
+                      float* dense_out, const int32_t* dense_dims3, int cout_split, sessd_stream_t stream);
 
 /* ------------------------------------------------------------------ dense BEV neck + heads (a9-a10)
  * replace the ATen/cuDNN conv2d, conv_transpose2d, batch_norm, relu, softmax calls made by

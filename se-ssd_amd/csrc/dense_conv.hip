@@ -166,6 +166,117 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution, ACTIVATION-STATIONARY variant: a workgroup = 32 pixels x 128 couts (4 waves x 32 couts).
+// The nine shifted 32-pixel rows of 16 input channels (one "chunk" = 8 k-steps) are staged ONCE per workgroup in
+// LDS as ready-made MFMA B operands [channel][tap][pixel] (zero padding already applied by the OOB buffer loads),
+// so the per-wave global traffic is only the weight rows (aligned 128-B lines); the unaligned, 9x redundant
+// activation loads of the direct kernel disappear (2 -> 1.25 VMEM instructions per MFMA, none unaligned).
+// Double-buffered LDS, one barrier per chunk; the 18 staging loads of chunk c+1 are spread over the 8 k-steps of
+// chunk c right behind that k-step's weight loads, so under the in-order vmcnt they get a full k-step of latency
+// cover like every other load. Same (cin pair, tap, parity) fmaf order as conv_body: bit-identical results.
+__global__ __launch_bounds__(256) void conv3x3s1_lds_kernel(ConvArgs A) {
+  constexpr int KC = 8;            // k-steps (cin pairs) per chunk
+  constexpr int CHF = 2 * KC * 288;  // floats per LDS buffer: 16 channels x 9 taps x 32 pixels
+  __shared__ float xs[2][CHF];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane & 31, h = lane >> 5;
+  const int npix = A.ht * A.wt;
+  const int p_base = blockIdx.x * 32;
+  const int m_base = (blockIdx.y * 4 + wave) * 32;
+  const int b = blockIdx.z;
+  const int in_plane = A.hin * A.win;
+  const rsrc_t xr = make_rsrc(A.in + (size_t)b * A.cin * in_plane, (unsigned)A.cin * in_plane * 4u);
+  const rsrc_t wr = make_rsrc(A.wpk, (unsigned)(A.cin >> 1) * 9u * 2u * A.cout_pad * 4u);
+  // staging loads: flat element e = tid + 256*n of the chunk image [16 ch][9 taps][32 px]
+  unsigned lo[18];
+#pragma unroll
+  for (int n = 0; n < 18; ++n) {
+    const int e = tid + 256 * n;
+    const int c = e / 288, pr = e - c * 288, t = pr >> 5, jj = pr & 31;
+    const int p = p_base + jj;
+    const bool live = p < npix;
+    const int y = live ? p / A.wt : 0, x = live ? p - (p / A.wt) * A.wt : 0;
+    const int iy = y + A.dy[t], ix = x + A.dx[t];
+    const bool ok = live && iy >= 0 && iy < A.hin && ix >= 0 && ix < A.win;
+    lo[n] = ok ? (unsigned)((c * in_plane + iy * A.win + ix) * 4) : SESSD_OOB;
+  }
+  const bool wave_live = m_base < A.cout_pad;  // waves beyond cout still stage and hit the barriers
+  const unsigned wo = (unsigned)((h * A.cout_pad + (wave_live ? m_base : 0) + j) * 4);
+  const unsigned wstep = 9u * 2u * A.cout_pad * 4u, wtap = 2u * A.cout_pad * 4u;
+  const unsigned xchunk = 2u * KC * (unsigned)in_plane * 4u;
+  const int KP = A.cin >> 1, NCH = KP / KC;
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float wa[2][9], xb[2][9], xg[18];
+
+#define SESSD_LOADW(SET, KPI)                                                                   \
+  {                                                                                             \
+    const unsigned ws = (unsigned)(KPI)*wstep;                                                  \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) wa[SET][t] = bufload(wr, wo, ws + t * wtap);  \
+  }
+#define SESSD_READB(SET, BUF, KPL)                                                              \
+  {                                                                                             \
+    const float* src = &xs[BUF][(2 * (KPL) + h) * 288 + j];                                     \
+    _Pragma("unroll") for (int t = 0; t < 9; ++t) xb[SET][t] = src[t * 32];                     \
+  }
+  // prologue: stage chunk 0, first weight set
+#pragma unroll
+  for (int n = 0; n < 18; ++n) xg[n] = bufload(xr, lo[n], 0);
+  SESSD_LOADW(0, 0)
+#pragma unroll
+  for (int n = 0; n < 18; ++n) xs[0][tid + 256 * n] = xg[n];
+  __syncthreads();
+
+  for (int ch = 0; ch < NCH; ++ch) {
+    const int cur = ch & 1;
+    const unsigned xs_next = (unsigned)min(ch + 1, NCH - 1) * xchunk;
+    SESSD_READB(0, cur, 0)
+#pragma unroll
+    for (int s = 0; s < KC; ++s) {
+      const int kp = ch * KC + s;
+      SESSD_LOADW((s + 1) & 1, min(kp + 1, KP - 1))
+      // this k-step's share of the next chunk's staging loads (18 over 8 steps: 2,2,2,2,2,2,3,3)
+      {
+        constexpr int lo_n[9] = {0, 2, 4, 6, 8, 10, 12, 15, 18};
+#pragma unroll
+        for (int n = lo_n[s]; n < lo_n[s + 1]; ++n) xg[n] = bufload(xr, lo[n], xs_next);
+      }
+      if (s + 1 < KC) SESSD_READB((s + 1) & 1, cur, s + 1)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[s & 1][t], xb[s & 1][t], acc, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int n = 0; n < 18; ++n) xs[cur ^ 1][tid + 256 * n] = xg[n];
+    __syncthreads();
+  }
+#undef SESSD_LOADW
+#undef SESSD_READB
+  if (!wave_live) return;
+  // epilogue (same as conv_body with CT = PT = 1)
+  const size_t out_plane = (size_t)A.hout * A.wout;
+  float* outb = A.out + (size_t)b * A.cout * out_plane;
+  const float* resb = A.residual ? A.residual + (size_t)b * A.cout * out_plane : nullptr;
+  const int p = p_base + j;
+  if (p >= npix) return;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = m_base + (r & 3) + 8 * (r >> 2) + 4 * h;
+    if (co >= A.cout) continue;
+    float v = acc[r];
+    const float sc = A.scale ? A.scale[co] : 1.f, sh = A.shift ? A.shift[co] : 0.f;
+    v = fmaf(v, sc, sh);
+    if (A.relu) v = fmaxf(v, 0.f);
+    if (resb) v += resb[(size_t)co * out_plane + p];
+    outb[(size_t)co * out_plane + p] = v;
+  }
+}
+
 template <int NTAPS, int CT, int PT, int WC, int WP>
 __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
   conv_body<NTAPS, CT, PT, WC, WP>(A, blockIdx.z);
@@ -291,6 +402,13 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
   ConvArgs A;
   const int eff = fill_args(A, in, cin, hin, win, wpk, ntaps, taps_dy, taps_dx, in_mul, tile_h, tile_w, out, cout, hout,
                             wout, out_mul, out_py, out_px, scale, shift, relu, residual);
+  if (tile_cfg == 10) {  // activation-stationary LDS variant (3x3, stride 1, cin % 16 == 0)
+    if (eff != 9 || in_mul != 1 || out_mul != 1 || cin % 16 || hin != tile_h || win != tile_w) return SESSD_EINVAL;
+    dim3 grid(sessd_divup(tile_h * tile_w, 32), sessd_divup(A.cout_pad, 128), batch);
+    hipLaunchKernelGGL(conv3x3s1_lds_kernel, grid, dim3(256), 0, stream, A);
+    SESSD_CHECK_LAUNCH();
+    return SESSD_OK;
+  }
   switch (eff) {
     case 1: return dispatch_tile<1>(&A, 1, batch, tile_cfg, stream);
     case 2: return dispatch_tile<2>(&A, 1, batch, tile_cfg, stream);

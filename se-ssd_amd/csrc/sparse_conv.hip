@@ -33,7 +33,9 @@ __device__ __forceinline__ f32x4 bufload4(rsrc_t r, unsigned voff, unsigned soff
 }
 #define SESSD_OOB 0x80000000u
 
-template <int CIN, int COUT, bool DENSE_OUT>
+// NTW = 16-wide cout tiles per wave; blockIdx.y selects the cout group (COUT/16/NTW groups): splitting Cout over
+// more waves fills the 1024 SIMDs when a level has fewer than 1024 site tiles (batch 1).
+template <int CIN, int COUT, int NTW, bool DENSE_OUT>
 __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restrict__ in_feat,
                                                            const int* __restrict__ nbr,
                                                            const uint32_t* __restrict__ tile_mask, int kv,
@@ -45,7 +47,9 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
                                                            const int* __restrict__ out_indices,
                                                            float* __restrict__ dense_out, int dD, int dH, int dW) {
   constexpr int STEPS = CIN / 4;          // MFMA k-steps per offset
-  constexpr int NTILE = COUT / 16;        // 16-wide cout tiles
+  constexpr int NTILE = NTW;              // 16-wide cout tiles handled by this wave
+  constexpr int NTALL = COUT / 16;        // ... of all groups
+  const int tbase = blockIdx.y * NTW;
   constexpr int G = STEPS < 4 ? STEPS : 4;  // floats per vector load
   constexpr int SG = STEPS / G;
   const int lane = threadIdx.x & 63;
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   // loop (the f32 MFMA shares the SIMD lanes with the VALU); a missing neighbour gets an out-of-range offset and
   // the hardware returns zeros for its row.
   const rsrc_t fr = make_rsrc(in_feat, 0x7FFFFFFFu);
-  const rsrc_t wrs = make_rsrc(wpk, (unsigned)kv * NTILE * STEPS * 64u * 4u);
+  const rsrc_t wrs = make_rsrc(wpk, (unsigned)kv * NTALL * STEPS * 64u * 4u);
   float a[2][STEPS], bw[2][NTILE][STEPS];
   uint32_t rest = tmask;
   int remaining = __builtin_popcount(tmask);
@@ -79,7 +83,7 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
 #define SESSD_LOADAB(SET, K, ROW)                                                                  \
   {                                                                                                \
     const unsigned ao = (ROW) >= 0 ? (unsigned)(((ROW)*CIN + kq * STEPS) * 4) : SESSD_OOB;          \
-    const unsigned ws = (unsigned)(K) * (NTILE * STEPS * 64 * 4);                                  \
+    const unsigned ws = (unsigned)(K) * (NTALL * STEPS * 64 * 4);                                  \
     if (G == 4) {                                                                                  \
       _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                             \
         const f32x4 v = bufload4(fr, ao + 16u * g, 0);                                             \
@@ -87,14 +91,14 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
       }                                                                                            \
       _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
         _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                           \
-          const f32x4 v = bufload4(wrs, (unsigned)lane * 16u + (unsigned)(t * SG + g) * 1024u, ws); \
+          const f32x4 v = bufload4(wrs, (unsigned)lane * 16u + (unsigned)((tbase + t) * SG + g) * 1024u, ws); \
           bw[SET][t][4 * g] = v.x; bw[SET][t][4 * g + 1] = v.y; bw[SET][t][4 * g + 2] = v.z; bw[SET][t][4 * g + 3] = v.w; \
         }                                                                                          \
     } else {                                                                                       \
       _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) a[SET][s2] = bufload1(fr, ao + 4u * s2, 0); \
       _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
         _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2)                                       \
-          bw[SET][t][s2] = bufload1(wrs, ((unsigned)(t * SG) * 64u + lane) * (G * 4u) + 4u * s2, ws); \
+          bw[SET][t][s2] = bufload1(wrs, ((unsigned)((tbase + t) * SG) * 64u + lane) * (G * 4u) + 4u * s2, ws); \
     }                                                                                              \
   }
 #define SESSD_MMA(SET)                                                                             \
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   // C/D layout: column (cout) = lane & 15, rows (sites) = (lane >> 4) * 4 + r
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) {
-    const int co = t * 16 + i;
+    const int co = (tbase + t) * 16 + i;
     const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -172,20 +176,37 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin,
   wpk[idx] = w[((size_t)k * cin + ci) * cout + co];
 }
 
-template <int CIN, int COUT>
-int launch(bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
-           int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
-           const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
+template <int CIN, int COUT, int NTW>
+int launch_ntw(bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
+               int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
+               const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
   const int tiles = sessd_divup(n_cap, 16);
-  dim3 grid(sessd_divup(tiles, 4)), block(256);
+  dim3 grid(sessd_divup(tiles, 4), COUT / 16 / NTW), block(256);
   if (dense)
-    hipLaunchKernelGGL((sparse_conv_kernel<CIN, COUT, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv, n_dev,
-                       n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2]);
+    hipLaunchKernelGGL((sparse_conv_kernel<CIN, COUT, NTW, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
+                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2]);
   else
-    hipLaunchKernelGGL((sparse_conv_kernel<CIN, COUT, false>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv, n_dev,
-                       n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0);
+    hipLaunchKernelGGL((sparse_conv_kernel<CIN, COUT, NTW, false>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
+                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
+}
+
+template <int CIN, int COUT>
+int launch(int split, bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
+           int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
+           const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
+  constexpr int NT = COUT / 16;
+  if (split <= 0) split = (n_cap / 16 < 2048 && NT >= 2) ? 2 : 1;  // heuristic: fill the chip on small levels
+#define SESSD_ARGS dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
+  if constexpr (NT % 4 == 0) {
+    if (split >= 4) return launch_ntw<CIN, COUT, NT / 4>(SESSD_ARGS);
+  }
+  if constexpr (NT % 2 == 0) {
+    if (split >= 2) return launch_ntw<CIN, COUT, NT / 2>(SESSD_ARGS);
+  }
+  return launch_ntw<CIN, COUT, NT>(SESSD_ARGS);
+#undef SESSD_ARGS
 }
 
 }  // namespace
@@ -204,20 +225,21 @@ int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, in
   return SESSD_OK;
 }
 
+// cout_split: 0 = heuristic, 1/2/4 = number of waves that share one 16-site tile (each takes Cout/split channels).
 // out[o] = act( (sum_k W[k]^T in[nbr[k][o]]) * scale + shift ). If dense_out != NULL the result is
 // scattered instead into the dense BEV tensor (B, cout*D, H, W) with dense_dims3 = (D,H,W) (pre-zeroed
 // by the caller) and out_feat may be NULL.
 int sessd_sparse_conv(const float* in_feat, int cin, const int* nbr, const uint32_t* tile_mask, int kernel_volume,
                       const int* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
                       const float* shift, int relu, float* out_feat, int cout, const int* out_indices,
-                      float* dense_out, const int* dense_dims3, hipStream_t stream) {
+                      float* dense_out, const int* dense_dims3, int cout_split, hipStream_t stream) {
   if (n_out_cap <= 0 || kernel_volume <= 0 || kernel_volume > 32) return SESSD_EINVAL;
   const bool dense = dense_out != nullptr;
   if (dense && (!out_indices || !dense_dims3)) return SESSD_EINVAL;
   if (!dense && !out_feat) return SESSD_EINVAL;
 #define SESSD_SC(CI, CO)                                                                                              \
   if (cin == CI && cout == CO)                                                                                        \
-    return launch<CI, CO>(dense, in_feat, nbr, tile_mask, kernel_volume, n_out_dev, n_out_cap, packed_weight, scale,  \
+    return launch<CI, CO>(cout_split, dense, in_feat, nbr, tile_mask, kernel_volume, n_out_dev, n_out_cap, packed_weight, scale,  \
                           shift, relu, out_feat, out_indices, dense_out, dense_dims3, stream);
   SESSD_SC(4, 16)
   SESSD_SC(16, 16)

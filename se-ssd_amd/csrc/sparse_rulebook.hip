@@ -166,7 +166,11 @@ __global__ __launch_bounds__(NT) void rulebook_kernel(const int* __restrict__ ou
   const bool live = o < n;
   if (live) c = *reinterpret_cast<const int4*>(out_indices + (size_t)o * 4);
   uint32_t tm = 0;
-  for (int k0 = 0; k0 < KV; k0 += 4) {
+  // fully unrolled (KV <= 28): the 7 hash probes of a lane are independent, so they are all in flight at once
+  // instead of 7 dependent global-memory round trips
+#pragma unroll
+  for (int k0 = 0; k0 < 28; k0 += 4) {
+    if (k0 >= KV) break;
     const int k = k0 + (lane >> 4);
     int found = -1;
     if (live && k < KV) {
@@ -275,7 +279,7 @@ int sessd_sparse_rulebook(const int* out_indices, const int* n_out_dev, int n_ou
                           uint32_t in_capacity, const int* in_dims3, int* nbr, uint32_t* tile_mask, hipStream_t stream) {
   if (n_out_cap <= 0 || (in_capacity & (in_capacity - 1)) != 0) return SESSD_EINVAL;
   const int kv = ksize3[0] * ksize3[1] * ksize3[2];
-  if (kv > 32) return SESSD_EINVAL;
+  if (kv > 28) return SESSD_EINVAL;
   ConvGeom G;
   fill_geom(G, ksize3, stride3, pad3, in_dims3, nullptr);
   const int tiles = sessd_divup(n_out_cap, 16);

@@ -215,6 +215,8 @@ class InferenceEngine:
         self.tile_cfg = {}
         self.tune_report = {}
         self._tuning = None
+        self.sparse_split = {}
+        self._tuning_sparse = None
 
     # ------------------------------------------------------------------ helpers
     def _i3(self, v):
@@ -250,7 +252,7 @@ class InferenceEngine:
                                         Li["hash"].vals.data_ptr(), Li["hash"].capacity, Li["hash"]._dims_t.data_ptr(),
                                         nbr.data_ptr(), tm.data_ptr(), s), "sparse_rulebook")
 
-    def _sconv(self, lay, in_feat, nbr, tm, out_li, out_feat, s, dense=False):
+    def _sconv(self, lay, in_feat, nbr, tm, out_li, out_feat, s, dense=False, idx=None):
         Lo = self.levels[out_li]
         kv = lay["ks"][0] * lay["ks"][1] * lay["ks"][2]
         # nbr buffers are allocated [27][cap]; a (3,1,1) kernel uses the first 3 rows
@@ -258,8 +260,10 @@ class InferenceEngine:
         check(lib.sessd_sparse_conv(in_feat.data_ptr(), lay["cin"], nbr.data_ptr(), tm.data_ptr(), kv, self._n(out_li),
                                     Lo["cap"], lay["wpk"].data_ptr(), lay["scale"].data_ptr(), lay["shift"].data_ptr(), 1,
                                     0 if dense else out_feat.data_ptr(), lay["cout"],
-                                    Lo["indices"].data_ptr() if dense else 0, self.bev.data_ptr() if dense else 0, dd, s),
-              "sparse_conv")
+                                    Lo["indices"].data_ptr() if dense else 0, self.bev.data_ptr() if dense else 0, dd,
+                                    self.sparse_split.get(idx, 0), s), "sparse_conv")
+        if self._tuning_sparse is not None and not dense:
+            self._tuning_sparse.append((idx, lay, in_feat, nbr, tm, out_li, out_feat))
 
     def _conv(self, x, layer, out, relu=True, residual=None, name=None):
         pc, scale, shift = layer
@@ -270,14 +274,40 @@ class InferenceEngine:
     def autotune(self, candidates=(1, 2, 3, 4, 6), reps=5):
         """Pick the wave/workgroup tiling of every dense conv launch by timing it on this device (one-off, ~0.1 s).
         Needs one representative frame already staged with set_points()."""
-        self._tuning = []
+        self._tuning, self._tuning_sparse = [], []
         self.enqueue()
         torch.cuda.synchronize()
         todo, self._tuning = self._tuning, None
+        todo_sp, self._tuning_sparse = self._tuning_sparse, None
+        st = torch.cuda.current_stream().cuda_stream
+        for idx, lay, in_feat, nbr, tm, out_li, out_feat in todo_sp:
+            if lay["cout"] < 32:
+                continue
+            best = (None, 1e30)
+            for split in (1, 2, 4):
+                if (lay["cout"] // 16) % split:
+                    continue
+                self.sparse_split[idx] = split
+                for _ in range(2):
+                    self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, idx=idx)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, idx=idx)
+                e1.record()
+                torch.cuda.synchronize()
+                t = e0.elapsed_time(e1) / reps
+                if t < best[1]:
+                    best = (split, t)
+            self.sparse_split[idx] = best[0]
+            self.tune_report["sparse%d" % idx] = best
         for name, x, layer, out, relu, residual in todo:
             pc, scale, shift = layer
             best = (None, 1e30)
-            for cfg in candidates:
+            cands = list(candidates)
+            if pc.kind == "conv" and pc.stride == 1 and pc.launches[0]["ntaps"] == 9 and pc.cin % 16 == 0:
+                cands.append(10)  # activation-stationary LDS variant
+            for cfg in cands:
                 if pc.cout <= 32 and cfg != 4:
                     continue
                 for _ in range(2):
@@ -333,7 +363,7 @@ class InferenceEngine:
                     self._rulebook(li, lay["ks"], 1, [k // 2 for k in lay["ks"]], li, L["nbr_subm"], L["tm_subm"], s)
                     have_subm = True
                 out = L["feat_a"] if feat is not L["feat_a"] else L["feat_b"]
-                self._sconv(lay, feat, L["nbr_subm"], L["tm_subm"], li, out, s)
+                self._sconv(lay, feat, L["nbr_subm"], L["tm_subm"], li, out, s, idx=idx)
                 feat = out
             else:
                 Li, Lo = self.levels[li], self.levels[li + 1]
@@ -348,9 +378,9 @@ class InferenceEngine:
                 self._rulebook(li + 1, lay["ks"], lay["st"], lay["pd"], li, Lo["nbr_down"], Lo["tm_down"], s)
                 if last:
                     check(lib.sessd_fill_u32(self.bev.data_ptr(), 0, self.bev.numel(), s), "fill")
-                    self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, None, s, dense=True)
+                    self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, None, s, dense=True, idx=idx)
                 else:
-                    self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, Lo["feat_a"], s)
+                    self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, Lo["feat_a"], s, idx=idx)
                     feat = Lo["feat_a"]
                 li += 1
                 have_subm = False

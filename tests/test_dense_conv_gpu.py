@@ -32,6 +32,23 @@ def test_conv2d(dev, cfg, cin, cout, k, stride, H, W):
     _close(got, ref)
 
 
+@pytest.mark.parametrize("cin,cout,H,W", [(128, 128, 24, 40), (256, 256, 13, 19), (16, 32, 9, 7), (128, 128, 200, 176)])
+def test_lds_variant_bit_identical(dev, cin, cout, H, W):
+    """tile_cfg 10 (activation-stationary, LDS staged) must equal the direct kernel bit for bit (same fmaf order)."""
+    g = torch.Generator().manual_seed(cin + H)
+    x = torch.randn(2, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(dev)
+    scale = (torch.rand(cout, generator=g) + 0.5).to(dev)
+    shift = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    res = torch.randn(2, cout, H, W, generator=g).to(dev)
+    pc = ops.pack_conv2d(w, 1)
+    a = ops.conv2d(x, pc, scale, shift, True, residual=res, tile_cfg=3)
+    b = ops.conv2d(x, pc, scale, shift, True, residual=res, tile_cfg=10)
+    assert torch.equal(a, b)
+    ref = torch.relu(F.conv2d(x.cpu(), w.cpu(), padding=1) * scale.cpu().view(1, -1, 1, 1) + shift.cpu().view(1, -1, 1, 1)) + res.cpu()
+    _close(b.cpu(), ref)
+
+
 @pytest.mark.parametrize("cfg", [1, 3])
 def test_deconv_s2_with_residual(dev, cfg):
     g = torch.Generator().manual_seed(9)
