@@ -174,6 +174,13 @@ def main():
                                "9-tap launches are 80.6 of the frame's 90.8 dense GFLOP)", "achieved": ach,
                                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
                                "avg_launch_ms": kms, "flops_per_launch": CONV_FLOPS, "traffic": None}
+            # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
+            # under profiles/; it cannot be collected inside this process
+            tpath = os.path.join(ROOT, "profiles", "r1_conv_traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                out["roofline"]["traffic"] = tj["traffic_bytes"]
+                out["roofline"]["traffic_source"] = tj["source"]
         # ---- CPU baseline: the oracle port of the reference path on the host cores of this box (bounded sample)
         if args.cpu_frames > 0 and world == 1:
             from oracle import pipeline, postprocess as pp

@@ -63,8 +63,21 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   const int j = lane & 31, h = lane >> 5;
   const int wc = wave % WC, wp = wave / WC;
   const int npix = A.ht * A.wt;
-  const int p_base = (blockIdx.x * WP + wp) * (PT * 32);
-  const int m_base = (blockIdx.y * WC + wc) * (CT * 32);
+  // XCD-aware workgroup order: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (private
+  // L2 each). Remap so that each XCD owns one contiguous run of pixel tiles (with all their cout groups): the
+  // 3-row halo that neighbouring tiles share then hits in that XCD's L2 instead of being fetched once per XCD
+  // (rocprofv3 FETCH_SIZE of the 128->128 layer: 131 MB -> see profiles/; the algorithmic input is 18.6 MB).
+  const int ny = sessd_divup(A.cout_pad, WC * CT * 32);
+  int bx, by;
+  {
+    const int total = gridDim.x, bid = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = bid & 7, loc = bid >> 3;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    bx = wgid / ny;
+    by = wgid - bx * ny;
+  }
+  const int p_base = (bx * WP + wp) * (PT * 32);
+  const int m_base = (by * WC + wc) * (CT * 32);
   if (p_base >= npix || m_base >= A.cout_pad) return;
   const int in_plane = A.hin * A.win;
 
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(256) void ssfa_fuse_kernel(const float* __restrict_
 template <int NTAPS, int CT, int PT, int WC, int WP>
 int launch_conv(const ConvArgs* A, int nconv, int batch, hipStream_t stream) {
   const int npix = A[0].ht * A[0].wt;
-  dim3 grid(sessd_divup(npix, WP * PT * 32), sessd_divup(A[0].cout_pad, WC * CT * 32), batch * (nconv > 1 ? 4 : 1));
+  dim3 grid(sessd_divup(npix, WP * PT * 32) * sessd_divup(A[0].cout_pad, WC * CT * 32), 1, batch * (nconv > 1 ? 4 : 1));
   if (nconv == 1) {
     hipLaunchKernelGGL((conv2d_mfma_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A[0]);
   } else {
