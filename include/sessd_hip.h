@@ -65,6 +65,12 @@ int sessd_boxes_pairwise(int mode, const float* boxes_a, int num_a, const float*
                          sessd_stream_t stream);
 int sessd_boxes_aligned_overlap_bev(const float* boxes_a, const float* boxes_b, int num, float* out,
                                     sessd_stream_t stream);
+/* numba-convention rotated IoU used by the KITTI AP evaluation: det3d/ops/nms/nms_gpu.py:541-577,636-672
+ * (rotate_iou_gpu / rotate_iou_gpu_eval). boxes (N,5), query (K,5) [cx,cy,w,l,angle] -> (N,K);
+ * criterion -1 IoU | 0 inter/area(query) | 1 inter/area(box) | 2 intersection area. */
+int sessd_rotate_iou_eval(const float* boxes, int num_boxes, const float* query, int num_query, int criterion, float* out,
+                          sessd_stream_t stream);
+/* sessd_nms_sorted modes 3 / 4 = numba rotate_nms_gpu (nms_gpu.py:422-499) / nms_gpu (+1 convention, :36-169) */
 size_t sessd_nms_workspace_bytes(int num_boxes);
 int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, long long* keep, int32_t* num_keep,
                      void* workspace, size_t workspace_bytes, sessd_stream_t stream);

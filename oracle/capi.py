@@ -35,8 +35,9 @@ def lib():
         L.oracle_quad_iou.argtypes = [_f32p, _f32p]
         L.oracle_rotate_nms.restype = C.c_int
         L.oracle_rotate_nms.argtypes = [_f32p, C.c_int, _i32p, C.c_float, _i32p, C.c_double, _i32p]
-        if hasattr(L, "oracle_rotate_iou_eval"):
-            L.oracle_rotate_iou_eval.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _f32p]
+        L.oracle_rotate_iou_eval.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _f32p]
+        L.oracle_rotate_iou_pair.restype = C.c_float
+        L.oracle_rotate_iou_pair.argtypes = [_f32p, _f32p, C.c_int]
     return _lib
 
 
@@ -159,3 +160,16 @@ def rotate_nms_cc(dets, thresh, order=None, margin=1e-4):
     near = np.zeros((1,), np.int32)
     n = lib().oracle_rotate_nms(dets, K, order, float(thresh), keep, float(margin), near)
     return keep[:n].astype(np.int64), int(near[0])
+
+
+# ---------------------------------------------------------------- numba-convention rotated IoU (AP evaluation family)
+def rotate_iou_eval(boxes, query_boxes, criterion=-1):
+    """nms_gpu.py:636-672 rotate_iou_gpu_eval: boxes (N,5), query (K,5) [cx,cy,w,l,angle] -> (N,K)."""
+    b, q = _f32(boxes).reshape(-1, 5), _f32(query_boxes).reshape(-1, 5)
+    out = np.zeros((b.shape[0], q.shape[0]), np.float32)
+    lib().oracle_rotate_iou_eval(b, b.shape[0], q, q.shape[0], int(criterion), out)
+    return out
+
+
+def rotate_iou_pair(r1, r2, criterion=-1):
+    return float(lib().oracle_rotate_iou_pair(_f32(r1), _f32(r2), int(criterion)))

@@ -145,6 +145,180 @@ __global__ __launch_bounds__(64) void nms_mask_kernel(int n, float thresh, const
   mask[(size_t)i * cb + cblk] = bits;
 }
 
+// ---- numba-convention rotated IoU (det3d/ops/nms/nms_gpu.py:183-419,580-633) ----------------------------
+// boxes [cx, cy, w, l, angle]; corners rotated clockwise-positive about the centre, intersection polygon =
+// corners of each quad inside the other (closed dot-product test) + 16 edge/edge crossings, ordered by a
+// pseudo-angle key with an insertion sort, area = fan of |triangle| areas. Per-thread scratch (8 points + keys)
+// lives in k-major LDS like the iou3d polygon lists.
+struct RotLds {
+  float px[8][256];
+  float py[8][256];
+  float vs[8][256];
+};
+
+__device__ __forceinline__ void rot_corners(const float* r, float* c) {
+  const float a_cos = cosf(r[4]), a_sin = sinf(r[4]);
+  const float xs[4] = {-r[2] / 2, -r[2] / 2, r[2] / 2, r[2] / 2}, ys[4] = {-r[3] / 2, r[3] / 2, r[3] / 2, -r[3] / 2};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    c[2 * i] = a_cos * xs[i] + a_sin * ys[i] + r[0];
+    c[2 * i + 1] = -a_sin * xs[i] + a_cos * ys[i] + r[1];
+  }
+}
+
+__device__ __forceinline__ bool rot_in_quad(float x, float y, const float* c) {
+  const float ab0 = c[2] - c[0], ab1 = c[3] - c[1], ad0 = c[6] - c[0], ad1 = c[7] - c[1];
+  const float ap0 = x - c[0], ap1 = y - c[1];
+  const float abab = ab0 * ab0 + ab1 * ab1, abap = ab0 * ap0 + ab1 * ap1;
+  const float adad = ad0 * ad0 + ad1 * ad1, adap = ad0 * ap0 + ad1 * ap1;
+  return abab >= abap && abap >= 0 && adad >= adap && adap >= 0;
+}
+
+__device__ __forceinline__ bool rot_seg_inter(const float* p1, const float* p2, int i, int j, float* ox, float* oy) {
+  const float A0 = p1[2 * i], A1 = p1[2 * i + 1], B0 = p1[2 * ((i + 1) & 3)], B1 = p1[2 * ((i + 1) & 3) + 1];
+  const float C0 = p2[2 * j], C1 = p2[2 * j + 1], D0 = p2[2 * ((j + 1) & 3)], D1 = p2[2 * ((j + 1) & 3) + 1];
+  const float BA0 = B0 - A0, BA1 = B1 - A1, DA0 = D0 - A0, CA0 = C0 - A0, DA1 = D1 - A1, CA1 = C1 - A1;
+  const bool acd = DA1 * CA0 > CA1 * DA0;
+  const bool bcd = (D1 - B1) * (C0 - B0) > (C1 - B1) * (D0 - B0);
+  if (acd == bcd) return false;
+  const bool abc = CA1 * BA0 > BA1 * CA0;
+  const bool abd = DA1 * BA0 > BA1 * DA0;
+  if (abc == abd) return false;
+  const float DC0 = D0 - C0, DC1 = D1 - C1;
+  const float ABBA = A0 * B1 - B0 * A1, CDDC = C0 * D1 - D0 * C1;
+  const float DH = BA1 * DC0 - BA0 * DC1;
+  *ox = (ABBA * DC0 - BA0 * CDDC) / DH;
+  *oy = (ABBA * DC1 - BA1 * CDDC) / DH;
+  return true;
+}
+
+__device__ float rot_inter(const float* r1, const float* r2, float* PX, float* PY, float* VS, int stride) {
+  {  // exact zero when the bounding circles are disjoint (no corner inside, no crossing)
+    const float dx = r1[0] - r2[0], dy = r1[1] - r2[1];
+    const float ra = 0.5f * sqrtf(r1[2] * r1[2] + r1[3] * r1[3]), rb = 0.5f * sqrtf(r2[2] * r2[2] + r2[3] * r2[3]);
+    const float reach = ra + rb + 1e-2f;
+    if (dx * dx + dy * dy > reach * reach) return 0.f;
+  }
+  float c1[8], c2[8];
+  rot_corners(r1, c1);
+  rot_corners(r2, c2);
+  int n = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if (rot_in_quad(c1[2 * i], c1[2 * i + 1], c2) && n < 8) { PX[n * stride] = c1[2 * i]; PY[n * stride] = c1[2 * i + 1]; ++n; }
+    if (rot_in_quad(c2[2 * i], c2[2 * i + 1], c1) && n < 8) { PX[n * stride] = c2[2 * i]; PY[n * stride] = c2[2 * i + 1]; ++n; }
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x, y;
+      if (rot_seg_inter(c1, c2, i, j, &x, &y) && n < 8) { PX[n * stride] = x; PY[n * stride] = y; ++n; }
+    }
+  if (n < 3) return 0.f;
+  float cx = 0.f, cy = 0.f;
+  for (int i = 0; i < n; ++i) { cx += PX[i * stride]; cy += PY[i * stride]; }
+  cx /= n; cy /= n;
+  for (int i = 0; i < n; ++i) {
+    float vx = PX[i * stride] - cx, vy = PY[i * stride] - cy;
+    const float d = sqrtf(vx * vx + vy * vy);
+    vx = vx / d; vy = vy / d;
+    if (vy < 0) vx = -2 - vx;
+    VS[i * stride] = vx;
+  }
+  for (int i = 1; i < n; ++i) {
+    if (VS[(i - 1) * stride] > VS[i * stride]) {
+      const float temp = VS[i * stride], tx = PX[i * stride], ty = PY[i * stride];
+      int j = i;
+      while (j > 0 && VS[(j - 1) * stride] > temp) {
+        VS[j * stride] = VS[(j - 1) * stride]; PX[j * stride] = PX[(j - 1) * stride]; PY[j * stride] = PY[(j - 1) * stride];
+        --j;
+      }
+      VS[j * stride] = temp; PX[j * stride] = tx; PY[j * stride] = ty;
+    }
+  }
+  float area = 0.f;
+  const float x0 = PX[0], y0 = PY[0];
+  for (int i = 0; i < n - 2; ++i) {
+    const float bx = PX[(i + 1) * stride], by = PY[(i + 1) * stride], c0 = PX[(i + 2) * stride], c1y = PY[(i + 2) * stride];
+    area += fabsf(((x0 - c0) * (by - c1y) - (y0 - c1y) * (bx - c0)) / 2.0f);
+  }
+  return area;
+}
+
+__device__ __forceinline__ float rot_iou_crit(const float* r1, const float* r2, int criterion, float* PX, float* PY,
+                                              float* VS, int stride) {
+  const float a1 = r1[2] * r1[3], a2 = r2[2] * r2[3];
+  const float it = rot_inter(r1, r2, PX, PY, VS, stride);
+  if (criterion == -1) return it / (a1 + a2 - it);
+  if (criterion == 0) return it / a1;
+  if (criterion == 1) return it / a2;
+  return it;
+}
+
+// out[n][k] = devRotateIoUEval(query[k], boxes[n], criterion) -- query FIRST, as rotate_iou_kernel_eval does
+__global__ __launch_bounds__(256) void rotate_iou_eval_kernel(const float* __restrict__ boxes, int N,
+                                                               const float* __restrict__ query, int K, int criterion,
+                                                               float* __restrict__ out) {
+  __shared__ RotLds S;
+  const int k = blockIdx.x * 16 + (threadIdx.x & 15), n = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (n >= N || k >= K) return;
+  float rb[5], rq[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) { rb[q] = boxes[(size_t)n * 5 + q]; rq[q] = query[(size_t)k * 5 + q]; }
+  const int t = threadIdx.x;
+  out[(size_t)n * K + k] = rot_iou_crit(rq, rb, criterion, &S.px[0][t], &S.py[0][t], &S.vs[0][t], 256);
+}
+
+// rotate_nms_kernel (nms_gpu.py:422-458): suppress when devRotateIoU(row, col) > thresh; boxes (N,5) sorted
+__global__ __launch_bounds__(64) void rotate_nms_numba_mask_kernel(int n, float thresh, const float* __restrict__ boxes,
+                                                                    unsigned long long* __restrict__ mask) {
+  const int rblk = blockIdx.y, cblk = blockIdx.x;
+  if (cblk < rblk) return;
+  __shared__ float bb[64][5];
+  __shared__ float px[8][64], py[8][64], vs[8][64];
+  const int t = threadIdx.x;
+  const int ncol = min(n - cblk * 64, 64), nrow = min(n - rblk * 64, 64);
+  if (t < ncol)
+#pragma unroll
+    for (int q = 0; q < 5; ++q) bb[t][q] = boxes[(size_t)(cblk * 64 + t) * 5 + q];
+  __syncthreads();
+  if (t >= nrow) return;
+  const int i = rblk * 64 + t;
+  float ri[5];
+#pragma unroll
+  for (int q = 0; q < 5; ++q) ri[q] = boxes[(size_t)i * 5 + q];
+  unsigned long long bits = 0;
+  for (int k = (rblk == cblk) ? t + 1 : 0; k < ncol; ++k)
+    if (rot_iou_crit(ri, bb[k], -1, &px[0][t], &py[0][t], &vs[0][t], 64) > thresh) bits |= 1ull << k;
+  mask[(size_t)i * sessd_divup(n, 64) + cblk] = bits;
+}
+
+// numba nms_kernel / iou_device (nms_gpu.py:22-104): axis aligned with the +1 pixel convention; boxes (N,5) x1,y1,x2,y2,score
+__global__ __launch_bounds__(64) void nms_plus1_mask_kernel(int n, float thresh, const float* __restrict__ boxes,
+                                                             unsigned long long* __restrict__ mask) {
+  const int rblk = blockIdx.y, cblk = blockIdx.x;
+  if (cblk < rblk) return;
+  __shared__ float bb[64][4];
+  const int t = threadIdx.x;
+  const int ncol = min(n - cblk * 64, 64), nrow = min(n - rblk * 64, 64);
+  if (t < ncol)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bb[t][q] = boxes[(size_t)(cblk * 64 + t) * 5 + q];
+  __syncthreads();
+  if (t >= nrow) return;
+  const int i = rblk * 64 + t;
+  const float a0 = boxes[(size_t)i * 5], a1 = boxes[(size_t)i * 5 + 1], a2 = boxes[(size_t)i * 5 + 2], a3 = boxes[(size_t)i * 5 + 3];
+  unsigned long long bits = 0;
+  for (int k = (rblk == cblk) ? t + 1 : 0; k < ncol; ++k) {
+    const float left = fmaxf(a0, bb[k][0]), right = fminf(a2, bb[k][2]), top = fmaxf(a1, bb[k][1]), bottom = fminf(a3, bb[k][3]);
+    const float w = fmaxf(right - left + 1, 0.f), h = fmaxf(bottom - top + 1, 0.f), inter = w * h;
+    const float sa = (a2 - a0 + 1) * (a3 - a1 + 1), sb = (bb[k][2] - bb[k][0] + 1) * (bb[k][3] - bb[k][1] + 1);
+    if (inter / (sa + sb - inter) > thresh) bits |= 1ull << k;
+  }
+  mask[(size_t)i * sessd_divup(n, 64) + cblk] = bits;
+}
+
 }  // namespace
 
 // Greedy reduction of a suppression bitmask by ONE wave, shared with nms.hip.
@@ -247,11 +421,12 @@ size_t sessd_nms_workspace_bytes(int num_boxes) {
   return sessd_align((size_t)num_boxes * sessd_divup(num_boxes > 0 ? num_boxes : 1, 64) * 8 + 8, 256);
 }
 
-// mode: 0 rotated BEV (N,5) | 1 3-D (N,7) | 2 axis aligned (N,5). Boxes sorted by descending score.
+// mode: 0 rotated BEV (N,5) | 1 3-D (N,7) | 2 axis aligned (N,5) | 3 numba rotate_nms (N,5 [cx,cy,w,l,r]) |
+// 4 numba nms (+1 pixel convention, N,5 [x1,y1,x2,y2,-]). Boxes sorted by descending score.
 // keep (device, int64[num_boxes]) and num_keep (device int) are written on `stream`; no host sync.
 int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, long long* keep, int* num_keep,
                      void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (num_boxes < 0 || mode < 0 || mode > 2) return SESSD_EINVAL;
+  if (num_boxes < 0 || mode < 0 || mode > 4) return SESSD_EINVAL;
   if (num_boxes > 64 * 64 * 4) return SESSD_EINVAL;
   if (workspace_bytes < sessd_nms_workspace_bytes(num_boxes)) return SESSD_EWORKSPACE;
   if (num_boxes == 0) {
@@ -265,11 +440,27 @@ int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, 
     hipLaunchKernelGGL((nms_mask_kernel<MODE_IOU_BEV, 5>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
   else if (mode == 1)
     hipLaunchKernelGGL((nms_mask_kernel<MODE_IOU_3D, 7>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
-  else
+  else if (mode == 2)
     hipLaunchKernelGGL((nms_mask_kernel<MODE_IOU_NORMAL, 5>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
+  else if (mode == 3)
+    hipLaunchKernelGGL(rotate_nms_numba_mask_kernel, grid, block, 0, stream, num_boxes, thresh, boxes, mask);
+  else
+    hipLaunchKernelGGL(nms_plus1_mask_kernel, grid, block, 0, stream, num_boxes, thresh, boxes, mask);
   SESSD_CHECK_LAUNCH();
   hipLaunchKernelGGL(sessd_nms_reduce_kernel, dim3(1), dim3(64), 0, stream, (const int*)nullptr, num_boxes, mask, cb,
                      num_boxes, keep, (int*)nullptr, num_keep);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// det3d/ops/nms/nms_gpu.py:636-672 rotate_iou_gpu_eval (and :541-577 rotate_iou_gpu with criterion -1):
+// boxes (N,5), query (K,5) [cx,cy,w,l,angle] -> out (N,K); criterion -1 IoU | 0 inter/area(query) | 1 inter/area(box) | 2 inter
+int sessd_rotate_iou_eval(const float* boxes, int num_boxes, const float* query, int num_query, int criterion, float* out,
+                          hipStream_t stream) {
+  if (num_boxes < 0 || num_query < 0) return SESSD_EINVAL;
+  if (num_boxes == 0 || num_query == 0) return SESSD_OK;
+  hipLaunchKernelGGL(rotate_iou_eval_kernel, dim3(sessd_divup(num_query, 16), sessd_divup(num_boxes, 16)), dim3(256), 0, stream,
+                     boxes, num_boxes, query, num_query, criterion, out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -63,13 +63,13 @@ def rotate_nms(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_thres
 
 
 def nms(bboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5):
-    """axis-aligned NMS (box_torch_ops.py:505-524); boxes (K,4) [x1,y1,x2,y2]. Uses the iou3d 'normal' bitmask NMS."""
+    """axis-aligned NMS (box_torch_ops.py:505-524 -> nms_gpu, numba kernel with the +1 pixel convention); boxes (K,4)."""
     if bboxes.shape[0] == 0:
         return torch.zeros([0]).long().to(bboxes.device)
     k = scores.shape[0] if pre_max_size is None else min(scores.shape[0], pre_max_size)
     scores, indices = torch.topk(scores, k=k)
     b5 = torch.cat([bboxes[indices].float(), torch.zeros((k, 1), device=bboxes.device)], 1).contiguous()
-    keep, num = ops.nms_sorted(2, b5, iou_threshold)
+    keep, num = ops.nms_sorted(4, b5, iou_threshold)
     keep = keep[: int(num.item())]
     if post_max_size is not None:
         keep = keep[:post_max_size]

@@ -24,6 +24,7 @@ SIGNATURES = {
     "sessd_vfe_mean": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "sessd_boxes_pairwise": (i32, [i32, vp, i32, vp, i32, vp, vp]),
     "sessd_boxes_aligned_overlap_bev": (i32, [vp, vp, i32, vp, vp]),
+    "sessd_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "sessd_nms_workspace_bytes": (sz, [i32]),
     "sessd_nms_sorted": (i32, [i32, vp, i32, f32, vp, vp, vp, sz, vp]),
     "sessd_conv2d_mfma": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32,

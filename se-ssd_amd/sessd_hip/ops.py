@@ -126,6 +126,16 @@ def boxes_aligned_overlap_bev(a, b, out=None):
     return out
 
 
+def rotate_iou_eval(boxes, query, criterion=-1):
+    """numba-convention rotated IoU: boxes (N,5), query (K,5) [cx,cy,w,l,angle] -> (N,K) float32 on the device."""
+    _req(boxes, torch.float32, "boxes")
+    _req(query, torch.float32, "query")
+    out = torch.zeros((boxes.shape[0], query.shape[0]), dtype=torch.float32, device=boxes.device)
+    check(lib.sessd_rotate_iou_eval(boxes.data_ptr(), boxes.shape[0], query.data_ptr(), query.shape[0], int(criterion),
+                                    out.data_ptr(), _stream()), "rotate_iou_eval")
+    return out
+
+
 def nms_sorted(mode, boxes, thresh):
     """boxes sorted by descending score. Returns (keep int64[N] device, num_keep int32[1] device)."""
     _req(boxes, torch.float32, "boxes")

@@ -89,3 +89,17 @@ def test_standup_iou_prefilter_matches_reference(golden_dir):
     iw = np.minimum(su[:, None, 2], su[None, :, 2]) - np.maximum(su[:, None, 0], su[None, :, 0])
     ih = np.minimum(su[:, None, 3], su[None, :, 3]) - np.maximum(su[:, None, 1], su[None, :, 1])
     assert np.array_equal((iw > 0) & (ih > 0), g["standup_iou"] > 0)
+
+
+def test_numba_rotate_iou_oracle_vs_reference_source(golden_dir):
+    """oracle/rotate_iou_eval.c vs the reference's numba device functions executed as Python (bit-equal)."""
+    g = np.load(os.path.join(golden_dir, "rotate_iou_numba_ref.npz"))
+    q = g["boxes"]
+    got = np.array([[oracle.rotate_iou_pair(q[i], q[j], -1) for j in range(24)] for i in range(24)], np.float32)
+    assert np.array_equal(got, g["iou"])
+    for crit, key in ((-1, "eval_m1"), (0, "eval_0"), (1, "eval_1"), (2, "eval_2")):
+        e = np.array([[oracle.rotate_iou_pair(q[i], q[j], crit) for j in range(12)] for i in range(12)], np.float32)
+        assert np.array_equal(e, g[key])
+    # the eval kernel passes the QUERY box first (nms_gpu.py:626-631)
+    ev = oracle.rotate_iou_eval(q[:5], q[5:9], 0)
+    assert ev[2, 1] == np.float32(oracle.rotate_iou_pair(q[6], q[2], 0))
