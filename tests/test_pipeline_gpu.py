@@ -109,3 +109,36 @@ def test_module_path_matches_engine(dev, model):
     if ref["box3d_lidar"].shape[0]:
         gb = got["box3d_lidar"].cpu().numpy()
         assert np.allclose(gb, ref["box3d_lidar"], rtol=1e-3, atol=1e-3)
+
+
+def test_data_pipeline_contract_to_detections(dev, model):
+    """Voxelization -> Reformat -> collate_kitti -> example_to_device -> VoxelNet.forward (reference call chain,
+    tools/test.py:121-146) on two frames == the fused engine on the same frames."""
+    from det3d.datasets.pipelines import Reformat, Voxelization
+    from det3d.torchie.parallel import collate_kitti, example_to_device
+    from det3d.torchie.utils.config import ConfigDict
+    vox = Voxelization(cfg=ConfigDict(range=VG["range"], voxel_size=VG["voxel_size"], max_points_in_voxel=5,
+                                      max_voxel_num=16000, far_points_first=False))
+    anchors = pp.create_anchors_3d_range().reshape(-1, 7)
+    cal = synth.kitti_calib()
+    fr = pp.get_valid_frustum(cal["rect"], cal["Trv2c"], cal["P2"], cal["image_shape"])
+    frames = [synth.make_frame(21, 20000), synth.make_frame(22, 17000)]
+    examples = []
+    for i, f in enumerate(frames):
+        res = dict(mode="val", labeled=False, metadata=dict(token=str(i)), calib=dict(frustum=fr),
+                   lidar=dict(points=f, targets=dict(anchors=[anchors])))
+        res, _ = vox(res, None)
+        ex, _ = Reformat()(res, None)
+        examples.append(ex)
+    batch = example_to_device(collate_kitti(examples), dev)
+    assert batch["coordinates"].shape[1] == 4 and int(batch["coordinates"][-1, 0]) == 1
+    with torch.no_grad():
+        dets = model(batch, return_loss=False)
+    eng = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 2, 20480, dev, use_frustum=True)
+    eng.set_points([torch.from_numpy(f).to(dev) for f in frames], torch.from_numpy(np.stack([fr, fr])).to(dev))
+    eng.enqueue()
+    ref = eng.results()
+    for d, r in zip(dets, ref):
+        assert d["box3d_lidar"].shape[0] == r["box3d_lidar"].shape[0]
+        assert np.allclose(d["scores"].cpu().numpy(), r["scores"], rtol=2e-3, atol=1e-6)
+    assert [d["metadata"]["token"] for d in dets] == ["0", "1"]
