@@ -7,7 +7,9 @@
 A "step" is ONE frame of BASELINE.json configs[1] ("Single MI355X inference, KITTI car voxel grid [1600,1408,40],
 max 16000 voxels, batch=1") through the whole path, input points already resident in HBM, detections left on the
 device (<= 100 boxes). Frames shard across ranks with no data-path collective (weak scaling: every rank runs K
-frames); value = total frames / max-over-ranks wall time. One JSON line on rank 0, with
+frames); value = total frames / max-over-ranks wall time. By default TWO frames are in flight per GPU (two independent
+batch-1 engines on two HIP streams, `--streams 1` for strictly sequential frames): a batch-1 layer is 4.3 wave tiles per
+SIMD, so the tail of one frame's kernels overlaps the other's. One JSON line on rank 0, with
   roofline      the dominant kernel (f32-MFMA 3x3 conv 128->128 @200x176, 5 launches per frame) against the dense
                 f32 MFMA peak, its duration measured live with HIP events on the launching stream
   cpu_baseline  the CPU oracle pipeline (port of the reference path: the reference itself cannot run here) on a
@@ -44,7 +46,8 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads of the baseline (capped by affinity)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU baseline sample")
-    ap.add_argument("--streams", type=int, default=1, help="frames in flight: independent engines on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="frames in flight: independent batch-1 engines on separate HIP streams (1 = strictly one frame at a time)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     return ap.parse_args()

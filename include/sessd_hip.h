@@ -95,6 +95,21 @@ int sessd_sparse_rulebook(const int32_t* out_indices, const int32_t* n_out_dev, 
                           const int32_t* stride3, const int32_t* pad3, const uint32_t* in_keys, const int32_t* in_vals,
                           uint32_t in_capacity, const int32_t* in_dims3, int32_t* nbr, uint32_t* tile_mask,
                           sessd_stream_t stream);
+/* two rulebooks over the SAME output sites in one launch (the strided conv into a level + the submanifold convs on it) */
+int sessd_sparse_rulebook_pair(const int32_t* out_indices, const int32_t* n_out_dev, int n_out_cap,
+                               const int32_t* ksize3_a, const int32_t* stride3_a, const int32_t* pad3_a,
+                               const uint32_t* keys_a, const int32_t* vals_a, uint32_t capacity_a, const int32_t* dims3_a,
+                               int32_t* nbr_a, uint32_t* tile_mask_a, const int32_t* ksize3_b, const int32_t* stride3_b,
+                               const int32_t* pad3_b, const uint32_t* keys_b, const int32_t* vals_b, uint32_t capacity_b,
+                               const int32_t* dims3_b, int32_t* nbr_b, uint32_t* tile_mask_b, sessd_stream_t stream);
+/* single-launch variant of sessd_sparse_downsample_sites: rows numbered by an atomic counter (numbering not
+ * reproducible run to run; everything computed from it is). Caller pre-clears out_keys/out_vals (0x7F7F7F7F) and
+ * *n_out_dev (0). */
+int sessd_sparse_downsample_sites_unordered(const int32_t* in_indices, const int32_t* n_in_dev, int n_in_cap,
+                                            const int32_t* ksize3, const int32_t* stride3, const int32_t* pad3,
+                                            const int32_t* out_dims3, uint32_t* out_keys, int32_t* out_vals,
+                                            uint32_t out_capacity, int32_t* out_indices, int n_out_cap,
+                                            int32_t* n_out_dev, int32_t* err_flag, sessd_stream_t stream);
 /* weight (kernel_volume, cin, cout) row-major == spconv's [kz,ky,kx,Cin,Cout] flattened -> MFMA fragment order */
 int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, int cout, float* packed,
                              sessd_stream_t stream);

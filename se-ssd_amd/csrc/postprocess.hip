@@ -256,10 +256,14 @@ __global__ __launch_bounds__(1024) void nms_reduce_lds_kernel(const int* __restr
   const int n = min(n_top[b], pre_max);
   const unsigned long long* mb = mask + (size_t)b * pre_max * words;
   const int cb = sessd_divup(n, 64);
-  // rows r < n, words w in [r/64, cb) are defined (the mask kernel skips the rest): copy only those
-  for (int idx = threadIdx.x; idx < n * words; idx += 1024) {
-    const int r = idx / words, w = idx - r * words;
-    sm[idx] = (w >= (r >> 6) && w < cb) ? mb[idx] : 0ull;
+  // blind 16-byte copy of the n x words matrix (words left of the diagonal were never written by the mask kernel
+  // and are never read below); 8 independent loads per thread in flight
+  {
+    const int total2 = (n * words + 1) >> 1;
+    const uint4* src = reinterpret_cast<const uint4*>(mb);
+    uint4* dst = reinterpret_cast<uint4*>(sm);
+#pragma unroll 8
+    for (int idx = threadIdx.x; idx < total2; idx += 1024) dst[idx] = src[idx];
   }
   __syncthreads();
   if (threadIdx.x >= 64) return;
@@ -267,26 +271,38 @@ __global__ __launch_bounds__(1024) void nms_reduce_lds_kernel(const int* __restr
   int* kb = keep + (size_t)b * post_max;
   unsigned long long removed = 0;  // lane w owns word w
   int nk = 0;
+  // the greedy walk is wave-uniform: rows' diagonal words are pulled out of the VGPR with v_readlane into scalars
+  // (no ds_bpermute round trip per candidate), the running "removed" word of the block lives in SGPRs
+  auto rdlane64 = [](unsigned long long v, int l) -> unsigned long long {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
+    const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+  };
   for (int blk = 0; blk < cb && nk < post_max; ++blk) {
     const int row = blk * 64 + lane;
     const unsigned long long diag = row < n ? sm[(size_t)row * words + blk] : 0ull;
-    unsigned long long rem = __shfl(removed, blk, 64);
+    unsigned long long rem = rdlane64(removed, blk);
     unsigned long long kept = 0;
     const int lim = min(64, n - blk * 64);
     for (int bb = 0; bb < lim; ++bb) {
-      const unsigned long long d = __shfl(diag, bb, 64);
       if (!((rem >> bb) & 1ull) && nk < post_max) {
         kept |= 1ull << bb;
-        if (lane == 0) kb[nk] = blk * 64 + bb;
         ++nk;
-        rem |= d;
+        rem |= rdlane64(diag, bb);
       }
+    }
+    // kept rows of this block -> output list (lane t writes the t-th kept row of the block)
+    {
+      const int base = nk - __popcll(kept);
+      unsigned long long k2 = kept;
+      for (int t = 0; k2; ++t, k2 &= k2 - 1)
+        if (lane == 0) kb[base + t] = blk * 64 + __builtin_ctzll(k2);
     }
     if (nk >= post_max) break;
     if (lane > blk && lane < cb) {
       unsigned long long acc = 0;
-      for (int bb = 0; bb < lim; ++bb)
-        if ((kept >> bb) & 1ull) acc |= sm[(size_t)(blk * 64 + bb) * words + lane];
+      for (unsigned long long k2 = kept; k2; k2 &= k2 - 1)
+        acc |= sm[(size_t)(blk * 64 + __builtin_ctzll(k2)) * words + lane];
       removed |= acc;
     }
   }

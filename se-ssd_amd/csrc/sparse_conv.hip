@@ -197,7 +197,7 @@ int launch(int split, bool dense, const float* in_feat, const int* nbr, const ui
            int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
            const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
   constexpr int NT = COUT / 16;
-  if (split <= 0) split = (n_cap / 16 < 2048 && NT >= 2) ? 2 : 1;  // heuristic: fill the chip on small levels
+  if (split <= 0) split = (n_cap / 16 < 4096) ? (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1)) : 1;  // fill 1024 SIMDs on small levels
 #define SESSD_ARGS dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
   if constexpr (NT % 4 == 0) {
     if (split >= 4) return launch_ntw<CIN, COUT, NT / 4>(SESSD_ARGS);

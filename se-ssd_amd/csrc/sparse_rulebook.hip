@@ -24,6 +24,7 @@ struct ConvGeom {
   int ks[3], st[3], pd[3];
   int in_dims[3];   // dims used by the INPUT hash keys / bounds
   int out_dims[3];  // output spatial shape
+  int cd[3];        // candidate outputs per dim of one input site = ceil(ks/st)
 };
 
 __device__ __forceinline__ uint32_t lin_key(int b, int z, int y, int x, const int* d) {
@@ -42,21 +43,26 @@ __global__ __launch_bounds__(NT) void hash_build_kernel(const int* __restrict__ 
 }
 
 // ---- strided conv output sites ------------------------------------------------------------
-// candidate id = i * KV + k. first[slot] = min candidate id that produced the cell.
+// An input site i reaches, per dimension, only the outputs (i + p - k)/s with k = (i+p) mod s, that + s, ...
+// (<= ceil(ks/st) of them: 2 for k=3/s=2), so a site has KC = cd0*cd1*cd2 candidates (8 instead of 27 kernel
+// offsets). candidate id = i * KC + c, c in ascending-k order; first[slot] = min candidate id that produced the cell,
+// which numbers the output sites in first-touch order of the serial loop (input row asc, offset asc).
 template <bool COUNT_ONLY>
-__device__ __forceinline__ bool cand_coord(const int* __restrict__ indices, int id, int KV, const ConvGeom& G, int& b,
+__device__ __forceinline__ bool cand_coord(const int* __restrict__ indices, int id, int KC, const ConvGeom& G, int& b,
                                            int* o) {
-  const int i = id / KV, k = id - i * KV;
-  const int4 c = *reinterpret_cast<const int4*>(indices + (size_t)i * 4);
-  const int kk[3] = {k / (G.ks[1] * G.ks[2]), (k / G.ks[2]) % G.ks[1], k % G.ks[2]};
-  const int ci[3] = {c.y, c.z, c.w};
-  b = c.x;
+  const int i = id / KC, c = id - i * KC;
+  const int4 ci4 = *reinterpret_cast<const int4*>(indices + (size_t)i * 4);
+  const int cc[3] = {c / (G.cd[1] * G.cd[2]), (c / G.cd[2]) % G.cd[1], c % G.cd[2]};
+  const int ci[3] = {ci4.y, ci4.z, ci4.w};
+  b = ci4.x;
   bool ok = true;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    int t = ci[d] + G.pd[d] - kk[d];
-    int q = t / G.st[d];
-    ok = ok && t >= 0 && (q * G.st[d] == t) && q < G.out_dims[d];
+    const int ip = ci[d] + G.pd[d];
+    const int k = ip % G.st[d] + cc[d] * G.st[d];
+    const int t = ip - k;
+    const int q = t / G.st[d];
+    ok = ok && k < G.ks[d] && t >= 0 && q < G.out_dims[d];
     o[d] = q;
   }
   return ok;
@@ -79,6 +85,40 @@ __global__ __launch_bounds__(NT) void down_insert_kernel(const int* __restrict__
     }
   }
   ent[id] = e;
+}
+
+// Single-kernel variant: the thread whose CAS creates a cell takes the next output row with an atomic counter.
+// Row numbering then depends on scheduling, but nothing downstream does: every output row is computed from its own
+// neighbour list in a fixed (offset, cin) order and the last layer scatters by coordinate, so the dense BEV tensor
+// and the detections are bit-identical for any numbering. Used by the inference engine (3 launches + 2 scratch
+// arrays fewer per level); the ordered 3-kernel version stays the default of the spconv-compatible API.
+__global__ __launch_bounds__(NT) void down_insert_unordered_kernel(const int* __restrict__ indices, const int* __restrict__ n_dev,
+                                                                    int n_cap, int KC, ConvGeom G, uint32_t* __restrict__ keys,
+                                                                    int* __restrict__ vals, uint32_t mask,
+                                                                    int* __restrict__ out_indices, int n_out_cap,
+                                                                    int* __restrict__ n_out_dev, int* __restrict__ err_flag) {
+  const int id = blockIdx.x * NT + threadIdx.x;
+  const int n = min(n_dev[0], n_cap);
+  if (id >= n * KC) return;
+  int b, o[3];
+  if (!cand_coord<false>(indices, id, KC, G, b, o)) return;
+  const uint32_t key = lin_key(b, o[0], o[1], o[2], G.out_dims);
+  uint32_t slot = sessd_hash_u32(key) & mask;
+  while (true) {
+    const uint32_t prev = atomicCAS(&keys[slot], SESSD_HASH_EMPTY, key);
+    if (prev == SESSD_HASH_EMPTY) {  // this thread created the cell
+      const int row = atomicAdd(n_out_dev, 1);
+      if (row < n_out_cap) {
+        vals[slot] = row;
+        *reinterpret_cast<int4*>(out_indices + (size_t)row * 4) = make_int4(b, o[0], o[1], o[2]);
+      } else {
+        atomicOr(err_flag, 1);  // vals stays SESSD_SENT: reads as absent
+      }
+      return;
+    }
+    if (prev == key) return;
+    slot = (slot + 1) & mask;
+  }
 }
 
 __global__ __launch_bounds__(NT) void down_count_kernel(int total, const int* __restrict__ ent,
@@ -148,10 +188,31 @@ __global__ __launch_bounds__(NT) void down_assign_kernel(const int* __restrict__
 // ---- gather rulebook ------------------------------------------------------------------------
 // One wave handles 16 consecutive output sites x 4 kernel offsets per pass: lane = (site&15) + 16*(k&3).
 // nbr is [KV][n_cap] (offset-major: the convolution reads 16 consecutive sites of one offset).
+struct RbJob {
+  ConvGeom G;
+  const uint32_t* keys;
+  const int* vals;
+  uint32_t mask;
+  int KV;
+  int* nbr;
+  uint32_t* tile_mask;
+};
+struct RbJobs {
+  RbJob j[2];
+};
+
+// blockIdx.y selects the job: up to two rulebooks over the SAME output sites (e.g. the strided conv into a level and
+// the submanifold convs on that level) are built by one launch.
 __global__ __launch_bounds__(NT) void rulebook_kernel(const int* __restrict__ out_indices, const int* __restrict__ n_dev,
-                                                       int n_cap, int KV, ConvGeom G, const uint32_t* __restrict__ keys,
-                                                       const int* __restrict__ vals, uint32_t mask,
-                                                       int* __restrict__ nbr, uint32_t* __restrict__ tile_mask) {
+                                                       int n_cap, RbJobs J) {
+  const RbJob& Jb = J.j[blockIdx.y];
+  const ConvGeom& G = Jb.G;
+  const int KV = Jb.KV;
+  const uint32_t* __restrict__ keys = Jb.keys;
+  const int* __restrict__ vals = Jb.vals;
+  const uint32_t mask = Jb.mask;
+  int* __restrict__ nbr = Jb.nbr;
+  uint32_t* __restrict__ tile_mask = Jb.tile_mask;
   const int n = min(n_dev[0], n_cap);
   const int wave = (blockIdx.x * NT + threadIdx.x) >> 6;
   const int lane = threadIdx.x & 63;
@@ -166,24 +227,45 @@ __global__ __launch_bounds__(NT) void rulebook_kernel(const int* __restrict__ ou
   const bool live = o < n;
   if (live) c = *reinterpret_cast<const int4*>(out_indices + (size_t)o * 4);
   uint32_t tm = 0;
-  // fully unrolled (KV <= 28): the 7 hash probes of a lane are independent, so they are all in flight at once
-  // instead of 7 dependent global-memory round trips
+  // Two phases of INDEPENDENT loads instead of 7 serial probe chains: (1) the home slot's key of all (<= 7) offsets
+  // of this lane, (2) the value of every hit. Only a collision (load factor <= 0.5: about one probe in four) falls
+  // back to the sequential probe loop.
+  constexpr int NP = 7;
+  uint32_t key[NP], slot[NP], k0v[NP];
+  bool want[NP];
 #pragma unroll
-  for (int k0 = 0; k0 < 28; k0 += 4) {
-    if (k0 >= KV) break;
-    const int k = k0 + (lane >> 4);
-    int found = -1;
+  for (int p = 0; p < NP; ++p) {
+    const int k = p * 4 + (lane >> 4);
+    want[p] = false;
+    key[p] = 0; slot[p] = 0;
     if (live && k < KV) {
       const int kz = k / (G.ks[1] * G.ks[2]), ky = (k / G.ks[2]) % G.ks[1], kx = k % G.ks[2];
       const int z = c.y * G.st[0] - G.pd[0] + kz, y = c.z * G.st[1] - G.pd[1] + ky, x = c.w * G.st[2] - G.pd[2] + kx;
-      if (z >= 0 && z < G.in_dims[0] && y >= 0 && y < G.in_dims[1] && x >= 0 && x < G.in_dims[2])
-        found = sessd_hash_find(keys, vals, mask, lin_key(c.x, z, y, x, G.in_dims));
+      if (z >= 0 && z < G.in_dims[0] && y >= 0 && y < G.in_dims[1] && x >= 0 && x < G.in_dims[2]) {
+        want[p] = true;
+        key[p] = lin_key(c.x, z, y, x, G.in_dims);
+        slot[p] = sessd_hash_u32(key[p]) & mask;
+      }
     }
-    if (k < KV && (lane & 15) + tile * 16 < n_cap) nbr[(size_t)k * n_cap + o] = found;
-    unsigned long long bal = __ballot(found >= 0);
+  }
+#pragma unroll
+  for (int p = 0; p < NP; ++p) k0v[p] = want[p] ? keys[slot[p]] : SESSD_HASH_EMPTY;
+  int found[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) found[p] = (want[p] && k0v[p] == key[p]) ? vals[slot[p]] : -1;
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    if (want[p] && k0v[p] == key[p]) {
+      if (found[p] == SESSD_SENT) found[p] = -1;
+    } else if (want[p] && k0v[p] != SESSD_HASH_EMPTY) {
+      found[p] = sessd_hash_find(keys, vals, mask, key[p]);  // collision: rare sequential path
+    }
+    const int k = p * 4 + (lane >> 4);
+    if (k < KV && o < n_cap) nbr[(size_t)k * n_cap + o] = found[p];
+    const unsigned long long bal = __ballot(found[p] >= 0);
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if ((bal >> (16 * q)) & 0xFFFFull) tm |= 1u << (k0 + q);
+      if ((bal >> (16 * q)) & 0xFFFFull) tm |= 1u << (p * 4 + q);
   }
   if (lane == 0) tile_mask[tile] = tm;
 }
@@ -195,6 +277,7 @@ void fill_geom(ConvGeom& G, const int* ks, const int* st, const int* pd, const i
     G.pd[d] = pd ? pd[d] : 0;
     G.in_dims[d] = in_dims ? in_dims[d] : 0;
     G.out_dims[d] = out_dims ? out_dims[d] : 0;
+    G.cd[d] = (G.ks[d] + G.st[d] - 1) / G.st[d];
   }
 }
 
@@ -250,12 +333,12 @@ int sessd_sparse_downsample_sites(const int* in_indices, const int* n_in_dev, in
                                   int* out_vals, uint32_t out_capacity, int* out_indices, int n_out_cap, int* n_out_dev,
                                   int* err_flag, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (n_in_cap <= 0 || n_out_cap <= 0 || (out_capacity & (out_capacity - 1)) != 0) return SESSD_EINVAL;
-  const int kv = ksize3[0] * ksize3[1] * ksize3[2];
+  ConvGeom G;
+  fill_geom(G, ksize3, stride3, pad3, nullptr, out_dims3);
+  const int kv = G.cd[0] * G.cd[1] * G.cd[2];  // candidates per input site (<= kernel volume)
   if ((long long)n_in_cap * kv >= 0x7F000000ll) return SESSD_EINVAL;
   DownWs w;
   if (down_ws_layout(n_in_cap, kv, out_capacity, &w, (char*)workspace) > workspace_bytes) return SESSD_EWORKSPACE;
-  ConvGeom G;
-  fill_geom(G, ksize3, stride3, pad3, nullptr, out_dims3);
   SESSD_FILL_SCRATCH(out_keys, SESSD_HASH_EMPTY, out_capacity, stream);
   SESSD_FILL_SCRATCH(out_vals, SESSD_HASH_EMPTY, out_capacity, stream);
   SESSD_FILL_SCRATCH(w.first, SESSD_HASH_EMPTY, out_capacity, stream);
@@ -280,11 +363,56 @@ int sessd_sparse_rulebook(const int* out_indices, const int* n_out_dev, int n_ou
   if (n_out_cap <= 0 || (in_capacity & (in_capacity - 1)) != 0) return SESSD_EINVAL;
   const int kv = ksize3[0] * ksize3[1] * ksize3[2];
   if (kv > 28) return SESSD_EINVAL;
-  ConvGeom G;
-  fill_geom(G, ksize3, stride3, pad3, in_dims3, nullptr);
+  RbJobs J;
+  fill_geom(J.j[0].G, ksize3, stride3, pad3, in_dims3, nullptr);
+  J.j[0].keys = in_keys; J.j[0].vals = in_vals; J.j[0].mask = in_capacity - 1; J.j[0].KV = kv;
+  J.j[0].nbr = nbr; J.j[0].tile_mask = tile_mask;
+  J.j[1] = J.j[0];
   const int tiles = sessd_divup(n_out_cap, 16);
-  hipLaunchKernelGGL(rulebook_kernel, dim3(sessd_divup(tiles, NT / 64)), dim3(NT), 0, stream, out_indices, n_out_dev,
-                     n_out_cap, kv, G, in_keys, in_vals, in_capacity - 1, nbr, tile_mask);
+  hipLaunchKernelGGL(rulebook_kernel, dim3(sessd_divup(tiles, NT / 64), 1), dim3(NT), 0, stream, out_indices, n_out_dev,
+                     n_out_cap, J);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// Two rulebooks over the same output sites in one launch (A: e.g. the strided conv INTO the level, looked up in the
+// previous level's hash; B: the submanifold convs ON the level, looked up in its own hash).
+int sessd_sparse_rulebook_pair(const int* out_indices, const int* n_out_dev, int n_out_cap, const int* ksize3_a,
+                               const int* stride3_a, const int* pad3_a, const uint32_t* keys_a, const int* vals_a,
+                               uint32_t capacity_a, const int* dims3_a, int* nbr_a, uint32_t* tile_mask_a,
+                               const int* ksize3_b, const int* stride3_b, const int* pad3_b, const uint32_t* keys_b,
+                               const int* vals_b, uint32_t capacity_b, const int* dims3_b, int* nbr_b,
+                               uint32_t* tile_mask_b, hipStream_t stream) {
+  if (n_out_cap <= 0 || (capacity_a & (capacity_a - 1)) != 0 || (capacity_b & (capacity_b - 1)) != 0) return SESSD_EINVAL;
+  RbJobs J;
+  fill_geom(J.j[0].G, ksize3_a, stride3_a, pad3_a, dims3_a, nullptr);
+  J.j[0].keys = keys_a; J.j[0].vals = vals_a; J.j[0].mask = capacity_a - 1;
+  J.j[0].KV = ksize3_a[0] * ksize3_a[1] * ksize3_a[2]; J.j[0].nbr = nbr_a; J.j[0].tile_mask = tile_mask_a;
+  fill_geom(J.j[1].G, ksize3_b, stride3_b, pad3_b, dims3_b, nullptr);
+  J.j[1].keys = keys_b; J.j[1].vals = vals_b; J.j[1].mask = capacity_b - 1;
+  J.j[1].KV = ksize3_b[0] * ksize3_b[1] * ksize3_b[2]; J.j[1].nbr = nbr_b; J.j[1].tile_mask = tile_mask_b;
+  if (J.j[0].KV > 28 || J.j[1].KV > 28) return SESSD_EINVAL;
+  const int tiles = sessd_divup(n_out_cap, 16);
+  hipLaunchKernelGGL(rulebook_kernel, dim3(sessd_divup(tiles, NT / 64), 2), dim3(NT), 0, stream, out_indices, n_out_dev,
+                     n_out_cap, J);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// Output sites of a strided sparse conv in ONE launch, rows numbered by an atomic counter (order not reproducible,
+// results downstream are -- see down_insert_unordered_kernel). The caller has cleared out_keys / out_vals to
+// 0x7F7F7F7F and *n_out_dev to 0 (e.g. with its per-frame arena fill); no workspace.
+int sessd_sparse_downsample_sites_unordered(const int* in_indices, const int* n_in_dev, int n_in_cap, const int* ksize3,
+                                            const int* stride3, const int* pad3, const int* out_dims3, uint32_t* out_keys,
+                                            int* out_vals, uint32_t out_capacity, int* out_indices, int n_out_cap,
+                                            int* n_out_dev, int* err_flag, hipStream_t stream) {
+  if (n_in_cap <= 0 || n_out_cap <= 0 || (out_capacity & (out_capacity - 1)) != 0) return SESSD_EINVAL;
+  ConvGeom G;
+  fill_geom(G, ksize3, stride3, pad3, nullptr, out_dims3);
+  const int kc = G.cd[0] * G.cd[1] * G.cd[2];
+  hipLaunchKernelGGL(down_insert_unordered_kernel, dim3(sessd_divup(n_in_cap * kc, NT)), dim3(NT), 0, stream, in_indices,
+                     n_in_dev, n_in_cap, kc, G, out_keys, out_vals, out_capacity - 1, out_indices, n_out_cap, n_out_dev,
+                     err_flag);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -154,9 +154,11 @@ class InferenceEngine:
         self.nump = E(cap0, dt=i32)
         self.vfeat = E(cap0, 4)
         # control words cleared to 0 by ONE fill per frame: prefix[B+1] | err
-        self.ctrl = torch.zeros((B + 2,), dtype=i32, device=dev)
+        nlv = len(self.levels)
+        self.ctrl = torch.zeros((B + 2 + nlv,), dtype=i32, device=dev)
         self.prefix = self.ctrl[:B + 1]
         self.err = self.ctrl[B + 1:B + 2]
+        self._lvl_n = [self.ctrl[B + 2 + i:B + 3 + i] for i in range(nlv)]  # atomic row counters of levels 1..
         # ---- one contiguous arena for everything that must read 0x7F7F7F7F at the start of a frame (hash tables,
         # per-cell point lists, first-touch words): cleared by ONE fill instead of ~17 small ones
         cap0h = int(lib.sessd_hash_capacity(self.P_cap * B))
@@ -191,7 +193,7 @@ class InferenceEngine:
             else:
                 hc, pk, pv, pw = lvl_parts[li - 1]
                 L["indices"] = E(c, 4, dt=i32)
-                L["n"] = torch.zeros((1,), dtype=i32, device=dev)
+                L["n"] = self._lvl_n[li]
                 L["hash"] = ops.SiteHash(hc, L["hash_dims"], dev, view_i32(pk), view_i32(pv))
                 L["down_ws"] = self.arena[pw[0]:pw[0] + pw[1]]
                 L["nbr_down"] = E(27, c, dt=i32)
@@ -333,7 +335,7 @@ class InferenceEngine:
         s = torch.cuda.current_stream().cuda_stream
         B = self.B
         # ---- voxelize (a1-a3)
-        check(lib.sessd_fill_u32(self.ctrl.data_ptr(), 0, B + 2, s), "fill")
+        check(lib.sessd_fill_u32(self.ctrl.data_ptr(), 0, self.ctrl.numel(), s), "fill")
         check(lib.sessd_fill_u32(self.arena.data_ptr(), 0x7F7F7F7F, self.arena.numel() // 4, s), "fill")
         lib.sessd_set_external_clear(1)  # the arena fill above replaces the per-call scratch clears
         try:
@@ -367,15 +369,27 @@ class InferenceEngine:
                 feat = out
             else:
                 Li, Lo = self.levels[li], self.levels[li + 1]
-                kv = lay["ks"][0] * lay["ks"][1] * lay["ks"][2]
-                check(lib.sessd_sparse_downsample_sites(Li["indices"].data_ptr(), self._n(li), Li["cap"],
-                                                        self._i3(lay["ks"]).data_ptr(), self._i3(lay["st"]).data_ptr(),
-                                                        self._i3(lay["pd"]).data_ptr(), self._i3(Lo["shape"]).data_ptr(),
-                                                        Lo["hash"].keys.data_ptr(), Lo["hash"].vals.data_ptr(),
-                                                        Lo["hash"].capacity, Lo["indices"].data_ptr(), Lo["cap"],
-                                                        Lo["n"].data_ptr(), self.err.data_ptr(), Lo["down_ws"].data_ptr(),
-                                                        Lo["down_ws"].numel(), s), "sparse_downsample_sites")
-                self._rulebook(li + 1, lay["ks"], lay["st"], lay["pd"], li, Lo["nbr_down"], Lo["tm_down"], s)
+                # output sites in ONE launch (atomic row numbering; hash / counter pre-cleared by the arena + ctrl fills)
+                check(lib.sessd_sparse_downsample_sites_unordered(
+                    Li["indices"].data_ptr(), self._n(li), Li["cap"], self._i3(lay["ks"]).data_ptr(),
+                    self._i3(lay["st"]).data_ptr(), self._i3(lay["pd"]).data_ptr(), self._i3(Lo["shape"]).data_ptr(),
+                    Lo["hash"].keys.data_ptr(), Lo["hash"].vals.data_ptr(), Lo["hash"].capacity, Lo["indices"].data_ptr(),
+                    Lo["cap"], Lo["n"].data_ptr(), self.err.data_ptr(), s), "sparse_downsample_sites_unordered")
+                nxt = self.sp.layers[idx + 1] if idx + 1 < n_layers else None
+                if nxt is not None and nxt["kind"] == "subm":
+                    # rulebook of this strided conv AND of the submanifold convs on the new level: one launch
+                    Hi, Ho = Li["hash"], Lo["hash"]
+                    check(lib.sessd_sparse_rulebook_pair(
+                        Lo["indices"].data_ptr(), self._n(li + 1), Lo["cap"], self._i3(lay["ks"]).data_ptr(),
+                        self._i3(lay["st"]).data_ptr(), self._i3(lay["pd"]).data_ptr(), Hi.keys.data_ptr(), Hi.vals.data_ptr(),
+                        Hi.capacity, Hi._dims_t.data_ptr(), Lo["nbr_down"].data_ptr(), Lo["tm_down"].data_ptr(),
+                        self._i3(nxt["ks"]).data_ptr(), self._i3(1).data_ptr(), self._i3([k // 2 for k in nxt["ks"]]).data_ptr(),
+                        Ho.keys.data_ptr(), Ho.vals.data_ptr(), Ho.capacity, Ho._dims_t.data_ptr(), Lo["nbr_subm"].data_ptr(),
+                        Lo["tm_subm"].data_ptr(), s), "sparse_rulebook_pair")
+                    subm_ready = True
+                else:
+                    self._rulebook(li + 1, lay["ks"], lay["st"], lay["pd"], li, Lo["nbr_down"], Lo["tm_down"], s)
+                    subm_ready = False
                 if last:
                     check(lib.sessd_fill_u32(self.bev.data_ptr(), 0, self.bev.numel(), s), "fill")
                     self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, None, s, dense=True, idx=idx)
@@ -383,7 +397,7 @@ class InferenceEngine:
                     self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, Lo["feat_a"], s, idx=idx)
                     feat = Lo["feat_a"]
                 li += 1
-                have_subm = False
+                have_subm = subm_ready
         # ---- SSFA (a9) rpn_v1.py:220-235
         t, h, d = self.t, self.h, self.dn
         x = self._conv(self.bev, d.b0[0], t["a"], name="b0.0")

@@ -346,11 +346,11 @@ def default_tile_cfg(cout, npix, ntaps):
     key = (cout, npix, ntaps)
     if key in _TILE_CFG_OVERRIDE:
         return _TILE_CFG_OVERRIDE[key]
-    if cout <= 32:
-        return 4
-    if npix * ((cout + 63) // 64) < 64 * 1024 and ntaps != 9:
-        return 3  # few-tap convs on small maps: 32c x 32p wave tiles to fill the 1024 SIMDs
-    return 1
+    # measured on MI355X at batch 1 (engine.autotune() refines per layer): 32c x 32p wave tiles fill the 1024 SIMDs
+    # best; pixel-major workgroups (cfg 4) for the 3x3 / 1x1 layers, cout-major (cfg 3) for the merged deconv
+    if ntaps == 4 and cout > 32:
+        return 3
+    return 4
 
 
 def ssfa_fuse(x0, x1, w0, w1, s0, t0, s1, t1, out=None):
