@@ -56,7 +56,7 @@ __device__ __forceinline__ float bufload(rsrc_t rsrc, unsigned voff, unsigned so
 }
 #define SESSD_OOB 0x80000000u  // a lane offset beyond any buffer: the load returns 0 (out-of-image tap)
 
-template <int NTAPS, int CT, int PT, int WC, int WP>
+template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   static_assert(WC * WP == 4, "four waves per workgroup");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   const unsigned wtap = 2u * A.cout_pad * 4u;                          // weight bytes per tap
   const unsigned xstep = 2u * (unsigned)A.cgroup * (unsigned)in_plane * 4u;  // activation bytes per k-step
 
-  float wa[2][NTAPS][CT], xb[2][NTAPS][PT];
+  float wa[DEEP ? 3 : 2][NTAPS][CT], xb[DEEP ? 3 : 2][NTAPS][PT];
 
 #define SESSD_LOAD(SET, KPI)                                                                   \
   {                                                                                            \
@@ -137,18 +137,42 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   // Two register sets, one cin pair of look-ahead. Every load in the loop is UNCONDITIONAL (the last one is
   // clamped and unused): a load under a branch makes hipcc's vmcnt bookkeeping conservative at the merge and it
   // then waits for the loads it has just issued -- the whole memory latency, every iteration.
-  SESSD_LOAD(0, 0)
-  for (int kp = 0; kp + 2 <= KP; kp += 2) {
-    SESSD_LOAD(1, kp + 1)
-    __builtin_amdgcn_sched_barrier(0);  // keep "issue next set, then consume current set" in program order
-    SESSD_MMA(0)
-    __builtin_amdgcn_sched_barrier(0);
-    SESSD_LOAD(0, min(kp + 2, KP - 1))
-    __builtin_amdgcn_sched_barrier(0);
-    SESSD_MMA(1)
-    __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!DEEP) {
+    SESSD_LOAD(0, 0)
+    for (int kp = 0; kp + 2 <= KP; kp += 2) {
+      SESSD_LOAD(1, kp + 1)
+      __builtin_amdgcn_sched_barrier(0);  // keep "issue next set, then consume current set" in program order
+      SESSD_MMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_LOAD(0, min(kp + 2, KP - 1))
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_MMA(1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (KP & 1) SESSD_MMA(0)  // odd KP tail (set 0 holds KP-1)
+  } else {
+    // three register sets = two k-steps of look-ahead: a wave hides an L2 round trip by itself, which matters in the
+    // tail of a batch-1 launch when few waves are left on a SIMD
+    SESSD_LOAD(0, 0)
+    SESSD_LOAD(1, min(1, KP - 1))
+    int kp = 0;
+    for (; kp + 3 <= KP; kp += 3) {
+      SESSD_LOAD(2, min(kp + 2, KP - 1))
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_MMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_LOAD(0, min(kp + 3, KP - 1))
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_MMA(1)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_LOAD(1, min(kp + 4, KP - 1))
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_MMA(2)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (kp < KP) SESSD_MMA(0)      // set 0 holds kp
+    if (kp + 1 < KP) SESSD_MMA(1)  // set 1 holds kp+1
   }
-  if (KP & 1) SESSD_MMA(0)  // odd KP tail (set 0 holds KP-1)
 #undef SESSD_LOAD
 #undef SESSD_MMA
 
@@ -290,9 +314,9 @@ __global__ __launch_bounds__(256) void conv3x3s1_lds_kernel(ConvArgs A) {
   }
 }
 
-template <int NTAPS, int CT, int PT, int WC, int WP>
+template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
 __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
-  conv_body<NTAPS, CT, PT, WC, WP>(A, blockIdx.z);
+  conv_body<NTAPS, CT, PT, WC, WP, DEEP>(A, blockIdx.z);
 }
 
 // Up to four convolutions that share shapes but not weights / taps / output phase in ONE launch
@@ -345,12 +369,12 @@ __global__ __launch_bounds__(256) void ssfa_fuse_kernel(const float* __restrict_
   }
 }
 
-template <int NTAPS, int CT, int PT, int WC, int WP>
+template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
 int launch_conv(const ConvArgs* A, int nconv, int batch, hipStream_t stream) {
   const int npix = A[0].ht * A[0].wt;
   dim3 grid(sessd_divup(npix, WP * PT * 32) * sessd_divup(A[0].cout_pad, WC * CT * 32), 1, batch * (nconv > 1 ? 4 : 1));
   if (nconv == 1) {
-    hipLaunchKernelGGL((conv2d_mfma_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A[0]);
+    hipLaunchKernelGGL((conv2d_mfma_kernel<NTAPS, CT, PT, WC, WP, DEEP>), grid, dim3(256), 0, stream, A[0]);
   } else {
     ConvArgs4 A4;
     for (int i = 0; i < 4; ++i) A4.c[i] = A[i];
@@ -372,6 +396,9 @@ int dispatch_tile(const ConvArgs* A, int nconv, int batch, int tile_cfg, hipStre
     case 6: return launch_conv<NTAPS, 2, 1, 1, 4>(A, nconv, batch, stream);  // wave 64c x 32p, WG 64c x 128p (weights shared by the 4 waves)
     case 7: return launch_conv<NTAPS, 2, 2, 1, 4>(A, nconv, batch, stream);  // wave 64c x 64p, WG 64c x 256p
     case 8: return launch_conv<NTAPS, 4, 1, 1, 4>(A, nconv, batch, stream);  // wave 128c x 32p, WG 128c x 128p
+    case 11: if (nconv == 1) return launch_conv<NTAPS, 1, 1, 1, 4, true>(A, nconv, batch, stream); return SESSD_EINVAL;  // cfg 4, 2-step look-ahead
+    case 12: if (nconv == 1) return launch_conv<NTAPS, 1, 1, 4, 1, true>(A, nconv, batch, stream); return SESSD_EINVAL;  // cfg 3, 2-step look-ahead
+    case 13: if (nconv == 1) return launch_conv<NTAPS, 1, 2, 4, 1, true>(A, nconv, batch, stream); return SESSD_EINVAL;  // cfg 2, 2-step look-ahead
     default: return SESSD_EINVAL;
   }
 }

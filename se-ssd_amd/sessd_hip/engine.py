@@ -273,7 +273,7 @@ class InferenceEngine:
             self._tuning.append((name, x, layer, out, relu, residual))
         return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name))
 
-    def autotune(self, candidates=(1, 2, 3, 4, 6), reps=5):
+    def autotune(self, candidates=(1, 2, 3, 4, 6, 11, 12), reps=5):
         """Pick the wave/workgroup tiling of every dense conv launch by timing it on this device (one-off, ~0.1 s).
         Needs one representative frame already staged with set_points()."""
         self._tuning, self._tuning_sparse = [], []
@@ -311,6 +311,8 @@ class InferenceEngine:
                 cands.append(10)  # activation-stationary LDS variant
             for cfg in cands:
                 if pc.cout <= 32 and cfg != 4:
+                    continue
+                if cfg in (11, 12, 13) and pc.kind != "conv":
                     continue
                 for _ in range(2):
                     ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg)
