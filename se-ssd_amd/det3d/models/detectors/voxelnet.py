@@ -1,8 +1,14 @@
-"""mirrors det3d/models/detectors/voxelnet_sessd.py:7-43 + single_stage.py:8-19 (VoxelNet / SingleStageDetector)."""
+"""VoxelNet detector: reader -> sparse backbone -> BEV neck -> head (+ predict), the inference surface of
+det3d/models/detectors/voxelnet_sessd.py:7-43 and single_stage.py:8-19. Same constructor kwargs and the same
+`forward(example, is_ema=[False, None], return_loss=True)` contract:
+  * `is_ema[0]` selects the un-augmented `*_raw` inputs (SE-SSD teacher pass) and returns raw head outputs,
+  * `return_loss=False` returns `bbox_head.predict(...)`: a list of dict(box3d_lidar, scores, label_preds, metadata)."""
 from torch import nn
 
 from .. import builder
 from ..registry import DETECTORS
+
+_INPUT_KEYS = ("voxels", "coordinates", "num_points", "num_voxels", "shape")
 
 
 @DETECTORS.register_module
@@ -14,34 +20,26 @@ class VoxelNet(nn.Module):
         if neck is not None:
             self.neck = builder.build_neck(neck)
         self.bbox_head = builder.build_head(bbox_head)
-        self.train_cfg = train_cfg
-        self.test_cfg = test_cfg
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
 
     @property
     def with_neck(self):
-        return hasattr(self, "neck") and self.neck is not None
+        return getattr(self, "neck", None) is not None
 
     def extract_feat(self, data):
-        input_features = self.reader(data["voxels"], data["num_points_per_voxel"])
-        x = self.backbone(input_features, data["coors"], data["batch_size"], data["input_shape"])
-        if self.with_neck:
-            x = self.neck(x)
-        return x
+        feats = self.reader(data["voxels"], data["num_points_per_voxel"])
+        bev = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
+        return self.neck(bev) if self.with_neck else bev
 
     def forward(self, example, is_ema=[False, None], return_loss=True, **kwargs):
-        key_tag = "_raw" if is_ema[0] else ""
-        voxels = example["voxels" + key_tag]
-        coordinates = example["coordinates" + key_tag]
-        num_points_per_voxel = example["num_points" + key_tag]
-        num_voxels = example["num_voxels" + key_tag]
-        batch_size = len(num_voxels)
-        input_shape = example["shape" + key_tag][0]
-        data = dict(voxels=voxels, num_points_per_voxel=num_points_per_voxel, coors=coordinates, batch_size=batch_size,
-                    input_shape=input_shape)
-        x = self.extract_feat(data)
-        preds = self.bbox_head(x)
-        if is_ema[0]:
+        teacher_pass, teacher_preds = is_ema[0], is_ema[1]
+        suffix = "_raw" if teacher_pass else ""
+        voxels, coords, npts, nvox, shape = (example[k + suffix] for k in _INPUT_KEYS)
+        bev = self.extract_feat(dict(voxels=voxels, num_points_per_voxel=npts, coors=coords, batch_size=len(nvox),
+                                     input_shape=shape[0]))
+        preds = self.bbox_head(bev)
+        if teacher_pass:
             return preds
         if return_loss:
-            return self.bbox_head.loss(example, preds, is_ema[1])
+            return self.bbox_head.loss(example, preds, teacher_preds)
         return self.bbox_head.predict(example, preds, self.test_cfg)

@@ -1,8 +1,6 @@
+"""The six model registries of det3d/models/registry.py, created from one table."""
 from det3d.utils import Registry
 
-READERS = Registry("reader")
-BACKBONES = Registry("backbone")
-NECKS = Registry("neck")
-HEADS = Registry("head")
-LOSSES = Registry("loss")
-DETECTORS = Registry("detector")
+_KINDS = dict(READERS="reader", BACKBONES="backbone", NECKS="neck", HEADS="head", LOSSES="loss", DETECTORS="detector")
+globals().update({var: Registry(label) for var, label in _KINDS.items()})
+__all__ = sorted(_KINDS)
