@@ -136,6 +136,12 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
                       const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out, int cout,
                       int hout, int wout, int out_mul, int out_py, int out_px, const float* scale, const float* shift,
                       int relu, const float* residual, int tile_cfg, sessd_stream_t stream);
+/* Conv2d(cin, cout, 3, stride 1, padding 1) by fused Winograd F(2x2,3x3) on the f32 matrix cores: 2.25x fewer MFMAs
+ * than sessd_conv2d_mfma for the same layer (not bit-identical to it: Winograd rounding, ~1e-6 of the output scale).
+ * upk = U = G g G^T packed as a 16-"tap" weight [cin/2][16][2][cout_pad], xi = 4*row + col. Even H and W, cin % 8 == 0. */
+int sessd_conv3x3_winograd(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
+                           const float* scale, const float* shift, int relu, const float* residual,
+                           sessd_stream_t stream);
 /* ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
  * classes (py,px) = (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps: wpk4[c] packed like above, taps_dy4/taps_dx4 are
  * 4 rows of 4 ints. input (B,cin,hin,win) -> output (B,cout,2*hin,2*win); cin % 8 == 0. */

@@ -9,7 +9,7 @@ w = (torch.randn(128, 128, 3, 3, generator=g) * 0.03).to(dev)
 pc = ops.pack_conv2d(w, 1)
 x = torch.randn(1, 128, 200, 176, generator=g).to(dev)
 ref = None
-for cfg in (3, 4, 11, 12, 13, 2):
+for cfg in (4, 12, 20):
     out = ops.conv2d(x, pc, None, None, False, tile_cfg=cfg)
     torch.cuda.synchronize()
     if ref is None: ref = out.clone()

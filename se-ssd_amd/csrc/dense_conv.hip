@@ -314,6 +314,195 @@ __global__ __launch_bounds__(256) void conv3x3s1_lds_kernel(ConvArgs A) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 convolution by fused Winograd F(2x2,3x3) on the f32 matrix cores (tile_cfg 20).
+//   Y = A^T [ sum_cin (G g G^T) .* (B^T d B) ] A      d = 4x4 input patch, Y = 2x2 outputs, 16 products instead of 36
+// i.e. 16 independent GEMMs  M_xi[cout][tile] = sum_cin U_xi[cout][cin] V_xi[cin][tile]  -> 2.25x fewer MFMAs than the
+// direct kernel for the same layer. Everything is fused in one launch:
+//   workgroup = 32 tiles (128 output pixels) x 32 couts, 4 waves; wave w owns the transform points xi = 4w..4w+3
+//   round = 4 k-steps (8 input channels). In a round every wave (a) issues the patch loads (4 x 16 B per lane: lane =
+//   (tile, channel parity)) and the U loads of the NEXT round, (b) runs its 16 MFMAs of THIS round with B operands
+//   read from LDS (V of this round) and A operands (U) from registers, (c) transforms its patches (32 adds, in
+//   registers) and writes V of the next round to the other LDS buffer; one barrier per round.
+//   epilogue: the 16 M_xi of a (cout, tile) live in 4 waves -> through LDS, then the 2x2 output transform, BatchNorm,
+//   ReLU, residual and 8-byte stores (consecutive lanes = consecutive tiles of one output row).
+// U = G g G^T is precomputed on the host and packed like a 16-tap weight: [cin/2][16][2][cout_pad].
+// Zero padding: rows outside the image get an out-of-range buffer offset (hardware returns 0); the column left of
+// x = 0 / right of x = W-1 is masked in registers. Needs even H and W and cin % 8 == 0.
+// Numerics: NOT the fmaf chain of the direct kernel -- Winograd rounding (about 1e-6 of the output scale in float32);
+// deterministic (fixed order), covered by the same tolerance as the other float stages.
+__global__ __launch_bounds__(256, 2) void conv3x3s1_winograd_kernel(ConvArgs A) {
+  constexpr int TT = 32;  // tiles per workgroup
+  __shared__ __attribute__((aligned(16))) float lds[16 * 32 * 32];  // 64 KB: V double buffer (2 x 16 KB) / M exchange
+  const int tid = threadIdx.x, lane = tid & 63;
+  // readfirstlane: tells hipcc the wave index is wave-uniform, otherwise every buffer load whose SGPR offset depends
+  // on it is wrapped in a readfirstlane "waterfall" loop (measured: VALU time = 75 % of the MFMA time)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int tw = A.win >> 1, th = A.hin >> 1, ntiles = tw * th;
+  const int b = blockIdx.z;
+  // XCD-aware order over (tile block, cout block), as in conv_body
+  const int ny = sessd_divup(A.cout_pad, 32);
+  int bx, by;
+  {
+    const int total = gridDim.x, bid = blockIdx.x;
+    const int q = total >> 3, r = total & 7, xcd = bid & 7, loc = bid >> 3;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    bx = wgid / ny;
+    by = wgid - bx * ny;
+  }
+  const int t_base = bx * TT, m_base = by * 32;
+  const int in_plane = A.hin * A.win;
+  const rsrc_t xr = make_rsrc(A.in + (size_t)b * A.cin * in_plane, (unsigned)A.cin * in_plane * 4u);
+  const rsrc_t wr = make_rsrc(A.wpk, (unsigned)(A.cin >> 1) * 16u * 2u * A.cout_pad * 4u);
+
+  // ---- transform role: lane = (tile j, channel parity h); 4 row offsets of its 4x4 patch
+  const int t = t_base + j;
+  const bool tlive = t < ntiles;
+  const int ty = tlive ? t / tw : 0, tx = tlive ? t - (t / tw) * tw : 0;
+  const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+  unsigned ro[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int y = y0 + r;
+    // x0 may be -1: the 16-byte load then starts one float before the row (still inside the buffer except for the very
+    // first row of channel 0 with h = 0, which is out of the image anyway when y = -1... y >= 0 here); masked below
+    // tiles in the first column start their 16-byte row load at x = 0 (a negative offset would be range-checked away
+    // as a whole) and shift the components in registers instead
+    ro[r] = (tlive && y >= 0 && y < A.hin) ? (unsigned)((h * in_plane + y * A.win + max(x0, 0)) * 4) : SESSD_OOB;
+  }
+  const bool mask_l = (tx == 0), mask_r = (tx == tw - 1);
+  // ---- GEMM role: wave owns xi = 4*wave .. 4*wave+3 ; A operand lane (i = j, h)
+  const unsigned wo = (unsigned)((h * A.cout_pad + m_base + j) * 4);
+  const unsigned wtap = 2u * A.cout_pad * 4u, wstep = 16u * wtap;
+  const unsigned xstep = 2u * (unsigned)in_plane * 4u;  // bytes per k-step (2 channels)
+  const int KP = A.cin >> 1, NR = KP / 4;               // rounds of 4 k-steps
+
+  f32x16 acc[4];
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+  using f32x4v = __attribute__((ext_vector_type(4))) float;
+  f32x4v pr[4];      // patch rows of the k-step this wave transforms
+  float ua[2][16];   // U operands: [set][ks_local*4 + xi_local]
+
+#define SESSD_WG_LOADP(ROUND)                                                                      \
+  {                                                                                                \
+    const unsigned xs = (unsigned)(min((ROUND), NR - 1) * 4 + wave) * xstep;                       \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
+      pr[r] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)ro[r], (int)xs, 0)); \
+  }
+#define SESSD_WG_LOADU(SET, ROUND)                                                                 \
+  {                                                                                                \
+    const unsigned rb = (unsigned)(min((ROUND), NR - 1) * 4) * wstep + (unsigned)(wave * 4) * wtap; \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                               \
+      _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                \
+        ua[SET][ks * 4 + x] = bufload(wr, wo, rb + ks * wstep + x * wtap);                         \
+  }
+  // V of one round in LDS: [ks 4][xi 16][h 2][tile 32]
+#define SESSD_WG_TRANSFORM(BUF)                                                                    \
+  {                                                                                                \
+    float d[4][4];                                                                                 \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
+      d[r][0] = mask_l ? 0.f : pr[r].x; d[r][1] = mask_l ? pr[r].x : pr[r].y; d[r][2] = mask_l ? pr[r].y : pr[r].z; \
+      d[r][3] = mask_l ? pr[r].z : (mask_r ? 0.f : pr[r].w);                                       \
+    }                                                                                              \
+    float tq[4][4];                                                                                \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                \
+      tq[0][c] = d[0][c] - d[2][c]; tq[1][c] = d[1][c] + d[2][c];                                  \
+      tq[2][c] = d[2][c] - d[1][c]; tq[3][c] = d[1][c] - d[3][c];                                  \
+    }                                                                                              \
+    float* dst = &lds[(BUF)*4096 + wave * 1024 + h * 32 + j];                                      \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                \
+      dst[(a * 4 + 0) * 64] = tq[a][0] - tq[a][2];                                                 \
+      dst[(a * 4 + 1) * 64] = tq[a][1] + tq[a][2];                                                 \
+      dst[(a * 4 + 2) * 64] = tq[a][2] - tq[a][1];                                                 \
+      dst[(a * 4 + 3) * 64] = tq[a][1] - tq[a][3];                                                 \
+    }                                                                                              \
+  }
+#define SESSD_WG_MMA(SET, BUF)                                                                     \
+  {                                                                                                \
+    const float* vb = &lds[(BUF)*4096 + (wave * 4) * 64 + h * 32 + j];                             \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                               \
+      _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                \
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[SET][ks * 4 + x], vb[ks * 1024 + x * 64], acc[x], 0, 0, 0); \
+  }
+
+  // prologue: V of round 0, U of round 0
+  SESSD_WG_LOADP(0)
+  SESSD_WG_LOADU(0, 0)
+  SESSD_WG_TRANSFORM(0)
+  __syncthreads();
+  for (int R = 0; R < NR; R += 2) {
+    // even round: V buffer 0, U set 0
+    SESSD_WG_LOADP(R + 1)
+    SESSD_WG_LOADU(1, R + 1)
+    __builtin_amdgcn_sched_barrier(0);
+    SESSD_WG_MMA(0, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    SESSD_WG_TRANSFORM(1)
+    __syncthreads();
+    if (R + 1 >= NR) break;
+    // odd round: V buffer 1, U set 1
+    SESSD_WG_LOADP(R + 2)
+    SESSD_WG_LOADU(0, R + 2)
+    __builtin_amdgcn_sched_barrier(0);
+    SESSD_WG_MMA(1, 1)
+    __builtin_amdgcn_sched_barrier(0);
+    SESSD_WG_TRANSFORM(0)
+    __syncthreads();
+  }
+#undef SESSD_WG_LOADP
+#undef SESSD_WG_LOADU
+#undef SESSD_WG_TRANSFORM
+#undef SESSD_WG_MMA
+
+  // ---- epilogue: M_xi[cout][tile] of all 16 xi through LDS, then Y = A^T M A per (cout, tile)
+  // D layout: column = lane&31 (tile), row = (r&3) + 8*(r>>2) + 4*h (cout)
+#pragma unroll
+  for (int x = 0; x < 4; ++x)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = (r & 3) + 8 * (r >> 2) + 4 * h;
+      lds[((wave * 4 + x) * 32 + co) * 32 + j] = acc[x][r];
+    }
+  __syncthreads();
+  const size_t out_plane = (size_t)A.hout * A.wout;
+  float* outb = A.out + (size_t)b * A.cout * out_plane;
+  const float* resb = A.residual ? A.residual + (size_t)b * A.cout * out_plane : nullptr;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int pidx = tid + 256 * n;
+    const int tl = pidx & 31, col = pidx >> 5;
+    const int tt = t_base + tl, co = m_base + col;
+    if (tt >= ntiles || co >= A.cout) continue;
+    float m[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x) m[x] = lds[(x * 32 + col) * 32 + tl];
+    float q0[4], q1[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      q0[c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
+      q1[c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
+    }
+    float y[2][2];
+    y[0][0] = q0[0] + q0[1] + q0[2]; y[0][1] = q0[1] - q0[2] - q0[3];
+    y[1][0] = q1[0] + q1[1] + q1[2]; y[1][1] = q1[1] - q1[2] - q1[3];
+    const int oy = 2 * (tt / tw), ox = 2 * (tt - (tt / tw) * tw);
+    const float sc = A.scale ? A.scale[co] : 1.f, sh = A.shift ? A.shift[co] : 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const size_t o = (size_t)co * out_plane + (size_t)(oy + a) * A.wout + ox;
+      float v0 = fmaf(y[a][0], sc, sh), v1 = fmaf(y[a][1], sc, sh);
+      if (A.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }
+      if (resb) { v0 += resb[o]; v1 += resb[o + 1]; }
+      *reinterpret_cast<float2*>(outb + o) = make_float2(v0, v1);
+    }
+  }
+}
+
 template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
 __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
   conv_body<NTAPS, CT, PT, WC, WP, DEEP>(A, blockIdx.z);
@@ -456,6 +645,21 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
     case 9: return dispatch_tile<9>(&A, 1, batch, tile_cfg, stream);
     default: return SESSD_EINVAL;
   }
+}
+
+// Fused Winograd F(2x2,3x3) for Conv2d(cin, cout, 3, stride 1, padding 1): upk = packed U = G g G^T as
+// [cin/2][16][2][cout_pad] (xi = 4*row + col of the 4x4 transform domain). Even H, W; cin % 8 == 0.
+int sessd_conv3x3_winograd(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
+                           const float* scale, const float* shift, int relu, const float* residual, hipStream_t stream) {
+  if (cin % 8 || (h & 1) || (w & 1) || batch < 1 || cout < 1) return SESSD_EINVAL;
+  ConvArgs A;
+  const int z9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  fill_args(A, in, cin, h, w, upk, 9, z9, z9, 1, h, w, out, cout, h, w, 1, 0, 0, scale, shift, relu, residual);
+  const int ntiles = (h / 2) * (w / 2);
+  dim3 grid(sessd_divup(ntiles, 32) * sessd_divup(A.cout_pad, 32), 1, batch);
+  hipLaunchKernelGGL(conv3x3s1_winograd_kernel, grid, dim3(256), 0, stream, A);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
 }
 
 // ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity

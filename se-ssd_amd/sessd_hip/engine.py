@@ -98,7 +98,7 @@ class DensePlan:
 class InferenceEngine:
     def __init__(self, model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, batch_size=1,
                  max_points_per_frame=32768, device=None, growth=(1.5, 1.0, 0.75, 0.75), anchors=None,
-                 use_frustum=False):
+                 use_frustum=False, allow_winograd=True):
         """growth[i]: capacity of sparse level i+1 relative to level i (observed ratios on KITTI-like scans are
         ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results()."""
         self.dev = torch.device("cuda:0") if device is None else device
@@ -124,6 +124,7 @@ class InferenceEngine:
         self.post_range = torch.tensor([float(v) for v in test_cfg["post_center_limit_range"]], dtype=torch.float32)
         self.dir_offset = float(getattr(model.bbox_head, "direction_offset", 0.0))
         self.use_frustum = use_frustum
+        self.allow_winograd = allow_winograd
         B = self.B
         # ---------------- level geometry and capacities
         self.levels = []  # dict(shape, cap)
@@ -309,6 +310,8 @@ class InferenceEngine:
             cands = list(candidates)
             if pc.kind == "conv" and pc.stride == 1 and pc.launches[0]["ntaps"] == 9 and pc.cin % 16 == 0:
                 cands.append(10)  # activation-stationary LDS variant
+                if getattr(pc, "upk", None) is not None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and self.allow_winograd:
+                    cands.append(20)  # fused Winograd F(2x2,3x3)
             for cfg in cands:
                 if pc.cout <= 32 and cfg != 4:
                     continue

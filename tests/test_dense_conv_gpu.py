@@ -49,6 +49,28 @@ def test_lds_variant_bit_identical(dev, cin, cout, H, W):
     _close(b.cpu(), ref)
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B", [(128, 128, 24, 40, 2), (256, 256, 14, 18, 1), (8, 32, 6, 4, 1), (128, 128, 200, 176, 1), (16, 40, 10, 66, 3)])
+def test_winograd_variant(dev, cin, cout, H, W, B):
+    """tile_cfg 20: fused Winograd F(2x2,3x3). Not bit-identical to the direct kernel (different rounding): compared with
+    float64 torch conv at 3e-6 * max|ref| * sqrt(K)/8 -- and it must not be worse than 4x the direct kernel's own error."""
+    g = torch.Generator().manual_seed(cin + H + W)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g)
+    ref = (torch.relu(F.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+           + res.double())
+    pc = ops.pack_conv2d(w.to(dev), 1)
+    args = (x.to(dev), pc, scale.to(dev), shift.to(dev), True)
+    wino = ops.conv2d(*args, residual=res.to(dev), tile_cfg=20).cpu().double()
+    direct = ops.conv2d(*args, residual=res.to(dev), tile_cfg=3).cpu().double()
+    e_w, e_d = float((wino - ref).abs().max()), float((direct - ref).abs().max())
+    print("winograd err %.2e  direct err %.2e  (max|ref| %.2f)" % (e_w, e_d, float(ref.abs().max())))
+    assert e_w < 2e-4 * max(1.0, float(ref.abs().max()))
+    assert e_w < 8 * e_d + 1e-6
+
+
 @pytest.mark.parametrize("cfg", [1, 3])
 def test_deconv_s2_with_residual(dev, cfg):
     g = torch.Generator().manual_seed(9)
