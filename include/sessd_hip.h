@@ -138,9 +138,11 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
                       int relu, const float* residual, int tile_cfg, sessd_stream_t stream);
 /* Conv2d(cin, cout, 3, stride 1, padding 1) by fused Winograd F(2x2,3x3) on the f32 matrix cores: 2.25x fewer MFMAs
  * than sessd_conv2d_mfma for the same layer (not bit-identical to it: Winograd rounding, ~1e-6 of the output scale).
- * upk = U = G g G^T packed as a 16-"tap" weight [cin/2][16][2][cout_pad], xi = 4*row + col. Even H and W, cin % 8 == 0. */
+ * upk = U = G g G^T packed [cin/2][4][2][cout_pad][4] = [k-step][xi / 4][channel parity][cout][xi % 4], xi = 4*row + col.
+ * Even H and W, cin % 8 == 0. variant 0 / 1: operands fetched one / two rounds (8 / 16 input channels) ahead of their
+ * use (variant 1: cin % 32 == 0) -- same arithmetic, same results. */
 int sessd_conv3x3_winograd(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
-                           const float* scale, const float* shift, int relu, const float* residual,
+                           const float* scale, const float* shift, int relu, const float* residual, int variant,
                            sessd_stream_t stream);
 /* ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
  * classes (py,px) = (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps: wpk4[c] packed like above, taps_dy4/taps_dx4 are

@@ -326,14 +326,21 @@ __global__ __launch_bounds__(256) void conv3x3s1_lds_kernel(ConvArgs A) {
 //   registers) and writes V of the next round to the other LDS buffer; one barrier per round.
 //   epilogue: the 16 M_xi of a (cout, tile) live in 4 waves -> through LDS, then the 2x2 output transform, BatchNorm,
 //   ReLU, residual and 8-byte stores (consecutive lanes = consecutive tiles of one output row).
-// U = G g G^T is precomputed on the host and packed like a 16-tap weight: [cin/2][16][2][cout_pad].
+// U = G g G^T is precomputed on the host and packed [cin/2][wave 4][h 2][cout_pad][xi_local 4] (xi = 4*wave + xi_local):
+// the four A operands of a lane and k-step are one 16-byte load.
 // Zero padding: rows outside the image get an out-of-range buffer offset (hardware returns 0); the column left of
 // x = 0 / right of x = W-1 is masked in registers. Needs even H and W and cin % 8 == 0.
 // Numerics: NOT the fmaf chain of the direct kernel -- Winograd rounding (about 1e-6 of the output scale in float32);
 // deterministic (fixed order), covered by the same tolerance as the other float stages.
+// DEEP = false: patches and U are fetched one round ahead (2 U register sets, 1 patch set);
+// DEEP = true : two rounds ahead (4 U sets, 2 patch sets; the round body is unrolled 4x so every set index is a
+//               compile-time constant; cin % 32 == 0) -- the loads come from L2 (each workgroup streams 256 KB of patches and 256 KB
+//               of U with no reuse), whose loaded latency exceeds one round of MFMA time.
+template <bool DEEP>
 __global__ __launch_bounds__(256, 2) void conv3x3s1_winograd_kernel(ConvArgs A) {
-  constexpr int TT = 32;  // tiles per workgroup
-  __shared__ __attribute__((aligned(16))) float lds[16 * 32 * 32];  // 64 KB: V double buffer (2 x 16 KB) / M exchange
+  constexpr int TT = 32;    // tiles per workgroup
+  constexpr int VBUF = 4096;  // floats of one V buffer: [ks 4][xi 16][h 2][tile 32]
+  __shared__ __attribute__((aligned(16))) float lds[16384];  // 64 KB: V double buffer (32 KB) / M exchange (64 KB)
   const int tid = threadIdx.x, lane = tid & 63;
   // readfirstlane: tells hipcc the wave index is wave-uniform, otherwise every buffer load whose SGPR offset depends
   // on it is wrapped in a readfirstlane "waterfall" loop (measured: VALU time = 75 % of the MFMA time)
@@ -365,18 +372,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_winograd_kernel(ConvArgs A) 
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int y = y0 + r;
-    // x0 may be -1: the 16-byte load then starts one float before the row (still inside the buffer except for the very
-    // first row of channel 0 with h = 0, which is out of the image anyway when y = -1... y >= 0 here); masked below
-    // tiles in the first column start their 16-byte row load at x = 0 (a negative offset would be range-checked away
-    // as a whole) and shift the components in registers instead
+    // rows outside the image: out-of-range offset -> the hardware returns 0. Tiles in the first column start their
+    // 16-byte row load at x = 0 (a negative offset would be range-checked away as a whole) and shift the components
+    // in registers instead
     ro[r] = (tlive && y >= 0 && y < A.hin) ? (unsigned)((h * in_plane + y * A.win + max(x0, 0)) * 4) : SESSD_OOB;
   }
   const bool mask_l = (tx == 0), mask_r = (tx == tw - 1);
-  // ---- GEMM role: wave owns xi = 4*wave .. 4*wave+3 ; A operand lane (i = j, h)
-  const unsigned wo = (unsigned)((h * A.cout_pad + m_base + j) * 4);
-  const unsigned wtap = 2u * A.cout_pad * 4u, wstep = 16u * wtap;
-  const unsigned xstep = 2u * (unsigned)in_plane * 4u;  // bytes per k-step (2 channels)
-  const int KP = A.cin >> 1, NR = KP / 4;               // rounds of 4 k-steps
+  const bool edge = __builtin_amdgcn_ballot_w64(tlive && (mask_l || mask_r)) != 0;
+  // ---- GEMM role: wave owns xi = 4*wave .. 4*wave+3 ; A operand lane (cout i = j, channel parity h).
+  // U is packed [cin/2][wave 4][h 2][cout_pad][xi_local 4]: one 16-byte load per lane and k-step
+  const unsigned wo = (unsigned)(((wave * 2 + h) * A.cout_pad + m_base + j) * 16);
+  const unsigned wstep = 4u * 2u * (unsigned)A.cout_pad * 16u;  // bytes per k-step
+  const unsigned xstep = 2u * (unsigned)in_plane * 4u;          // bytes per k-step (2 channels)
+  const int KP = A.cin >> 1, NR = KP / 4;                       // rounds of 4 k-steps
 
   f32x16 acc[4];
 #pragma unroll
@@ -385,74 +393,102 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_winograd_kernel(ConvArgs A) 
     for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
   using f32x4v = __attribute__((ext_vector_type(4))) float;
-  f32x4v pr[4];      // patch rows of the k-step this wave transforms
-  float ua[2][16];   // U operands: [set][ks_local*4 + xi_local]
+  using f32x2v = __attribute__((ext_vector_type(2))) float;
+  f32x4v pr[DEEP ? 2 : 1][4];  // patch rows of the k-step this wave transforms, per set
+  f32x4v ua[DEEP ? 4 : 2][4];  // U operands of one round, per set: [ks_local] . xi_local
 
-#define SESSD_WG_LOADP(ROUND)                                                                      \
+#define SESSD_WG_LOADP(PS, ROUND)                                                                  \
   {                                                                                                \
     const unsigned xs = (unsigned)(min((ROUND), NR - 1) * 4 + wave) * xstep;                       \
     _Pragma("unroll") for (int r = 0; r < 4; ++r)                                                  \
-      pr[r] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)ro[r], (int)xs, 0)); \
+      pr[PS][r] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)ro[r], (int)xs, 0)); \
   }
-#define SESSD_WG_LOADU(SET, ROUND)                                                                 \
+#define SESSD_WG_LOADU(US, ROUND)                                                                  \
   {                                                                                                \
-    const unsigned rb = (unsigned)(min((ROUND), NR - 1) * 4) * wstep + (unsigned)(wave * 4) * wtap; \
+    const unsigned rb = (unsigned)(min((ROUND), NR - 1) * 4) * wstep;                              \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                               \
-      _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                \
-        ua[SET][ks * 4 + x] = bufload(wr, wo, rb + ks * wstep + x * wtap);                         \
+      ua[US][ks] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wo, (int)(rb + ks * wstep), 0)); \
   }
   // V of one round in LDS: [ks 4][xi 16][h 2][tile 32]
-#define SESSD_WG_TRANSFORM(BUF)                                                                    \
+#define SESSD_WG_TRANSFORM(PS, BUF)                                                                \
   {                                                                                                \
-    float d[4][4];                                                                                 \
-    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
-      d[r][0] = mask_l ? 0.f : pr[r].x; d[r][1] = mask_l ? pr[r].x : pr[r].y; d[r][2] = mask_l ? pr[r].y : pr[r].z; \
-      d[r][3] = mask_l ? pr[r].z : (mask_r ? 0.f : pr[r].w);                                       \
+    if (edge) { /* workgroup-uniform: only 1 tile block in 3 touches the left / right image border */ \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                              \
+        const f32x4v p = pr[PS][r];                                                                \
+        pr[PS][r].x = mask_l ? 0.f : p.x; pr[PS][r].y = mask_l ? p.x : p.y;                        \
+        pr[PS][r].z = mask_l ? p.y : p.z; pr[PS][r].w = mask_l ? p.z : (mask_r ? 0.f : p.w);       \
+      }                                                                                            \
     }                                                                                              \
-    float tq[4][4];                                                                                \
-    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                \
-      tq[0][c] = d[0][c] - d[2][c]; tq[1][c] = d[1][c] + d[2][c];                                  \
-      tq[2][c] = d[2][c] - d[1][c]; tq[3][c] = d[1][c] - d[3][c];                                  \
-    }                                                                                              \
-    float* dst = &lds[(BUF)*4096 + wave * 1024 + h * 32 + j];                                      \
+    /* rows: t = B^T d, two columns per packed add */                                              \
+    f32x2v tl[4], tr[4];                                                                           \
+    tl[0] = pr[PS][0].xy - pr[PS][2].xy; tr[0] = pr[PS][0].zw - pr[PS][2].zw;                      \
+    tl[1] = pr[PS][1].xy + pr[PS][2].xy; tr[1] = pr[PS][1].zw + pr[PS][2].zw;                      \
+    tl[2] = pr[PS][2].xy - pr[PS][1].xy; tr[2] = pr[PS][2].zw - pr[PS][1].zw;                      \
+    tl[3] = pr[PS][1].xy - pr[PS][3].xy; tr[3] = pr[PS][1].zw - pr[PS][3].zw;                      \
+    float* dst = &lds[(BUF)*VBUF + wave * 1024 + h * 32 + j];                                      \
     _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                \
-      dst[(a * 4 + 0) * 64] = tq[a][0] - tq[a][2];                                                 \
-      dst[(a * 4 + 1) * 64] = tq[a][1] + tq[a][2];                                                 \
-      dst[(a * 4 + 2) * 64] = tq[a][2] - tq[a][1];                                                 \
-      dst[(a * 4 + 3) * 64] = tq[a][1] - tq[a][3];                                                 \
+      dst[(a * 4 + 0) * 64] = tl[a].x - tr[a].x;                                                   \
+      dst[(a * 4 + 1) * 64] = tl[a].y + tr[a].x;                                                   \
+      dst[(a * 4 + 2) * 64] = tr[a].x - tl[a].y;                                                   \
+      dst[(a * 4 + 3) * 64] = tl[a].y - tr[a].y;                                                   \
     }                                                                                              \
   }
-#define SESSD_WG_MMA(SET, BUF)                                                                     \
+#define SESSD_WG_MMA(US, BUF)                                                                      \
   {                                                                                                \
-    const float* vb = &lds[(BUF)*4096 + (wave * 4) * 64 + h * 32 + j];                             \
+    const float* vb = &lds[(BUF)*VBUF + (wave * 4) * 64 + h * 32 + j];                             \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                               \
       _Pragma("unroll") for (int x = 0; x < 4; ++x)                                                \
-        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[SET][ks * 4 + x], vb[ks * 1024 + x * 64], acc[x], 0, 0, 0); \
+        acc[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[US][ks][x], vb[ks * 1024 + x * 64], acc[x], 0, 0, 0); \
   }
 
-  // prologue: V of round 0, U of round 0
-  SESSD_WG_LOADP(0)
-  SESSD_WG_LOADU(0, 0)
-  SESSD_WG_TRANSFORM(0)
-  __syncthreads();
-  for (int R = 0; R < NR; R += 2) {
-    // even round: V buffer 0, U set 0
-    SESSD_WG_LOADP(R + 1)
-    SESSD_WG_LOADU(1, R + 1)
-    __builtin_amdgcn_sched_barrier(0);
-    SESSD_WG_MMA(0, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    SESSD_WG_TRANSFORM(1)
+  if constexpr (!DEEP) {
+    // round RR computes from V buffer PAR / U set PAR while the loads and the transform of round RR+1 proceed
+#define SESSD_WG_ROUND(RR, PAR)                                                                    \
+  {                                                                                                \
+    SESSD_WG_LOADP(0, (RR) + 1)                                                                    \
+    SESSD_WG_LOADU((PAR) ^ 1, (RR) + 1)                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_WG_MMA(PAR, PAR)                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_WG_TRANSFORM(0, (PAR) ^ 1)                                                               \
+    __syncthreads();                                                                               \
+  }
+    SESSD_WG_LOADP(0, 0)
+    SESSD_WG_LOADU(0, 0)
+    SESSD_WG_TRANSFORM(0, 0)
     __syncthreads();
-    if (R + 1 >= NR) break;
-    // odd round: V buffer 1, U set 1
-    SESSD_WG_LOADP(R + 2)
-    SESSD_WG_LOADU(0, R + 2)
-    __builtin_amdgcn_sched_barrier(0);
-    SESSD_WG_MMA(1, 1)
-    __builtin_amdgcn_sched_barrier(0);
-    SESSD_WG_TRANSFORM(0)
+    for (int R = 0; R < NR; R += 2) {
+      SESSD_WG_ROUND(R, 0)
+      if (R + 1 >= NR) break;
+      SESSD_WG_ROUND(R + 1, 1)
+    }
+#undef SESSD_WG_ROUND
+  } else {
+    // round RR: MMA on V buffer P2 / U set U4; issue the loads of round RR+2 (patch set P2, U set (U4+2)%4);
+    // transform the patches of round RR+1 (patch set P2^1) into V buffer P2^1
+#define SESSD_WG_ROUND(RR, P2, U4)                                                                 \
+  {                                                                                                \
+    SESSD_WG_LOADP(P2, (RR) + 2)                                                                   \
+    SESSD_WG_LOADU(((U4) + 2) & 3, (RR) + 2)                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_WG_MMA(U4, P2)                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_WG_TRANSFORM((P2) ^ 1, (P2) ^ 1)                                                         \
+    __syncthreads();                                                                               \
+  }
+    SESSD_WG_LOADP(0, 0)
+    SESSD_WG_LOADU(0, 0)
+    SESSD_WG_LOADP(1, 1)
+    SESSD_WG_LOADU(1, 1)
+    SESSD_WG_TRANSFORM(0, 0)
     __syncthreads();
+    for (int R = 0; R < NR; R += 4) {
+      SESSD_WG_ROUND(R, 0, 0)
+      SESSD_WG_ROUND(R + 1, 1, 1)
+      SESSD_WG_ROUND(R + 2, 0, 2)
+      SESSD_WG_ROUND(R + 3, 1, 3)
+    }
+#undef SESSD_WG_ROUND
   }
 #undef SESSD_WG_LOADP
 #undef SESSD_WG_LOADU
@@ -648,16 +684,22 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
 }
 
 // Fused Winograd F(2x2,3x3) for Conv2d(cin, cout, 3, stride 1, padding 1): upk = packed U = G g G^T as
-// [cin/2][16][2][cout_pad] (xi = 4*row + col of the 4x4 transform domain). Even H, W; cin % 8 == 0.
+// [cin/2][4][2][cout_pad][4] (xi = 4*row + col of the 4x4 transform domain, row-major outer/inner). Even H, W;
+// cin % 8 == 0. variant 0 / 1 = loads one / two rounds ahead of their use.
 int sessd_conv3x3_winograd(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
-                           const float* scale, const float* shift, int relu, const float* residual, hipStream_t stream) {
+                           const float* scale, const float* shift, int relu, const float* residual, int variant,
+                           hipStream_t stream) {
   if (cin % 8 || (h & 1) || (w & 1) || batch < 1 || cout < 1) return SESSD_EINVAL;
+  if (variant < 0 || variant > 1 || (variant == 1 && cin % 32)) return SESSD_EINVAL;
   ConvArgs A;
   const int z9[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   fill_args(A, in, cin, h, w, upk, 9, z9, z9, 1, h, w, out, cout, h, w, 1, 0, 0, scale, shift, relu, residual);
   const int ntiles = (h / 2) * (w / 2);
   dim3 grid(sessd_divup(ntiles, 32) * sessd_divup(A.cout_pad, 32), 1, batch);
-  hipLaunchKernelGGL(conv3x3s1_winograd_kernel, grid, dim3(256), 0, stream, A);
+  if (variant == 1)
+    hipLaunchKernelGGL(conv3x3s1_winograd_kernel<true>, grid, dim3(256), 0, stream, A);
+  else
+    hipLaunchKernelGGL(conv3x3s1_winograd_kernel<false>, grid, dim3(256), 0, stream, A);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -65,9 +65,12 @@ __global__ __launch_bounds__(VOX_NT) void vox_insert_kernel(const float* __restr
 
 __global__ __launch_bounds__(VOX_NT) void vox_count_kernel(int P, const int* __restrict__ ent,
                                                              const int* __restrict__ lists, int MP,
-                                                             int* __restrict__ blk_cnt) {
+                                                             int* __restrict__ blk_cnt, int* __restrict__ meta) {
   __shared__ int sm[VOX_NT / 64];
   int i = blockIdx.x * VOX_NT + threadIdx.x;
+  // per-FRAME reset of the break index: the workspace is shared by the frames of a batch, and an engine clears its
+  // arena once per batch, so a frame that hit max_voxels must not leave its cut behind for the next frame
+  if (i == 0) meta[0] = SESSD_SENT;
   int f = 0;
   if (i < P) {
     int e = ent[i];
@@ -312,7 +315,8 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
                        hash_keys, hash_capacity - 1, w.lists, MP, w.ent);
     SESSD_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(vox_count_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, num_points, w.ent, w.lists, MP, w.blk_cnt);
+  hipLaunchKernelGGL(vox_count_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, num_points, w.ent, w.lists, MP, w.blk_cnt,
+                     w.meta);
   SESSD_CHECK_LAUNCH();
   hipLaunchKernelGGL(vox_assign_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, num_points, w.ent, w.lists, MP, w.blk_cnt,
                      nblk, hash_keys, key_base, G, max_voxels, batch_index, prefix + batch_index, hash_vals,

@@ -312,6 +312,8 @@ class InferenceEngine:
                 cands.append(10)  # activation-stationary LDS variant
                 if getattr(pc, "upk", None) is not None and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and self.allow_winograd:
                     cands.append(20)  # fused Winograd F(2x2,3x3)
+                    if pc.cin % 32 == 0:
+                        cands.append(21)  # same, operands fetched two rounds ahead
             for cfg in cands:
                 if pc.cout <= 32 and cfg != 4:
                     continue

@@ -280,13 +280,16 @@ def pack_conv2d(weight, stride=1, padding=None):
 
 
 def pack_winograd(weight):
-    """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) for sessd_conv3x3_winograd, packed [Cin/2][16][2][Cout_pad]."""
+    """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) for sessd_conv3x3_winograd, packed
+    [Cin/2][xi/4][channel parity][Cout_pad][xi%4]."""
     w = weight.detach().to(torch.float64)
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
     G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
     U = torch.einsum("ia,ocab,jb->ocij", G, w, G).to(torch.float32)
-    return _pack_taps(U.reshape(co, ci, 16).contiguous(), co)
+    p = _pack_taps(U.reshape(co, ci, 16).contiguous(), co)  # [Cin/2][16][2][Cout_pad]
+    cp = p.shape[3]
+    return p.view(ci // 2, 4, 4, 2, cp).permute(0, 1, 3, 4, 2).contiguous()
 
 
 def pack_deconv2d_s2(weight):
@@ -332,11 +335,12 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         th, tw = H, W
     if out is None:
         out = torch.empty((B, pc.cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    if tile_cfg == 20:
+    if tile_cfg in (20, 21):
         if getattr(pc, "upk", None) is None or (H & 1) or (W & 1):
-            raise ValueError("tile_cfg 20 (Winograd) needs a 3x3 stride-1 conv with cin % 8 == 0 and even H, W")
+            raise ValueError("tile_cfg 20/21 (Winograd) needs a 3x3 stride-1 conv with cin % 8 == 0 and even H, W")
         check(lib.sessd_conv3x3_winograd(x.data_ptr(), B, ci, H, W, pc.upk.data_ptr(), out.data_ptr(), pc.cout, _p(scale),
-                                         _p(shift), 1 if relu else 0, _p(residual), _stream()), "conv3x3_winograd")
+                                         _p(shift), 1 if relu else 0, _p(residual), tile_cfg - 20, _stream()),
+              "conv3x3_winograd")
         return out
     if pc.kind == "deconv" and ci % 8 == 0:
         import ctypes
