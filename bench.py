@@ -41,6 +41,10 @@ def parse():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--points", type=int, default=20000)
     ap.add_argument("--max-voxels", type=int, default=16000)
+    ap.add_argument("--batch", type=int, default=1, help="frames per step (BASELINE configs[1] is batch 1)")
+    ap.add_argument("--supersample", type=int, default=1, help="ray supersampling of the synthetic scanner (3 for 200k points)")
+    ap.add_argument("--stress", action="store_true",
+                    help="BASELINE configs[4]: 200k points/frame, max 64000 voxels, batch 8 (a parity/roofline case, not the metric line)")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames cycled through")
     ap.add_argument("--eager", action="store_true", help="no hipGraph: launch every kernel from Python")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
@@ -63,6 +67,9 @@ _T0 = time.perf_counter()
 
 def main():
     args = parse()
+    if args.stress:
+        args.points, args.max_voxels, args.batch, args.supersample, args.pool = 200000, 64000, 8, 3, 8
+        args.streams = 1
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -80,15 +87,18 @@ def main():
 
     model = configs.build_synthetic_detector(dev, seed=0, max_voxels=args.max_voxels, num_points=args.points)
     engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], args.max_voxels,
-                               configs.TEST_CFG, batch_size=1, max_points_per_frame=args.points, device=dev)
+                               configs.TEST_CFG, batch_size=args.batch, max_points_per_frame=args.points, device=dev)
                for _ in range(max(1, args.streams))]
     streams = [torch.cuda.Stream() for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream()]
     eng = engines[0]
     # frames of this rank, resident in HBM before the clock starts (rank r takes seeds r*pool ...)
-    frames_np = [synth.make_frame(rank * args.pool + i, args.points) for i in range(args.pool)]
+    frames_np = [synth.make_frame(rank * args.pool + i, args.points, supersample=args.supersample) for i in range(args.pool)]
     frames = [torch.from_numpy(f).to(dev) for f in frames_np]
     log("model + engine built")
-    eng.set_points([frames[0]])
+    def batch_of(i):
+        return [frames[(i * args.batch + b) % args.pool] for b in range(args.batch)]
+
+    eng.set_points(batch_of(0))
     eng.enqueue()
     torch.cuda.synchronize()
     first = eng.results()[0]
@@ -99,7 +109,7 @@ def main():
     for e in engines[1:]:
         e.tile_cfg = dict(eng.tile_cfg)
         e.sparse_split = dict(eng.sparse_split)
-        e.set_points([frames[0]])
+        e.set_points(batch_of(0))
         e.enqueue()
     torch.cuda.synchronize()
     if not args.eager:
@@ -112,7 +122,7 @@ def main():
     def step(i):
         e, st = engines[i % len(engines)], streams[i % len(engines)]
         with torch.cuda.stream(st):
-            e.set_points([frames[i % args.pool]])  # device-to-device staging into the engine's static input buffer
+            e.set_points(batch_of(i))  # device-to-device staging into the engine's static input buffer
             if args.eager:
                 e.enqueue()
             else:
@@ -145,13 +155,14 @@ def main():
     if rank == 0:
         out = {
             "metric": "KITTI frames/sec (voxelize->backbone->head->NMS)",
-            "value": world * args.steps / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": world * args.steps * args.batch / dt, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SE-SSD KITTI-car inference, 1 frame/step: %d-point synthetic HDL-64E front-FOV scans, "
-                                   "voxel grid [1408,1600,40], max_voxels %d, batch 1 (BASELINE.json configs[1]); "
-                                   "seeded random weights, BatchNorm calibrated" % (args.points, args.max_voxels),
-                       "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps,
+            "config": {"workload": "SE-SSD KITTI-car inference, %d frame(s)/step: %d-point synthetic HDL-64E front-FOV scans, "
+                                   "voxel grid [1408,1600,40], max_voxels %d, batch %d (BASELINE.json configs[%d]); "
+                                   "seeded random weights, BatchNorm calibrated"
+                                   % (args.batch, args.points, args.max_voxels, args.batch, 4 if args.stress else 1),
+                       "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps * args.batch,
                        "frames_in_flight": len(engines),
                        "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                        "detections_last_frame": dets, "detections_first_frame": int(len(first["scores"]))},
@@ -161,6 +172,7 @@ def main():
             pc, scale, shift = eng.dn.b0[1]
             x, y = eng.t["a"], eng.t["b"]
             rcfg = eng.tile_cfg.get("b0.1")
+            wino = rcfg in (20, 21) or (rcfg is None and ops.USE_WINOGRAD)
             for _ in range(5):
                 ops.conv2d(x, pc, scale, shift, True, None, y, rcfg)
             n_l = 50
@@ -171,19 +183,38 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             kms = e0.elapsed_time(e1) / n_l
-            ach = CONV_FLOPS / (kms * 1e-3) / 1e12
+            flops = CONV_FLOPS * args.batch
+            ach = flops / (kms * 1e-3) / 1e12
             log("roofline kernel: %.3f ms" % kms)
-            out["roofline"] = {"bound": "mfma", "kernel": "conv2d_mfma_kernel<9 taps> 3x3 128->128 @200x176 (5 of 14 SSFA convs; all "
-                               "9-tap launches are 80.6 of the frame's 90.8 dense GFLOP)", "achieved": ach,
-                               "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TFLOPS,
-                               "avg_launch_ms": kms, "flops_per_launch": CONV_FLOPS, "traffic": None}
+            kname = ("conv3x3s1_winograd_kernel (fused Winograd F(2x2,3x3) on f32 MFMA)" if wino
+                     else "conv2d_mfma_kernel<9 taps> (direct implicit GEMM on f32 MFMA)")
+            out["roofline"] = {"bound": "mfma", "kernel": kname + ": Conv2d 3x3 128->128 @200x176, 5 launches per frame "
+                               "(+2 at 256->256 @100x88 with the same FLOPs); the seven are 72.6 of the frame's 90.8 dense GFLOP",
+                               "achieved": ach, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": ach / F32_MFMA_PEAK_TFLOPS, "avg_launch_ms": kms, "flops_per_launch": flops,
+                               "flops_definition": "algorithmic = direct-convolution FLOPs 2*H*W*Cin*Cout*9 of the layer",
+                               "traffic": None}
+            if wino:
+                # Winograd F(2x2,3x3) executes 16 multiplies per 2x2 outputs and channel pair instead of 36
+                out["roofline"]["mfma_executed_tflops"] = ach * 16.0 / 36.0
+                out["roofline"]["mfma_executed_frac"] = ach * 16.0 / 36.0 / F32_MFMA_PEAK_TFLOPS
             # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
             # under profiles/; it cannot be collected inside this process
-            tpath = os.path.join(ROOT, "profiles", "r1_conv_traffic.json")
-            if os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "r1_winograd_traffic.json" if wino else "r1_conv_traffic.json")
+            if os.path.exists(tpath) and args.batch == 1:
                 tj = json.load(open(tpath))
                 out["roofline"]["traffic"] = tj["traffic_bytes"]
                 out["roofline"]["traffic_source"] = tj["source"]
+            # ---- per-stage time (eager, events) and the HBM roofline of SpMiddleFHD (algorithmic bytes / time)
+            eng.set_points(batch_of(0))
+            st = eng.stage_times()
+            sp_bytes, sites = eng.spmiddle_algorithmic_bytes()
+            out["stages_ms_eager"] = {k: round(v, 4) for k, v in st.items()}
+            gbs = sp_bytes / (st["spmiddle"] * 1e-3) / 1e9
+            out["roofline_spmiddle"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                        "algorithmic_bytes": sp_bytes, "sites_per_level": sites, "ms": st["spmiddle"],
+                                        "note": "all 14 sparse layers + rulebooks of one batch, eager launches; at batch 1 "
+                                                "the stage is launch/latency-bound, see --stress for the meaningful case"}
         # ---- CPU baseline: the oracle port of the reference path on the host cores of this box (bounded sample)
         if args.cpu_frames > 0 and world == 1:
             from oracle import pipeline, postprocess as pp

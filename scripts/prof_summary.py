@@ -1,14 +1,36 @@
-"""Summarise a rocprofv3 --kernel-trace rocpd database (gpurun_out/.../*_results.db) into a per-kernel table."""
+"""Summarise a rocprofv3 --kernel-trace rocpd database (*_results.db) into a per-kernel table.
+
+    python scripts/prof_summary.py DB [FRAMES] [ROWS]
+
+FRAMES > 0: only the kernels of the LAST `FRAMES` frames are counted (a frame starts at each vox_insert_kernel launch),
+i.e. the timed region of bench.py without model set-up, BatchNorm calibration and autotuning; per-frame figures."""
 import sqlite3
 import sys
+from collections import defaultdict
 
 db = sqlite3.connect(sys.argv[1])
-frames = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
-rows = list(db.execute("select name, count(*), sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 "
-                       "from kernels group by name order by 3 desc"))
-tot = sum(r[2] for r in rows)
-print("# rocprofv3 --kernel-trace summary of %s" % sys.argv[1])
-print("# total kernel time %.1f us over %g frames = %.1f us/frame" % (tot, frames, tot / frames))
-print("%-100s %7s %11s %9s %9s %9s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "pct"))
-for r in rows[:int(sys.argv[3]) if len(sys.argv) > 3 else 45]:
-    print("%-100s %7d %11.0f %9.1f %9.1f %9.1f %5.1f%%" % (r[0][:100], r[1], r[2], r[3], r[4], r[5], 100 * r[2] / tot))
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+nrows = int(sys.argv[3]) if len(sys.argv) > 3 else 45
+rows = list(db.execute("select name, start, end from kernels order by start"))
+div = 1.0
+if frames > 0:
+    starts = [i for i, r in enumerate(rows) if "vox_insert_kernel" in r[0]]
+    rows = rows[starts[-frames]:]
+    div = float(frames)
+agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])
+for n, s, e in rows:
+    d = (e - s) / 1e3
+    a = agg[n]
+    a[0] += 1
+    a[1] += d
+    a[2] = min(a[2], d)
+    a[3] = max(a[3], d)
+tot = sum(a[1] for a in agg.values())
+print("# rocprofv3 --kernel-trace summary of %s" % sys.argv[1].split("/")[-1])
+if frames > 0:
+    print("# last %d frames: kernel time %.1f us/frame, wall %.1f us/frame" % (frames, tot / div, (rows[-1][2] - rows[0][1]) / 1e3 / div))
+else:
+    print("# total kernel time %.1f us" % tot)
+print("%-100s %9s %11s %9s %9s %9s %6s" % ("kernel", "calls/fr" if frames else "calls", "us/frame" if frames else "total_us", "avg_us", "min_us", "max_us", "pct"))
+for n, a in sorted(agg.items(), key=lambda x: -x[1][1])[:nrows]:
+    print("%-100s %9.1f %11.1f %9.1f %9.1f %9.1f %5.1f%%" % (n[:100], a[0] / div, a[1] / div, a[1] / a[0], a[2], a[3], 100 * a[1] / tot))

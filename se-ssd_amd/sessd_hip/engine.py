@@ -215,6 +215,7 @@ class InferenceEngine:
         self._ks = {}
         self._npts = [0] * B
         self.graph = None
+        self._marks = None
         self.tile_cfg = {}
         self.tune_report = {}
         self._tuning = None
@@ -359,6 +360,7 @@ class InferenceEngine:
                                            self.voxels.data_ptr(), self.coors.data_ptr(), 4, self.nump.data_ptr(),
                                            self.vfeat.data_ptr(), self.prefix.data_ptr(), self.vox_ws.data_ptr(),
                                            self.vox_ws.numel(), s), "voxelize_frame")
+        self._mark("voxelize")
         # ---- SpMiddleFHD (a4-a8)
         li = 0
         feat = self.vfeat
@@ -405,6 +407,7 @@ class InferenceEngine:
                     feat = Lo["feat_a"]
                 li += 1
                 have_subm = subm_ready
+        self._mark("spmiddle")
         # ---- SSFA (a9) rpn_v1.py:220-235
         t, h, d = self.t, self.h, self.dn
         x = self._conv(self.bev, d.b0[0], t["a"], name="b0.0")
@@ -422,12 +425,56 @@ class InferenceEngine:
         ops.ssfa_fuse(o0, o1, d.w0, d.w1, *d.wbn, out=t["out"])
         # ---- heads (a10) + predict (a11-a14)
         self._conv(t["out"], d.head, self.head.view(B, 22, self.H, self.W), relu=False, name="head")
+        self._mark("ssfa_head")
         check(lib.sessd_predict(self.head.data_ptr(), B, self.H * self.W, self.anchors.data_ptr(), 0,
                                 0 if self.frustum is None else self.frustum.data_ptr(), self.score_thresh, self.pre_max,
                                 self.post_max, self.nms_thresh, self.post_range.data_ptr(), self.dir_offset,
                                 self.out["box"].data_ptr(), self.out["score"].data_ptr(), self.out["label"].data_ptr(),
                                 self.out["count"].data_ptr(), self.pred_ws.data_ptr(), self.pred_ws.numel(), s), "predict")
+        self._mark("predict")
         return self.out
+
+    def _mark(self, name):
+        if self._marks is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            self._marks.append((name, ev))
+
+    def stage_times(self, reps=10):
+        """Eager (no graph) per-stage GPU time in ms of the staged batch, HIP events on the current stream:
+        dict(clear, voxelize, spmiddle, ssfa_head, predict). Informational; launch gaps of eager mode included."""
+        acc = {}
+        for _ in range(2):
+            self.enqueue()
+        for _ in range(reps):
+            self._marks = []
+            e0 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.enqueue()
+            marks, self._marks = self._marks, None
+            torch.cuda.synchronize()
+            prev = e0
+            for name, ev in marks:
+                acc[name] = acc.get(name, 0.0) + prev.elapsed_time(ev) / reps
+                prev = ev
+        return acc
+
+    def spmiddle_algorithmic_bytes(self):
+        """per sparse layer (N_in*Cin + N_out*Cout)*4 + K*Cin*Cout*4 + (N_in + N_out)*16 bytes (features in
+        and out once, weights once, indices once) with the live site counts of the last batch, plus the dense BEV
+        write. Synchronises."""
+        ns = [int(self.prefix[self.B].item())] + [int(L["n"].item()) for L in self.levels[1:]]
+        total, li = 0, 0
+        for lay in self.sp.layers:
+            kv = lay["ks"][0] * lay["ks"][1] * lay["ks"][2]
+            n_in = ns[li]
+            if lay["kind"] != "subm":
+                li += 1
+            n_out = ns[li]
+            total += (n_in * lay["cin"] + n_out * lay["cout"]) * 4 + kv * lay["cin"] * lay["cout"] * 4 + (n_in + n_out) * 16
+        total -= ns[-1] * self.sp.layers[-1]["cout"] * 4  # the last layer writes the dense map instead of a feature table
+        total += self.bev.numel() * 4
+        return total, ns
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, warmup=2):
