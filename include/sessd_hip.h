@@ -121,6 +121,20 @@ int sessd_sparse_conv(const float* in_feat, int cin, const int32_t* nbr, const u
                       const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
                       float* dense_out, const int32_t* dense_dims3, int cout_split, sessd_stream_t stream);
 
+/* ---- sparse conv backward (spconv's indice_conv backward as differentiated by the SE-SSD training
+ * step, det3d/torchie/trainer/trainer_sessd.py:250-275 through det3d/models/backbones/scn.py:106-148) -------------
+ * Data gradient: dx = sessd_sparse_conv(dy, nbr_t, tile_mask_t, weights W_k^T) over the INPUT sites, with
+ * nbr_t[k][i] = j <=> nbr[k][j] = i built here (collision-free scatter; nbr_t (kv, n_in_cap), tile_mask_t
+ * (ceil(n_in_cap/16)) are cleared by the call). */
+int sessd_sparse_rulebook_transpose(const int32_t* nbr, int kernel_volume, const int32_t* n_out_dev, int n_out_cap,
+                                    int n_in_cap, int32_t* nbr_t, uint32_t* tile_mask_t, sessd_stream_t stream);
+size_t sessd_sparse_conv_wgrad_workspace_bytes(int kernel_volume, int cin, int cout);
+/* Weight gradient: grad_weight (kv, cin, cout) = sum over rulebook pairs of in_feat[nbr[k][j]] (outer) grad_out[j];
+ * deterministic (site chunks summed in order on the matrix cores, then <= 64 partials in order). */
+int sessd_sparse_conv_wgrad(const float* in_feat, int cin, const float* grad_out, int cout, const int32_t* nbr,
+                            const uint32_t* tile_mask, int kernel_volume, const int32_t* n_out_dev, int n_out_cap,
+                            float* grad_weight, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+
 /* ------------------------------------------------------------------ dense BEV neck + heads (a9-a10)
  * replace the ATen/cuDNN conv2d, conv_transpose2d, batch_norm, relu, softmax calls made by
  * det3d/models/necks/rpn_v1.py:220-235 (SSFA.forward; RPN.forward :107-116 uses the same layers) and

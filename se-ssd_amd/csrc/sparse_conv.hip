@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   float a[2][STEPS], bw[2][NTILE][STEPS];
   uint32_t rest = tmask;
   int remaining = __builtin_popcount(tmask);
-  const int* nb = nbr + tile * 16 + i;
+  // lanes of the last tile whose site is >= n read the tile's first site instead (their results are discarded below):
+  // with a capacity that is not a multiple of 16 their own column would lie past the end of the last rulebook row
+  const int* nb = nbr + tile * 16 + (tile * 16 + i < n ? i : 0);
   int klast = 0;
 #define SESSD_NEXTK() (rest ? (klast = __builtin_ctz(rest), rest &= rest - 1, klast) : klast)
 #define SESSD_LOADAB(SET, K, ROW)                                                                  \
@@ -251,6 +253,8 @@ int sessd_sparse_conv(const float* in_feat, int cin, const int* nbr, const uint3
   SESSD_SC(16, 64)
   SESSD_SC(64, 128)
   SESSD_SC(128, 128)
+  SESSD_SC(32, 16)  // data-gradient shapes of the 16->32 and 32->64 strided convs
+  SESSD_SC(64, 32)
 #undef SESSD_SC
   return SESSD_EINVAL;  // channel pair not instantiated
 }

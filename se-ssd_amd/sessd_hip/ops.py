@@ -244,6 +244,31 @@ def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, sc
     return out if dense_out is None else dense_out
 
 
+def sparse_rulebook_transpose(nbr, n_out_dev, n_in_cap):
+    """Rulebook of the data-gradient pass: nbr_t (kv, n_in_cap) with nbr_t[k][i] = j <=> nbr[k][j] = i, and its tile masks."""
+    kv, cap = nbr.shape
+    nbr_t = torch.empty((kv, n_in_cap), dtype=torch.int32, device=nbr.device)
+    tm_t = torch.empty(((n_in_cap + 15) // 16,), dtype=torch.int32, device=nbr.device)
+    check(lib.sessd_sparse_rulebook_transpose(nbr.data_ptr(), kv, n_out_dev.data_ptr(), cap, n_in_cap, nbr_t.data_ptr(),
+                                              tm_t.data_ptr(), _stream()), "sparse_rulebook_transpose")
+    return nbr_t, tm_t
+
+
+def sparse_conv_wgrad(in_feat, grad_out, nbr, tile_mask, n_out_dev, cin, cout):
+    """grad_weight (kv, cin, cout) of sparse_conv(in_feat, nbr, ...) given grad_out (n_out_cap, cout)."""
+    _req(in_feat, torch.float32, "in_feat")
+    _req(grad_out, torch.float32, "grad_out")
+    kv, cap = nbr.shape
+    if grad_out.shape[0] < cap or grad_out.shape[1] != cout or in_feat.shape[1] != cin:
+        raise ValueError("grad_out must be (n_out_cap, cout) and in_feat (n_in, cin)")
+    gw = torch.empty((kv, cin, cout), dtype=torch.float32, device=in_feat.device)
+    ws = torch.empty(int(lib.sessd_sparse_conv_wgrad_workspace_bytes(kv, cin, cout)), dtype=torch.uint8, device=in_feat.device)
+    check(lib.sessd_sparse_conv_wgrad(in_feat.data_ptr(), cin, grad_out.data_ptr(), cout, nbr.data_ptr(), tile_mask.data_ptr(),
+                                      kv, n_out_dev.data_ptr(), cap, gw.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "sparse_conv_wgrad")
+    return gw
+
+
 # ------------------------------------------------------------------ dense BEV convolutions
 class PackedConv:
     """A conv layer lowered to one or more sessd_conv2d_mfma launches (weights in MFMA fragment order)."""

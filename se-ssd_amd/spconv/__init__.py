@@ -53,6 +53,39 @@ class SparseModule(nn.Module):
     pass
 
 
+class IndiceConvFunction(torch.autograd.Function):
+    """Differentiable sparse convolution y[j] = sum_k W_k^T x[nbr[k][j]] (+ bias) on the HIP kernels.
+    backward: dx through the transposed rulebook with the same output-stationary kernel, dW by the site-reduction
+    GEMM kernel (sessd_sparse_conv_wgrad), db = column sums. Deterministic (no atomics on floats)."""
+
+    @staticmethod
+    def forward(ctx, feats, weight, bias, nbr, tm, n_out):
+        cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
+        out = ops.sparse_conv(feats, nbr, tm, n_out, ops.sparse_pack_weight(weight), cin, cout, None, bias, relu=False)
+        ctx.save_for_backward(feats, weight, nbr, tm, n_out)
+        ctx.has_bias = bias is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        feats, weight, nbr, tm, n_out = ctx.saved_tensors
+        cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
+        kv = nbr.shape[0]
+        g = grad_out.float().contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            n_in = feats.shape[0]
+            nbr_t, tm_t = ops.sparse_rulebook_transpose(nbr, n_out, n_in)
+            w_t = weight.detach().reshape(kv, cin, cout).transpose(1, 2).contiguous()  # per offset W_k^T: (cout, cin)
+            n_in_dev = torch.tensor([n_in], dtype=torch.int32, device=feats.device)
+            gx = ops.sparse_conv(g, nbr_t, tm_t, n_in_dev, ops.sparse_pack_weight(w_t), cout, cin, None, None, relu=False)
+        if ctx.needs_input_grad[1]:
+            gw = ops.sparse_conv_wgrad(feats, g, nbr, tm, n_out, cin, cout).view_as(weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum(0)
+        return gx, gw, gb, None, None, None
+
+
 class SparseConvolution(SparseModule):
     def __init__(self, ndim, in_channels, out_channels, kernel_size=3, stride=1, padding=0, dilation=1, groups=1,
                  bias=True, subm=False, output_padding=0, transposed=False, inverse=False, indice_key=None):
@@ -109,8 +142,11 @@ class SparseConvolution(SparseModule):
             n_out = torch.tensor([m], dtype=torch.int32, device=oidx.device)
             out.indice_dict["__hash__"] = (ops.SiteHash(ohash.capacity, oshape, oidx.device, ohash.keys, ohash.vals), n_out)
         feats = x.features.float().contiguous()
-        out.features = ops.sparse_conv(feats, nbr, tm, n_out, self._wpk(), self.in_channels, self.out_channels, None,
-                                       self.bias, relu=False)
+        if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
+            out.features = IndiceConvFunction.apply(feats, self.weight, self.bias, nbr, tm, n_out)
+        else:
+            out.features = ops.sparse_conv(feats, nbr, tm, n_out, self._wpk(), self.in_channels, self.out_channels, None,
+                                           self.bias, relu=False)
         return out
 
 
