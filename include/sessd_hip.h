@@ -135,6 +135,20 @@ int sessd_sparse_conv_wgrad(const float* in_feat, int cin, const float* grad_out
                             const uint32_t* tile_mask, int kernel_volume, const int32_t* n_out_dev, int n_out_cap,
                             float* grad_weight, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 
+/* ---- parameter update of the training step: replaces the per-tensor host loops of
+ * det3d/torchie/trainer/hooks/optimizer.py:50-53 (clip_grad_norm_), det3d/solver/fastai_optim.py:155-176
+ * (OptimWrapper.step with true_wd, then torch.optim.Adam.step) and det3d/torchie/trainer/trainer_sessd.py:315-318
+ * (EMA teacher) by two launches over FLAT float32 buffers. All pointers device, 16-byte aligned. */
+size_t sessd_grad_clip_workspace_bytes(void);
+/* out2 (device float[2]) = { ||grad||_2, min(1, max_norm/(norm + 1e-6)) }; max_norm <= 0: coefficient 1. No host sync. */
+int sessd_grad_clip_coef(const float* grad, size_t n, float max_norm, void* workspace, size_t workspace_bytes, float* out2,
+                         sessd_stream_t stream);
+/* g' = grad*clip2[1] (clip2 may be NULL); p *= 1 - weight_decay*lr; Adam(beta1, beta2, eps) step number `step` >= 1 on
+ * (param, exp_avg, exp_avg_sq); ema_param = ema_alpha*ema_param + (1-ema_alpha)*param (ema_param may be NULL). */
+int sessd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema_param, size_t n,
+                        double lr, double weight_decay, double beta1, double beta2, double eps, int step,
+                        const float* clip2, double ema_alpha, sessd_stream_t stream);
+
 /* ------------------------------------------------------------------ dense BEV neck + heads (a9-a10)
  * replace the ATen/cuDNN conv2d, conv_transpose2d, batch_norm, relu, softmax calls made by
  * det3d/models/necks/rpn_v1.py:220-235 (SSFA.forward; RPN.forward :107-116 uses the same layers) and

@@ -10,7 +10,12 @@ import torch.nn.functional as F
 EPS = 1e-3  # rpn_v1.py:131 norm_cfg = dict(type="BN", eps=1e-3, momentum=0.01)
 
 
+_TRAIN = [False]  # set by ssfa_forward(training=...): batch statistics instead of the running ones
+
+
 def _bn(x, sd, p):
+    if _TRAIN[0]:
+        return F.batch_norm(x, None, None, sd[p + ".weight"], sd[p + ".bias"], True, 0.0, EPS)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"], sd[p + ".weight"], sd[p + ".bias"], False, 0.0, EPS)
 
 
@@ -20,7 +25,15 @@ def _cbr(x, sd, p, ci, bi, stride=1, pad=1, relu=True):
     return torch.relu(x) if relu else x
 
 
-def ssfa_forward(x, sd, prefix="neck."):
+def ssfa_forward(x, sd, prefix="neck.", training=False):
+    try:
+        _TRAIN[0] = bool(training)
+        return _ssfa_forward(x, sd, prefix)
+    finally:
+        _TRAIN[0] = False
+
+
+def _ssfa_forward(x, sd, prefix):
     sd = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
     x0 = _cbr(x, sd, "bottom_up_block_0", 1, 2)      # ZeroPad2d(1) + unpadded 3x3 == padding 1
     x0 = _cbr(x0, sd, "bottom_up_block_0", 4, 5)

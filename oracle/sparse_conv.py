@@ -93,9 +93,14 @@ def sparse_conv(features, indices, spatial_shape, weight, ksize, stride=1, paddi
     return out, out_idx, oshape, rb
 
 
-def bn_relu(x, bn, relu=True, eps=1e-3):
-    """bn = dict(weight, bias, running_mean, running_var): eval-mode BatchNorm1d (scn.py:103-104 eps=1e-3)."""
-    y = torch.nn.functional.batch_norm(x, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, eps)
+def bn_relu(x, bn, relu=True, eps=1e-3, training=False):
+    """bn = dict(weight, bias, running_mean, running_var): BatchNorm1d (scn.py:103-104 eps=1e-3); eval mode by default,
+    training=True normalises with the batch statistics (the SE-SSD training step runs both nets in train mode,
+    trainer_sessd.py:321-322) without touching the running statistics."""
+    if training:
+        y = torch.nn.functional.batch_norm(x, None, None, bn["weight"], bn["bias"], True, 0.0, eps)
+    else:
+        y = torch.nn.functional.batch_norm(x, bn["running_mean"], bn["running_var"], bn["weight"], bn["bias"], False, 0.0, eps)
     return torch.relu(y) if relu else y
 
 
@@ -120,7 +125,8 @@ SPMIDDLE_FHD_LAYERS = [
 ]
 
 
-def spmiddle_fhd(voxel_features, coors, batch_size, input_shape, weights, bns, layers=None, return_levels=False):
+def spmiddle_fhd(voxel_features, coors, batch_size, input_shape, weights, bns, layers=None, return_levels=False,
+                 training=False):
     """SpMiddleFHD.forward (scn.py:176-189). weights[i] (kz,ky,kx,Cin,Cout), bns[i] dict. input_shape = [x,y,z] grid."""
     layers = layers or SPMIDDLE_FHD_LAYERS
     shape = [int(v) for v in (np.array(input_shape[::-1]) + [1, 0, 0])]
@@ -136,7 +142,7 @@ def spmiddle_fhd(voxel_features, coors, batch_size, input_shape, weights, bns, l
         else:
             feat, idx2, shape2, rb = sparse_conv(feat, idx, shape, weights[i], ks, st, pd, False)
         idx, shape = idx2, shape2
-        feat = bn_relu(feat, bns[i])
+        feat = bn_relu(feat, bns[i], training=training)
         levels.append((feat, idx, list(shape)))
     d = dense(feat, idx, shape, batch_size)
     N, C, D, H, W = d.shape

@@ -25,6 +25,15 @@ class Head(nn.Module):
             self.conv_dir = nn.Conv2d(num_input, num_dir, 1)
         self._packed = None
 
+    def __deepcopy__(self, memo):
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, None if k == "_packed" else copy.deepcopy(v, memo))
+        return new
+
     def planar(self, x):
         """(B, 14+2+4+2, H, W): the four 1x1 convs as ONE fused launch, channels [box | cls | dir | iou]."""
         convs = [self.conv_box, self.conv_cls] + ([self.conv_dir] if self.use_dir else []) + [self.conv_iou]
@@ -37,6 +46,13 @@ class Head(nn.Module):
         return ops.conv2d(x.float().contiguous(), pc, None, b, False), split
 
     def forward(self, x):
+        if self.training:  # autograd path: the four 1x1 convs as torch modules (mg_head_sessd.py:217-230)
+            ret = dict(box_preds=self.conv_box(x).permute(0, 2, 3, 1).contiguous(),
+                       cls_preds=self.conv_cls(x).permute(0, 2, 3, 1).contiguous())
+            if self.use_dir:
+                ret["dir_cls_preds"] = self.conv_dir(x).permute(0, 2, 3, 1).contiguous()
+            ret["iou_preds"] = self.conv_iou(x).permute(0, 2, 3, 1).contiguous()
+            return ret
         y, split = self.planar(x)
         parts = torch.split(y, split, dim=1)
         names = ["box_preds", "cls_preds"] + (["dir_cls_preds"] if self.use_dir else []) + ["iou_preds"]

@@ -31,13 +31,17 @@ class VoxelNet(nn.Module):
         bev = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
         return self.neck(bev) if self.with_neck else bev
 
-    def forward(self, example, is_ema=[False, None], return_loss=True, **kwargs):
-        teacher_pass, teacher_preds = is_ema[0], is_ema[1]
-        suffix = "_raw" if teacher_pass else ""
+    def forward_preds(self, example, raw=False):
+        """Head outputs of one pass: `raw` selects the un-augmented `*_raw` voxelization (teacher input)."""
+        suffix = "_raw" if raw else ""
         voxels, coords, npts, nvox, shape = (example[k + suffix] for k in _INPUT_KEYS)
         bev = self.extract_feat(dict(voxels=voxels, num_points_per_voxel=npts, coors=coords, batch_size=len(nvox),
                                      input_shape=shape[0]))
-        preds = self.bbox_head(bev)
+        return self.bbox_head(bev)
+
+    def forward(self, example, is_ema=[False, None], return_loss=True, **kwargs):
+        teacher_pass, teacher_preds = is_ema[0], is_ema[1]
+        preds = self.forward_preds(example, raw=teacher_pass)
         if teacher_pass:
             return preds
         if return_loss:

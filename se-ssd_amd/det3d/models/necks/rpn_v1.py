@@ -19,6 +19,9 @@ class _Lowered:
     def __init__(self):
         self._cache = {}
 
+    def __deepcopy__(self, memo):  # packed launches hold raw device pointers: a copied model re-packs on first use
+        return _Lowered()
+
     def get(self, name, conv, bn, deconv=False):
         key = (conv.weight.data_ptr(), conv.weight._version, None if bn is None else bn.running_mean._version)
         hit = self._cache.get(name)
@@ -94,8 +97,24 @@ class SSFA(nn.Module):
             if isinstance(m, nn.Conv2d):
                 nn.init.xavier_uniform_(m.weight)
 
+    def _forward_train(self, x):
+        """Train mode (batch-statistics BatchNorm, autograd): the module tree itself, composed as rpn_v1.py:220-235.
+        Dense convs go through torch here; the HIP conv kernels have no hand-written backward yet."""
+        x_0 = self.bottom_up_block_0(x)
+        x_1 = self.bottom_up_block_1(x_0)
+        x_trans_0 = self.trans_0(x_0)
+        x_trans_1 = self.trans_1(x_1)
+        x_middle_0 = self.deconv_block_0(x_trans_1) + x_trans_0
+        x_middle_1 = self.deconv_block_1(x_trans_1)
+        x_output_0 = self.conv_0(x_middle_0)
+        x_output_1 = self.conv_1(x_middle_1)
+        w = torch.softmax(torch.cat([self.w_0(x_output_0), self.w_1(x_output_1)], dim=1), dim=1)
+        return x_output_0 * w[:, 0:1] + x_output_1 * w[:, 1:]
+
     def forward(self, x):
         x = x.float().contiguous()
+        if self.training:
+            return self._forward_train(x)
         L = self._low
         x_0 = _run_block(L, "b0", self.bottom_up_block_0, x)
         x_1 = _run_block(L, "b1", self.bottom_up_block_1, x_0)

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsessd_hip.so")
 
-vp, i32, u32, f32, sz, i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t, C.c_longlong
+vp, i32, u32, f32, sz, i64, f64 = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t, C.c_longlong, C.c_double
 
 # name -> (restype, argtypes). Kept in step with include/sessd_hip.h (tests/test_abi.py checks it).
 SIGNATURES = {
@@ -47,6 +47,9 @@ SIGNATURES = {
     "sessd_sparse_rulebook_transpose": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
     "sessd_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
     "sessd_sparse_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, vp, sz, vp]),
+    "sessd_grad_clip_workspace_bytes": (sz, []),
+    "sessd_grad_clip_coef": (i32, [vp, sz, f32, vp, sz, vp, vp]),
+    "sessd_adam_ema_step": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
 }
 
 

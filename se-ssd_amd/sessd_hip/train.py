@@ -1,0 +1,154 @@
+"""Host side of the SE-SSD training step on the HIP library (BASELINE configs[2] / [3]).
+
+What is here
+  * FlatParams        all parameters (and all gradients) of a model in ONE 16-byte-aligned float32 buffer each; the
+                      model's tensors become views, so autograd accumulates straight into the flat gradient buffer
+  * one_cycle         the OneCycle schedule of det3d/solver/learning_schedules_fastai.py:70-95 (config.py:260)
+  * FusedAdamEMA      clip_grad_norm_ + true-weight-decay Adam + EMA teacher as two launches over the flat buffers
+                      (sessd_grad_clip_coef, sessd_adam_ema_step) instead of ~100 x 6 per-tensor host-issued kernels
+                      (hooks/optimizer.py:50-53, fastai_optim.py:155-176, trainer_sessd.py:315-318)
+  * allreduce_flat    ONE all-reduce of the flat gradient buffer (15.2 MB) over RCCL, replacing DDP's buckets plus the
+                      duplicate DistOptimizerHook all-reduce (dist_utils.py:45-57); pre-divides like the reference
+  * TrainStep         teacher forward (no grad, `*_raw` inputs) -> student forward -> loss -> backward -> all-reduce ->
+                      fused update, in the order of trainer_sessd.py:250-275,340-357
+The sparse backbone runs forward AND backward on the HIP kernels (spconv.IndiceConvFunction); the dense neck / heads
+train through torch autograd for now (their forward kernels have no hand-written backward yet -- DESIGN.md section 8)."""
+import copy
+import math
+
+import torch
+import torch.distributed as dist
+
+from ._lib import check, lib
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class FlatParams:
+    """Flatten `model.parameters()` (in order, each tensor padded to a multiple of 4 floats) into `self.data` and their
+    gradients into `self.grad`; every parameter's `.data` / `.grad` become views of those buffers."""
+
+    def __init__(self, model, with_grad=True):
+        self.params = [p for p in model.parameters()]
+        if not self.params:
+            raise ValueError("model has no parameters")
+        dev = self.params[0].device
+        self.offsets, n = [], 0
+        for p in self.params:
+            if p.dtype != torch.float32 or p.device != dev:
+                raise ValueError("FlatParams needs float32 parameters on one device")
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        self.numel = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev) if with_grad else None
+        for p, o in zip(self.params, self.offsets):
+            view = self.data[o:o + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            if with_grad:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+    def zero_grad(self):
+        if self.grad is None:
+            return
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):  # re-attach in case something set .grad to None / a new tensor
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view_as(p)
+
+
+def one_cycle(step, total_steps, lr_max=3e-3, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
+    """(lr, momentum) of OneCycle at `step` (learning_schedules_fastai.py:70-95: cosine low->max over the first
+    pct_start, then max->low/1e4; momentum mirrors it)."""
+    def cos(a, b, pct):
+        return b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)
+
+    a1 = int(total_steps * pct_start)
+    low = lr_max / div_factor
+    if step < a1:
+        pct = step / float(a1)
+        return cos(low, lr_max, pct), cos(moms[0], moms[1], pct)
+    pct = (step - a1) / float(total_steps - a1)
+    return cos(lr_max, low / 1e4, pct), cos(moms[1], moms[0], pct)
+
+
+def ema_alpha(global_step):
+    """trainer_sessd.py:316"""
+    return min(1.0 - 1.0 / (global_step + 1), 0.999)
+
+
+class FusedAdamEMA:
+    """Adam(betas=(mom, 0.99), eps=1e-8) with decoupled decay wd on ALL parameters (bn_wd=True) and the EMA teacher,
+    on the flat buffers of a student FlatParams and (optionally) a teacher FlatParams of identical layout."""
+
+    def __init__(self, student, teacher=None, weight_decay=0.01, beta2=0.99, eps=1e-8, max_grad_norm=35.0):
+        if teacher is not None and teacher.numel != student.numel:
+            raise ValueError("teacher / student layouts differ")
+        self.s, self.t = student, teacher
+        self.wd, self.beta2, self.eps, self.max_norm = weight_decay, beta2, eps, max_grad_norm
+        dev = student.data.device
+        self.exp_avg = torch.zeros_like(student.data)
+        self.exp_avg_sq = torch.zeros_like(student.data)
+        self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)  # [grad norm, clip coefficient], device side
+        self._ws = torch.empty(int(lib.sessd_grad_clip_workspace_bytes()), dtype=torch.uint8, device=dev)
+        self.steps = 0
+
+    def step(self, lr, beta1, global_step):
+        self.steps += 1
+        s = _stream()
+        check(lib.sessd_grad_clip_coef(self.s.grad.data_ptr(), self.s.numel, float(self.max_norm or 0.0), self._ws.data_ptr(),
+                                       self._ws.numel(), self.norm_coef.data_ptr(), s), "grad_clip_coef")
+        check(lib.sessd_adam_ema_step(self.s.data.data_ptr(), self.s.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                      self.exp_avg_sq.data_ptr(), 0 if self.t is None else self.t.data.data_ptr(), self.s.numel,
+                                      float(lr), float(self.wd), float(beta1), float(self.beta2), float(self.eps), self.steps,
+                                      self.norm_coef.data_ptr(), float(ema_alpha(global_step)), s), "adam_ema_step")
+
+
+def allreduce_flat(flat_grad, group=None):
+    """Average the flat gradient buffer over the ranks with ONE collective (dist_utils.py:38-42 divides before the
+    all-reduce; kept so the summation order matches)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return flat_grad
+    world = dist.get_world_size(group)
+    if world == 1:
+        return flat_grad
+    flat_grad.div_(world)
+    dist.all_reduce(flat_grad, group=group)
+    return flat_grad
+
+
+class TrainStep:
+    """One SE-SSD iteration. `loss_fn(example, student_preds, teacher_preds, consistency_weight) -> scalar tensor`
+    stands for MultiGroupHead.loss (mg_head_sessd.py:780; not part of this slice). The teacher is a deep copy of the
+    student (both start from the same checkpoint, trainer_sessd.py:212-217) and is never back-propagated."""
+
+    def __init__(self, student, loss_fn, total_steps, teacher=None, weight_decay=0.01, max_grad_norm=35.0,
+                 lr_max=3e-3, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
+        self.student = student
+        self.teacher = copy.deepcopy(student) if teacher is None else teacher
+        for p in self.teacher.parameters():
+            p.requires_grad_(False)
+        self.loss_fn = loss_fn
+        self.total_steps = int(total_steps)
+        self.sched = dict(lr_max=lr_max, moms=moms, div_factor=div_factor, pct_start=pct_start)
+        self.flat_s, self.flat_t = FlatParams(self.student), FlatParams(self.teacher, with_grad=False)
+        self.opt = FusedAdamEMA(self.flat_s, self.flat_t, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        self.global_step = 0
+
+    def __call__(self, example, consistency_weight=1.0):
+        lr, mom = one_cycle(self.global_step, self.total_steps, **self.sched)  # lr_scheduler.step(global_step) first
+        self.student.train()
+        self.teacher.train()  # trainer_sessd.py:321-322: both nets in train mode
+        with torch.no_grad():
+            teacher_preds = self.teacher.forward_preds(example, raw="voxels_raw" in example)
+        self.flat_s.zero_grad()
+        student_preds = self.student.forward_preds(example)
+        loss = self.loss_fn(example, student_preds, teacher_preds, consistency_weight)
+        loss.backward()
+        allreduce_flat(self.flat_s.grad)
+        self.opt.step(lr, mom, self.global_step)
+        self.global_step += 1
+        return loss.detach(), lr, mom

@@ -1,0 +1,125 @@
+"""Training-step slice on the GPU against the CPU oracles:
+  * fused clip + true-wd Adam + EMA kernels vs oracle/optim.py (itself pinned to the reference's own optimizer run);
+  * gradients of EVERY stage's parameters of the whole detector in train mode (HIP sparse forward/backward, torch dense
+    neck/head) vs torch autograd through the CPU oracle forward with batch-statistics BatchNorm;
+  * TrainStep: teacher/student/EMA bookkeeping over flat buffers.
+Tolerances: optimizer 2e-6 relative (same float32 formula, fused multiply-adds may differ by an ulp); gradients 2e-3 of
+the largest reference magnitude per tensor (float32 through 28 train-mode BatchNorm layers, different summation orders,
+MIOpen convolution algorithms on the dense part)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import capi, dense_head, optim as ooptim, pipeline, sparse_conv as osc
+from sessd_hip import configs, ops, synth, train as strain
+
+pytestmark = pytest.mark.gpu
+VG = configs.VOXEL_GENERATOR
+
+
+@pytest.mark.parametrize("n,with_teacher", [(1000003, True), (4096, False)])
+def test_fused_adam_ema_vs_oracle(dev, n, with_teacher):
+    rng = np.random.RandomState(0)
+    p = rng.randn(n).astype(np.float32)
+    t = p.copy() if with_teacher else None
+    m, v = np.zeros(n, np.float32), np.zeros(n, np.float32)
+    s = types.SimpleNamespace(data=torch.from_numpy(p.copy()).to(dev), grad=torch.zeros(n, device=dev), numel=n)
+    tt = types.SimpleNamespace(data=torch.from_numpy(p.copy()).to(dev), numel=n) if with_teacher else None
+    opt = strain.FusedAdamEMA(s, tt, weight_decay=0.01, max_grad_norm=35.0)
+    for step in range(4):
+        g = (rng.randn(n) * (1.0 if step % 2 else 1e-3)).astype(np.float32)  # odd steps are clipped (norm ~ sqrt(n))
+        lr, mom = strain.one_cycle(step, 10)
+        s.grad.copy_(torch.from_numpy(g))
+        opt.step(lr, mom, step)
+        norm, coef = ooptim.clip_coef(g, 35.0)
+        got = opt.norm_coef.cpu().numpy()
+        assert abs(got[0] - norm) <= 1e-5 * norm and abs(got[1] - coef) <= 1e-5 * coef
+        ooptim.adam_true_wd_ema_step(p, g, m, v, t, lr, 0.01, mom, 0.99, 1e-8, step + 1, max_norm=35.0, alpha=ooptim.ema_alpha(step))
+        assert np.allclose(s.data.cpu().numpy(), p, rtol=2e-6, atol=1e-7), step
+        assert np.allclose(opt.exp_avg_sq.cpu().numpy(), v, rtol=2e-6, atol=1e-12), step
+        if with_teacher:
+            assert np.allclose(tt.data.cpu().numpy(), t, rtol=2e-6, atol=1e-7), step
+
+
+def _example(dev, seeds, npts, max_voxels):
+    frames = [synth.make_frame(s, npts) for s in seeds]
+    r = ops.voxelize_batch([torch.from_numpy(f).to(dev) for f in frames], VG["voxel_size"], VG["range"], 5, max_voxels)
+    m = int(r["prefix"][len(frames)].item())
+    ex = dict(voxels=r["voxels"][:m], coordinates=r["coors"][:m], num_points=r["num_points"][:m],
+              num_voxels=torch.tensor(np.diff(r["prefix"].cpu().numpy())), shape=[[1408, 1600, 40]] * len(frames))
+    return frames, ex
+
+
+def _loss(preds):
+    p = preds[0] if isinstance(preds, (list, tuple)) else preds
+    return (p["box_preds"].pow(2).mean() + torch.sigmoid(p["cls_preds"]).mean() + 0.2 * p["dir_cls_preds"].pow(2).mean()
+            + p["iou_preds"].abs().mean())
+
+
+def test_whole_model_gradients_vs_oracle(dev):
+    model = configs.build_synthetic_detector(dev, seed=0)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    model.train()
+    frames, ex = _example(dev, (41, 42), 8000, 8000)
+    for p in model.parameters():
+        p.grad = None
+    loss = _loss(model.forward_preds(ex))
+    loss.backward()
+    # ---- oracle: the same forward in training mode on CPU, torch autograd
+    ref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd.items()}
+    feats, coors = [], []
+    for b, pts in enumerate(frames):
+        v, c, n = capi.points_to_voxel(pts, VG["voxel_size"], VG["range"], 5, 8000)
+        feats.append(capi.vfe_mean(v, n, 4))
+        coors.append(np.concatenate([np.full((c.shape[0], 1), b, np.int32), c], 1))
+    convs = [ref["backbone.middle_conv.%d.weight" % (3 * i)] for i in range(14)]
+    bns = [{k: ref["backbone.middle_conv.%d.%s" % (3 * i + 1, k)] for k in ("weight", "bias", "running_mean", "running_var")}
+           for i in range(14)]
+    bev = osc.spmiddle_fhd(torch.from_numpy(np.concatenate(feats, 0)), np.concatenate(coors, 0), 2, [1408, 1600, 40], convs, bns,
+                           training=True)
+    x = dense_head.ssfa_forward(bev, ref, training=True)
+    loss_ref = _loss(dense_head.head_forward(x, ref))
+    loss_ref.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) <= 1e-4 * abs(float(loss_ref.detach()))
+    checked = 0
+    for name, p in model.named_parameters():
+        want = ref[name].grad
+        assert want is not None and p.grad is not None, name
+        scale = float(want.abs().max())
+        err = float((p.grad.cpu() - want).abs().max())
+        assert err <= 2e-3 * scale + 1e-9, (name, err, scale)
+        checked += 1
+    assert checked == len(list(model.parameters())) and checked > 90
+
+
+def test_train_step_bookkeeping(dev):
+    model = configs.build_synthetic_detector(dev, seed=0)
+    step = strain.TrainStep(model, lambda ex, s, t, w: _loss(s) + w * (s[0]["cls_preds"] - t[0]["cls_preds"]).pow(2).mean(),
+                            total_steps=10)
+    _, ex = _example(dev, (43,), 6000, 6000)
+    p0 = step.flat_s.data.clone()
+    t0 = step.flat_t.data.clone()
+    assert torch.equal(p0, t0) and step.flat_s.numel >= 3811674
+    rm0 = step.teacher.backbone.middle_conv[1].running_mean.clone()
+    loss, lr, mom = step(ex)
+    assert np.isfinite(float(loss)) and abs(lr - 3e-4) < 1e-12 and abs(mom - 0.95) < 1e-12
+    # the device update == the oracle update applied to the device gradients
+    g = step.flat_s.grad.cpu().numpy()
+    p = p0.cpu().numpy().copy()
+    t = t0.cpu().numpy().copy()
+    m, v = np.zeros_like(p), np.zeros_like(p)
+    ooptim.adam_true_wd_ema_step(p, g, m, v, t, lr, 0.01, mom, 0.99, 1e-8, 1, max_norm=35.0, alpha=ooptim.ema_alpha(0))
+    assert np.allclose(step.flat_s.data.cpu().numpy(), p, rtol=2e-6, atol=1e-7)
+    assert np.allclose(step.flat_t.data.cpu().numpy(), t, rtol=2e-6, atol=1e-7)
+    # alpha(0) = 0: after the first iteration the teacher equals the student (trainer_sessd.py:316)
+    assert torch.allclose(step.flat_t.data, step.flat_s.data)
+    assert not torch.equal(step.teacher.backbone.middle_conv[1].running_mean, rm0)  # teacher ran in train mode
+    w_before = step.student.neck.conv_0[0].weight.detach().clone()
+    loss2, lr2, _ = step(ex)
+    assert lr2 > lr and not torch.equal(step.student.neck.conv_0[0].weight.detach(), w_before)
+    # the model's tensors are still views of the flat buffers
+    o = step.flat_s.offsets[0]
+    p_first = step.flat_s.params[0]
+    assert p_first.data_ptr() == step.flat_s.data.data_ptr() + 4 * o
