@@ -12,7 +12,7 @@ What is here
   * TrainStep         teacher forward (no grad, `*_raw` inputs) -> student forward -> loss -> backward -> all-reduce ->
                       fused update, in the order of trainer_sessd.py:250-275,340-357
 The sparse backbone runs forward AND backward on the HIP kernels (spconv.IndiceConvFunction); the dense neck / heads
-train through torch autograd for now (their forward kernels have no hand-written backward yet -- DESIGN.md section 8)."""
+train through torch autograd for now (their forward kernels have no hand-written backward yet -- DESIGN.md section 7)."""
 import copy
 import math
 
