@@ -149,6 +149,17 @@ int sessd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* 
                         double lr, double weight_decay, double beta1, double beta2, double eps, int step,
                         const float* clip2, double ema_alpha, sessd_stream_t stream);
 
+/* ---- dense conv backward (training step): data gradients are launches of the forward entry points
+ * above with re-packed weights (3x3 s1 <-> flipped 3x3 s1, 3x3 s2 <-> sessd_deconv2d_s2_mfma, 1x1 <-> 1x1); the weight
+ * gradient of Conv2d(cin, cout, k, stride, padding k/2) is this pixel-reduction GEMM (deterministic: <= 64 row chunks
+ * summed in order). k in {1,3}, stride in {1,2}, wout % 8 == 0. For ConvTranspose2d(3, s2, p1, op1) swap the roles
+ * (input := its grad_out, grad_out := its input): the result is its (Cin, Cout, 3, 3) weight gradient.
+ * Replaces the ATen/MIOpen backward of det3d/models/necks/rpn_v1.py:135-235 under trainer_sessd.py:250-275. */
+size_t sessd_conv2d_wgrad_workspace_bytes(int cout, int cin, int ksize);
+int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win, const float* grad_out, int cout, int hout,
+                       int wout, int ksize, int stride, float* grad_weight, void* workspace, size_t workspace_bytes,
+                       sessd_stream_t stream);
+
 /* ------------------------------------------------------------------ dense BEV neck + heads (a9-a10)
  * replace the ATen/cuDNN conv2d, conv_transpose2d, batch_norm, relu, softmax calls made by
  * det3d/models/necks/rpn_v1.py:220-235 (SSFA.forward; RPN.forward :107-116 uses the same layers) and

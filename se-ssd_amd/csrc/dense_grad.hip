@@ -1,0 +1,174 @@
+// Weight gradient of the dense BEV convolutions on gfx950 (backward of det3d/models/necks/rpn_v1.py:135-235
+// inside the training step, det3d/torchie/trainer/trainer_sessd.py:250-275). The DATA gradients need no kernel of their
+// own: d(conv3x3 s1) is a 3x3 s1 conv with flipped, transposed weights, d(conv3x3 s2) is the 3x3 s2 transposed conv,
+// d(transposed conv) is the 3x3 s2 conv, d(1x1) is a 1x1 -- all launches of dense_conv.hip with re-packed weights.
+//
+//   dW[co][ci][ky][kx] = sum over (b, y, x) of  gout[b][co][y][x] * inp[b][ci][y*S + ky - P][x*S + kx - P]
+//
+// A GEMM with the output PIXELS as the reduction axis, on v_mfma_f32_32x32x2_f32:
+//   D_tap[co 32][ci 32] += A[co][pixel 2] * B_tap[pixel 2][ci]
+//   A lane (i, h): 4 consecutive pixels x0+4h .. x0+4h+3 of gout row y, channel co0+i  (one aligned 16-byte load);
+//                  MFMA step c uses component c, i.e. the k index of the MFMA is the pixel pair {x0+c, x0+4+c}
+//   B lane (j, h): the same 4 pixels of inp channel ci0+j shifted by the tap: per input row one aligned 16-byte load plus
+//                  the left / right neighbour (stride 1) or two 16-byte loads plus the left neighbour (stride 2); rows or
+//                  columns outside the image get an out-of-range buffer offset (the hardware returns 0 = zero padding)
+// One wave owns a 32x32 (co, ci) tile with all taps (9 accumulators) over one chunk of output rows; the <= 64 chunk
+// partials are summed in order by a second kernel: deterministic, no float atomics.
+#include "common.hpp"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float ld1(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ f32x4 ld4(rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+#define SESSD_OOB 0x80000000u
+
+struct WgArgs {
+  const float* inp;   // (B, ci, hi, wi)
+  const float* gout;  // (B, co, ho, wo)
+  float* partial;     // [nchunks][co][ci][KS*KS]
+  int batch, ci, hi, wi, co, ho, wo;
+  int rows_per_chunk, cib_n;
+};
+
+template <int KS, int S>
+__global__ __launch_bounds__(64) void conv_wgrad_partial_kernel(WgArgs A) {
+  constexpr int NT = KS * KS, P = KS / 2;
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int cob = blockIdx.x / A.cib_n, cib = blockIdx.x - cob * A.cib_n;
+  const int co = cob * 32 + i, ci = cib * 32 + i;
+  const bool co_ok = co < A.co, ci_ok = ci < A.ci;
+  const int R = A.batch * A.ho;
+  const int r0 = blockIdx.y * A.rows_per_chunk, r1 = min(R, r0 + A.rows_per_chunk);
+  const rsrc_t gr = make_rsrc(A.gout, (unsigned)((size_t)A.batch * A.co * A.ho * A.wo * 4));
+  const rsrc_t xr = make_rsrc(A.inp, (unsigned)((size_t)A.batch * A.ci * A.hi * A.wi * 4));
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  for (int r = r0; r < r1; ++r) {
+    const int b = r / A.ho, y = r - b * A.ho;
+    const unsigned grow = co_ok ? (unsigned)((((size_t)b * A.co + co) * A.ho + y) * A.wo * 4) : SESSD_OOB;
+    unsigned xrow[KS];
+#pragma unroll
+    for (int ky = 0; ky < KS; ++ky) {
+      const int yin = y * S + ky - P;
+      xrow[ky] = (ci_ok && yin >= 0 && yin < A.hi) ? (unsigned)((((size_t)b * A.ci + ci) * A.hi + yin) * A.wi * 4) : SESSD_OOB;
+    }
+    for (int x0 = 0; x0 < A.wo; x0 += 8) {
+      const int xa = x0 + 4 * h;  // first of this lane's 4 output pixels
+      const f32x4 a = ld4(gr, grow == SESSD_OOB ? SESSD_OOB : grow + (unsigned)xa * 4u);
+      f32x4 bt[NT];
+#pragma unroll
+      for (int ky = 0; ky < KS; ++ky) {
+        const unsigned row = xrow[ky];
+        if (KS == 1) {
+          bt[0] = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xa * 4u);
+        } else if (S == 1) {
+          const f32x4 c = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xa * 4u);
+          const float l = ld1(xr, (row == SESSD_OOB || xa == 0) ? SESSD_OOB : row + (unsigned)(xa - 1) * 4u);
+          const float rr = ld1(xr, (row == SESSD_OOB || xa + 4 >= A.wi) ? SESSD_OOB : row + (unsigned)(xa + 4) * 4u);
+          bt[ky * 3 + 0] = (f32x4){l, c.x, c.y, c.z};
+          bt[ky * 3 + 1] = c;
+          bt[ky * 3 + 2] = (f32x4){c.y, c.z, c.w, rr};
+        } else {
+          const int xi = 2 * xa;  // input column of output pixel xa at kx = 1
+          const f32x4 v0 = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xi * 4u);
+          const f32x4 v1 = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)(xi + 4) * 4u);
+          const float l = ld1(xr, (row == SESSD_OOB || xi == 0) ? SESSD_OOB : row + (unsigned)(xi - 1) * 4u);
+          bt[ky * 3 + 0] = (f32x4){l, v0.y, v0.w, v1.y};
+          bt[ky * 3 + 1] = (f32x4){v0.x, v0.z, v1.x, v1.z};
+          bt[ky * 3 + 2] = (f32x4){v0.y, v0.w, v1.y, v1.w};
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], bt[t][c], acc[t], 0, 0, 0);
+    }
+  }
+  // D layout: column (ci) = lane & 31, row (co) = (e & 3) + 8 * (e >> 2) + 4 * h
+  float* dst = A.partial + (size_t)blockIdx.y * A.co * A.ci * NT;
+  if (ci_ok) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int cor = cob * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (cor < A.co) dst[((size_t)cor * A.ci + ci) * NT + t] = acc[t][e];
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int total,
+                                                                 float* __restrict__ gw) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  if (e >= total) return;
+  float s = 0.f;
+  for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * total + e];
+  gw[e] = s;
+}
+
+constexpr int WG_MAX_CHUNKS = 64;
+
+}  // namespace
+
+extern "C" {
+
+size_t sessd_conv2d_wgrad_workspace_bytes(int cout, int cin, int ksize) {
+  return (size_t)WG_MAX_CHUNKS * cout * cin * ksize * ksize * sizeof(float);
+}
+
+// grad_weight (cout, cin, k, k) of Conv2d(cin, cout, k, stride, padding = k/2, bias-free part): input (B, cin, hin, win),
+// grad_out (B, cout, hout, wout) with hout = (hin + 2*(k/2) - k)/stride + 1. k in {1, 3}, stride in {1, 2} (k = 1: stride 1);
+// wout % 8 == 0. For ConvTranspose2d(3, stride 2, padding 1, output_padding 1) call it with the roles swapped (input :=
+// the transposed conv's grad_out, grad_out := its input): the result is that layer's (Cin, Cout, 3, 3) weight gradient.
+int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win, const float* grad_out, int cout, int hout,
+                       int wout, int ksize, int stride, float* grad_weight, void* workspace, size_t workspace_bytes,
+                       hipStream_t stream) {
+  if (batch < 1 || cin < 1 || cout < 1 || (ksize != 1 && ksize != 3) || (stride != 1 && stride != 2)) return SESSD_EINVAL;
+  if (ksize == 1 && stride != 1) return SESSD_EINVAL;
+  const int p = ksize / 2;
+  if (hout != (hin + 2 * p - ksize) / stride + 1 || wout != (win + 2 * p - ksize) / stride + 1) return SESSD_EINVAL;
+  if (wout % 8 || (stride == 2 && win != 2 * wout)) return SESSD_EINVAL;
+  if ((size_t)batch * cin * hin * win * 4 >= 0x7FFFFFFFull || (size_t)batch * cout * hout * wout * 4 >= 0x7FFFFFFFull)
+    return SESSD_EINVAL;
+  if (workspace_bytes < sessd_conv2d_wgrad_workspace_bytes(cout, cin, ksize)) return SESSD_EWORKSPACE;
+  WgArgs A;
+  A.inp = input; A.gout = grad_out; A.partial = (float*)workspace;
+  A.batch = batch; A.ci = cin; A.hi = hin; A.wi = win; A.co = cout; A.ho = hout; A.wo = wout;
+  const int cob_n = sessd_divup(cout, 32);
+  A.cib_n = sessd_divup(cin, 32);
+  const int tiles = cob_n * A.cib_n, rows = batch * hout;
+  int nchunks = 2048 / tiles;
+  nchunks = nchunks < 8 ? 8 : (nchunks > WG_MAX_CHUNKS ? WG_MAX_CHUNKS : nchunks);
+  if (nchunks > rows) nchunks = rows;
+  A.rows_per_chunk = sessd_divup(rows, nchunks);
+  nchunks = sessd_divup(rows, A.rows_per_chunk);
+  dim3 grid(tiles, nchunks);
+  if (ksize == 1)
+    hipLaunchKernelGGL((conv_wgrad_partial_kernel<1, 1>), grid, dim3(64), 0, stream, A);
+  else if (stride == 1)
+    hipLaunchKernelGGL((conv_wgrad_partial_kernel<3, 1>), grid, dim3(64), 0, stream, A);
+  else
+    hipLaunchKernelGGL((conv_wgrad_partial_kernel<3, 2>), grid, dim3(64), 0, stream, A);
+  SESSD_CHECK_LAUNCH();
+  const int total = cout * cin * ksize * ksize;
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(sessd_divup(total, 256)), dim3(256), 0, stream, (const float*)workspace,
+                     nchunks, total, grad_weight);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+}  // extern "C"

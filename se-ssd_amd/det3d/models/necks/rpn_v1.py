@@ -98,16 +98,24 @@ class SSFA(nn.Module):
                 nn.init.xavier_uniform_(m.weight)
 
     def _forward_train(self, x):
-        """Train mode (batch-statistics BatchNorm, autograd): the module tree itself, composed as rpn_v1.py:220-235.
-        Dense convs go through torch here; the HIP conv kernels have no hand-written backward yet."""
-        x_0 = self.bottom_up_block_0(x)
-        x_1 = self.bottom_up_block_1(x_0)
-        x_trans_0 = self.trans_0(x_0)
-        x_trans_1 = self.trans_1(x_1)
-        x_middle_0 = self.deconv_block_0(x_trans_1) + x_trans_0
-        x_middle_1 = self.deconv_block_1(x_trans_1)
-        x_output_0 = self.conv_0(x_middle_0)
-        x_output_1 = self.conv_1(x_middle_1)
+        """Train mode (batch-statistics BatchNorm, autograd), composed as rpn_v1.py:220-235. The twelve conv layers that
+        carry the FLOPs run forward AND backward on the HIP kernels (ops.Conv2dFunction); BatchNorm, ReLU, the two
+        128->1 weight branches and the softmax fusion are torch ops."""
+        def block(seq, inp):
+            for m in seq._modules.values():
+                if isinstance(m, nn.ZeroPad2d):
+                    continue  # ZeroPad2d(1) + unpadded 3x3 == the padding-1 conv the kernels implement
+                inp = ops.conv2d_module(inp, m) if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) else m(inp)
+            return inp
+
+        x_0 = block(self.bottom_up_block_0, x)
+        x_1 = block(self.bottom_up_block_1, x_0)
+        x_trans_0 = block(self.trans_0, x_0)
+        x_trans_1 = block(self.trans_1, x_1)
+        x_middle_0 = block(self.deconv_block_0, x_trans_1) + x_trans_0
+        x_middle_1 = block(self.deconv_block_1, x_trans_1)
+        x_output_0 = block(self.conv_0, x_middle_0)
+        x_output_1 = block(self.conv_1, x_middle_1)
         w = torch.softmax(torch.cat([self.w_0(x_output_0), self.w_1(x_output_1)], dim=1), dim=1)
         return x_output_0 * w[:, 0:1] + x_output_1 * w[:, 1:]
 

@@ -395,6 +395,63 @@ _TILE_CFG_OVERRIDE = {}
 USE_WINOGRAD = True
 
 
+def conv2d_wgrad(inp, grad_out, ksize, stride):
+    """Weight gradient (Cout, Cin, k, k) of Conv2d(k, stride, padding k//2): inp (B,Cin,H,W), grad_out (B,Cout,Ho,Wo).
+    For ConvTranspose2d(3, s2, p1, op1) pass (inp=its grad_out, grad_out=its input) and get its (Cin, Cout, 3, 3) gradient."""
+    _req(inp, torch.float32, "inp")
+    _req(grad_out, torch.float32, "grad_out")
+    B, ci, hi, wi = inp.shape
+    B2, co, ho, wo = grad_out.shape
+    assert B == B2
+    gw = torch.empty((co, ci, ksize, ksize), dtype=torch.float32, device=inp.device)
+    ws = torch.empty(int(lib.sessd_conv2d_wgrad_workspace_bytes(co, ci, ksize)), dtype=torch.uint8, device=inp.device)
+    check(lib.sessd_conv2d_wgrad(inp.data_ptr(), B, ci, hi, wi, grad_out.data_ptr(), co, ho, wo, ksize, stride, gw.data_ptr(),
+                                 ws.data_ptr(), ws.numel(), _stream()), "conv2d_wgrad")
+    return gw
+
+
+class Conv2dFunction(torch.autograd.Function):
+    """Differentiable Conv2d(k in {1,3}, stride in {1,2}, padding k//2) / ConvTranspose2d(3, s2, p1, op1) on the HIP kernels.
+    forward: sessd_conv2d_mfma / sessd_conv3x3_winograd / sessd_deconv2d_s2_mfma (no BatchNorm fold, no ReLU);
+    backward: dx = the adjoint layer through the same kernels with re-packed weights, dW = sessd_conv2d_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, transposed, stride):
+        x = x.float().contiguous()
+        pc = pack_deconv2d_s2(weight) if transposed else pack_conv2d(weight, stride)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (bool(transposed), int(stride), bias is not None)
+        return conv2d(x, pc, None, None if bias is None else bias.detach().float().contiguous(), False)
+
+    @staticmethod
+    def backward(ctx, grad):
+        x, weight = ctx.saved_tensors
+        transposed, stride, has_bias = ctx.cfg
+        g = grad.float().contiguous()
+        w = weight.detach().float()
+        k = w.shape[-1]
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            if transposed:      # adjoint of a stride-2 transposed conv = the stride-2 conv with the same weight tensor
+                gx = conv2d(g, pack_conv2d(w, 2), None, None, False)
+            elif stride == 2:   # adjoint of the stride-2 conv = the transposed conv with the same weight tensor
+                gx = conv2d(g, pack_deconv2d_s2(w), None, None, False)
+            else:               # stride 1: correlation with the flipped kernel, channels swapped
+                wd = (w.flip(2, 3) if k == 3 else w).transpose(0, 1).contiguous()
+                gx = conv2d(g, pack_conv2d(wd, 1), None, None, False)
+        if ctx.needs_input_grad[1]:
+            gw = conv2d_wgrad(g, x, 3, 2) if transposed else conv2d_wgrad(x, g, k, stride)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2, 3))
+        return gx, gw, gb, None, None
+
+
+def conv2d_module(x, m):
+    """Apply an nn.Conv2d / nn.ConvTranspose2d of the SSFA neck through Conv2dFunction (autograd-capable HIP path)."""
+    transposed = isinstance(m, torch.nn.ConvTranspose2d)
+    return Conv2dFunction.apply(x, m.weight, m.bias, transposed, int(m.stride[0]))
+
+
 def default_tile_cfg(cout, npix, ntaps):
     key = (cout, npix, ntaps)
     if key in _TILE_CFG_OVERRIDE:
