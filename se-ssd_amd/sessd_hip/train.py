@@ -11,8 +11,8 @@ What is here
                       duplicate DistOptimizerHook all-reduce (dist_utils.py:45-57); pre-divides like the reference
   * TrainStep         teacher forward (no grad, `*_raw` inputs) -> student forward -> loss -> backward -> all-reduce ->
                       fused update, in the order of trainer_sessd.py:250-275,340-357
-The sparse backbone runs forward AND backward on the HIP kernels (spconv.IndiceConvFunction); the dense neck / heads
-train through torch autograd for now (their forward kernels have no hand-written backward yet -- DESIGN.md section 7)."""
+The sparse backbone (spconv.IndiceConvFunction) and the twelve dense convs of the neck (ops.Conv2dFunction) run forward
+AND backward on the HIP kernels; BatchNorm, activations, the four 1x1 heads and the loss are torch ops."""
 import copy
 import math
 
