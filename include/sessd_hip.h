@@ -74,6 +74,10 @@ int sessd_rotate_iou_eval(const float* boxes, int num_boxes, const float* query,
 size_t sessd_nms_workspace_bytes(int num_boxes);
 int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, long long* keep, int32_t* num_keep,
                      void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+/* det3d.ops.nms.nms.non_max_suppression_cpu (det3d/ops/nms/nms_cpu.h:24-70; nms_cpu.py:34-37 nms_cc passes eps = 1) on the
+ * device: boxes (N, stride >= 4) [x1,y1,x2,y2,..] in descending-score order, extents widened by eps, suppress at IoU >= thresh. */
+int sessd_nms_axis_eps_sorted(const float* boxes, int stride, int num_boxes, float thresh, float eps, long long* keep,
+                              int32_t* num_keep, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 
 /* ------------------------------------------------------------------ sparse 3-D convolution (a4-a8)
  * replace the third-party spconv calls of det3d/models/backbones/scn.py:106-148,179-187:
@@ -212,6 +216,10 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
 size_t sessd_rotate_nms_workspace_bytes(int num_boxes);
 int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float iou_thresh, int post_max_size, int32_t* keep,
                             int32_t* num_keep, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+/* det3d.ops.nms.nms.rotate_non_max_suppression_cpu (nms_cpu.h:72-168) on the device: caller-supplied corner quads (N,4,2)
+ * in descending-score order; the stand-up IoU prefilter is recomputed from the corners' bounding boxes. */
+int sessd_rotate_nms_corners_sorted(const float* corners, int num_boxes, float iou_thresh, int post_max_size, int32_t* keep,
+                                    int32_t* num_keep, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 
 #ifdef __cplusplus
 }

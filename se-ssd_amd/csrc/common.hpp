@@ -13,6 +13,14 @@
 #define SESSD_EINVAL (-1)
 #define SESSD_EWORKSPACE (-2)
 
+// hipGetLastError() is sticky per thread: an error left behind by ANOTHER library's runtime call (observed: 100 from
+// torch's lazy device initialisation) would be reported by the next SESSD_CHECK_LAUNCH. Every launch clears it first.
+#define SESSD_LAUNCH(...)              \
+  do {                                  \
+    (void)hipGetLastError();            \
+    hipLaunchKernelGGL(__VA_ARGS__);    \
+  } while (0)
+
 #define SESSD_CHECK_LAUNCH()                          \
   do {                                                \
     hipError_t e__ = hipGetLastError();               \

@@ -599,11 +599,11 @@ int launch_conv(const ConvArgs* A, int nconv, int batch, hipStream_t stream) {
   const int npix = A[0].ht * A[0].wt;
   dim3 grid(sessd_divup(npix, WP * PT * 32) * sessd_divup(A[0].cout_pad, WC * CT * 32), 1, batch * (nconv > 1 ? 4 : 1));
   if (nconv == 1) {
-    hipLaunchKernelGGL((conv2d_mfma_kernel<NTAPS, CT, PT, WC, WP, DEEP>), grid, dim3(256), 0, stream, A[0]);
+    SESSD_LAUNCH((conv2d_mfma_kernel<NTAPS, CT, PT, WC, WP, DEEP>), grid, dim3(256), 0, stream, A[0]);
   } else {
     ConvArgs4 A4;
     for (int i = 0; i < 4; ++i) A4.c[i] = A[i];
-    hipLaunchKernelGGL((conv2d_mfma4_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A4);
+    SESSD_LAUNCH((conv2d_mfma4_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A4);
   }
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -670,7 +670,7 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
   if (tile_cfg == 10) {  // activation-stationary LDS variant (3x3, stride 1, cin % 16 == 0)
     if (eff != 9 || in_mul != 1 || out_mul != 1 || cin % 16 || hin != tile_h || win != tile_w) return SESSD_EINVAL;
     dim3 grid(sessd_divup(tile_h * tile_w, 32), sessd_divup(A.cout_pad, 128), batch);
-    hipLaunchKernelGGL(conv3x3s1_lds_kernel, grid, dim3(256), 0, stream, A);
+    SESSD_LAUNCH(conv3x3s1_lds_kernel, grid, dim3(256), 0, stream, A);
     SESSD_CHECK_LAUNCH();
     return SESSD_OK;
   }
@@ -697,9 +697,9 @@ int sessd_conv3x3_winograd(const float* in, int batch, int cin, int h, int w, co
   const int ntiles = (h / 2) * (w / 2);
   dim3 grid(sessd_divup(ntiles, 32) * sessd_divup(A.cout_pad, 32), 1, batch);
   if (variant == 1)
-    hipLaunchKernelGGL(conv3x3s1_winograd_kernel<true>, grid, dim3(256), 0, stream, A);
+    SESSD_LAUNCH(conv3x3s1_winograd_kernel<true>, grid, dim3(256), 0, stream, A);
   else
-    hipLaunchKernelGGL(conv3x3s1_winograd_kernel<false>, grid, dim3(256), 0, stream, A);
+    SESSD_LAUNCH(conv3x3s1_winograd_kernel<false>, grid, dim3(256), 0, stream, A);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -728,7 +728,7 @@ int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const flo
                     float* out, hipStream_t stream) {
   if (batch < 1 || channels < 1 || num_pixels < 1) return SESSD_EINVAL;
   if (channels % 4) return SESSD_EINVAL;
-  hipLaunchKernelGGL(ssfa_fuse_kernel, dim3(sessd_divup(num_pixels, 64), batch), dim3(256), 0, stream, x0, x1, w0, w1,
+  SESSD_LAUNCH(ssfa_fuse_kernel, dim3(sessd_divup(num_pixels, 64), batch), dim3(256), 0, stream, x0, x1, w0, w1,
                      bn_scale0, bn_shift0, bn_scale1, bn_shift1, channels, num_pixels, out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

@@ -158,14 +158,14 @@ int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win,
   nchunks = sessd_divup(rows, A.rows_per_chunk);
   dim3 grid(tiles, nchunks);
   if (ksize == 1)
-    hipLaunchKernelGGL((conv_wgrad_partial_kernel<1, 1>), grid, dim3(64), 0, stream, A);
+    SESSD_LAUNCH((conv_wgrad_partial_kernel<1, 1>), grid, dim3(64), 0, stream, A);
   else if (stride == 1)
-    hipLaunchKernelGGL((conv_wgrad_partial_kernel<3, 1>), grid, dim3(64), 0, stream, A);
+    SESSD_LAUNCH((conv_wgrad_partial_kernel<3, 1>), grid, dim3(64), 0, stream, A);
   else
-    hipLaunchKernelGGL((conv_wgrad_partial_kernel<3, 2>), grid, dim3(64), 0, stream, A);
+    SESSD_LAUNCH((conv_wgrad_partial_kernel<3, 2>), grid, dim3(64), 0, stream, A);
   SESSD_CHECK_LAUNCH();
   const int total = cout * cin * ksize * ksize;
-  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3(sessd_divup(total, 256)), dim3(256), 0, stream, (const float*)workspace,
+  SESSD_LAUNCH(conv_wgrad_reduce_kernel, dim3(sessd_divup(total, 256)), dim3(256), 0, stream, (const float*)workspace,
                      nchunks, total, grad_weight);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void fill_u32_kernel(uint32_t* __restrict__ p,
 int sessd_fill_u32_launch(void* p, uint32_t value, size_t n_words, hipStream_t stream) {
   if (n_words == 0) return SESSD_OK;
   const size_t threads = (n_words + 3) / 4;
-  hipLaunchKernelGGL(fill_u32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (uint32_t*)p, value,
+  SESSD_LAUNCH(fill_u32_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, stream, (uint32_t*)p, value,
                      n_words);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

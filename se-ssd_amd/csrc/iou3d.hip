@@ -319,6 +319,38 @@ __global__ __launch_bounds__(64) void nms_plus1_mask_kernel(int n, float thresh,
   mask[(size_t)i * sessd_divup(n, 64) + cblk] = bits;
 }
 
+// det3d/ops/nms/nms_cpu.h:24-70 non_max_suppression_cpu (and nms_cpu.py:100-127 nms_jit): axis aligned, areas and
+// overlaps widened by eps, suppress when IoU >= thresh; boxes (N, stride >= 4) x1,y1,x2,y2
+__global__ __launch_bounds__(64) void nms_eps_mask_kernel(int n, float thresh, float eps, const float* __restrict__ boxes,
+                                                           int stride, unsigned long long* __restrict__ mask) {
+  const int rblk = blockIdx.y, cblk = blockIdx.x;
+  if (cblk < rblk) return;
+  __shared__ float bb[64][4];
+  const int t = threadIdx.x;
+  const int ncol = min(n - cblk * 64, 64), nrow = min(n - rblk * 64, 64);
+  if (t < ncol)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) bb[t][q] = boxes[(size_t)(cblk * 64 + t) * stride + q];
+  __syncthreads();
+  if (t >= nrow) return;
+  const int i = rblk * 64 + t;
+  const float a0 = boxes[(size_t)i * stride], a1 = boxes[(size_t)i * stride + 1], a2 = boxes[(size_t)i * stride + 2],
+              a3 = boxes[(size_t)i * stride + 3];
+  const float sa = (a2 - a0 + eps) * (a3 - a1 + eps);
+  unsigned long long bits = 0;
+  for (int k = (rblk == cblk) ? t + 1 : 0; k < ncol; ++k) {
+    const float w = fminf(a2, bb[k][2]) - fmaxf(a0, bb[k][0]) + eps;
+    if (w > 0.f) {
+      const float hgt = fminf(a3, bb[k][3]) - fmaxf(a1, bb[k][1]) + eps;
+      if (hgt > 0.f) {
+        const float inter = w * hgt, sb = (bb[k][2] - bb[k][0] + eps) * (bb[k][3] - bb[k][1] + eps);
+        if (inter / (sa + sb - inter) >= thresh) bits |= 1ull << k;
+      }
+    }
+  }
+  mask[(size_t)i * sessd_divup(n, 64) + cblk] = bits;
+}
+
 }  // namespace
 
 // Greedy reduction of a suppression bitmask by ONE wave, shared with nms.hip.
@@ -392,13 +424,13 @@ int sessd_boxes_pairwise(int mode, const float* boxes_a, int num_a, const float*
   dim3 grid(sessd_divup(num_b, TP), sessd_divup(num_a, TP)), block(TP, TP);
   switch (mode) {
     case MODE_OVERLAP:
-      hipLaunchKernelGGL((pairwise_kernel<MODE_OVERLAP, 5>), grid, block, 0, stream, num_a, boxes_a, num_b, boxes_b, out);
+      SESSD_LAUNCH((pairwise_kernel<MODE_OVERLAP, 5>), grid, block, 0, stream, num_a, boxes_a, num_b, boxes_b, out);
       break;
     case MODE_IOU_BEV:
-      hipLaunchKernelGGL((pairwise_kernel<MODE_IOU_BEV, 5>), grid, block, 0, stream, num_a, boxes_a, num_b, boxes_b, out);
+      SESSD_LAUNCH((pairwise_kernel<MODE_IOU_BEV, 5>), grid, block, 0, stream, num_a, boxes_a, num_b, boxes_b, out);
       break;
     case MODE_IOU_3D:
-      hipLaunchKernelGGL((pairwise_kernel<MODE_IOU_3D, 7>), grid, block, 0, stream, num_a, boxes_a, num_b, boxes_b, out);
+      SESSD_LAUNCH((pairwise_kernel<MODE_IOU_3D, 7>), grid, block, 0, stream, num_a, boxes_a, num_b, boxes_b, out);
       break;
     default:
       return SESSD_EINVAL;
@@ -411,7 +443,7 @@ int sessd_boxes_aligned_overlap_bev(const float* boxes_a, const float* boxes_b, 
                                     hipStream_t stream) {
   if (num < 0) return SESSD_EINVAL;
   if (num == 0) return SESSD_OK;
-  hipLaunchKernelGGL(aligned_overlap_kernel, dim3(sessd_divup(num, 256)), dim3(256), 0, stream, num, boxes_a, boxes_b,
+  SESSD_LAUNCH(aligned_overlap_kernel, dim3(sessd_divup(num, 256)), dim3(256), 0, stream, num, boxes_a, boxes_b,
                      out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -437,17 +469,37 @@ int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, 
   const int cb = sessd_divup(num_boxes, 64);
   dim3 grid(cb, cb), block(64);
   if (mode == 0)
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_IOU_BEV, 5>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
+    SESSD_LAUNCH((nms_mask_kernel<MODE_IOU_BEV, 5>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
   else if (mode == 1)
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_IOU_3D, 7>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
+    SESSD_LAUNCH((nms_mask_kernel<MODE_IOU_3D, 7>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
   else if (mode == 2)
-    hipLaunchKernelGGL((nms_mask_kernel<MODE_IOU_NORMAL, 5>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
+    SESSD_LAUNCH((nms_mask_kernel<MODE_IOU_NORMAL, 5>), grid, block, 0, stream, num_boxes, thresh, boxes, mask);
   else if (mode == 3)
-    hipLaunchKernelGGL(rotate_nms_numba_mask_kernel, grid, block, 0, stream, num_boxes, thresh, boxes, mask);
+    SESSD_LAUNCH(rotate_nms_numba_mask_kernel, grid, block, 0, stream, num_boxes, thresh, boxes, mask);
   else
-    hipLaunchKernelGGL(nms_plus1_mask_kernel, grid, block, 0, stream, num_boxes, thresh, boxes, mask);
+    SESSD_LAUNCH(nms_plus1_mask_kernel, grid, block, 0, stream, num_boxes, thresh, boxes, mask);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sessd_nms_reduce_kernel, dim3(1), dim3(64), 0, stream, (const int*)nullptr, num_boxes, mask, cb,
+  SESSD_LAUNCH(sessd_nms_reduce_kernel, dim3(1), dim3(64), 0, stream, (const int*)nullptr, num_boxes, mask, cb,
+                     num_boxes, keep, (int*)nullptr, num_keep);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// det3d.ops.nms.nms.non_max_suppression_cpu (nms_cpu.h:24-70) on the device: boxes (N, stride >= 4) [x1,y1,x2,y2,...]
+// already in descending-score order; IoU with eps-widened extents, suppress at >= thresh.
+int sessd_nms_axis_eps_sorted(const float* boxes, int stride, int num_boxes, float thresh, float eps, long long* keep,
+                              int* num_keep, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (num_boxes < 0 || stride < 4 || num_boxes > 64 * 64 * 4) return SESSD_EINVAL;
+  if (workspace_bytes < sessd_nms_workspace_bytes(num_boxes)) return SESSD_EWORKSPACE;
+  if (num_boxes == 0) {
+    SESSD_FILL(num_keep, 0, 1, stream);
+    return SESSD_OK;
+  }
+  unsigned long long* mask = (unsigned long long*)workspace;
+  const int cb = sessd_divup(num_boxes, 64);
+  SESSD_LAUNCH(nms_eps_mask_kernel, dim3(cb, cb), dim3(64), 0, stream, num_boxes, thresh, eps, boxes, stride, mask);
+  SESSD_CHECK_LAUNCH();
+  SESSD_LAUNCH(sessd_nms_reduce_kernel, dim3(1), dim3(64), 0, stream, (const int*)nullptr, num_boxes, mask, cb,
                      num_boxes, keep, (int*)nullptr, num_keep);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -459,7 +511,7 @@ int sessd_rotate_iou_eval(const float* boxes, int num_boxes, const float* query,
                           hipStream_t stream) {
   if (num_boxes < 0 || num_query < 0) return SESSD_EINVAL;
   if (num_boxes == 0 || num_query == 0) return SESSD_OK;
-  hipLaunchKernelGGL(rotate_iou_eval_kernel, dim3(sessd_divup(num_query, 16), sessd_divup(num_boxes, 16)), dim3(256), 0, stream,
+  SESSD_LAUNCH(rotate_iou_eval_kernel, dim3(sessd_divup(num_query, 16), sessd_divup(num_boxes, 16)), dim3(256), 0, stream,
                      boxes, num_boxes, query, num_query, criterion, out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

@@ -105,9 +105,9 @@ size_t sessd_grad_clip_workspace_bytes(void) { return NORM_BLOCKS * sizeof(doubl
 int sessd_grad_clip_coef(const float* grad, size_t n, float max_norm, void* workspace, size_t workspace_bytes, float* out2,
                          hipStream_t stream) {
   if (workspace_bytes < sessd_grad_clip_workspace_bytes() || ((uintptr_t)grad & 15)) return SESSD_EINVAL;
-  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, (double*)workspace);
+  SESSD_LAUNCH(sumsq_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grad, n, (double*)workspace);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, max_norm, out2);
+  SESSD_LAUNCH(sumsq_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, max_norm, out2);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -133,7 +133,7 @@ int sessd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* 
   A.one_m_alpha = (float)(1.0 - ema_alpha);
   const size_t n4 = n >> 2;
   const unsigned blocks = (unsigned)((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1);
-  hipLaunchKernelGGL(adam_ema_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, ema_param, n, A, clip2);
+  SESSD_LAUNCH(adam_ema_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, ema_param, n, A, clip2);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

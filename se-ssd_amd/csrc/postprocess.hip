@@ -423,14 +423,14 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
   for (int i = 0; i < 6; ++i) C.range[i] = post_center_range6[i];
   C.dir_offset = direction_offset;
   SESSD_FILL(w.count, 0, batch, stream);
-  hipLaunchKernelGGL(score_filter_kernel, dim3(sessd_divup(num_pixels, 256), batch), dim3(256), 0, stream, head, C,
+  SESSD_LAUNCH(score_filter_kernel, dim3(sessd_divup(num_pixels, 256), batch), dim3(256), 0, stream, head, C,
                      w.keys, A, w.count);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(topk_decode_kernel, dim3(batch), dim3(SORT_NT), 0, stream, head, anchors, anchors_per_frame, C,
+  SESSD_LAUNCH(topk_decode_kernel, dim3(batch), dim3(SORT_NT), 0, stream, head, anchors, anchors_per_frame, C,
                      w.keys, A, w.count, w.cand_box, w.cand_score, w.cand_dir, w.corners, w.standup, w.n_top);
   SESSD_CHECK_LAUNCH();
   const int words = sessd_divup(pre_max_size, 64);
-  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, sessd_divup(pre_max_size, 4), batch), dim3(256), 0, stream, w.n_top,
+  SESSD_LAUNCH(rnms_mask_kernel, dim3(words, sessd_divup(pre_max_size, 4), batch), dim3(256), 0, stream, w.n_top,
                      pre_max_size, nms_iou_thresh, w.corners, w.standup, w.mask, words);
   SESSD_CHECK_LAUNCH();
   {
@@ -442,15 +442,15 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
                                       160 * 1024 - 1024));
         attr_set = true;
       }
-      hipLaunchKernelGGL(nms_reduce_lds_kernel, dim3(batch), dim3(1024), lds, stream, w.n_top, pre_max_size, w.mask, words,
+      SESSD_LAUNCH(nms_reduce_lds_kernel, dim3(batch), dim3(1024), lds, stream, w.n_top, pre_max_size, w.mask, words,
                          post_max_size, w.keep, w.n_keep);
     } else {
-      hipLaunchKernelGGL(nms_reduce_batch_kernel, dim3(batch), dim3(64), 0, stream, w.n_top, pre_max_size, w.mask, words,
+      SESSD_LAUNCH(nms_reduce_batch_kernel, dim3(batch), dim3(64), 0, stream, w.n_top, pre_max_size, w.mask, words,
                          post_max_size, w.keep, w.n_keep);
     }
   }
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(finalize_kernel, dim3(batch), dim3(64), 0, stream, C, w.keep, w.n_keep, w.cand_box, w.cand_score,
+  SESSD_LAUNCH(finalize_kernel, dim3(batch), dim3(64), 0, stream, C, w.keep, w.n_keep, w.cand_box, w.cand_score,
                      w.cand_dir, frustum, out_box, out_score, out_label, out_count);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -483,10 +483,28 @@ __global__ __launch_bounds__(256) void rnms_prep_kernel(const float* __restrict_
   standup[(size_t)i * 4 + 0] = x0; standup[(size_t)i * 4 + 1] = y0; standup[(size_t)i * 4 + 2] = x1; standup[(size_t)i * 4 + 3] = y1;
 }
 __global__ void set_int_kernel(int* p, int v) { *p = v; }
+// corners given by the caller (det3d.ops.nms.nms.rotate_non_max_suppression_cpu, nms_cpu.h:72-168): copy + AABB
+__global__ __launch_bounds__(256) void rnms_prep_corners_kernel(const float* __restrict__ in_corners, int n,
+                                                                 float* __restrict__ corners, float* __restrict__ standup) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float c8[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) c8[q] = in_corners[(size_t)i * 8 + q];
+  float x0 = c8[0], y0 = c8[1], x1 = c8[0], y1 = c8[1];
+#pragma unroll
+  for (int q = 1; q < 4; ++q) {
+    x0 = fminf(x0, c8[2 * q]); x1 = fmaxf(x1, c8[2 * q]);
+    y0 = fminf(y0, c8[2 * q + 1]); y1 = fmaxf(y1, c8[2 * q + 1]);
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) corners[(size_t)i * 8 + q] = c8[q];
+  standup[(size_t)i * 4 + 0] = x0; standup[(size_t)i * 4 + 1] = y0; standup[(size_t)i * 4 + 2] = x1; standup[(size_t)i * 4 + 3] = y1;
+}
 }  // namespace
 
-extern "C" int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float iou_thresh, int post_max_size, int* keep,
-                                       int* num_keep, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int rotate_nms_common(const float* dets, const float* in_corners, int num_boxes, float iou_thresh, int post_max_size,
+                             int* keep, int* num_keep, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (num_boxes < 0 || num_boxes > 4096 || post_max_size < 1) return SESSD_EINVAL;
   if (workspace_bytes < sessd_rotate_nms_workspace_bytes(num_boxes)) return SESSD_EWORKSPACE;
   if (num_boxes == 0) {
@@ -501,15 +519,36 @@ extern "C" int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float i
   unsigned long long* mask = (unsigned long long*)(base + off);
   off += sessd_align((size_t)num_boxes * words * 8, 256);
   int* n_top = (int*)(base + off);
-  hipLaunchKernelGGL(set_int_kernel, dim3(1), dim3(1), 0, stream, n_top, num_boxes);
-  hipLaunchKernelGGL(rnms_prep_kernel, dim3(sessd_divup(num_boxes, 256)), dim3(256), 0, stream, dets, num_boxes, corners,
-                     standup);
+  SESSD_LAUNCH(set_int_kernel, dim3(1), dim3(1), 0, stream, n_top, num_boxes);
+  if (in_corners)
+    SESSD_LAUNCH(rnms_prep_corners_kernel, dim3(sessd_divup(num_boxes, 256)), dim3(256), 0, stream, in_corners,
+                       num_boxes, corners, standup);
+  else
+    SESSD_LAUNCH(rnms_prep_kernel, dim3(sessd_divup(num_boxes, 256)), dim3(256), 0, stream, dets, num_boxes, corners,
+                       standup);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rnms_mask_kernel, dim3(words, sessd_divup(num_boxes, 4), 1), dim3(256), 0, stream, n_top, num_boxes,
+  SESSD_LAUNCH(rnms_mask_kernel, dim3(words, sessd_divup(num_boxes, 4), 1), dim3(256), 0, stream, n_top, num_boxes,
                      iou_thresh, corners, standup, mask, words);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(nms_reduce_batch_kernel, dim3(1), dim3(64), 0, stream, n_top, num_boxes, mask, words, post_max_size,
+  SESSD_LAUNCH(nms_reduce_batch_kernel, dim3(1), dim3(64), 0, stream, n_top, num_boxes, mask, words, post_max_size,
                      keep, num_keep);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
+}
+
+// The same greedy rotated NMS on caller-supplied corner quads (N,4,2), already in descending-score order: the device
+// form of det3d.ops.nms.nms.rotate_non_max_suppression_cpu (nms_cpu.h:72-168; the stand-up IoU prefilter is recomputed
+// from the corners' bounding boxes = what nms_cpu.py:45-49 passes in).
+extern "C" int sessd_rotate_nms_corners_sorted(const float* corners, int num_boxes, float iou_thresh, int post_max_size,
+                                               int* keep, int* num_keep, void* workspace, size_t workspace_bytes,
+                                               hipStream_t stream) {
+  if (!corners && num_boxes > 0) return SESSD_EINVAL;
+  return rotate_nms_common(nullptr, corners, num_boxes, iou_thresh, post_max_size, keep, num_keep, workspace, workspace_bytes,
+                           stream);
+}
+
+extern "C" int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float iou_thresh, int post_max_size, int* keep,
+                                       int* num_keep, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return rotate_nms_common(dets, nullptr, num_boxes, iou_thresh, post_max_size, keep, num_keep, workspace, workspace_bytes,
+                           stream);
 }

@@ -185,10 +185,10 @@ int launch_ntw(bool dense, const float* in_feat, const int* nbr, const uint32_t*
   const int tiles = sessd_divup(n_cap, 16);
   dim3 grid(sessd_divup(tiles, 4), COUT / 16 / NTW), block(256);
   if (dense)
-    hipLaunchKernelGGL((sparse_conv_kernel<CIN, COUT, NTW, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
+    SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
                        n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2]);
   else
-    hipLaunchKernelGGL((sparse_conv_kernel<CIN, COUT, NTW, false>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
+    SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, false>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
                        n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -221,7 +221,7 @@ int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, in
   const int steps = cin / 4;
   if (steps > 4 && steps % 4) return SESSD_EINVAL;
   size_t total = (size_t)kernel_volume * cin * cout;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, weight,
+  SESSD_LAUNCH(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, weight,
                      kernel_volume, cin, cout, packed);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

@@ -111,11 +111,11 @@ int launch_wgrad(const float* x, const float* dy, const int* nbr, const uint32_t
   const int tiles = sessd_divup(n_cap, 16);
   const int chunk_tiles = sessd_divup(tiles, WG_CHUNKS);
   const int nchunks = sessd_divup(tiles, chunk_tiles);
-  hipLaunchKernelGGL((wgrad_partial_kernel<CIN, COUT>), dim3(nchunks, kv), dim3(64), 0, stream, x, dy, nbr, tile_mask,
+  SESSD_LAUNCH((wgrad_partial_kernel<CIN, COUT>), dim3(nchunks, kv), dim3(64), 0, stream, x, dy, nbr, tile_mask,
                      n_dev, n_cap, chunk_tiles, partial);
   SESSD_CHECK_LAUNCH();
   const int total = kv * CIN * COUT;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(sessd_divup(total, 256)), dim3(256), 0, stream, partial, nchunks, total,
+  SESSD_LAUNCH(wgrad_reduce_kernel, dim3(sessd_divup(total, 256)), dim3(256), 0, stream, partial, nchunks, total,
                      grad_weight);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -132,7 +132,7 @@ int sessd_sparse_rulebook_transpose(const int* nbr, int kernel_volume, const int
   if (kernel_volume <= 0 || kernel_volume > 32 || n_out_cap <= 0 || n_in_cap <= 0) return SESSD_EINVAL;
   SESSD_FILL(nbr_t, 0xFFFFFFFFu, (size_t)kernel_volume * n_in_cap, stream);
   SESSD_FILL(tile_mask_t, 0u, (size_t)sessd_divup(n_in_cap, 16), stream);
-  hipLaunchKernelGGL(rulebook_transpose_kernel, dim3(sessd_divup(n_out_cap, 256), kernel_volume), dim3(256), 0, stream,
+  SESSD_LAUNCH(rulebook_transpose_kernel, dim3(sessd_divup(n_out_cap, 256), kernel_volume), dim3(256), 0, stream,
                      nbr, n_out_dev, n_out_cap, n_in_cap, nbr_t, tile_mask_t);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

@@ -316,7 +316,7 @@ int sessd_sparse_hash_build(const int* indices, const int* n_dev, int n_cap, con
   if (n_cap <= 0 || (capacity & (capacity - 1)) != 0) return SESSD_EINVAL;
   ConvGeom G;
   fill_geom(G, nullptr, nullptr, nullptr, dims3, nullptr);
-  hipLaunchKernelGGL(hash_build_kernel, dim3(sessd_divup(n_cap, NT)), dim3(NT), 0, stream, indices, n_dev, n_cap, G, keys,
+  SESSD_LAUNCH(hash_build_kernel, dim3(sessd_divup(n_cap, NT)), dim3(NT), 0, stream, indices, n_dev, n_cap, G, keys,
                      vals, capacity - 1);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -344,12 +344,12 @@ int sessd_sparse_downsample_sites(const int* in_indices, const int* n_in_dev, in
   SESSD_FILL_SCRATCH(w.first, SESSD_HASH_EMPTY, out_capacity, stream);
   const int total = n_in_cap * kv;
   const int nblk = sessd_divup(total, NT);
-  hipLaunchKernelGGL(down_insert_kernel, dim3(nblk), dim3(NT), 0, stream, in_indices, n_in_dev, n_in_cap, kv, G, out_keys,
+  SESSD_LAUNCH(down_insert_kernel, dim3(nblk), dim3(NT), 0, stream, in_indices, n_in_dev, n_in_cap, kv, G, out_keys,
                      out_capacity - 1, w.first, w.ent);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(down_count_kernel, dim3(nblk), dim3(NT), 0, stream, total, w.ent, w.first, w.blk_cnt);
+  SESSD_LAUNCH(down_count_kernel, dim3(nblk), dim3(NT), 0, stream, total, w.ent, w.first, w.blk_cnt);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(down_assign_kernel, dim3(nblk), dim3(NT), 0, stream, in_indices, total, kv, G, w.ent, w.first,
+  SESSD_LAUNCH(down_assign_kernel, dim3(nblk), dim3(NT), 0, stream, in_indices, total, kv, G, w.ent, w.first,
                      w.blk_cnt, nblk, out_vals, out_indices, n_out_cap, n_out_dev, err_flag);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -369,7 +369,7 @@ int sessd_sparse_rulebook(const int* out_indices, const int* n_out_dev, int n_ou
   J.j[0].nbr = nbr; J.j[0].tile_mask = tile_mask;
   J.j[1] = J.j[0];
   const int tiles = sessd_divup(n_out_cap, 16);
-  hipLaunchKernelGGL(rulebook_kernel, dim3(sessd_divup(tiles, NT / 64), 1), dim3(NT), 0, stream, out_indices, n_out_dev,
+  SESSD_LAUNCH(rulebook_kernel, dim3(sessd_divup(tiles, NT / 64), 1), dim3(NT), 0, stream, out_indices, n_out_dev,
                      n_out_cap, J);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -393,7 +393,7 @@ int sessd_sparse_rulebook_pair(const int* out_indices, const int* n_out_dev, int
   J.j[1].KV = ksize3_b[0] * ksize3_b[1] * ksize3_b[2]; J.j[1].nbr = nbr_b; J.j[1].tile_mask = tile_mask_b;
   if (J.j[0].KV > 28 || J.j[1].KV > 28) return SESSD_EINVAL;
   const int tiles = sessd_divup(n_out_cap, 16);
-  hipLaunchKernelGGL(rulebook_kernel, dim3(sessd_divup(tiles, NT / 64), 2), dim3(NT), 0, stream, out_indices, n_out_dev,
+  SESSD_LAUNCH(rulebook_kernel, dim3(sessd_divup(tiles, NT / 64), 2), dim3(NT), 0, stream, out_indices, n_out_dev,
                      n_out_cap, J);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -410,7 +410,7 @@ int sessd_sparse_downsample_sites_unordered(const int* in_indices, const int* n_
   ConvGeom G;
   fill_geom(G, ksize3, stride3, pad3, nullptr, out_dims3);
   const int kc = G.cd[0] * G.cd[1] * G.cd[2];
-  hipLaunchKernelGGL(down_insert_unordered_kernel, dim3(sessd_divup(n_in_cap * kc, NT)), dim3(NT), 0, stream, in_indices,
+  SESSD_LAUNCH(down_insert_unordered_kernel, dim3(sessd_divup(n_in_cap * kc, NT)), dim3(NT), 0, stream, in_indices,
                      n_in_dev, n_in_cap, kc, G, out_keys, out_vals, out_capacity - 1, out_indices, n_out_cap, n_out_dev,
                      err_flag);
   SESSD_CHECK_LAUNCH();

@@ -311,24 +311,24 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
   SESSD_FILL_SCRATCH(w.meta, SESSD_HASH_EMPTY, 1, stream);  // cut = SESSD_SENT
   const int nblk = sessd_divup(num_points > 0 ? num_points : 1, VOX_NT);
   if (num_points > 0) {
-    hipLaunchKernelGGL(vox_insert_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, points, num_points, ndim, G, key_base,
+    SESSD_LAUNCH(vox_insert_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, points, num_points, ndim, G, key_base,
                        hash_keys, hash_capacity - 1, w.lists, MP, w.ent);
     SESSD_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(vox_count_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, num_points, w.ent, w.lists, MP, w.blk_cnt,
+  SESSD_LAUNCH(vox_count_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, num_points, w.ent, w.lists, MP, w.blk_cnt,
                      w.meta);
   SESSD_CHECK_LAUNCH();
-  hipLaunchKernelGGL(vox_assign_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, num_points, w.ent, w.lists, MP, w.blk_cnt,
+  SESSD_LAUNCH(vox_assign_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, num_points, w.ent, w.lists, MP, w.blk_cnt,
                      nblk, hash_keys, key_base, G, max_voxels, batch_index, prefix + batch_index, hash_vals,
                      w.entry_of_vid, coors, coors_stride, w.meta, prefix + batch_index + 1);
   SESSD_CHECK_LAUNCH();
   const int gblk = sessd_divup(max_voxels < num_points ? max_voxels : (num_points > 0 ? num_points : 1), VOX_NT);
   if (ndim == 4) {
-    hipLaunchKernelGGL(vox_gather_kernel<4>, dim3(gblk), dim3(VOX_NT), 0, stream, points, ndim, w.lists, MP,
+    SESSD_LAUNCH(vox_gather_kernel<4>, dim3(gblk), dim3(VOX_NT), 0, stream, points, ndim, w.lists, MP,
                        w.entry_of_vid, w.meta, max_voxels, prefix + batch_index, voxels, num_points_per_voxel,
                        mean_feat);
   } else {
-    hipLaunchKernelGGL(vox_gather_kernel<0>, dim3(gblk), dim3(VOX_NT), 0, stream, points, ndim, w.lists, MP,
+    SESSD_LAUNCH(vox_gather_kernel<0>, dim3(gblk), dim3(VOX_NT), 0, stream, points, ndim, w.lists, MP,
                        w.entry_of_vid, w.meta, max_voxels, prefix + batch_index, voxels, num_points_per_voxel,
                        mean_feat);
   }
@@ -340,7 +340,7 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
 int sessd_stage_points(const float* points, int num_points, float* dst, int capacity, hipStream_t stream) {
   if (num_points < 0 || capacity < num_points) return SESSD_EINVAL;
   if (capacity == 0) return SESSD_OK;
-  hipLaunchKernelGGL(stage_points_kernel, dim3(sessd_divup(capacity, VOX_NT)), dim3(VOX_NT), 0, stream,
+  SESSD_LAUNCH(stage_points_kernel, dim3(sessd_divup(capacity, VOX_NT)), dim3(VOX_NT), 0, stream,
                      (const float4*)points, num_points, (float4*)dst, capacity);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -351,7 +351,7 @@ int sessd_vfe_mean(const float* voxels, const int* num_points, const int* num_vo
                    int max_points_per_voxel, int ndim, int num_features, float* out, hipStream_t stream) {
   if (num_features > ndim) return SESSD_EINVAL;
   if (num_voxels_host <= 0) return SESSD_OK;
-  hipLaunchKernelGGL(vfe_mean_kernel, dim3(sessd_divup(num_voxels_host, 256)), dim3(256), 0, stream, voxels, num_points,
+  SESSD_LAUNCH(vfe_mean_kernel, dim3(sessd_divup(num_voxels_host, 256)), dim3(256), 0, stream, voxels, num_points,
                      num_voxels_dev, num_voxels_host, max_points_per_voxel, ndim, num_features, out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

@@ -1,2 +1,55 @@
-"""numpy helpers of the predict path (mirrors det3d/core/bbox/box_np_ops.py:780-833,995-1004)."""
+"""numpy box helpers of det3d/core/bbox/box_np_ops.py that the SE-SSD inference path and its NMS wrappers touch
+(anchors / frustum live in sessd_hip.anchors). Vectorised restatements; pinned by tests/golden/nms_helpers_ref.npz."""
+import numpy as np
+
 from sessd_hip.anchors import create_anchors_3d_range, get_valid_frustum, projection_matrix_to_CRT_kitti  # noqa: F401
+
+
+def corners_nd(dims, origin=0.5):
+    """(N, ndim) sizes -> (N, 2**ndim, ndim) corner offsets around `origin` (box_np_ops.py:433-463); 2-D order:
+    (0,0), (0,1), (1,1), (1,0) in units of the box size."""
+    dims = np.asarray(dims)
+    ndim = dims.shape[1]
+    unit = np.stack(np.unravel_index(np.arange(2 ** ndim), [2] * ndim), axis=1).astype(dims.dtype)
+    if ndim == 2:
+        unit = unit[[0, 1, 3, 2]]
+    elif ndim == 3:
+        unit = unit[[0, 1, 3, 2, 4, 5, 7, 6]]
+    unit = unit - np.asarray(origin, dtype=dims.dtype)
+    return dims[:, None, :] * unit[None, :, :]
+
+
+def rotation_2d(points, angles):
+    """(N, P, 2) points rotated by angles (N,), clockwise-positive convention of box_np_ops.py:267-294:
+    x' = x cos a + y sin a, y' = -x sin a + y cos a."""
+    s, c = np.sin(angles)[:, None], np.cos(angles)[:, None]
+    x, y = points[..., 0], points[..., 1]
+    return np.stack([x * c + y * s, -x * s + y * c], axis=-1)
+
+
+def center_to_corner_box2d(centers, dims, angles=None, origin=0.5):
+    """box_np_ops.py:512-532"""
+    corners = corners_nd(dims, origin=origin)
+    if angles is not None:
+        corners = rotation_2d(corners, angles)
+    return corners + np.asarray(centers).reshape(-1, 1, 2)
+
+
+def corner_to_standup_nd(boxes_corner):
+    """(N, P, ndim) corners -> (N, 2*ndim) [mins, maxs] (box_np_ops.py:346-351)."""
+    assert boxes_corner.ndim == 3
+    return np.concatenate([boxes_corner.min(axis=1), boxes_corner.max(axis=1)], axis=-1)
+
+
+def iou_jit(boxes, query_boxes, eps=1.0):
+    """Axis-aligned IoU matrix (N, K) with eps-widened extents; zero where the widened overlap is not positive in both
+    axes (box_np_ops.py:1008-1046)."""
+    b, q = np.asarray(boxes), np.asarray(query_boxes)
+    iw = np.minimum(b[:, None, 2], q[None, :, 2]) - np.maximum(b[:, None, 0], q[None, :, 0]) + eps
+    ih = np.minimum(b[:, None, 3], q[None, :, 3]) - np.maximum(b[:, None, 1], q[None, :, 1]) + eps
+    area_b = (b[:, 2] - b[:, 0] + eps) * (b[:, 3] - b[:, 1] + eps)
+    area_q = (q[:, 2] - q[:, 0] + eps) * (q[:, 3] - q[:, 1] + eps)
+    ok = (iw > 0) & (ih > 0)
+    inter = np.where(ok, iw * ih, 0).astype(b.dtype)
+    ua = area_b[:, None] + area_q[None, :] - inter
+    return np.where(ok, inter / np.where(ok, ua, 1), 0).astype(b.dtype)

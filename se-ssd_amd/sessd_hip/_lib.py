@@ -27,6 +27,7 @@ SIGNATURES = {
     "sessd_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
     "sessd_nms_workspace_bytes": (sz, [i32]),
     "sessd_nms_sorted": (i32, [i32, vp, i32, f32, vp, vp, vp, sz, vp]),
+    "sessd_nms_axis_eps_sorted": (i32, [vp, i32, i32, f32, f32, vp, vp, vp, sz, vp]),
     "sessd_conv2d_mfma": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32,
                                 vp, vp, i32, vp, i32, vp]),
     "sessd_conv3x3_winograd": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
@@ -36,6 +37,7 @@ SIGNATURES = {
     "sessd_predict": (i32, [vp, i32, i32, vp, i32, vp, f32, i32, i32, f32, vp, f32, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_rotate_nms_workspace_bytes": (sz, [i32]),
     "sessd_rotate_nms_sorted": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
+    "sessd_rotate_nms_corners_sorted": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
     "sessd_sparse_hash_build": (i32, [vp, vp, i32, vp, vp, vp, u32, vp]),
     "sessd_sparse_downsample_workspace_bytes": (sz, [i32, i32, u32]),
     "sessd_sparse_downsample_sites": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, u32, vp, i32, vp, vp, vp, sz, vp]),

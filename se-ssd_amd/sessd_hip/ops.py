@@ -149,6 +149,19 @@ def nms_sorted(mode, boxes, thresh):
     return keep, num
 
 
+def nms_axis_eps_sorted(boxes, thresh, eps):
+    """Axis-aligned greedy NMS of nms_cpu.h:24-70: boxes (N, >=4) sorted by descending score, IoU with eps-widened extents,
+    suppress at >= thresh. Returns (keep int64[N] device, num_keep int32[1] device)."""
+    _req(boxes, torch.float32, "boxes")
+    n = boxes.shape[0]
+    keep = torch.empty((max(n, 1),), dtype=torch.int64, device=boxes.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=boxes.device)
+    ws = workspace(lib.sessd_nms_workspace_bytes(n), boxes.device, "nms")
+    check(lib.sessd_nms_axis_eps_sorted(boxes.data_ptr(), boxes.shape[1], n, float(thresh), float(eps), keep.data_ptr(),
+                                        num.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "nms_axis_eps_sorted")
+    return keep, num
+
+
 # ------------------------------------------------------------------ sparse 3-D convolution
 def _i3(v):
     v = [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
@@ -505,6 +518,19 @@ def predict(head, anchors, frustum=None, score_thresh=0.3, pre_max=1000, post_ma
                             out["box"].data_ptr(), out["score"].data_ptr(), out["label"].data_ptr(),
                             out["count"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "predict")
     return out
+
+
+def rotate_nms_corners_sorted(corners, thresh, post_max):
+    """corners (N,4,2) sorted by descending score -> (keep int32[post_max], num int32[1]) on the device
+    (rotate_non_max_suppression_cpu of nms_cpu.h:72-168)."""
+    _req(corners, torch.float32, "corners")
+    n = corners.shape[0]
+    keep = torch.empty((post_max,), dtype=torch.int32, device=corners.device)
+    num = torch.zeros((1,), dtype=torch.int32, device=corners.device)
+    ws = workspace(lib.sessd_rotate_nms_workspace_bytes(n), corners.device, "rnms")
+    check(lib.sessd_rotate_nms_corners_sorted(corners.data_ptr(), n, float(thresh), int(post_max), keep.data_ptr(),
+                                              num.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "rotate_nms_corners_sorted")
+    return keep, num
 
 
 def rotate_nms_sorted(dets, thresh, post_max):

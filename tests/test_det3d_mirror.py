@@ -75,3 +75,19 @@ def test_box_coder_roundtrip():
     anchors = torch.rand(50, 7, generator=g) + 0.5
     boxes = torch.rand(50, 7, generator=g) + 0.5
     assert torch.allclose(bc.decode_torch(bc.encode_torch(boxes, anchors), anchors), boxes, atol=1e-5)
+
+
+def test_box_np_ops_helpers_match_reference_numpy(golden_dir):
+    """det3d.core.bbox.box_np_ops (mirror) vs the reference's own functions run from source (nms_helpers_ref.npz)."""
+    import os
+    import numpy as np
+    from det3d.core.bbox import box_np_ops
+    g = np.load(os.path.join(golden_dir, "nms_helpers_ref.npz"))
+    d = g["dets"]
+    c = box_np_ops.center_to_corner_box2d(d[:, :2], d[:, 2:4], d[:, 4])
+    assert c.shape == (64, 4, 2) and np.allclose(c, g["corners"], atol=2e-6, rtol=0)
+    su = box_np_ops.corner_to_standup_nd(c)
+    assert np.allclose(su, g["standup"], atol=2e-6, rtol=0)
+    iou = box_np_ops.iou_jit(g["standup"], g["standup"], eps=0.0)
+    assert np.allclose(iou, g["standup_iou"], atol=1e-6, rtol=1e-5)
+    assert np.array_equal(iou > 0, g["standup_iou"] > 0)
