@@ -215,6 +215,24 @@ def main():
                                         "algorithmic_bytes": sp_bytes, "sites_per_level": sites, "ms": st["spmiddle"],
                                         "note": "all 14 sparse layers + rulebooks of one batch, eager launches; at batch 1 "
                                                 "the stage is launch/latency-bound, see --stress for the meaningful case"}
+        # ---- informational: the same frames handed over as HOST numpy buffers and detections read back to the host, one
+        # frame at a time (H2D of P*16 B from pinned memory + graph replay + D2H of <= 100 boxes, synchronous per frame).
+        # Never part of `value` (inputs are resident in HBM inside the timed region).
+        if not args.eager and args.batch == 1:
+            pinned = [torch.from_numpy(f).pin_memory() for f in frames_np[:8]]
+            stage = torch.empty((args.points, 4), dtype=torch.float32, device=dev)
+            nio = 100
+            torch.cuda.synchronize()
+            h0 = time.perf_counter()
+            for i in range(nio):
+                src = pinned[i % len(pinned)]
+                dst = stage[:src.shape[0]]
+                dst.copy_(src, non_blocking=True)
+                eng.set_points([dst])
+                eng.replay()
+                eng.results()
+            out["host_io"] = {"frames_per_s": nio / (time.perf_counter() - h0), "what": "pinned host points -> H2D -> replay -> D2H "
+                              "detections, strictly sequential with a host sync per frame (latency mode, 1 frame in flight)"}
         # ---- CPU baseline: the oracle port of the reference path on the host cores of this box (bounded sample)
         if args.cpu_frames > 0 and world == 1:
             from oracle import pipeline, postprocess as pp
