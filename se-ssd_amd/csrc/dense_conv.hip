@@ -545,10 +545,12 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
 }
 
 // Up to four convolutions that share shapes but not weights / taps / output phase in ONE launch
-// (the four output-parity classes of the stride-2 transposed conv): blockIdx.z = batch*4 + class.
+// (the four output-parity classes of the stride-2 transposed conv): blockIdx.z = batch*4 + (3 - class). The classes
+// have 1, 2, 2, 4 taps, i.e. 1x, 2x, 2x, 4x the work per workgroup: the heaviest class is dispatched first so that
+// the tail of the launch is made of the light workgroups.
 template <int NTAPS, int CT, int PT, int WC, int WP>
 __global__ __launch_bounds__(256) void conv2d_mfma4_kernel(ConvArgs4 A4) {
-  conv_body<NTAPS, CT, PT, WC, WP>(A4.c[blockIdx.z & 3], blockIdx.z >> 2);
+  conv_body<NTAPS, CT, PT, WC, WP>(A4.c[3 - (blockIdx.z & 3)], blockIdx.z >> 2);
 }
 
 // SSFA tail (rpn_v1.py:227-233): w0 = BN(conv1x1(x0)), w1 = BN(conv1x1(x1)) (C -> 1 channel, no ReLU),
