@@ -99,25 +99,41 @@ __global__ __launch_bounds__(NT) void down_insert_unordered_kernel(const int* __
                                                                     int* __restrict__ n_out_dev, int* __restrict__ err_flag) {
   const int id = blockIdx.x * NT + threadIdx.x;
   const int n = min(n_dev[0], n_cap);
-  if (id >= n * KC) return;
-  int b, o[3];
-  if (!cand_coord<false>(indices, id, KC, G, b, o)) return;
-  const uint32_t key = lin_key(b, o[0], o[1], o[2], G.out_dims);
-  uint32_t slot = sessd_hash_u32(key) & mask;
-  while (true) {
-    const uint32_t prev = atomicCAS(&keys[slot], SESSD_HASH_EMPTY, key);
-    if (prev == SESSD_HASH_EMPTY) {  // this thread created the cell
-      const int row = atomicAdd(n_out_dev, 1);
-      if (row < n_out_cap) {
-        vals[slot] = row;
-        *reinterpret_cast<int4*>(out_indices + (size_t)row * 4) = make_int4(b, o[0], o[1], o[2]);
-      } else {
-        atomicOr(err_flag, 1);  // vals stays SESSD_SENT: reads as absent
+  int b = 0, o[3] = {0, 0, 0};
+  bool active = id < n * KC;
+  if (active) active = cand_coord<false>(indices, id, KC, G, b, o);
+  bool created = false;
+  uint32_t slot = 0;
+  if (active) {
+    const uint32_t key = lin_key(b, o[0], o[1], o[2], G.out_dims);
+    slot = sessd_hash_u32(key) & mask;
+    while (true) {
+      const uint32_t prev = atomicCAS(&keys[slot], SESSD_HASH_EMPTY, key);
+      if (prev == SESSD_HASH_EMPTY) {  // this thread created the cell
+        created = true;
+        break;
       }
-      return;
+      if (prev == key) break;
+      slot = (slot + 1) & mask;
     }
-    if (prev == key) return;
-    slot = (slot + 1) & mask;
+  }
+  // Row numbers for the cells this WAVE created with ONE atomic on the shared counter (a per-thread atomicAdd on one
+  // address serialises: 285 k creators of the dense-scene level cost 0.5 ms).
+  const unsigned long long made = __ballot(created);
+  if (made == 0ull) return;
+  const int lane = threadIdx.x & 63;
+  const int leader = __ffsll((long long)made) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(n_out_dev, __popcll(made));
+  base = __shfl(base, leader, 64);
+  if (created) {
+    const int row = base + __popcll(made & ((1ull << lane) - 1ull));
+    if (row < n_out_cap) {
+      vals[slot] = row;
+      *reinterpret_cast<int4*>(out_indices + (size_t)row * 4) = make_int4(b, o[0], o[1], o[2]);
+    } else {
+      atomicOr(err_flag, 1);  // vals stays SESSD_SENT: reads as absent
+    }
   }
 }
 
