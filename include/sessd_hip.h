@@ -164,6 +164,13 @@ int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win,
                        int wout, int ksize, int stride, float* grad_weight, void* workspace, size_t workspace_bytes,
                        sessd_stream_t stream);
 
+/* ---- ODIoU loss as one differentiable device op: det3d/models/losses/odious.py:837-900 (odiou_3D and
+ * the host-side numpy / scipy functions it composes, :15-643). gboxes (targets), qboxes (predictions) (n,7) float32
+ * [x,y,z,w,l,h,r] -> term (n,) = 1 - IoU3D + centre-distance / enclosing-diagonal + 1.25(1 - |cos dr|) and grad_q (n,7) =
+ * d term / d qboxes (float64 forward-mode differentiation inside the kernel). The reference's loss is
+ * 2 * sum(weights * term) / batch_size. */
+int sessd_odiou3d(const float* gboxes, const float* qboxes, int n, float* term, float* grad_q, sessd_stream_t stream);
+
 /* ------------------------------------------------------------------ dense BEV neck + heads (a9-a10)
  * replace the ATen/cuDNN conv2d, conv_transpose2d, batch_norm, relu, softmax calls made by
  * det3d/models/necks/rpn_v1.py:220-235 (SSFA.forward; RPN.forward :107-116 uses the same layers) and

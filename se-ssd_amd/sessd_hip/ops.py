@@ -408,6 +408,36 @@ _TILE_CFG_OVERRIDE = {}
 USE_WINOGRAD = True
 
 
+class OdiouFunction(torch.autograd.Function):
+    """ODIoU loss of odious.py:837-900 on the device: loss = 2 * sum(weights * term) / batch_size, differentiable with
+    respect to the predicted boxes (the kernel returns the per-pair gradient with the value)."""
+
+    @staticmethod
+    def forward(ctx, gboxes, qboxes, weights, batch_size):
+        g = gboxes.detach().float().contiguous()
+        q = qboxes.detach().float().contiguous()
+        _req(g, torch.float32, "gboxes")
+        n = q.shape[0]
+        term = torch.empty((n,), dtype=torch.float32, device=q.device)
+        grad = torch.empty((n, 7), dtype=torch.float32, device=q.device)
+        check(lib.sessd_odiou3d(g.data_ptr(), q.data_ptr(), n, term.data_ptr(), grad.data_ptr(), _stream()), "odiou3d")
+        w = weights.detach().float()
+        ctx.save_for_backward(grad, w)
+        ctx.scale = 2.0 / float(batch_size)
+        ctx.terms = term
+        return (term * w).sum() * ctx.scale
+
+    @staticmethod
+    def backward(ctx, gl):
+        grad, w = ctx.saved_tensors
+        return None, grad * (w * (ctx.scale * gl)).unsqueeze(1), None, None
+
+
+def odiou_3d_loss(gboxes, qboxes, weights, batch_size):
+    """Drop-in for `odiou_3D()(gboxes, qboxes, weights, batch_size)` (odious.py:845); boxes (N,7) [x,y,z,w,l,h,r]."""
+    return OdiouFunction.apply(gboxes, qboxes, weights, batch_size)
+
+
 def conv2d_wgrad(inp, grad_out, ksize, stride):
     """Weight gradient (Cout, Cin, k, k) of Conv2d(k, stride, padding k//2): inp (B,Cin,H,W), grad_out (B,Cout,Ho,Wo).
     For ConvTranspose2d(3, s2, p1, op1) pass (inp=its grad_out, grad_out=its input) and get its (Cin, Cout, 3, 3) gradient."""
