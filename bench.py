@@ -10,10 +10,15 @@ device (<= 100 boxes). Frames shard across ranks with no data-path collective (w
 frames); value = total frames / max-over-ranks wall time. By default TWO frames are in flight per GPU (two independent
 batch-1 engines on two HIP streams, `--streams 1` for strictly sequential frames): a batch-1 layer is 4.3 wave tiles per
 SIMD, so the tail of one frame's kernels overlaps the other's. One JSON line on rank 0, with
-  roofline      the dominant kernel (f32-MFMA 3x3 conv 128->128 @200x176, 5 launches per frame) against the dense
-                f32 MFMA peak, its duration measured live with HIP events on the launching stream
+  roofline      the dominant kernel (fused-Winograd f32-MFMA 3x3 conv 128->128 @200x176, 5 launches per frame + 2 of the
+                same FLOPs at 256->256 @100x88) against the dense f32 MFMA peak: ALGORITHMIC (direct-convolution) FLOPs
+                / launch time measured live with HIP events on the launching stream; `mfma_executed_*` = the 16/36 of
+                them Winograd actually multiplies; `traffic` = rocprofv3 FETCH_SIZE/WRITE_SIZE (profiles/)
+  roofline_spmiddle / stages_ms_eager   SURVEY 8(d)'s HBM figure for the sparse stage and per-stage times (informational)
+  host_io       PCIe-inclusive latency-mode rate (informational, never `value`)
   cpu_baseline  the CPU oracle pipeline (port of the reference path: the reference itself cannot run here) on a
                 bounded sample of the same frames, on this box's host cores.
+`--stress` = BASELINE configs[4] (200k points, 64k voxels, batch 8), `--batch B` = B frames per step.
 """
 import argparse
 import json
