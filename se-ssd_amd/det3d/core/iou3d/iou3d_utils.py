@@ -5,38 +5,64 @@ import iou3d_cuda
 
 
 def boxes3d_to_bev_torch(boxes3d, box_mode="wlh", rect=False):
-    """[x,y,z,w,l,h,r] -> [x1,y1,x2,y2,ry] (utils.py:74-101)."""
-    boxes_bev = boxes3d.new(torch.Size((boxes3d.shape[0], 5)))
-    if box_mode == "wlh":
-        cu, cv = boxes3d[:, 0], boxes3d[:, 1]
-        half_w, half_l = boxes3d[:, 3] / 2, boxes3d[:, 4] / 2
-    elif box_mode == "hwl":
-        cu, cv = boxes3d[:, 0], (boxes3d[:, 2] if rect else boxes3d[:, 1])
-        half_w, half_l = boxes3d[:, 4] / 2, boxes3d[:, 5] / 2
-    else:
+    """(N,7) [x,y,z,<box_mode>,ry] or (N,5) [x,y,<w,l order>,ry] -> [x1,y1,x2,y2,ry] (utils.py:74-101).
+    velodyne (rect=False): centre (x, y), half extents (w/2, l/2); camera (rect=True): centre (x, z), half extents (l/2, w/2)."""
+    cols = boxes3d.shape[-1]
+    if cols not in (5, 7):
         raise NotImplementedError
-    boxes_bev[:, 0], boxes_bev[:, 1] = cu - half_w, cv - half_l
-    boxes_bev[:, 2], boxes_bev[:, 3] = cu + half_w, cv + half_l
-    boxes_bev[:, 4] = boxes3d[:, 6]
-    return boxes_bev
+    first = 2 if cols == 5 else 3
+    half_w, half_l = boxes3d[:, box_mode.index("w") + first] / 2, boxes3d[:, box_mode.index("l") + first] / 2
+    cu = boxes3d[:, 0]
+    cv, eu, ev = (boxes3d[:, 2], half_l, half_w) if rect else (boxes3d[:, 1], half_w, half_l)
+    return torch.stack([cu - eu, cv - ev, cu + eu, cv + ev, boxes3d[:, -1]], dim=1)
 
 
 def boxes3d_to_bev_3d_torch(boxes3d, box_mode="wlh", rect=False):
-    """[x,y,z,w,l,h,r] -> [x1,y1,z1,x2,y2,z2,ry] with z +- h/2 (utils.py:104-126)."""
-    assert box_mode == "wlh"
-    out = boxes3d.new(torch.Size((boxes3d.shape[0], 7)))
-    out[:, 0], out[:, 1] = boxes3d[:, 0] - boxes3d[:, 3] / 2, boxes3d[:, 1] - boxes3d[:, 4] / 2
-    out[:, 2] = boxes3d[:, 2] - boxes3d[:, 5] / 2
-    out[:, 3], out[:, 4] = boxes3d[:, 0] + boxes3d[:, 3] / 2, boxes3d[:, 1] + boxes3d[:, 4] / 2
-    out[:, 5] = boxes3d[:, 2] + boxes3d[:, 5] / 2
-    out[:, 6] = boxes3d[:, 6]
+    """(N,7) -> [x1,y1,z1,x2,y2,z2,ry] (utils.py:104-126): velodyne z +- h/2; camera: (x, z) footprint with swapped half
+    extents and the height interval [y - h, y]."""
+    half_w, half_l = boxes3d[:, box_mode.index("w") + 3] / 2, boxes3d[:, box_mode.index("l") + 3] / 2
+    h = boxes3d[:, box_mode.index("h") + 3]
+    cu = boxes3d[:, 0]
+    if rect:
+        cv, cw = boxes3d[:, 2], boxes3d[:, 1]
+        lo, hi = [cu - half_l, cv - half_w, cw - h], [cu + half_l, cv + half_w, cw]
+    else:
+        cv, cw = boxes3d[:, 1], boxes3d[:, 2]
+        lo, hi = [cu - half_w, cv - half_l, cw - h / 2], [cu + half_w, cv + half_l, cw + h / 2]
+    return torch.stack(lo + hi + [boxes3d[:, 6]], dim=1)
+
+
+def rbbox2d_to_near_bbox_torch(in_boxes, box_mode="wlh", rect=False):
+    """Rotated box -> the nearest axis-aligned ('standing' or 'lying') box [x1,y1,x2,y2,0]: sizes swap when the yaw folded
+    into [-pi/2, pi/2) is more than 45 degrees off the axis (utils.py:46-72)."""
+    import math
+    if in_boxes.shape[-1] == 7:
+        wi, li = box_mode.index("w") + 3, box_mode.index("l") + 3
+        b = in_boxes[:, [0, 2 if rect else 1, wi, li, -1]]
+    else:
+        wi, li = box_mode.index("w") + 2, box_mode.index("l") + 2
+        b = in_boxes[:, [0, 1, wi, li, -1]]
+    rot = b[:, 4]
+    folded = torch.abs(rot - torch.floor(rot / math.pi + 0.5) * math.pi)  # limit_period(rot, 0.5, pi)
+    swap = (folded > math.pi / 4).unsqueeze(-1)
+    ctr = torch.where(swap, b[:, [0, 1, 3, 2]], b[:, :4])
+    out = torch.zeros((b.shape[0], 5), dtype=b.dtype, device=b.device)
+    out[:, :2] = ctr[:, :2] - ctr[:, 2:4] / 2
+    out[:, 2:4] = ctr[:, :2] + ctr[:, 2:4] / 2
     return out
 
 
-def boxes_iou_bev_gpu(boxes_a, boxes_b):
-    """(N,5),(M,5) [x1,y1,x2,y2,ry] -> (N,M)  (iou3d_utils.py:32-52)."""
+def boxes_iou_bev_gpu(boxes_a, boxes_b, box_mode="wlh", metric="rotate_iou", rect=False):
+    """(M,7),(N,7) [x,y,z,w,l,h,ry] -> BEV IoU (M,N)  (iou3d_utils.py:32-52). metric 'rotate_iou': rotated rectangles;
+    'nearest_iou': their nearest axis-aligned boxes through the same kernel (yaw 0)."""
+    if metric == "rotate_iou":
+        a_bev, b_bev = boxes3d_to_bev_torch(boxes_a, box_mode, rect), boxes3d_to_bev_torch(boxes_b, box_mode, rect)
+    elif metric == "nearest_iou":
+        a_bev, b_bev = rbbox2d_to_near_bbox_torch(boxes_a, box_mode, rect), rbbox2d_to_near_bbox_torch(boxes_b, box_mode, rect)
+    else:
+        raise NotImplementedError
     ans = torch.cuda.FloatTensor(torch.Size((boxes_a.shape[0], boxes_b.shape[0]))).zero_()
-    iou3d_cuda.boxes_iou_bev_gpu(boxes_a.contiguous(), boxes_b.contiguous(), ans)
+    iou3d_cuda.boxes_iou_bev_gpu(a_bev.contiguous(), b_bev.contiguous(), ans)
     return ans
 
 
