@@ -119,3 +119,16 @@ def test_loss_modules_match_reference_run(golden_dir):
     y.sum().backward()
     assert np.allclose(y.detach().numpy(), g["dir_out"], rtol=1e-5, atol=1e-7)
     assert np.allclose(d.grad.numpy(), g["dir_grad"], rtol=1e-5, atol=1e-7)
+
+
+def test_second_box_codec_matches_reference_run(golden_dir):
+    """box_torch_ops.second_box_decode / second_box_encode (mirror) vs decode_ref.npz (the reference's function run from source)."""
+    import os
+    import numpy as np
+    import torch
+    from det3d.core.bbox import box_torch_ops as B
+    g = np.load(os.path.join(golden_dir, "decode_ref.npz"))
+    dec = B.second_box_decode(torch.from_numpy(g["enc"]), torch.from_numpy(g["anchors"]))
+    assert np.allclose(dec.numpy(), g["dec"], rtol=1e-6, atol=1e-6)
+    enc = B.second_box_encode(dec, torch.from_numpy(g["anchors"]))
+    assert np.allclose(enc.numpy(), g["enc"], rtol=1e-5, atol=2e-6)
