@@ -43,6 +43,22 @@ def second_box_decode(box_encodings, anchors, encode_angle_to_vector=False, bin_
     return torch.cat([xg, yg, zg, wg, lg, hg, rg], dim=-1)
 
 
+def rotation_points_single_angle(points, angle, axis=0):
+    """points (N,3) @ R^T for one scalar angle about `axis` (box_torch_ops.py:320-345); axis 2: x' = x cos + y sin,
+    y' = -x sin + y cos."""
+    import math
+    s, c = math.sin(angle), math.cos(angle)
+    if axis == 1:
+        m = [[c, 0.0, -s], [0.0, 1.0, 0.0], [s, 0.0, c]]
+    elif axis in (2, -1):
+        m = [[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]]
+    elif axis == 0:
+        m = [[1.0, 0.0, 0.0], [0.0, c, -s], [0.0, s, c]]
+    else:
+        raise ValueError("axis should in range")
+    return points @ torch.tensor(m, dtype=points.dtype, device=points.device)
+
+
 def rotate_nms(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5):
     """rbboxes (K,5) [x,y,w,l,r], scores (K,) -> LongTensor of kept indices into the input (<= post_max_size)."""
     if rbboxes.shape[0] == 0:

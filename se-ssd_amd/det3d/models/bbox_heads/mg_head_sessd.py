@@ -1,7 +1,11 @@
 """mirrors det3d/models/bbox_heads/mg_head_sessd.py: Head (:195-230), MultiGroupHead ctor (:379-493),
-forward (:518-523), predict / get_task_detections (:893-1057) -- inference surface only."""
+forward (:518-523), predict / get_task_detections (:893-1057), and the training losses: loss (:706-808),
+get_model_ema_loss (:810-890), consistency_loss (:618-704), nn_distance (:573-607), prepare_loss_weights (:525-571) with the
+module-level helpers (:27-77). The geometric pieces of the loss run on the HIP kernels (ODIoU: sessd_odiou3d; IoU targets and
+teacher-student matching: the iou3d operators); the rest is elementwise torch on the same device."""
 import logging
 
+import numpy as np
 import torch
 from torch import nn
 
@@ -61,6 +65,36 @@ class Head(nn.Module):
         return ret
 
 
+def one_hot_f(tensor, depth, dim=-1, on_value=1.0, dtype=torch.float32):
+    out = torch.zeros(*tensor.shape, depth, dtype=dtype, device=tensor.device)
+    return out.scatter_(dim, tensor.unsqueeze(dim).long(), on_value)
+
+
+def add_sin_difference(boxes1, boxes2):
+    """sin(a - b) = sin a cos b - cos a sin b: replace the yaw of the prediction by sin(a)cos(b) and of the target by
+    cos(a)sin(b), so that their smooth-L1 difference is sin(a - b) (mg_head_sessd.py:39-44)."""
+    a, b = boxes1[..., -1:], boxes2[..., -1:]
+    return (torch.cat([boxes1[..., :-1], torch.sin(a) * torch.cos(b)], dim=-1),
+            torch.cat([boxes2[..., :-1], torch.cos(a) * torch.sin(b)], dim=-1))
+
+
+def get_direction_target(anchors, reg_targets, one_hot=True, dir_offset=0.0):
+    """Direction class = (target yaw + anchor yaw - offset) > 0 (mg_head_sessd.py:62-76)."""
+    B = reg_targets.shape[0]
+    rot_gt = reg_targets[..., -1] + anchors.view(B, -1, anchors.shape[-1])[..., -1]
+    t = ((rot_gt - dir_offset) > 0).long()
+    return one_hot_f(t, 2, dtype=anchors.dtype) if one_hot else t
+
+
+def _get_pos_neg_loss(cls_loss, labels):
+    """Sum of the classification loss over the positive / the negative anchors, per batch sample (mg_head_sessd.py:47-59)."""
+    B = cls_loss.shape[0]
+    if cls_loss.shape[-1] == 1 or cls_loss.dim() == 2:
+        flat = cls_loss.view(B, -1)
+        return ((labels > 0).type_as(flat) * flat).sum() / B, ((labels == 0).type_as(flat) * flat).sum() / B
+    return cls_loss[..., 1:].sum() / B, cls_loss[..., 0].sum() / B
+
+
 @HEADS.register_module
 class MultiGroupHead(nn.Module):
     def __init__(self, mode="3d", in_channels=[128, ], norm_cfg=None, tasks=[], weights=[], num_classes=[1, ],
@@ -114,6 +148,12 @@ class MultiGroupHead(nn.Module):
         # attributes so that the module can be built without a device
         self.post_center_range = [0, -40.0, -5.0, 70.4, 40.0, 5.0]
         self.thresh = 0.3
+        # training-only members (mg_head_sessd.py:430-431, 488-491); the geometric loss is the device op
+        sl1 = dict(type="WeightedSmoothL1Loss", sigma=3.0, code_weights=None, codewise=True, loss_weight=1.0)
+        self.loss_iou_pred = build_loss(dict(sl1))
+        self.loss_iou_consistency = build_loss(dict(sl1))
+        self.loss_score_consistency = build_loss(dict(sl1))
+        self.loss_dir_consistency = nn.MSELoss(reduction="mean")
 
     def init_weights(self, pretrained=None):
         for m in self.modules():
@@ -125,8 +165,147 @@ class MultiGroupHead(nn.Module):
     def forward(self, x):
         return [task(x) for task in self.tasks]
 
-    def loss(self, example, preds_dicts, preds_ema=None, **kwargs):
-        raise NotImplementedError("SE-SSD training step: SURVEY.md section 8f row 1 (not part of the inference hot path)")
+    # ------------------------------------------------------------------ training losses
+    def prepare_loss_weights(self, labels, loss_norm=None, dtype=torch.float32):
+        """labels (B,A) in {-1 ignore, 0 negative, >0 positive} -> cls_weights, reg_weights, cared (mg_head_sessd.py:525-571)."""
+        loss_norm = loss_norm or self.loss_norm
+        pos, neg, cared = labels > 0, labels == 0, labels >= 0
+        cls_w = neg.type(dtype) * loss_norm["neg_cls_weight"] + pos.type(dtype) * loss_norm["pos_cls_weight"]
+        reg_w = pos.type(dtype)
+        n_pos = torch.clamp(pos.sum(1, keepdim=True).type(dtype), min=1.0)
+        kind = loss_norm["type"]
+        if kind == "NormByNumPositives":
+            reg_w, cls_w = reg_w / n_pos, cls_w / n_pos
+        elif kind == "NormByNumExamples":
+            cls_w = cls_w / torch.clamp(cared.type(dtype).sum(1, keepdim=True), min=1.0)
+            reg_w = reg_w / n_pos
+        elif kind == "DontNorm":
+            reg_w = reg_w / n_pos
+        elif kind == "NormByNumPosNeg":
+            pn = torch.stack([pos, neg], dim=-1).type(dtype)
+            norm = pn.sum(1, keepdim=True)
+            cls_w = cls_w / torch.clamp((pn * norm).sum(-1), min=1.0)
+            reg_w = reg_w / torch.clamp(norm, min=1.0)[:, 0:1, 0]
+        else:
+            raise ValueError("unknown loss norm type %r" % (kind,))
+        return cls_w, reg_w, cared
+
+    def _supervised(self, preds, labels, reg_targets, anchors, with_odiou):
+        """The per-task supervised terms shared by loss() (:715-780) and get_model_ema_loss() (:815-868):
+        focal classification, (logged) smooth-L1 localisation on sin-encoded yaw, direction softmax on the positives, smooth-L1
+        regression of the predicted IoU towards 2*IoU3D(decoded prediction, decoded target) - 1, and (student only) ODIoU."""
+        from det3d.core.iou3d import iou3d_utils
+        B = anchors.shape[0]
+        cls_w, reg_w, cared = self.prepare_loss_weights(labels)
+        cls_targets = (labels * cared.type_as(labels)).unsqueeze(-1)
+        box = preds["box_preds"].view(B, -1, self.box_n_dim)
+        cls = preds["cls_preds"].view(B, -1, self.num_classes[0])
+        enc_p, enc_t = add_sin_difference(box, reg_targets) if self.encode_rad_error_by_sin else (box, reg_targets)
+        loc = self.loss_reg(enc_p, enc_t, weights=reg_w)
+        focal = self.loss_cls(cls, cls_targets, weights=cls_w)
+        out = dict(loc_loss_reduced=self.loss_reg._loss_weight * loc.sum() / B, cls_loss_reduced=self.loss_cls._loss_weight * focal.sum() / B,
+                   loc_loss_elem=[loc[:, :, i].sum() / B for i in range(loc.shape[-1])])
+        pos_l, neg_l = _get_pos_neg_loss(focal, labels)
+        out["cls_pos_loss"], out["cls_neg_loss"] = pos_l / self.loss_norm["pos_cls_weight"], neg_l / self.loss_norm["neg_cls_weight"]
+        dir_loss = box.new_zeros(())
+        if self.use_direction_classifier:
+            dir_targets = get_direction_target(anchors, reg_targets, dir_offset=self.direction_offset)
+            w = (labels > 0).type_as(box)
+            w = w / torch.clamp(w.sum(-1, keepdim=True), min=1.0)
+            dir_loss = self.loss_aux._loss_weight * self.loss_aux(preds["dir_cls_preds"].view(B, -1, 2), dir_targets, weights=w).sum() / B
+        out["dir_loss"] = dir_loss
+        pos = reg_w > 0
+        qboxes = self.box_coder.decode_torch(box[pos], anchors[pos])
+        gboxes = self.box_coder.decode_torch(reg_targets[pos], anchors[pos])
+        if int(pos.sum()) > 0:
+            iou_t = 2 * iou3d_utils.boxes_aligned_iou3d_gpu(qboxes.detach(), gboxes).detach() - 1
+        else:
+            iou_t = box.new_zeros((0, 1))
+        out["iou_pred_loss"] = self.loss_iou_pred(preds["iou_preds"].view(B, -1, 1)[pos], iou_t, reg_w[pos]).sum() / B
+        if with_odiou:
+            out["ious_loss"] = ops.odiou_3d_loss(gboxes, qboxes, reg_w[pos], B) if int(pos.sum()) > 0 else box.new_zeros(())
+        out["num_pos"], out["num_neg"] = (labels > 0)[0].sum(), (labels == 0)[0].sum()
+        return out
+
+    def nn_distance(self, box1, box2, iou_thres=0.7):
+        """Mutual matching of student (box1) and teacher (box2) boxes by BEV IoU > iou_thres (mg_head_sessd.py:573-607, return
+        mode '10'): smooth-L1 (yaw sin-encoded) between every kept student box and its best teacher box, averaged."""
+        from det3d.core.iou3d import iou3d_utils
+        iou = iou3d_utils.boxes_iou_bev_gpu(box1.detach().contiguous(), box2.detach().contiguous())
+        m1, m2 = iou.max(dim=1)[0] > iou_thres, iou.max(dim=0)[0] > iou_thres
+        iou = iou[m1][:, m2]
+        if iou.shape[0] == 0 or iou.shape[1] == 0:
+            return [None] * 5
+        idx1, idx2 = iou.max(dim=1)[1], iou.max(dim=0)[1]
+        enc_s, enc_t = add_sin_difference(box1[m1], box2[m2][idx1])
+        per_box = self.loss_reg(enc_s, enc_t).sum(-1) / 7.0
+        return per_box.sum() / per_box.shape[0], idx1, idx2, m1, m2
+
+    def consistency_loss(self, preds_stu, preds_tea, example):
+        """Teacher-student consistency (mg_head_sessd.py:618-704): per sample, boxes with sigmoid score >= 0.3 inside the
+        post-centre range; teacher boxes mapped into the student's frame with the recorded global augmentation (flip, rotation,
+        scale); box / score / IoU-prediction terms over the mutually matched pairs. (box + cls + iou) / batch_size."""
+        from det3d.core.bbox import box_torch_ops
+        B = preds_stu[0]["box_preds"].shape[0]
+        anchors0 = example["anchors"][0][0]   # :649-650: every sample is decoded with the anchors of sample 0
+        dev = anchors0.device
+        lo, hi = (torch.tensor(self.post_center_range[:3], device=dev), torch.tensor(self.post_center_range[3:], device=dev))
+        V = lambda d, k, c: d[0][k].view(B, -1, c)
+        box_l = cls_l = iou_l = torch.zeros((1,), dtype=torch.float32, device=dev)
+        for b in range(B):
+            trans = example["transformation"][b]
+            bs = self.box_coder.decode_torch(V(preds_stu, "box_preds", 7)[b], anchors0)
+            bt = self.box_coder.decode_torch(V(preds_tea, "box_preds", 7)[b], anchors0)
+            cs, ct = V(preds_stu, "cls_preds", 1)[b], V(preds_tea, "cls_preds", 1)[b]
+            ms = (bs[:, :3] >= lo).all(1) & (bs[:, :3] <= hi).all(1) & (torch.sigmoid(cs).squeeze(-1) >= 0.3)
+            mt = (bt[:, :3] >= lo).all(1) & (bt[:, :3] <= hi).all(1) & (torch.sigmoid(ct).squeeze(-1) >= 0.3)
+            if int(ms.sum()) == 0 or int(mt.sum()) == 0:
+                continue
+            top_s, top_t = bs[ms], bt[mt].clone()
+            if trans["flipped"]:
+                top_t[:, 1] = -top_t[:, 1]
+                top_t[:, -1] = -top_t[:, -1] + np.pi
+            top_t[:, :3] = box_torch_ops.rotation_points_single_angle(top_t[:, :3], trans["noise_rotation"], axis=2)
+            top_t[:, -1] += trans["noise_rotation"]
+            top_t[:, :-1] *= trans["noise_scale"]
+            box_c, idx1, idx2, m1, m2 = self.nn_distance(top_s, top_t)
+            if box_c is None:
+                continue
+            box_l = box_l + box_c
+            score_s, score_t = torch.sigmoid(cs[ms][m1]), torch.sigmoid(ct[mt][m2][idx1])
+            cls_l = cls_l + self.loss_score_consistency(score_s, score_t).mean()
+            iou_s = (V(preds_stu, "iou_preds", 1)[b][ms][m1] + 1) * 0.5
+            iou_t = (V(preds_tea, "iou_preds", 1)[b][mt][m2][idx1] + 1) * 0.5
+            iou_l = iou_l + self.loss_iou_consistency(iou_s, iou_t).mean()
+        return (box_l + cls_l + iou_l) / B
+
+    def get_model_ema_loss(self, example, preds_dicts):
+        """The teacher's own supervised terms on the un-augmented targets, for logging only (mg_head_sessd.py:810-890)."""
+        t = self._supervised(preds_dicts[0], example["labels_raw"][0], example["reg_targets_raw"][0], example["anchors_raw"][0], False)
+        loss = t["cls_loss_reduced"] + t["dir_loss"] + t["iou_pred_loss"]
+        d = lambda v: v.detach().cpu()
+        return {"loss_ema": [d(loss)], "cls_loss_reduced_ema": [d(t["cls_loss_reduced"]).mean()],
+                "loc_loss_reduced_ema": [d(t["loc_loss_reduced"]).mean()], "dir_loss_reduced_ema": [d(t["dir_loss"])],
+                "iou_pred_loss_ema": [d(t["iou_pred_loss"])], "loc_loss_elem_ema": [[d(e) for e in t["loc_loss_elem"]]],
+                "cls_pos_loss_ema": [d(t["cls_pos_loss"])], "cls_neg_loss_ema": [d(t["cls_neg_loss"])],
+                "num_pos_ema": [t["num_pos"]], "num_neg_ema": [t["num_neg"]]}
+
+    def loss(self, example, preds_dicts, preds_ema, **kwargs):
+        """MultiGroupHead.loss (mg_head_sessd.py:706-808) for the single-task car head: dict of one-element lists with
+        loss = focal + ODIoU + direction + IoU-prediction (the smooth-L1 localisation loss is computed for the log only),
+        consistency_loss to be weighted by the trainer (trainer_sessd.py:267), and the teacher's *_ema log terms."""
+        assert len(preds_dicts) == 1, "single-task head (config.py tasks = [Car])"
+        consistency = self.consistency_loss(preds_dicts, preds_ema, example)
+        ema = self.get_model_ema_loss(example, preds_ema)
+        t = self._supervised(preds_dicts[0], example["labels"][0], example["reg_targets"][0], example["anchors"][0], True)
+        d = lambda v: v.detach().cpu()
+        ret = {"loss": [t["cls_loss_reduced"] + t["ious_loss"] + t["dir_loss"] + t["iou_pred_loss"]],
+               "cls_loss_reduced": [d(t["cls_loss_reduced"]).mean()], "loc_loss_reduced": [d(t["loc_loss_reduced"]).mean()],
+               "dir_loss_reduced": [d(t["dir_loss"])], "iou_pred_loss": [d(t["iou_pred_loss"])], "consistency_loss": [consistency],
+               "loc_loss_elem": [[d(e) for e in t["loc_loss_elem"]]], "cls_pos_loss": [d(t["cls_pos_loss"])],
+               "cls_neg_loss": [d(t["cls_neg_loss"])], "ious_loss": [d(t["ious_loss"])], "num_pos": [t["num_pos"]], "num_neg": [t["num_neg"]]}
+        ret.update(ema)
+        return ret
 
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):

@@ -120,12 +120,23 @@ def allreduce_flat(flat_grad, group=None):
     return flat_grad
 
 
-class TrainStep:
-    """One SE-SSD iteration. `loss_fn(example, student_preds, teacher_preds, consistency_weight) -> scalar tensor`
-    stands for MultiGroupHead.loss (mg_head_sessd.py:780; not part of this slice). The teacher is a deep copy of the
-    student (both start from the same checkpoint, trainer_sessd.py:212-217) and is never back-propagated."""
+def consistency_rampup(epoch, max_epochs=60):
+    """trainer_sessd.py:306-312 sigmoid_rampup: exp(-5 (1 - min(epoch, 15)/15)^2); 1 when there are no epochs."""
+    if max_epochs == 0:
+        return 1.0
+    phase = 1.0 - min(max(float(epoch), 0.0), 15.0) / 15.0
+    return float(math.exp(-5.0 * phase * phase))
 
-    def __init__(self, student, loss_fn, total_steps, teacher=None, weight_decay=0.01, max_grad_norm=35.0,
+
+class TrainStep:
+    """One SE-SSD iteration in the order of trainer_sessd.py:250-275,340-357. With loss_fn=None the loss is the reference's:
+    teacher_preds = teacher(example, is_ema=[True, None]); losses = student(example, is_ema=[False, teacher_preds],
+    return_loss=True) (= MultiGroupHead.loss); loss = losses['loss'][0] + consistency_weight * losses['consistency_loss'][0][0].
+    A custom `loss_fn(example, student_preds, teacher_preds, consistency_weight) -> scalar` replaces it (tests / timing
+    without targets). The teacher is a deep copy of the student (both start from the same checkpoint,
+    trainer_sessd.py:212-217) and is never back-propagated."""
+
+    def __init__(self, student, loss_fn=None, total_steps=1000, teacher=None, weight_decay=0.01, max_grad_norm=35.0,
                  lr_max=3e-3, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
         self.student = student
         self.teacher = copy.deepcopy(student) if teacher is None else teacher
@@ -145,8 +156,12 @@ class TrainStep:
         with torch.no_grad():
             teacher_preds = self.teacher.forward_preds(example, raw="voxels_raw" in example)
         self.flat_s.zero_grad()
-        student_preds = self.student.forward_preds(example)
-        loss = self.loss_fn(example, student_preds, teacher_preds, consistency_weight)
+        if self.loss_fn is None:
+            losses = self.student(example, is_ema=[False, teacher_preds], return_loss=True)
+            loss = losses["loss"][0] + losses["consistency_loss"][0][0] * consistency_weight
+            self.last_losses = losses
+        else:
+            loss = self.loss_fn(example, self.student.forward_preds(example), teacher_preds, consistency_weight)
         loss.backward()
         allreduce_flat(self.flat_s.grad)
         self.opt.step(lr, mom, self.global_step)

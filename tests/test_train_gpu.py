@@ -123,3 +123,36 @@ def test_train_step_bookkeeping(dev):
     o = step.flat_s.offsets[0]
     p_first = step.flat_s.params[0]
     assert p_first.data_ptr() == step.flat_s.data.data_ptr() + 4 * o
+
+
+def test_train_step_with_the_reference_loss(dev):
+    """A complete iteration with MultiGroupHead.loss (focal + ODIoU + direction + IoU prediction + consistency) on synthetic
+    targets: finite, composed as trainer_sessd.py:267, gradients reach the first sparse layer, the update moves the weights."""
+    from oracle import postprocess as pp
+    model = configs.build_synthetic_detector(dev, seed=0)
+    step = strain.TrainStep(model, None, total_steps=10)
+    _, ex = _example(dev, (44, 45), 6000, 6000)
+    B, A = 2, 70400
+    anchors = torch.from_numpy(pp.create_anchors_3d_range().reshape(1, A, 7)).to(dev).repeat(B, 1, 1)
+    rng = np.random.RandomState(0)
+    labels = np.zeros((B, A), np.int64)
+    reg = np.zeros((B, A, 7), np.float32)
+    for b in range(B):
+        pos = rng.choice(A, 40, replace=False)
+        labels[b, pos] = 1
+        labels[b, rng.choice(A, 200, replace=False)] = -1
+        labels[b, pos] = 1
+        reg[b, pos] = rng.normal(0, 0.1, (40, 7))
+    ex.update(anchors=[anchors], anchors_raw=[anchors], labels=[torch.from_numpy(labels).to(dev)], reg_targets=[torch.from_numpy(reg).to(dev)],
+              labels_raw=[torch.from_numpy(labels).to(dev)], reg_targets_raw=[torch.from_numpy(reg).to(dev)], metadata=[{}] * B,
+              transformation=[dict(flipped=False, noise_rotation=0.0, noise_scale=1.0)] * B)
+    w0 = model.backbone.middle_conv[0].weight.detach().clone()
+    loss, lr, mom = step(ex, consistency_weight=strain.consistency_rampup(3))
+    L = step.last_losses
+    want = L["loss"][0] + strain.consistency_rampup(3) * L["consistency_loss"][0][0]
+    assert np.isfinite(float(loss)) and abs(float(loss) - float(want.detach())) < 1e-5 * abs(float(loss))
+    for k in ("cls_loss_reduced", "ious_loss", "dir_loss_reduced", "iou_pred_loss", "loss_ema"):
+        assert np.isfinite(float(L[k][0])), k
+    assert float(L["ious_loss"][0]) > 0 and int(L["num_pos"][0]) == 40
+    assert float(step.flat_s.grad.abs().sum()) > 0 and not torch.equal(model.backbone.middle_conv[0].weight.detach(), w0)
+    assert abs(strain.consistency_rampup(15) - 1.0) < 1e-12 and abs(strain.consistency_rampup(0) - np.exp(-5.0)) < 1e-12
