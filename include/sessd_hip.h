@@ -171,6 +171,17 @@ int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win,
  * 2 * sum(weights * term) / batch_size. */
 int sessd_odiou3d(const float* gboxes, const float* qboxes, int n, float* term, float* grad_q, sessd_stream_t stream);
 
+/* ---- anchor target assignment: det3d/datasets/pipelines/preprocess.py:236-358 (AssignTarget) ->
+ * det3d/core/anchor/target_assigner.py:68-136 -> det3d/core/anchor/target_ops_v3.py:11-137 (create_target_np) with the
+ * nearest-IoU similarity (region_similarity.py:85-98) and second_box_encode (box_np_ops.py:52-110). anchors (n,7), gt_boxes
+ * (m,7) [x,y,z,w,l,h,r], gt_classes (m,) or NULL (all 1), m <= 128. labels in {-1 ignore, 0 background, class};
+ * gt_id = assigned ground-truth index of the foreground anchors, -1 elsewhere. */
+size_t sessd_assign_targets_workspace_bytes(int num_anchors);
+int sessd_assign_targets(const float* anchors, int num_anchors, const float* gt_boxes, const int32_t* gt_classes, int num_gt,
+                         float matched_threshold, float unmatched_threshold, int32_t* labels, float* bbox_targets,
+                         float* bbox_outside_weights, int32_t* gt_id, void* workspace, size_t workspace_bytes,
+                         sessd_stream_t stream);
+
 /* ------------------------------------------------------------------ dense BEV neck + heads (a9-a10)
  * replace the ATen/cuDNN conv2d, conv_transpose2d, batch_norm, relu, softmax calls made by
  * det3d/models/necks/rpn_v1.py:220-235 (SSFA.forward; RPN.forward :107-116 uses the same layers) and

@@ -1,2 +1,2 @@
-from .preprocess import Voxelization  # noqa: F401
+from .preprocess import AssignTarget, Voxelization  # noqa: F401
 from .formating import Reformat  # noqa: F401

@@ -53,6 +53,8 @@ SIGNATURES = {
     "sessd_grad_clip_coef": (i32, [vp, sz, f32, vp, sz, vp, vp]),
     "sessd_conv2d_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
     "sessd_conv2d_wgrad": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i32, i32, i32, vp, vp, sz, vp]),
+    "sessd_assign_targets_workspace_bytes": (sz, [i32]),
+    "sessd_assign_targets": (i32, [vp, i32, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_odiou3d": (i32, [vp, vp, i32, vp, vp, vp]),
     "sessd_adam_ema_step": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
 }

@@ -408,6 +408,23 @@ _TILE_CFG_OVERRIDE = {}
 USE_WINOGRAD = True
 
 
+def assign_targets(anchors, gt_boxes, gt_classes=None, matched_threshold=0.6, unmatched_threshold=0.45):
+    """Anchor target assignment of create_target_np (target_ops_v3.py:11-137) on the device: anchors (N,7), gt_boxes (M,7).
+    Returns dict(labels (N,) int32, bbox_targets (N,7), bbox_outside_weights (N,), gt_id (N,) int32)."""
+    _req(anchors, torch.float32, "anchors")
+    n, m = anchors.shape[0], gt_boxes.shape[0]
+    dev = anchors.device
+    g = gt_boxes.to(device=dev, dtype=torch.float32).contiguous() if m else torch.zeros((1, 7), dtype=torch.float32, device=dev)
+    c = None if gt_classes is None or m == 0 else gt_classes.to(device=dev, dtype=torch.int32).contiguous()
+    out = dict(labels=torch.empty((n,), dtype=torch.int32, device=dev), bbox_targets=torch.empty((n, 7), dtype=torch.float32, device=dev),
+               bbox_outside_weights=torch.empty((n,), dtype=torch.float32, device=dev), gt_id=torch.empty((n,), dtype=torch.int32, device=dev))
+    ws = workspace(lib.sessd_assign_targets_workspace_bytes(n), dev, "assign")
+    check(lib.sessd_assign_targets(anchors.data_ptr(), n, g.data_ptr(), _p(c), m, float(matched_threshold), float(unmatched_threshold),
+                                   out["labels"].data_ptr(), out["bbox_targets"].data_ptr(), out["bbox_outside_weights"].data_ptr(),
+                                   out["gt_id"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "assign_targets")
+    return out
+
+
 class OdiouFunction(torch.autograd.Function):
     """ODIoU loss of odious.py:837-900 on the device: loss = 2 * sum(weights * term) / batch_size, differentiable with
     respect to the predicted boxes (the kernel returns the per-pair gradient with the value)."""

@@ -103,3 +103,18 @@ def test_numba_rotate_iou_oracle_vs_reference_source(golden_dir):
     # the eval kernel passes the QUERY box first (nms_gpu.py:626-631)
     ev = oracle.rotate_iou_eval(q[:5], q[5:9], 0)
     assert ev[2, 1] == np.float32(oracle.rotate_iou_pair(q[6], q[2], 0))
+
+
+def test_assign_target_oracle_vs_reference_run(golden_dir):
+    """oracle/assign_target.py vs the reference's create_target_np + NearestIouSimilarity + second_box_encode run from source."""
+    from oracle import assign_target as oat, postprocess as pp
+    g = np.load(os.path.join(golden_dir, "assign_ref.npz"))
+    anchors = pp.create_anchors_3d_range().reshape(-1, 7).astype(np.float32)
+    assert np.allclose(anchors.sum(0), g["anchors_checksum"], rtol=1e-6)
+    for c in "abcd":
+        r = oat.assign(anchors, g[c + "_gt"])
+        pos = np.nonzero(r["labels"] > 0)[0]
+        assert np.array_equal(r["labels"], g[c + "_labels"]) and np.array_equal(pos, g[c + "_pos"])
+        assert np.array_equal(r["positive_gt_id"], g[c + "_gt_id"])
+        if len(pos):
+            assert np.abs(r["bbox_targets"][pos] - g[c + "_targets_pos"]).max() < 1e-6
