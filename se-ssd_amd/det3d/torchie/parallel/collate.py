@@ -17,6 +17,14 @@ def collate_kitti(batch_list, samples_per_gpu=1):
         if key in ["voxels", "num_points", "num_gt", "voxel_labels", "num_voxels", "voxels_raw", "num_points_raw",
                    "num_gt_raw", "voxel_labels_raw", "num_voxels_raw"]:
             ret[key] = torch.tensor(np.concatenate(elems, axis=0))
+        elif key == "gt_boxes":  # per task: boxes of every sample zero-padded to the longest list of the batch
+            ret[key] = []
+            for task in range(len(elems[0])):
+                width = max(len(e[task]) for e in elems)
+                padded = np.zeros((len(elems), width, 7))
+                for b, e in enumerate(elems):
+                    padded[b, :len(e[task])] = e[task]
+                ret[key].append(padded)
         elif key == "metadata":
             ret[key] = elems
         elif key == "calib":
@@ -42,13 +50,16 @@ def collate_kitti(batch_list, samples_per_gpu=1):
 
 
 def example_to_device(example, device=None, non_blocking=False):
-    """mirrors det3d/torchie/apis/train_sessd.py:88-106."""
+    """mirrors det3d/torchie/apis/train_sessd.py:88-106 and the trainer's variant det3d/torchie/trainer/trainer_sessd.py:20-38,
+    which also moves the teacher's `*_raw` inputs and targets."""
     assert device is not None
     out = {}
     for k, v in example.items():
-        if k in ["anchors", "anchors_mask", "reg_targets", "reg_weights", "labels"]:
+        if k in ["anchors", "anchors_mask", "reg_targets", "reg_weights", "labels", "anchors_raw", "anchors_mask_raw",
+                 "reg_targets_raw", "reg_weights_raw", "labels_raw"]:
             out[k] = [res.to(device, non_blocking=non_blocking) for res in v]
-        elif k in ["voxels", "bev_map", "coordinates", "num_points", "points", "num_voxels"]:
+        elif k in ["voxels", "bev_map", "coordinates", "num_points", "points", "num_voxels", "voxels_raw", "coordinates_raw",
+                   "num_points_raw", "points_raw", "num_voxels_raw"]:
             out[k] = v.to(device, non_blocking=non_blocking)
         elif k == "calib":
             out[k] = {k1: torch.as_tensor(v1).to(device, non_blocking=non_blocking) for k1, v1 in v.items()}

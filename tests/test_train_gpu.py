@@ -156,3 +156,36 @@ def test_train_step_with_the_reference_loss(dev):
     assert float(L["ious_loss"][0]) > 0 and int(L["num_pos"][0]) == 40
     assert float(step.flat_s.grad.abs().sum()) > 0 and not torch.equal(model.backbone.middle_conv[0].weight.detach(), w0)
     assert abs(strain.consistency_rampup(15) - 1.0) < 1e-12 and abs(strain.consistency_rampup(0) - np.exp(-5.0)) < 1e-12
+
+
+def test_training_data_contract_to_an_iteration(dev):
+    """Voxelization -> AssignTarget -> Reformat -> collate_kitti -> example_to_device (the reference's train pipeline tail,
+    config.py:183-189 + trainer_sessd.py:20-38) on two synthetic labelled samples, then one TrainStep with the reference loss."""
+    from det3d.datasets.pipelines import AssignTarget, Reformat, Voxelization
+    from det3d.torchie.parallel import collate_kitti, example_to_device
+    from det3d.torchie.utils.config import ConfigDict
+    vox = Voxelization(cfg=ConfigDict(range=VG["range"], voxel_size=VG["voxel_size"], max_points_in_voxel=5, max_voxel_num=8000))
+    assign = AssignTarget(cfg=dict(target_assigner=dict(anchor_generators=[dict(
+        type="anchor_generator_range", sizes=[1.6, 3.9, 1.56], anchor_ranges=[0, -40.0, -1.0, 70.4, 40.0, -1.0], rotations=[0, 1.57],
+        matched_threshold=0.6, unmatched_threshold=0.45, class_name="Car")]), out_size_factor=8, enable_similar_type=True))
+    rng = np.random.RandomState(5)
+    examples = []
+    for i in range(2):
+        pts = synth.make_frame(60 + i, 7000)
+        gt = np.zeros((5, 7), np.float32)
+        gt[:, 0] = rng.uniform(8, 55, 5); gt[:, 1] = rng.uniform(-25, 25, 5); gt[:, 2] = -1.0
+        gt[:, 3:6] = [1.6, 3.9, 1.56]; gt[:, 6] = rng.uniform(-3, 3, 5)
+        ann = lambda: dict(gt_boxes=gt.copy(), gt_classes=np.ones(5, np.int32), gt_names=np.array(["Car"] * 5))
+        res = dict(mode="train", labeled=True, metadata=dict(token=str(i)),
+                   lidar=dict(points=pts, points_raw=pts.copy(), annotations=ann(), annotations_raw=ann(),
+                              transformation=dict(flipped=False, noise_rotation=0.0, noise_scale=1.0)))
+        for stage in (vox, assign, Reformat()):
+            res, _ = stage(res, None)
+        examples.append(res)
+    batch = example_to_device(collate_kitti(examples), dev)
+    assert batch["labels"][0].shape == (2, 70400) and batch["reg_targets_raw"][0].shape == (2, 70400, 7) and batch["anchors"][0].is_cuda
+    assert batch["voxels_raw"].is_cuda and int((batch["labels"][0] > 0).sum()) >= 10 and batch["transformation"][1]["noise_scale"] == 1.0
+    model = configs.build_synthetic_detector(dev, seed=0)
+    step = strain.TrainStep(model, None, total_steps=10)
+    loss, _, _ = step(batch, consistency_weight=1.0)
+    assert np.isfinite(float(loss)) and float(step.last_losses["ious_loss"][0]) > 0
