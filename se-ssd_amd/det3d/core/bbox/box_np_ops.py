@@ -53,3 +53,53 @@ def iou_jit(boxes, query_boxes, eps=1.0):
     inter = np.where(ok, iw * ih, 0).astype(b.dtype)
     ua = area_b[:, None] + area_q[None, :] - inter
     return np.where(ok, inter / np.where(ok, ua, 1), 0).astype(b.dtype)
+
+
+def limit_period(val, offset=0.5, period=2 * np.pi):
+    """val folded into [-offset*period, (1-offset)*period) (box_np_ops.py:619-620)."""
+    return val - np.floor(val / period + offset) * period
+
+
+def lidar_to_camera(points, r_rect, velo2cam):
+    """(…,3) lidar points -> rectified camera frame: [p, 1] (R0_rect Tr_velo_to_cam)^T (box_np_ops.py:945-965)."""
+    if points.shape[-1] == 3:
+        points = np.concatenate([points, np.ones(list(points.shape[:-1]) + [1])], axis=-1)
+    return (points @ (r_rect @ velo2cam).T)[..., :3]
+
+
+def box_lidar_to_camera(data, r_rect, velo2cam):
+    """[x,y,z,w,l,h,r] lidar -> [x',y',z',l,h,w,r] camera (box_np_ops.py:973-978)."""
+    xyz = lidar_to_camera(data[:, 0:3], r_rect, velo2cam)
+    return np.concatenate([xyz, data[:, 4:5], data[:, 5:6], data[:, 3:4], data[:, 6:7]], axis=1)
+
+
+def rotation_3d_in_axis(points, angles, axis=0):
+    """(N,P,3) points rotated per box about `axis` with the reference's (clockwise-positive) matrices (box_np_ops.py:369-405)."""
+    s, c = np.sin(angles), np.cos(angles)
+    one, zero = np.ones_like(c), np.zeros_like(c)
+    if axis == 1:
+        m = [[c, zero, -s], [zero, one, zero], [s, zero, c]]
+    elif axis in (2, -1):
+        m = [[c, -s, zero], [s, c, zero], [zero, zero, one]]
+    elif axis == 0:
+        m = [[zero, c, -s], [zero, s, c], [one, zero, zero]]
+    else:
+        raise ValueError("axis should in range")
+    return np.einsum("aij,jka->aik", points, np.stack(m))
+
+
+def center_to_corner_box3d(centers, dims, angles=None, origin=(0.5, 0.5, 0.5), axis=2):
+    """(N,3) centres, (N,3) sizes, yaw -> (N,8,3) corners; origin = where the centre sits inside the box
+    ([0.5, 1.0, 0.5] camera, [0.5, 0.5, 0] lidar), axis = rotation axis (1 camera, 2 lidar) (box_np_ops.py:467-503)."""
+    corners = corners_nd(dims, origin=origin)
+    if angles is not None:
+        corners = rotation_3d_in_axis(corners, angles, axis=axis)
+    return corners + np.asarray(centers).reshape(-1, 1, 3)
+
+
+def project_to_image(points_3d, proj_mat):
+    """(…,3) camera points -> pixels with the 4x4 P2: [p, 0] P^T, divided by depth (box_np_ops.py:928-934; the homogeneous
+    coordinate appended by the reference is 0, not 1: the translation column of P2 is ignored)."""
+    p4 = np.concatenate([points_3d, np.zeros(list(points_3d.shape[:-1]) + [1])], axis=-1)
+    uvw = p4 @ proj_mat.T
+    return uvw[..., :2] / uvw[..., 2:3]
