@@ -150,39 +150,99 @@ def print_str(value, *arg, sstream=None):
     return sstream.getvalue()
 
 
-def get_official_eval_result(gt_annos, dt_annos, current_classes, difficultys=[0, 1, 2], z_axis=1, z_center=1.0):
-    """{'result': the printed table, 'detail': {class: {'bbox@0.70': [easy, moderate, hard], 'bev@..', '3d@..', 'aos'}}} with
-    the official overlap thresholds and their relaxed variant (:467-569)."""
+def _class_ids(current_classes):
+    if not isinstance(current_classes, (list, tuple)):
+        current_classes = [current_classes]
+    return [CLASS_NAMES.index(c.lower()) if isinstance(c, str) else c for c in current_classes]
+
+
+def _has_alpha(dt_annos):
+    for anno in dt_annos:
+        if anno["alpha"].shape[0] != 0:
+            return bool(anno["alpha"][0] != -10)
+    return False
+
+
+def _official(gt_annos, dt_annos, current_classes, difficultys, z_axis, z_center, ap):
     strict = np.array([[0.7, 0.5, 0.5, 0.7, 0.7, 0.7, 0.7, 0.5, 0.5, 0.5, 0.5]] * 3)
     relaxed = np.array([[0.7, 0.5, 0.5, 0.7, 0.7, 0.7, 0.7, 0.5, 0.25, 0.25, 0.5],
                         [0.5, 0.25, 0.25, 0.5, 0.5, 0.5, 0.5, 0.25, 0.25, 0.25, 0.25],
                         [0.5, 0.25, 0.25, 0.5, 0.5, 0.5, 0.5, 0.25, 0.25, 0.25, 0.25]])
-    if not isinstance(current_classes, (list, tuple)):
-        current_classes = [current_classes]
-    classes = [CLASS_NAMES.index(c.lower()) if isinstance(c, str) else c for c in current_classes]
+    classes = _class_ids(current_classes)
     min_overlaps = np.stack([strict, relaxed], axis=0)[:, :, classes]
-    compute_aos = False
-    for anno in dt_annos:
-        if anno["alpha"].shape[0] != 0:
-            compute_aos = anno["alpha"][0] != -10
-            break
+    compute_aos = _has_alpha(dt_annos)
     metrics = do_eval_v3(gt_annos, dt_annos, classes, min_overlaps, compute_aos, difficultys, z_axis=z_axis, z_center=z_center)
     result, detail = "", {}
+    fmt = lambda v: ", ".join("%.2f" % x for x in v)
     for j, cls in enumerate(classes):
         name = CLASS_NAMES[cls]
         detail[name] = {}
         for i in range(min_overlaps.shape[0]):
-            ap = {k: get_mAP(metrics[k]["precision"][j, :, i]) for k in ("bbox", "bev", "3d")}
-            detail[name]["bbox@%.2f" % min_overlaps[i, 0, j]] = ap["bbox"].tolist()
-            detail[name]["bev@%.2f" % min_overlaps[i, 1, j]] = ap["bev"].tolist()
-            detail[name]["3d@%.2f" % min_overlaps[i, 2, j]] = ap["3d"].tolist()
+            val = {k: ap(metrics[k]["precision"][j, :, i]) for k in ("bbox", "bev", "3d")}
+            detail[name]["bbox@%.2f" % min_overlaps[i, 0, j]] = val["bbox"].tolist()
+            detail[name]["bev@%.2f" % min_overlaps[i, 1, j]] = val["bev"].tolist()
+            detail[name]["3d@%.2f" % min_overlaps[i, 2, j]] = val["3d"].tolist()
             result += print_str("%s AP(Average Precision)@%.2f, %.2f, %.2f:" % ((name,) + tuple(min_overlaps[i, :, j])))
-            fmt = lambda v: ", ".join("%.2f" % x for x in v)
-            result += print_str("bbox AP:" + fmt(ap["bbox"]))
-            result += print_str("bev  AP:" + fmt(ap["bev"]))
-            result += print_str("3d   AP:" + fmt(ap["3d"]))
+            result += print_str("bbox AP:" + fmt(val["bbox"]))
+            result += print_str("bev  AP:" + fmt(val["bev"]))
+            result += print_str("3d   AP:" + fmt(val["3d"]))
             if compute_aos:
-                a = get_mAP(metrics["bbox"]["orientation"][j, :, i])
+                a = ap(metrics["bbox"]["orientation"][j, :, i])
                 detail[name]["aos"] = a.tolist()
                 result += print_str("aos  AP:" + fmt(a))
+    return {"result": result, "detail": detail}
+
+
+def get_official_eval_result(gt_annos, dt_annos, current_classes, difficultys=[0, 1, 2], z_axis=1, z_center=1.0):
+    """{'result': the printed table, 'detail': {class: {'bbox@0.70': [easy, moderate, hard], 'bev@..', '3d@..', 'aos'}}} with
+    the official overlap thresholds and their relaxed variant, 11-point AP (:467-569)."""
+    return _official(gt_annos, dt_annos, current_classes, difficultys, z_axis, z_center, get_mAP)
+
+
+def get_official_eval_result_v2(gt_annos, dt_annos, current_classes, difficultys=[0, 1, 2], z_axis=1, z_center=1.0):
+    """The same table with the 40-point AP (R40) (:571-672)."""
+    return _official(gt_annos, dt_annos, current_classes, difficultys, z_axis, z_center, get_mAP_v2)
+
+
+def do_eval_v2(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos=False, difficultys=(0, 1, 2), z_axis=1, z_center=1.0):
+    """(mAP_bbox, mAP_bev, mAP_3d, mAP_aos), each [class, difficulty, overlap] (:343-392)."""
+    r = eval_class_v3(gt_annos, dt_annos, current_classes, difficultys, 0, min_overlaps, compute_aos, z_axis=z_axis, z_center=z_center)
+    bbox, aos = get_mAP(r["precision"]), (get_mAP(r["orientation"]) if compute_aos else None)
+    bev = get_mAP(eval_class_v3(gt_annos, dt_annos, current_classes, difficultys, 1, min_overlaps, z_axis=z_axis, z_center=z_center)["precision"])
+    d3 = get_mAP(eval_class_v3(gt_annos, dt_annos, current_classes, difficultys, 2, min_overlaps, z_axis=z_axis, z_center=z_center)["precision"])
+    return bbox, bev, d3, aos
+
+
+def do_coco_style_eval(gt_annos, dt_annos, current_classes, overlap_ranges, compute_aos, z_axis=1, z_center=1.0):
+    """AP averaged over 10 overlap thresholds per (metric, class): overlap_ranges [start/stop/num, metric, class] (:424-455)."""
+    min_overlaps = np.zeros([10, *overlap_ranges.shape[1:]])
+    for i in range(overlap_ranges.shape[1]):
+        for j in range(overlap_ranges.shape[2]):
+            start, stop, num = overlap_ranges[:, i, j]
+            min_overlaps[:, i, j] = np.linspace(start, stop, int(num))
+    bbox, bev, d3, aos = do_eval_v2(gt_annos, dt_annos, current_classes, min_overlaps, compute_aos, z_axis=z_axis, z_center=z_center)
+    return bbox.mean(-1), bev.mean(-1), d3.mean(-1), (None if aos is None else aos.mean(-1))
+
+
+def get_coco_eval_result(gt_annos, dt_annos, current_classes, z_axis=1, z_center=1.0):
+    """COCO-style AP over overlap 0.50:0.05:0.95 (vehicles) / 0.25:0.05:0.70 (small classes) (:675-790)."""
+    wide = {0, 3, 4, 5, 6}
+    classes = _class_ids(current_classes)
+    ranges = np.zeros([3, 3, len(classes)])
+    for i, c in enumerate(classes):
+        ranges[:, :, i] = np.array([0.5, 0.95, 10] if c in wide else [0.25, 0.7, 10])[:, np.newaxis]
+    compute_aos = _has_alpha(dt_annos)
+    bbox, bev, d3, aos = do_coco_style_eval(gt_annos, dt_annos, classes, ranges, compute_aos, z_axis=z_axis, z_center=z_center)
+    result, detail = "", {}
+    for j, c in enumerate(classes):
+        name = CLASS_NAMES[c]
+        start, stop, num = ([0.5, 0.95, 10] if c in wide else [0.25, 0.7, 10])
+        result += print_str("%s coco AP@%.2f:%.2f:%.2f:" % (name, start, (stop - start) / (num - 1), stop))
+        result += print_str("bbox AP:%.2f, %.2f, %.2f" % tuple(bbox[j]))
+        result += print_str("bev  AP:%.2f, %.2f, %.2f" % tuple(bev[j]))
+        result += print_str("3d   AP:%.2f, %.2f, %.2f" % tuple(d3[j]))
+        detail[name] = {"bbox": bbox[j].tolist(), "bev": bev[j].tolist(), "3d": d3[j].tolist()}
+        if compute_aos:
+            detail[name]["aos"] = aos[j].tolist()
+            result += print_str("aos  AP:%.2f, %.2f, %.2f" % tuple(aos[j]))
     return {"result": result, "detail": detail}

@@ -5,7 +5,7 @@ are handed in."""
 import numpy as np
 
 from det3d.core.bbox import box_np_ops
-from det3d.datasets.kitti.eval import get_official_eval_result
+from det3d.datasets.kitti.eval import get_coco_eval_result, get_official_eval_result, get_official_eval_result_v2
 
 _KEYS = ("name", "truncated", "occluded", "alpha", "bbox", "dimensions", "location", "rotation_y", "score")
 
@@ -21,7 +21,8 @@ def convert_detection_to_kitti_annos(detection, kitti_infos, class_names, partia
     kitti_infos: list of dict(image=dict(image_idx, image_shape (h, w)), calib=dict(R0_rect, Tr_velo_to_cam, P2)).
     One annotation dict per info (per detection key with partial=True). Boxes whose projection lies outside the image are dropped,
     the rest clipped to it; alpha = -atan2(-y, x) + ry; yaw folded into [-pi, pi); z moved from the centre to the bottom face."""
-    to_np = lambda v: v.detach().cpu().numpy() if hasattr(v, "detach") else np.asarray(v)
+    # copies: the yaw fold / bottom-face shift below must not write through to the caller's detections
+    to_np = lambda v: v.detach().cpu().numpy().copy() if hasattr(v, "detach") else np.array(v)
     gt_ids = [str(info["image"]["image_idx"]) for info in kitti_infos]
     annos = []
     for key in (list(detection.keys()) if partial else gt_ids):
@@ -80,6 +81,10 @@ class KittiDataset(object):
         dt_annos = self.convert_detection_to_kitti_annos(detections)
         results = None
         if get_results:
-            official = get_official_eval_result(self.ground_truth_annotations, dt_annos, self._class_names, z_axis=1, z_center=1.0)
-            results = {"results": {"official_AP_11": official["result"]}, "detail": {"eval.kitti": {"official": official["detail"]}}}
+            gt = self.ground_truth_annotations
+            official = get_official_eval_result(gt, dt_annos, self._class_names, z_axis=1, z_center=1.0)
+            coco = get_coco_eval_result(gt, dt_annos, self._class_names, z_axis=1, z_center=1.0)
+            r40 = get_official_eval_result_v2(gt, dt_annos, self._class_names, z_axis=1, z_center=1.0)
+            results = {"results": {"official_AP_11": official["result"]}, "results_2": {"official_AP_40": r40["result"]},
+                       "detail": {"eval.kitti": {"official": official["detail"], "coco": coco["detail"]}}}
         return results, dt_annos

@@ -81,6 +81,15 @@ def main():
     for cls, d in res["detail"].items():
         for k, v in d.items():
             out["%s|%s" % (cls, k)] = np.array(v, np.float64)
+    r40 = ev.get_official_eval_result_v2(gts, dts, ["Car", "Pedestrian"])
+    for cls, d in r40["detail"].items():
+        for k, v in d.items():
+            out["r40|%s|%s" % (cls, k)] = np.array(v, np.float64)
+    coco = ev.get_coco_eval_result(gts, dts, ["Car", "Pedestrian"])
+    for cls, d in coco["detail"].items():
+        for k, v in d.items():
+            out["coco|%s|%s" % (cls, k)] = np.array(v, np.float64)
+    out["coco_text"] = np.array(coco["result"])
     # the raw precision / threshold arrays of one metric for a finer comparison
     min_overlaps = np.array([[[0.7, 0.5], [0.7, 0.5], [0.7, 0.5]], [[0.7, 0.5], [0.5, 0.25], [0.5, 0.25]]])
     for metric in (0, 1, 2):

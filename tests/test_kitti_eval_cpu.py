@@ -31,7 +31,16 @@ def test_official_result_matches_reference_run(golden_dir, monkeypatch):
         for k, v in d.items():
             assert np.allclose(np.array(v), g["%s|%s" % (cls, k)], rtol=0, atol=1e-9), (cls, k, v, g["%s|%s" % (cls, k)])
             seen += 1
-    assert seen == len([k for k in g.files if "|" in k]) and "car AP(Average Precision)@0.70, 0.70, 0.70:" in res["result"]
+    assert seen == len([k for k in g.files if k.count("|") == 1]) and "car AP(Average Precision)@0.70, 0.70, 0.70:" in res["result"]
+    r40 = K.get_official_eval_result_v2(gts, dts, ["Car", "Pedestrian"])
+    for cls, d in r40["detail"].items():
+        for k, v in d.items():
+            assert np.allclose(np.array(v), g["r40|%s|%s" % (cls, k)], rtol=0, atol=1e-9), (cls, k)
+    coco = K.get_coco_eval_result(gts, dts, ["Car", "Pedestrian"])
+    for cls, d in coco["detail"].items():
+        for k, v in d.items():
+            assert np.allclose(np.array(v), g["coco|%s|%s" % (cls, k)], rtol=0, atol=1e-9), (cls, k)
+    assert coco["result"] == str(g["coco_text"])
     min_overlaps = np.array([[[0.7, 0.5], [0.7, 0.5], [0.7, 0.5]], [[0.7, 0.5], [0.5, 0.25], [0.5, 0.25]]])
     for metric in (0, 1, 2):
         r = K.eval_class_v3(gts, dts, [0, 1], [0, 1, 2], metric, min_overlaps, compute_aos=(metric == 0))
@@ -72,3 +81,35 @@ def test_detection_to_kitti_annos_matches_reference_run(golden_dir):
         assert list(a["name"]) == list(g["%d_name" % i]) and a["metadata"] == dict(token="%06d" % (i * 7))
         for k in ("truncated", "occluded", "alpha", "bbox", "dimensions", "location", "rotation_y", "score"):
             assert np.allclose(np.asarray(a[k], np.float64), g["%d_%s" % (i, k)], rtol=1e-12, atol=1e-12), (i, k)
+
+
+def test_dataset_evaluation_surface(monkeypatch):
+    """KittiDataset.evaluation (reference kitti.py:141-166): conversion + the three result tables; detections scored against
+    annotations derived from themselves (nudged by centimetres) have precision 1 wherever recall is sampled."""
+    import det3d.datasets.utils.eval as U
+    monkeypatch.setattr(U, "rotate_iou_gpu_eval", _oracle_rotate_iou)
+    from make_golden_kitti_convert import make_case
+    from det3d.datasets.kitti import eval as K
+    from det3d.datasets.kitti.kitti import KittiDataset
+    infos, dets = make_case()
+    for info, a in zip(infos, KittiDataset(infos, ["Car"]).convert_detection_to_kitti_annos(dets)):
+        gt = {k: np.array(v, copy=True) for k, v in a.items() if k not in ("metadata", "score")}
+        gt["bbox"] = gt["bbox"].reshape(-1, 4).copy()
+        if gt["bbox"].shape[0]:
+            gt["location"] = gt["location"] + np.array([0.03, 0.0, 0.02])   # identical rotated boxes are ill-conditioned
+        info["annos"] = gt
+    ds = KittiDataset(infos, ["Car"])
+    results, dt_annos = ds.evaluation(dets)
+    assert len(dt_annos) == len(ds) == 4
+    assert set(results) == {"results", "results_2", "detail"} and set(results["detail"]["eval.kitti"]) == {"official", "coco"}
+    assert "car AP(Average Precision)@0.70, 0.70, 0.70:" in results["results"]["official_AP_11"]
+    assert "car AP(Average Precision)@0.70, 0.70, 0.70:" in results["results_2"]["official_AP_40"]
+    # a dozen objects give a dozen recall samples of the 41 (one threshold per matched detection, eval.py get_thresholds):
+    # every reached sample has precision 1, i.e. AP = reached samples / 11 -- the same on every metric
+    car = results["detail"]["eval.kitti"]["official"]["car"]
+    assert car["bev@0.70"] == car["3d@0.70"] == car["bbox@0.70"] and min(car["bev@0.70"]) > 0
+    assert all(abs(v * 11 / 100 - round(v * 11 / 100)) < 1e-9 for v in car["bev@0.70"])
+    direct = K.get_official_eval_result(ds.ground_truth_annotations, dt_annos, ["Car"])
+    assert direct["detail"] == results["detail"]["eval.kitti"]["official"] and direct["result"] == results["results"]["official_AP_11"]
+    assert min(results["detail"]["eval.kitti"]["coco"]["car"]["bev"]) > 0
+    assert ds.evaluation(dets, get_results=False)[0] is None
