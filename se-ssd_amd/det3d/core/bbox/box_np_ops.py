@@ -103,3 +103,84 @@ def project_to_image(points_3d, proj_mat):
     p4 = np.concatenate([points_3d, np.zeros(list(points_3d.shape[:-1]) + [1])], axis=-1)
     uvw = p4 @ proj_mat.T
     return uvw[..., :2] / uvw[..., 2:3]
+
+
+# ---- helpers of the training data path ---------------------------------------------------------------------
+_FACE_CORNERS = np.array([0, 1, 2, 3, 7, 6, 5, 4, 0, 3, 7, 4, 1, 5, 6, 2, 0, 4, 5, 1, 3, 2, 6, 7]).reshape(6, 4)
+
+
+def corner_to_surfaces_3d(corners):
+    """(N, 8, 3) box corners of center_to_corner_box3d -> (N, 6, 4, 3) faces whose normals point inwards
+    (box_np_ops.py:1160-1189 and its jit twin :1192-1212)."""
+    return corners[:, _FACE_CORNERS]
+
+
+corner_to_surfaces_3d_jit = corner_to_surfaces_3d
+
+
+def points_in_rbbox(points, rbbox, z_axis=2, origin=(0.5, 0.5, 0.5)):
+    """(P, >=3) points, (N, 7) [x,y,z,w,l,h,r] boxes -> (P, N) bool membership (box_np_ops.py:1152-1157)."""
+    from det3d.core.bbox.geometry import points_in_convex_polygon_3d_jit
+    corners = center_to_corner_box3d(rbbox[:, :3], rbbox[:, 3:6], rbbox[:, -1], origin=origin, axis=z_axis)
+    return points_in_convex_polygon_3d_jit(points[:, :3], corner_to_surfaces_3d(corners))
+
+
+def points_count_rbbox(points, rbbox, z_axis=2, origin=(0.5, 0.5, 0.5)):
+    """points per box (box_np_ops.py:12-17)."""
+    return points_in_rbbox(points, rbbox, z_axis, origin).sum(axis=0)
+
+
+def box2d_to_corner_jit(boxes):
+    """(N, 5) [x, y, w, l, r] -> (N, 4, 2) BEV corners, order (-,-), (-,+), (+,+), (+,-) in box axes, rotated with
+    x' = x cos r + y sin r, y' = -x sin r + y cos r (box_np_ops.py:535-566)."""
+    unit = np.array([[-0.5, -0.5], [-0.5, 0.5], [0.5, 0.5], [0.5, -0.5]], dtype=boxes.dtype)
+    local = boxes[:, None, 2:4] * unit[None]
+    s, c = np.sin(boxes[:, -1])[:, None], np.cos(boxes[:, -1])[:, None]
+    out = np.empty_like(local)
+    out[..., 0] = local[..., 0] * c + local[..., 1] * s
+    out[..., 1] = local[..., 0] * -s + local[..., 1] * c
+    return out + boxes[:, None, :2]
+
+
+def corner_to_standup_nd_jit(boxes_corner):
+    """(N, P, ndim) -> (N, 2 ndim) [mins, maxs] (box_np_ops.py:319-329)."""
+    return np.concatenate([boxes_corner.min(axis=1), boxes_corner.max(axis=1)], axis=-1)
+
+
+def minmax_to_corner_2d(minmax_box):
+    """(..., 4) [x0, y0, x1, y1] -> corners (box_np_ops.py:581-585)."""
+    nd = minmax_box.shape[-1] // 2
+    lo = minmax_box[..., :nd]
+    return center_to_corner_box2d(lo, minmax_box[..., nd:] - lo, origin=0.0)
+
+
+def rotation_points_single_angle(points, angle, axis=0):
+    """(N, 3) points times the reference's transposed rotation matrix of one angle (box_np_ops.py:408-430)."""
+    s, c = np.sin(angle), np.cos(angle)
+    if axis == 1:
+        m = [[c, 0, -s], [0, 1, 0], [s, 0, c]]
+    elif axis in (2, -1):
+        m = [[c, -s, 0], [s, c, 0], [0, 0, 1]]
+    elif axis == 0:
+        m = [[1, 0, 0], [0, c, -s], [0, s, c]]
+    else:
+        raise ValueError("axis should in range")
+    return points @ np.array(m, dtype=points.dtype)
+
+
+def camera_to_lidar(points, r_rect, velo2cam):
+    """(…,3) rectified-camera points -> lidar frame (box_np_ops.py:937-942)."""
+    if points.shape[-1] == 3:
+        points = np.concatenate([points, np.ones(list(points.shape[:-1]) + [1])], axis=-1)
+    return (points @ np.linalg.inv((r_rect @ velo2cam).T))[..., :3]
+
+
+def box_camera_to_lidar(data, r_rect, velo2cam):
+    """[x,y,z,l,h,w,r] camera -> [x',y',z',w,l,h,r] lidar (box_np_ops.py:965-970)."""
+    xyz = camera_to_lidar(data[:, 0:3], r_rect, velo2cam)
+    return np.concatenate([xyz, data[:, 5:6], data[:, 3:4], data[:, 4:5], data[:, 6:7]], axis=1)
+
+
+def change_box3d_center_(box3d, src, dst):
+    """in place: move the reference point of the boxes from `src` to `dst` (fractions of the box size) (box_np_ops.py:1406-1409)."""
+    box3d[..., :3] += box3d[..., 3:6] * (np.array(dst, dtype=box3d.dtype) - np.array(src, dtype=box3d.dtype))

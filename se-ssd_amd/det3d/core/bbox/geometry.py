@@ -1,0 +1,42 @@
+"""Point-in-convex-body tests of det3d/core/bbox/geometry.py that the data pipeline uses (GT-AUG point removal, per-object noise,
+shape-aware augmentation, ground-truth range filter). The reference runs them as numba loops with early exits; here each is one
+broadcast over (points, bodies, faces) with the same elementwise arithmetic, so the masks are identical.
+Pinned by tests/golden/datapath_ref.npz (the reference functions run from source)."""
+import numpy as np
+
+
+def surface_equ_3d_jitv2(surfaces):
+    """(B, F, >=3, 3) face vertices -> inward-pointing normals (B, F, 3) and offsets d (B, F) of n.x + d = 0
+    (geometry.py:352-377): n = (v0 - v1) x (v1 - v2), d = -v0 . n."""
+    e0 = surfaces[:, :, 0] - surfaces[:, :, 1]
+    e1 = surfaces[:, :, 1] - surfaces[:, :, 2]
+    n = np.empty(surfaces.shape[:2] + (3,), dtype=surfaces.dtype)
+    n[..., 0] = e0[..., 1] * e1[..., 2] - e0[..., 2] * e1[..., 1]
+    n[..., 1] = e0[..., 2] * e1[..., 0] - e0[..., 0] * e1[..., 2]
+    n[..., 2] = e0[..., 0] * e1[..., 1] - e0[..., 1] * e1[..., 0]
+    v0 = surfaces[:, :, 0]
+    d = -v0[..., 0] * n[..., 0] - v0[..., 1] * n[..., 1] - v0[..., 2] * n[..., 2]
+    return n, d
+
+
+def points_in_convex_polygon_3d_jit(points, polygon_surfaces, num_surfaces=None):
+    """(P, 3) points, (B, F, V, 3) faces with inward normals -> (P, B) bool: strictly inside every face, n.p + d < 0
+    (geometry.py:215-276). `num_surfaces` (faces actually used per body) cuts the face list like the reference's loop bound."""
+    n, d = surface_equ_3d_jitv2(polygon_surfaces[:, :, :3, :])
+    p = points
+    sign = (p[:, None, None, 0] * n[None, :, :, 0] + p[:, None, None, 1] * n[None, :, :, 1]
+            + p[:, None, None, 2] * n[None, :, :, 2] + d[None])
+    outside = sign >= 0
+    if num_surfaces is not None:   # face k is looked at while k <= num_surfaces[body]
+        used = np.arange(polygon_surfaces.shape[1])[None, :] <= np.asarray(num_surfaces)[:, None]
+        outside = outside & used[None]
+    return ~outside.any(axis=2)
+
+
+def points_in_convex_polygon_jit(points, polygon, clockwise=True):
+    """(P, 2) points, (B, V, 2) convex polygons -> (P, B) bool: strictly on the inner side of every edge (geometry.py:279-325)."""
+    prev = np.roll(polygon, 1, axis=1)
+    vec = polygon - prev if clockwise else prev - polygon
+    cross = (vec[None, :, :, 1] * (polygon[None, :, :, 0] - points[:, None, None, 0])
+             - vec[None, :, :, 0] * (polygon[None, :, :, 1] - points[:, None, None, 1]))
+    return ~(cross >= 0).any(axis=2)

@@ -1,2 +1,3 @@
-from .preprocess import AssignTarget, Voxelization  # noqa: F401
+from .preprocess import AssignTarget, Preprocess, Voxelization  # noqa: F401
 from .formating import Reformat  # noqa: F401
+from .loading import LoadPointCloudAnnotations, LoadPointCloudFromFile  # noqa: F401

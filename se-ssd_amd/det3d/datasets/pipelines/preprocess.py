@@ -1,8 +1,7 @@
-"""mirrors det3d/datasets/pipelines/preprocess.py:178-232 (Voxelization): the pipeline stage that feeds the hot path.
-Same result dict (`res["lidar"]["voxels"]` = voxels / coordinates / num_points / num_voxels / shape, plus the `*_raw`
-twin when `points_raw` is present), voxelized on the MI355X through VoxelGenerator.generate -> sessd_voxelize_frame.
-The training-only ground-truth range filter of the reference (:200-206) belongs to data augmentation and is applied
-only if the caller provides `filter_gt_box_outside_range` (out of scope here)."""
+"""mirrors det3d/datasets/pipelines/preprocess.py: Preprocess (:30-175, the augmentation stage), Voxelization (:178-232, the
+stage that feeds the hot path) and AssignTarget (:236-358).
+Voxelization: same result dict (`res["lidar"]["voxels"]` = voxels / coordinates / num_points / num_voxels / shape, plus the
+`*_raw` twin when `points_raw` is present), voxelized on the MI355X through VoxelGenerator.generate -> sessd_voxelize_frame."""
 import numpy as np
 
 from det3d.core.input.voxel_generator import VoxelGenerator
@@ -12,6 +11,105 @@ from ..registry import PIPELINES
 
 def _get(cfg, key, default=None):
     return cfg[key] if key in cfg else default
+
+
+def _dict_select(dict_, inds):
+    """in place: every array of the (nested) dict indexed by inds / a mask (:19-27)."""
+    for k, v in dict_.items():
+        if isinstance(v, dict):
+            _dict_select(v, inds)
+        else:
+            dict_[k] = v[inds]
+
+
+@PIPELINES.register_module
+class Preprocess(object):
+    """The augmentation stage of the training pipeline and its pass-through validation mode (:30-175), host side as in the
+    reference. Labeled training frames: drop DontCare, paste database objects (GT-AUG) and remove the scene points they
+    cover, per-object noise, snapshot (`points_raw`, `annotations_raw`: the teacher's view), then global flip / rotation /
+    scaling recorded in `transformation` (what MultiGroupHead.consistency_loss undoes), shape-aware augmentation, point shuffle.
+    Unlabeled training frames only get the global transformation. Options the SE-SSD configuration leaves off
+    (remove_environment, remove_unknown, min_points_in_gt, rgb, reference detections, random_crop, npoints) are not mirrored."""
+
+    def __init__(self, cfg=None, db_sampler=None, **kwargs):
+        self.shuffle_points = cfg["shuffle_points"]
+        self.mode = cfg["mode"]
+        for key in ("remove_environment", "remove_unknown_examples", "add_rgb_to_points", "reference_detections",
+                    "remove_outside_points", "random_crop", "random_select", "symmetry_intensity"):
+            if _get(cfg, key, False):
+                raise NotImplementedError("Preprocess option %s is off in the SE-SSD configuration and not mirrored" % key)
+        if self.mode == "train":
+            self.gt_loc_noise_std = cfg["gt_loc_noise"]
+            self.gt_rotation_noise = cfg["gt_rot_noise"]
+            self.global_rotation_noise = cfg["global_rot_noise"]
+            self.global_scaling_noise = cfg["global_scale_noise"]
+            self.global_random_rot_range = cfg["global_rot_per_obj_range"]
+            self.remove_points_after_sample = cfg["remove_points_after_sample"]
+            self.class_names = cfg["class_names"]
+            self.enable_similar_type = _get(cfg, "enable_similar_type", False)
+            if self.enable_similar_type and "Car" in self.class_names and "Van" not in self.class_names:
+                self.class_names.append("Van")   # the reference appends to the config's own list (:54-55)
+            if db_sampler is not None:
+                self.db_sampler = db_sampler
+            elif _get(cfg, "db_sampler", None):
+                from det3d.builder import build_dbsampler
+                self.db_sampler = build_dbsampler(cfg["db_sampler"])
+            else:
+                self.db_sampler = None
+            self.data_aug_with_context = _get(cfg, "data_aug_with_context", -1)
+            self.data_aug_random_drop = _get(cfg, "data_aug_random_drop", -1)
+            self.sa_da = dict(enable_sa_dropout=0.25, enable_sa_sparsity=[0.05, 50], enable_sa_swap=[0.1, 50])  # cars (:134-138)
+
+    def _global(self, gt_boxes, points):
+        from det3d.core.sampler import preprocess as prep
+        gt_boxes, points, flipped = prep.random_flip_v2(gt_boxes, points)
+        gt_boxes, points, rot = prep.global_rotation_v3(gt_boxes, points, self.global_rotation_noise)
+        gt_boxes, points, scale = prep.global_scaling_v3(gt_boxes, points, *self.global_scaling_noise)
+        return gt_boxes, points, {"flipped": flipped, "noise_rotation": rot, "noise_scale": scale}
+
+    def __call__(self, res, info):
+        from det3d.core.bbox import box_np_ops
+        from det3d.core.sampler import preprocess as prep
+        from det3d.datasets.kitti import kitti_common as kitti
+        from det3d.datasets.utils import sa_da_v2
+        res["mode"] = self.mode
+        points = res["lidar"]["points"]
+        labeled = self.mode == "train" and res["labeled"]
+        if labeled:
+            anno = res["lidar"]["annotations"]
+            gt_dict = {"gt_boxes": anno["boxes"], "gt_names": np.array(anno["names"]).reshape(-1)}
+            _dict_select(gt_dict, kitti.drop_arrays_by_name(gt_dict["gt_names"], ["DontCare", "ignore"]))
+            target = np.array([n in self.class_names for n in gt_dict["gt_names"]], dtype=np.bool_)
+            if self.db_sampler:
+                pasted = self.db_sampler.sample_all(res["metadata"]["image_prefix"], gt_dict["gt_boxes"], gt_dict["gt_names"],
+                                                    res["metadata"]["num_point_features"], False, gt_group_ids=None,
+                                                    calib=res["calib"] if "calib" in res else None,
+                                                    targeted_class_names=self.class_names)
+                if pasted is not None:
+                    gt_dict["gt_names"] = np.concatenate([gt_dict["gt_names"], pasted["gt_names"]], axis=0)
+                    gt_dict["gt_boxes"] = np.concatenate([gt_dict["gt_boxes"], pasted["gt_boxes"]])
+                    target = np.concatenate([target, pasted["gt_masks"]], axis=0)
+                    if self.remove_points_after_sample:
+                        points = points[~box_np_ops.points_in_rbbox(points, pasted["gt_boxes"]).any(-1)]
+                    points = np.concatenate([pasted["points"], points], axis=0)
+            prep.noise_per_object_v4_(gt_dict["gt_boxes"], points, target, rotation_perturb=self.gt_rotation_noise,
+                                      center_noise_std=self.gt_loc_noise_std, global_random_rot_range=self.global_random_rot_range,
+                                      group_ids=None, num_try=100, data_aug_with_context=self.data_aug_with_context,
+                                      data_aug_random_drop=self.data_aug_random_drop)
+            _dict_select(gt_dict, target)
+            gt_dict["gt_classes"] = np.array([self.class_names.index(n) + 1 for n in gt_dict["gt_names"]], dtype=np.int32)
+            res["lidar"]["points_raw"] = points.copy()
+            res["lidar"]["annotations_raw"] = {k: v.copy() for k, v in gt_dict.items()}
+            gt_dict["gt_boxes"], points, res["lidar"]["transformation"] = self._global(gt_dict["gt_boxes"], points)
+            points = sa_da_v2.pyramid_augment_v0(gt_dict["gt_boxes"], points, **self.sa_da)
+        if self.shuffle_points:
+            points = points[np.random.choice(np.arange(points.shape[0]), points.shape[0], replace=False)]
+        if self.mode == "train" and not res["labeled"]:
+            _, points, res["lidar"]["transformation"] = self._global(None, points)
+        res["lidar"]["points"] = points
+        if labeled:
+            res["lidar"]["annotations"] = gt_dict
+        return res, info
 
 
 @PIPELINES.register_module
@@ -34,6 +132,13 @@ class Voxelization(object):
 
     def __call__(self, res, info):
         grid_size = self.voxel_generator.grid_size
+        if res.get("mode") == "train" and res.get("labeled", True) and "annotations" in res["lidar"]:
+            # ground truth with no BEV corner inside the x/y range is dropped before target assignment (:200-206)
+            from det3d.core.sampler import preprocess as prep
+            gt_dict = res["lidar"]["annotations"]
+            r = np.asarray(self.voxel_generator.point_cloud_range)
+            _dict_select(gt_dict, prep.filter_gt_box_outside_range(gt_dict["gt_boxes"], r[[0, 1, 3, 4]]))
+            self.shuffle = True
         res["lidar"]["voxels"] = self._voxelize(res["lidar"]["points"], grid_size)
         if "points_raw" in res["lidar"].keys():
             res["lidar"]["voxels_raw"] = self._voxelize(res["lidar"]["points_raw"], grid_size)
