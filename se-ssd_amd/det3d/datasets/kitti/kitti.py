@@ -1,7 +1,10 @@
-"""mirrors the evaluation side of det3d/datasets/kitti/kitti.py (KittiDataset): detections of the model (lidar boxes) ->
-KITTI annotation dicts in the rectified camera frame with 2-D boxes by projection (:71-139), and `evaluation` (:141-166) =
-that conversion + the official average precision. Dataset IO (info pickles, point-cloud files) is outside the scope: the infos
-are handed in."""
+"""mirrors det3d/datasets/kitti/kitti.py (KittiDataset): the per-frame entry of the data pipeline (`get_sensor_data` :170-216:
+the `res` dict every pipeline stage reads and writes), detections of the model (lidar boxes) -> KITTI annotation dicts in the
+rectified camera frame with 2-D boxes by projection (:71-139), and `evaluation` (:141-166) = that conversion + the official
+average precision. The infos come from `info_path` (the reference's kitti_infos_*.pkl) or are handed in as `kitti_infos`."""
+import os
+import pickle
+
 import numpy as np
 
 from det3d.core.bbox import box_np_ops
@@ -60,14 +63,56 @@ def convert_detection_to_kitti_annos(detection, kitti_infos, class_names, partia
 
 
 class KittiDataset(object):
-    """The evaluation surface of the reference dataset class on in-memory infos (no file IO)."""
     NumPointFeatures = 4
 
-    def __init__(self, kitti_infos, class_names):
+    def __init__(self, root_path=None, info_path=None, cfg=None, pipeline=None, class_names=None, test_mode=False,
+                 kitti_infos=None, **kwargs):
+        if kitti_infos is None:
+            assert info_path is not None
+            with open(info_path, "rb") as f:
+                kitti_infos = pickle.load(f)
         self._kitti_infos, self._class_names = kitti_infos, class_names
+        self._root_path, self._info_path, self.test_mode = root_path, info_path, test_mode
+        self.labeled = kwargs.get("labeled", True)
+        self.plane_dir = None if root_path is None else str(root_path) + "/training/planes"
+        if pipeline is None or callable(pipeline):
+            self.pipeline = pipeline
+        else:
+            from det3d.datasets.pipelines import Compose
+            self.pipeline = Compose(pipeline)
 
     def __len__(self):
         return len(self._kitti_infos)
+
+    num_point_features = property(lambda self: KittiDataset.NumPointFeatures)
+
+    def get_road_plane(self, idx):
+        """unit normal (facing up in the rectified camera frame) and offset of the frame's road plane, 4th line of planes/%06d.txt (:43-57)"""
+        with open(os.path.join(self.plane_dir, "%06d.txt" % idx), "r") as f:
+            plane = np.asarray([float(v) for v in f.readlines()[3].split()])
+        if plane[1] > 0:
+            plane = -plane
+        return plane / np.linalg.norm(plane[0:3])
+
+    def get_sensor_data(self, idx, with_image=False, with_gp=False, by_index=False):
+        """the frame's `res` dict run through the pipeline (:170-216). by_index: idx is an image index, not a position."""
+        if by_index:
+            idx = [int(i["image"]["image_idx"]) for i in self._kitti_infos].index(idx)
+        info = self._kitti_infos[idx]
+        if with_image:
+            raise NotImplementedError("camera images are not part of the lidar path")
+        res = {"type": "KittiDataset",
+               "lidar": {"type": "lidar", "points": None, "ground_plane": -self.get_road_plane(idx)[-1] if with_gp else None,
+                         "annotations": None, "names": None, "targets": None},
+               "metadata": {"image_prefix": self._root_path, "num_point_features": KittiDataset.NumPointFeatures,
+                            "image_idx": info["image"]["image_idx"], "image_shape": info["image"]["image_shape"],
+                            "token": str(info["image"]["image_idx"])},
+               "calib": None, "cam": {"annotations": None}, "mode": "val" if self.test_mode else "train", "labeled": self.labeled}
+        data, _ = self.pipeline(res, info)
+        return data
+
+    def __getitem__(self, idx):
+        return self.get_sensor_data(idx, with_gp=False)
 
     @property
     def ground_truth_annotations(self):

@@ -233,3 +233,49 @@ def test_voxelization_drops_ground_truth_outside_the_range():
     pcr = np.asarray([0, -40.0, -3.0, 70.4, 40.0, 1.0], np.float32)
     _dict_select(gt, prep.filter_gt_box_outside_range(gt["gt_boxes"], pcr[[0, 1, 3, 4]]))
     assert len(gt["gt_boxes"]) == len(b) - 1 == len(gt["gt_names"]) == len(gt["gt_classes"]) and np.array_equal(gt["gt_boxes"], b[1:])
+
+
+def test_dataset_entry_runs_the_configured_pipeline_from_files():
+    """KittiDataset.get_sensor_data -> Compose of the config's stage dicts (config.py:183-189 up to the device stages): info pickle,
+    point-cloud file, database pickle + object files on disk, exactly the reference's wire format."""
+    import pickle
+    from make_golden_datapath import SAMPLER_CFG, make_database, make_info, make_scene, train_cfg
+    from det3d.datasets.kitti.kitti import KittiDataset
+    with tempfile.TemporaryDirectory() as tmp:
+        infos = []
+        os.makedirs(os.path.join(tmp, "training/velodyne_reduced"))
+        for idx in (3, 8):
+            info = make_info(idx)
+            make_scene(idx)[0].tofile(os.path.join(tmp, "training/velodyne_reduced/%06d.bin" % idx))
+            infos.append(info)
+        with open(os.path.join(tmp, "kitti_infos_train.pkl"), "wb") as f:
+            pickle.dump(infos, f)
+        with open(os.path.join(tmp, "dbinfos_train.pkl"), "wb") as f:
+            pickle.dump(make_database(tmp), f)
+        cfg = train_cfg()
+        cfg["db_sampler"] = dict(SAMPLER_CFG, db_info_path=os.path.join(tmp, "dbinfos_train.pkl"))
+        pipeline = [dict(type="LoadPointCloudFromFile"), dict(type="LoadPointCloudAnnotations", with_bbox=True),
+                    dict(type="Preprocess", cfg=cfg)]
+        np.random.seed(9)
+        ds = KittiDataset(tmp, os.path.join(tmp, "kitti_infos_train.pkl"), pipeline=pipeline, class_names=["Car"])
+        assert len(ds) == 2 and ds.num_point_features == 4
+        res = ds[1]
+        L = res["lidar"]
+        assert res["metadata"]["token"] == "8" and res["mode"] == "train" and res["labeled"] and res["type"] == "KittiDataset"
+        assert set(L["annotations"]) == {"gt_boxes", "gt_names", "gt_classes"} and set(L["transformation"]) == {"flipped", "noise_rotation", "noise_scale"}
+        n = len(L["annotations"]["gt_names"])
+        assert n > 4 and set(L["annotations"]["gt_names"]) <= {"Car", "Van"} and L["annotations"]["gt_boxes"].shape == (n, 7)
+        assert L["points"].dtype == np.float32 and L["points"].shape[1] == 4 and L["points_raw"].shape[1] == 4
+        assert res["calib"]["frustum"].shape == (1, 6, 4, 3) and res["cam"]["annotations"]["boxes"].shape[1] == 4
+        same = ds.get_sensor_data(8, by_index=True)
+        assert same["metadata"]["image_idx"] == 8
+        val = KittiDataset(tmp, os.path.join(tmp, "kitti_infos_train.pkl"), test_mode=True, class_names=["Car"], pipeline=[
+            dict(type="LoadPointCloudFromFile"), dict(type="LoadPointCloudAnnotations", with_bbox=True),
+            dict(type="Preprocess", cfg=dict(mode="val", shuffle_points=False, remove_environment=False, remove_unknown_examples=False))])
+        r = val[0]
+        assert r["mode"] == "val" and np.array_equal(r["lidar"]["points"], make_scene(3)[0]) and "transformation" not in r["lidar"]
+        os.makedirs(os.path.join(tmp, "training/planes"))
+        with open(os.path.join(tmp, "training/planes/000000.txt"), "w") as f:
+            f.write("# Plane\nWidth 4\nHeight 1\n0.01 0.99 -0.02 -1.65\n")
+        pl = val.get_road_plane(0)
+        assert pl[1] < 0 and abs(np.linalg.norm(pl[:3]) - 1) < 1e-12

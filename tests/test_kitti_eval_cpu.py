@@ -75,7 +75,7 @@ def test_detection_to_kitti_annos_matches_reference_run(golden_dir):
     from det3d.datasets.kitti.kitti import KittiDataset
     g = np.load(os.path.join(golden_dir, "kitti_convert_ref.npz"))
     infos, dets = make_case()
-    annos = KittiDataset(infos, ["Car"]).convert_detection_to_kitti_annos(dets)
+    annos = KittiDataset(kitti_infos=infos, class_names=["Car"]).convert_detection_to_kitti_annos(dets)
     assert len(annos) == 4 and [a["name"].shape[0] for a in annos] == [4, 0, 7, 2]
     for i, a in enumerate(annos):
         assert list(a["name"]) == list(g["%d_name" % i]) and a["metadata"] == dict(token="%06d" % (i * 7))
@@ -92,13 +92,13 @@ def test_dataset_evaluation_surface(monkeypatch):
     from det3d.datasets.kitti import eval as K
     from det3d.datasets.kitti.kitti import KittiDataset
     infos, dets = make_case()
-    for info, a in zip(infos, KittiDataset(infos, ["Car"]).convert_detection_to_kitti_annos(dets)):
+    for info, a in zip(infos, KittiDataset(kitti_infos=infos, class_names=["Car"]).convert_detection_to_kitti_annos(dets)):
         gt = {k: np.array(v, copy=True) for k, v in a.items() if k not in ("metadata", "score")}
         gt["bbox"] = gt["bbox"].reshape(-1, 4).copy()
         if gt["bbox"].shape[0]:
             gt["location"] = gt["location"] + np.array([0.03, 0.0, 0.02])   # identical rotated boxes are ill-conditioned
         info["annos"] = gt
-    ds = KittiDataset(infos, ["Car"])
+    ds = KittiDataset(kitti_infos=infos, class_names=["Car"])
     results, dt_annos = ds.evaluation(dets)
     assert len(dt_annos) == len(ds) == 4
     assert set(results) == {"results", "results_2", "detail"} and set(results["detail"]["eval.kitti"]) == {"official", "coco"}
