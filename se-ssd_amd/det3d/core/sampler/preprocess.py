@@ -134,17 +134,21 @@ def noise_per_box(boxes, valid_mask, loc_noises, rot_noises):
         if not valid_mask[i]:
             continue
         local = corners[i] - boxes[i, :2]
-        s, c = np.sin(rot_noises[i])[:, None], np.cos(rot_noises[i])[:, None]
-        cand = np.empty((rot_noises.shape[1], 4, 2), dtype=boxes.dtype)
-        cand[..., 0] = local[None, :, 0] * c + local[None, :, 1] * s
-        cand[..., 1] = local[None, :, 0] * -s + local[None, :, 1] * c
-        cand += (boxes[i, :2] + loc_noises[i, :, :2])[:, None, :]
-        hit = box_collision_test(cand, corners)
-        hit[:, i] = False
-        free = np.nonzero(~hit.any(axis=1))[0]
-        if free.size:
-            chosen[i] = free[0]
-            corners[i] = cand[free[0]]
+        t0, step, T = 0, 4, rot_noises.shape[1]
+        while t0 < T and chosen[i] < 0:   # candidates in growing chunks: the first few almost always contain a free one
+            t1 = min(T, t0 + step)
+            s, c = np.sin(rot_noises[i, t0:t1])[:, None], np.cos(rot_noises[i, t0:t1])[:, None]
+            cand = np.empty((t1 - t0, 4, 2), dtype=boxes.dtype)
+            cand[..., 0] = local[None, :, 0] * c + local[None, :, 1] * s
+            cand[..., 1] = local[None, :, 0] * -s + local[None, :, 1] * c
+            cand += (boxes[i, :2] + loc_noises[i, t0:t1, :2])[:, None, :]
+            hit = box_collision_test(cand, corners)
+            hit[:, i] = False
+            free = np.nonzero(~hit.any(axis=1))[0]
+            if free.size:
+                chosen[i] = t0 + free[0]
+                corners[i] = cand[free[0]]
+            t0, step = t1, step * 4
     return chosen
 
 
