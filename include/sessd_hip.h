@@ -30,7 +30,8 @@ const char* sessd_version(void);
 int sessd_fill_u32(void* ptr, uint32_t value, size_t n_words, sessd_stream_t stream);
 /* on != 0: sessd_voxelize_frame / sessd_sparse_downsample_sites stop clearing their scratch (per-cell lists + cut word
  * at the start of the voxelizer workspace; output hash keys/vals and the first `out_hash_capacity` words of the
- * downsample workspace) -- the caller fills them with 0x7F7F7F7F itself, e.g. one fill over a contiguous arena. */
+ * downsample workspace) -- the caller fills them with 0x7F7F7F7F itself, e.g. one fill over a contiguous arena.
+ * The switch is per calling host thread (thread-local) and is read when an entry point is CALLED, not when its kernels run. */
 void sessd_set_external_clear(int on);
 
 /* ------------------------------------------------------------------ voxelizer (a1-a3)

@@ -27,7 +27,8 @@ int sessd_fill_u32_launch(void* p, uint32_t value, size_t n_words, hipStream_t s
 
 // When the caller clears the scratch of several stages with ONE fill over a contiguous arena (the inference
 // engine does), the per-call clears inside sessd_voxelize_frame / sessd_sparse_downsample_sites are skipped.
-static int g_external_clear = 0;
+// (per host thread: an engine enqueueing on one thread does not change these entry points for callers on other threads)
+static thread_local int g_external_clear = 0;
 int sessd_external_clear_enabled() { return g_external_clear; }
 extern "C" void sessd_set_external_clear(int on) { g_external_clear = on ? 1 : 0; }
 
