@@ -59,12 +59,39 @@ def stats(pairs, n_out, order):
     return useful, executed, float(distinct.mean()), float(present.sum(1).mean())
 
 
+def propagate(idx0, label):
+    """Second question: if ONLY level 0 is renumbered (one sort per frame) and every strided conv keeps numbering its output
+    sites by first touch, how much of the gain reaches the deeper levels?"""
+    idx, shape, tot = idx0, [41, 1600, 1408], [0, 0]
+    done = set()
+    for (kind, cin, cout, ks, st, pd, key) in osc.SPMIDDLE_FHD_LAYERS:
+        if kind == "subm":
+            if key in done:
+                continue
+            done.add(key)
+            out_idx, oshape, pairs = osc.rulebook(idx, shape, ks, 1, 0, True)
+            order, reps = np.arange(len(idx)), sum(1 for l in osc.SPMIDDLE_FHD_LAYERS if l[6] == key)
+        else:
+            out_idx, oshape, pairs = osc.rulebook(idx, shape, ks, st, pd, False)
+            creator = np.full(len(out_idx), np.iinfo(np.int64).max)
+            for ri, ro in pairs:
+                np.minimum.at(creator, ro, ri)
+            order, reps = np.argsort(creator, kind="stable"), 1
+        u, e, rows, offs = stats(pairs, len(out_idx), order)
+        tot[0] += u * reps * cin * cout; tot[1] += e * reps * cin * cout
+        if kind != "subm":
+            # renumber: site r of the next level = out_idx[order[r]]; the rulebook is recomputed from the new table
+            idx, shape = out_idx[order].astype(np.int32), oshape
+    print("   level 0 in %-22s -> first touch below: useful / executed = %5.1f %%" % (label, 100.0 * tot[0] / tot[1]))
+
+
 def main():
     seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
     pts = synth.make_frame(seed, 20000)
     voxels, coors, num = capi.points_to_voxel(pts, [0.05, 0.05, 0.1], [0, -40.0, -3.0, 70.4, 40.0, 1.0], 5, 20000)
     idx = np.concatenate([np.zeros((len(coors), 1), np.int32), coors], 1)
     shape = [41, 1600, 1408]
+    idx_level0 = idx.copy()
     done = set()
     tot = {}
     for (kind, cin, cout, ks, st, pd, key) in osc.SPMIDDLE_FHD_LAYERS:
@@ -95,6 +122,9 @@ def main():
     print("\nFLOP-weighted over the 14 layers:")
     for oname, (u, e) in tot.items():
         print("   %-26s useful / executed MFMA rows = %5.1f %%" % (oname, 100.0 * u / e))
+    print("\nRenumbering level 0 only:")
+    for oname, order in orders(idx_level0, np.arange(len(idx_level0))).items():
+        propagate(idx_level0[order], oname)
 
 
 if __name__ == "__main__":
