@@ -126,6 +126,18 @@ int sessd_sparse_conv(const float* in_feat, int cin, const int32_t* nbr, const u
                       const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
                       float* dense_out, const int32_t* dense_dims3, int cout_split, sessd_stream_t stream);
 
+/* ---- engine-internal site renumbering (no reference counterpart: spconv numbers sites as they come) ---------------
+ * EXPERIMENTAL -- compiled, not yet validated on hardware (round 1 ran out of GPU budget); off by default in the engine.
+ * Rewrites a level's site table in (batch, z, y) grid-row order so that the 16-site tiles of sessd_sparse_conv hold spatial
+ * neighbours. indices (n_cap,4) [b,z,y,x] + feat (n_cap, channels) -> out_indices / out_feat
+ * (distinct buffers), and the level's hash (keys ((b*D+z)*H+y)*W+x, dims3 = (D,H,W)) is pointed at the new rows.
+ * Convolution results do not depend on the numbering. Order inside a grid row is unspecified. */
+size_t sessd_sparse_renumber_workspace_bytes(int batch, const int32_t* dims3);
+int sessd_sparse_renumber_sites(const int32_t* indices, const int32_t* n_dev, int n_cap, int batch, const int32_t* dims3,
+                                const float* feat, int channels, const uint32_t* hash_keys, int32_t* hash_vals,
+                                uint32_t hash_capacity, int32_t* out_indices, float* out_feat, void* workspace,
+                                size_t workspace_bytes, sessd_stream_t stream);
+
 /* ---- sparse conv backward (spconv's indice_conv backward as differentiated by the SE-SSD training
  * step, det3d/torchie/trainer/trainer_sessd.py:250-275 through det3d/models/backbones/scn.py:106-148) -------------
  * Data gradient: dx = sessd_sparse_conv(dy, nbr_t, tile_mask_t, weights W_k^T) over the INPUT sites, with

@@ -98,9 +98,11 @@ class DensePlan:
 class InferenceEngine:
     def __init__(self, model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, batch_size=1,
                  max_points_per_frame=32768, device=None, growth=(1.5, 1.0, 0.75, 0.75), anchors=None,
-                 use_frustum=False, allow_winograd=True):
+                 use_frustum=False, allow_winograd=True, sort_sites=False):
         """growth[i]: capacity of sparse level i+1 relative to level i (observed ratios on KITTI-like scans are
-        ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results()."""
+        ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results().
+        sort_sites (EXPERIMENTAL, not yet validated on hardware): renumber the voxels by grid row between the voxelizer and
+        the first sparse conv (sessd_sparse_renumber_sites); results do not depend on it."""
         self.dev = torch.device("cuda:0") if device is None else device
         dev = self.dev
         self.B = int(batch_size)
@@ -212,6 +214,13 @@ class InferenceEngine:
                         count=torch.zeros((B,), dtype=i32, device=dev))
         self.pred_ws = torch.empty(int(lib.sessd_predict_workspace_bytes(B, 2 * H * W, self.pre_max, self.post_max)),
                                    dtype=torch.uint8, device=dev)
+        self.sort_sites = bool(sort_sites)
+        if self.sort_sites:
+            self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
+            self.levels[0]["indices"] = self.coors_s
+            self._hash0_dims = torch.tensor(self.levels[0]["hash_dims"], dtype=torch.int32)
+            self.renum_ws = torch.empty(int(lib.sessd_sparse_renumber_workspace_bytes(B, self._hash0_dims.data_ptr())),
+                                        dtype=torch.uint8, device=dev)
         self._ks = {}
         self._npts = [0] * B
         self.graph = None
@@ -360,10 +369,17 @@ class InferenceEngine:
                                            self.voxels.data_ptr(), self.coors.data_ptr(), 4, self.nump.data_ptr(),
                                            self.vfeat.data_ptr(), self.prefix.data_ptr(), self.vox_ws.data_ptr(),
                                            self.vox_ws.numel(), s), "voxelize_frame")
+        feat = self.vfeat
+        if self.sort_sites:
+            check(lib.sessd_sparse_renumber_sites(self.coors.data_ptr(), self._n(0), self.levels[0]["cap"], B,
+                                                  self._hash0_dims.data_ptr(), self.vfeat.data_ptr(), 4,
+                                                  self.hash0.keys.data_ptr(), self.hash0.vals.data_ptr(), self.hash0.capacity,
+                                                  self.coors_s.data_ptr(), self.vfeat_s.data_ptr(), self.renum_ws.data_ptr(),
+                                                  self.renum_ws.numel(), s), "sparse_renumber_sites")
+            feat = self.vfeat_s
         self._mark("voxelize")
         # ---- SpMiddleFHD (a4-a8)
         li = 0
-        feat = self.vfeat
         have_subm = False
         n_layers = len(self.sp.layers)
         for idx, lay in enumerate(self.sp.layers):

@@ -257,6 +257,21 @@ def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, sc
     return out if dense_out is None else dense_out
 
 
+def sparse_renumber_sites(indices, n_dev, feat, site_hash, batch):
+    """EXPERIMENTAL (not yet validated on hardware): the level's sites renumbered by (batch, z, y) grid row. Returns
+    (out_indices, out_feat); `site_hash` (SiteHash of the level) is updated in place to the new rows."""
+    _req(indices, torch.int32, "indices")
+    _req(feat, torch.float32, "feat")
+    cap, ch = indices.shape[0], feat.shape[1]
+    out_idx, out_feat = torch.empty_like(indices), torch.empty_like(feat)
+    ws = workspace(lib.sessd_sparse_renumber_workspace_bytes(int(batch), site_hash._dims_t.data_ptr()), indices.device, "renumber")
+    check(lib.sessd_sparse_renumber_sites(indices.data_ptr(), n_dev.data_ptr(), cap, int(batch), site_hash._dims_t.data_ptr(),
+                                          feat.data_ptr(), ch, site_hash.keys.data_ptr(), site_hash.vals.data_ptr(),
+                                          site_hash.capacity, out_idx.data_ptr(), out_feat.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          _stream()), "sparse_renumber_sites")
+    return out_idx, out_feat
+
+
 def sparse_rulebook_transpose(nbr, n_out_dev, n_in_cap):
     """Rulebook of the data-gradient pass: nbr_t (kv, n_in_cap) with nbr_t[k][i] = j <=> nbr[k][j] = i, and its tile masks."""
     kv, cap = nbr.shape
