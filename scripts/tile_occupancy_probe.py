@@ -32,6 +32,7 @@ def orders(out_idx, first_touch):
     z, y, x = out_idx[:, 1].astype(np.int64), out_idx[:, 2].astype(np.int64), out_idx[:, 3].astype(np.int64)
     o = {"device (first touch)": first_touch,
          "linear z,y,x": np.lexsort((x, y, z)),
+         "grid row z,y (x shuffled)": np.lexsort((np.random.RandomState(0).permutation(len(x)), y, z)),   # what site_renumber.hip produces
          "linear y,x,z": np.lexsort((z, x, y)),
          "morton(y,x) then z": np.lexsort((z, morton2(y, x))),
          "4x4 xy patch, z inside": np.lexsort((x % 4, y % 4, z, x // 4, y // 4)),
@@ -82,7 +83,7 @@ def propagate(idx0, label):
         if kind != "subm":
             # renumber: site r of the next level = out_idx[order[r]]; the rulebook is recomputed from the new table
             idx, shape = out_idx[order].astype(np.int32), oshape
-    print("   level 0 in %-22s -> first touch below: useful / executed = %5.1f %%" % (label, 100.0 * tot[0] / tot[1]))
+    print("   level 0 in %-28s -> first touch below: useful / executed = %5.1f %%" % (label, 100.0 * tot[0] / tot[1]))
 
 
 def main():
@@ -114,14 +115,14 @@ def main():
         print("\n%s: %d -> %d sites, %d pairs" % (name, len(idx), len(out_idx), sum(len(p[0]) for p in pairs)))
         for oname, order in orders(out_idx, first).items():
             u, e, rows, offs = stats(pairs, len(out_idx), order)
-            print("   %-26s occupancy %5.1f %%   offsets/tile %5.1f   distinct input rows/tile %6.1f" % (oname, 100.0 * u / e, offs, rows))
+            print("   %-28s occupancy %5.1f %%   offsets/tile %5.1f   distinct input rows/tile %6.1f" % (oname, 100.0 * u / e, offs, rows))
             t = tot.setdefault(oname, [0, 0])
             t[0] += u * reps * cin * cout; t[1] += e * reps * cin * cout
         if nxt is not None:
             idx, shape = nxt[0].astype(np.int32), nxt[1]
     print("\nFLOP-weighted over the 14 layers:")
     for oname, (u, e) in tot.items():
-        print("   %-26s useful / executed MFMA rows = %5.1f %%" % (oname, 100.0 * u / e))
+        print("   %-28s useful / executed MFMA rows = %5.1f %%" % (oname, 100.0 * u / e))
     print("\nRenumbering level 0 only:")
     for oname, order in orders(idx_level0, np.arange(len(idx_level0))).items():
         propagate(idx_level0[order], oname)
