@@ -37,7 +37,7 @@ def points_in_convex_polygon_3d_jit(points, polygon_surfaces, num_surfaces=None)
         used = np.arange(polygon_surfaces.shape[1])[None, :] <= np.asarray(num_surfaces)[:, None]
     verts = polygon_surfaces.reshape(B, -1, 3)
     lo, hi = verts.min(axis=1) - _CULL_PAD, verts.max(axis=1) + _CULL_PAD
-    order = np.argsort(points[:, 0], kind="stable")
+    order = np.argsort(points[:, 0])
     xs = points[order, 0]
     first, last = np.searchsorted(xs, lo[:, 0], side="left"), np.searchsorted(xs, hi[:, 0], side="right")
     for b in range(B):
