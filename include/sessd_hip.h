@@ -138,6 +138,16 @@ int sessd_sparse_renumber_sites(const int32_t* indices, const int32_t* n_dev, in
                                 uint32_t hash_capacity, int32_t* out_indices, float* out_feat, void* workspace,
                                 size_t workspace_bytes, sessd_stream_t stream);
 
+/* ---- training data path, point-level work -----------------------------------------------------------
+ * EXPERIMENTAL -- compiled, not yet validated on hardware; the pipeline uses the numpy host stage.
+ * replaces det3d/core/bbox/geometry.py:215-276 points_in_convex_polygon_3d_jit (numba) as used by
+ * box_np_ops.points_in_rbbox :1152, sampler/preprocess.py:645 (per-object noise) and sa_da_v2.py:65-74 (pyramids).
+ * points (num_points, point_stride) float32; planes (num_bodies, faces, 4) float32 [nx,ny,nz,d], inward normals, from the host
+ * (geometry.py:352-377 arithmetic); out_mask (num_points, ceil(num_bodies/32)) uint32, bit set = strictly inside
+ * (x*nx + y*ny + z*nz + d < 0 for every face, float32, left to right, no contraction: identical to the numba loop). */
+int sessd_points_in_bodies(const float* points, int num_points, int point_stride, const float* planes, int num_bodies,
+                           int faces, uint32_t* out_mask, sessd_stream_t stream);
+
 /* ---- sparse conv backward (spconv's indice_conv backward as differentiated by the SE-SSD training
  * step, det3d/torchie/trainer/trainer_sessd.py:250-275 through det3d/models/backbones/scn.py:106-148) -------------
  * Data gradient: dx = sessd_sparse_conv(dy, nbr_t, tile_mask_t, weights W_k^T) over the INPUT sites, with

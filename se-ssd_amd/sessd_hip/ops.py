@@ -272,6 +272,20 @@ def sparse_renumber_sites(indices, n_dev, feat, site_hash, batch):
     return out_idx, out_feat
 
 
+def points_in_bodies(points, planes):
+    """EXPERIMENTAL (not yet validated on hardware): points (P, >=3) float32 on the device, planes (M, F, 4) float32 on the
+    device [nx, ny, nz, d] with inward normals -> (P, M) bool on the device (strictly inside every face)."""
+    _req(points, torch.float32, "points")
+    _req(planes, torch.float32, "planes")
+    P, M, F = points.shape[0], planes.shape[0], planes.shape[1]
+    words = (M + 31) // 32
+    mask = torch.zeros((P, words), dtype=torch.int32, device=points.device)
+    check(lib.sessd_points_in_bodies(points.data_ptr(), P, points.shape[1], planes.data_ptr(), M, F, mask.data_ptr(), _stream()),
+          "points_in_bodies")
+    bit = torch.arange(M, device=points.device)
+    return ((mask[:, bit // 32] >> (bit % 32)) & 1).bool()
+
+
 def sparse_rulebook_transpose(nbr, n_out_dev, n_in_cap):
     """Rulebook of the data-gradient pass: nbr_t (kv, n_in_cap) with nbr_t[k][i] = j <=> nbr[k][j] = i, and its tile masks."""
     kv, cap = nbr.shape
