@@ -279,3 +279,52 @@ def test_dataset_entry_runs_the_configured_pipeline_from_files():
             f.write("# Plane\nWidth 4\nHeight 1\n0.01 0.99 -0.02 -1.65\n")
         pl = val.get_road_plane(0)
         assert pl[1] < 0 and abs(np.linalg.norm(pl[:3]) - 1) < 1e-12
+
+
+def test_ground_truth_database_creation_round_trip():
+    """create_groundtruth_database (reference create_gt_database.py:20-131) writes what DataBaseSamplerV2 reads: crops are the
+    points inside each labelled box, centre-relative; the records carry the box and the point count; the sampler pastes them back."""
+    import pickle
+    from make_golden_datapath import CALIB, SAMPLER_CFG, make_scene
+    from det3d.builder import build_dbsampler
+    from det3d.core.bbox import box_np_ops
+    from det3d.datasets.utils.create_gt_database import create_groundtruth_database
+    with tempfile.TemporaryDirectory() as tmp:
+        os.makedirs(os.path.join(tmp, "training/velodyne_reduced"))
+        infos, scenes = [], {}
+        for idx in (1, 2, 5):
+            pts, boxes, names = make_scene(idx)
+            pts.tofile(os.path.join(tmp, "training/velodyne_reduced/%06d.bin" % idx))
+            # lidar boxes -> the camera-frame annotation the info file holds (bottom-centre location, l,h,w sizes)
+            low = boxes.copy(); low[:, 2] -= low[:, 5] / 2
+            cam = box_np_ops.box_lidar_to_camera(low.astype(np.float64), CALIB["R0_rect"], CALIB["Tr_velo_to_cam"])
+            annos = dict(name=names.copy(), location=cam[:, :3], dimensions=cam[:, 3:6], rotation_y=cam[:, 6],
+                         bbox=np.zeros((len(names), 4)), difficulty=np.arange(len(names)) % 3)
+            infos.append(dict(image=dict(image_idx=idx, image_shape=np.array([375, 1242], np.int32)), calib=dict(CALIB), annos=annos,
+                              point_cloud=dict(num_features=4, velodyne_path="training/velodyne/%06d.bin" % idx)))
+            scenes[idx] = (pts, boxes, names)
+        with open(os.path.join(tmp, "kitti_infos_train.pkl"), "wb") as f:
+            pickle.dump(infos, f)
+        db = create_groundtruth_database("KITTI", tmp, os.path.join(tmp, "kitti_infos_train.pkl"))
+        assert set(db) == {"Car", "Pedestrian", "Van"} and len(db["Car"]) == 15 and len(db["Van"]) == 3
+        assert pickle.load(open(os.path.join(tmp, "dbinfos_train.pkl"), "rb")).keys() == db.keys()
+        assert sorted(r["group_id"] for v in db.values() for r in v) == list(range(21))
+        rec = db["Car"][7]
+        pts, boxes, names = scenes[rec["image_idx"]]
+        assert np.allclose(rec["box3d_lidar"], boxes[rec["gt_idx"]], atol=1e-4) and rec["path"].startswith("gt_database/")
+        obj = np.fromfile(os.path.join(tmp, rec["path"]), dtype=np.float32).reshape(-1, 4)
+        assert obj.shape[0] == rec["num_points_in_gt"] and abs(obj.shape[0] - 330) <= 3   # the cluster the scene put into the box
+        back = obj.copy(); back[:, :3] += rec["box3d_lidar"][:3]
+        assert box_np_ops.points_in_rbbox(back, rec["box3d_lidar"][None]).all()
+        # ... and the sampler consumes it
+        np.random.seed(3)
+        sampler = build_dbsampler(dict(SAMPLER_CFG, db_prep_steps=[dict(filter_by_min_num_points=dict(Car=5))]), db_infos=db)
+        _, b, n = make_scene(77)
+        got = sampler.sample_all(tmp, b, n, 4)
+        assert got is not None and set(got["gt_names"]) <= {"Car", "Van"} and got["points"].shape[1] == 4
+        assert box_np_ops.points_in_rbbox(got["points"], got["gt_boxes"]).any(1).all()
+        # widened crops go to their own files
+        wide = create_groundtruth_database("KITTI", tmp, os.path.join(tmp, "kitti_infos_train.pkl"), used_classes=["Car"], gt_aug_with_context=0.5)
+        assert set(wide) == {"Car"} and os.path.exists(os.path.join(tmp, "dbinfos_enlarged_train.pkl"))
+        w0 = np.fromfile(os.path.join(tmp, wide["Car"][7]["path"]), dtype=np.float32).reshape(-1, 4)
+        assert w0.shape[0] >= obj.shape[0] and wide["Car"][7]["num_points_in_gt"] == rec["num_points_in_gt"]
