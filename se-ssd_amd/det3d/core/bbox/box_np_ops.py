@@ -184,3 +184,11 @@ def box_camera_to_lidar(data, r_rect, velo2cam):
 def change_box3d_center_(box3d, src, dst):
     """in place: move the reference point of the boxes from `src` to `dst` (fractions of the box size) (box_np_ops.py:1406-1409)."""
     box3d[..., :3] += box3d[..., 3:6] * (np.array(dst, dtype=box3d.dtype) - np.array(src, dtype=box3d.dtype))
+
+
+def remove_outside_points(points, rect, Trv2c, P2, image_shape):
+    """the points whose projection falls inside the camera image: inside the image frustum (near 0.001 m, far 100 m) taken to
+    the lidar frame (box_np_ops.py:981-992; what `velodyne_reduced` is made with)."""
+    from det3d.core.bbox.geometry import points_in_convex_polygon_3d_jit
+    inside = points_in_convex_polygon_3d_jit(points[:, :3], get_valid_frustum(rect, Trv2c, P2, image_shape))
+    return points[inside.reshape([-1])]
