@@ -328,3 +328,27 @@ def test_ground_truth_database_creation_round_trip():
         assert set(wide) == {"Car"} and os.path.exists(os.path.join(tmp, "dbinfos_enlarged_train.pkl"))
         w0 = np.fromfile(os.path.join(tmp, wide["Car"][7]["path"]), dtype=np.float32).reshape(-1, 4)
         assert w0.shape[0] >= obj.shape[0] and wide["Car"][7]["num_points_in_gt"] == rec["num_points_in_gt"]
+
+
+def test_preprocess_with_empty_or_untargeted_ground_truth():
+    """frames without labelled cars: no boxes at all, or only classes outside the target list; with and without the sampler"""
+    from make_golden_datapath import SAMPLER_CFG, make_database, make_scene, train_cfg
+    from det3d.builder import build_dbsampler
+    from det3d.datasets.pipelines import Preprocess
+    from det3d.datasets.utils import sa_da_v2
+    pts, b, n = make_scene(3)
+    assert sa_da_v2.pyramid_augment_v0(b[:0], pts.copy()).shape == pts.shape
+    frame = lambda tmp, bb, nn: dict(labeled=True, metadata=dict(image_prefix=tmp, num_point_features=4),
+                                     lidar=dict(points=pts.copy(), annotations=dict(boxes=bb.copy(), names=nn.copy())))
+    with tempfile.TemporaryDirectory() as tmp:
+        np.random.seed(1)
+        stage = Preprocess(cfg=train_cfg(), db_sampler=build_dbsampler(dict(SAMPLER_CFG), db_infos=make_database(tmp)))
+        res, _ = stage(frame(tmp, b[:0], n[:0]), None)
+        a = res["lidar"]["annotations"]
+        assert len(a["gt_names"]) > 5 and a["gt_boxes"].shape == (len(a["gt_names"]), 7) and res["lidar"]["points"].shape[0] > pts.shape[0]
+        res, _ = stage(frame(tmp, b[5:6], n[5:6]), None)     # a lone pedestrian blocks pasted cars but is not a target itself
+        assert "Pedestrian" not in res["lidar"]["annotations"]["gt_names"] and len(res["lidar"]["annotations"]["gt_names"]) > 5
+        bare = Preprocess(cfg=train_cfg())
+        res, _ = bare(frame(tmp, b[:0], n[:0]), None)
+        assert res["lidar"]["annotations"]["gt_boxes"].shape == (0, 7) and res["lidar"]["points"].shape == pts.shape
+        assert res["lidar"]["annotations"]["gt_classes"].dtype == np.int32 and res["lidar"]["annotations_raw"]["gt_boxes"].shape == (0, 7)
