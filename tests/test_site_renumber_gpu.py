@@ -18,7 +18,10 @@ pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SESSD_EXPERIME
 
 
 def _sites(rng, B, shape, n):
-    lin = rng.choice(B * shape[0] * shape[1] * shape[2], n, replace=False)
+    cells = B * shape[0] * shape[1] * shape[2]
+    lin = np.unique(rng.randint(0, cells, size=4 * n + 64)) if cells > 4 * n else np.arange(cells)
+    lin = rng.permutation(lin)[:n]
+    assert len(lin) == n
     x = lin % shape[2]; y = (lin // shape[2]) % shape[1]; z = (lin // (shape[2] * shape[1])) % shape[0]; b = lin // (shape[2] * shape[1] * shape[0])
     return np.stack([b, z, y, x], 1).astype(np.int32)
 
