@@ -40,6 +40,21 @@ def orders(out_idx, first_touch):
     return o
 
 
+def mask_orders(pairs, out_idx):
+    """spconv-v2 style: group sites with the same set of present offsets. Plain mask sort destroys locality (distinct gathered
+    rows per tile double); sorting by mask inside blocks of linearly ordered sites keeps the working set of a block in L2."""
+    n = len(out_idx)
+    mask = np.zeros(n, np.int64)
+    for k, (ri, ro) in enumerate(pairs):
+        mask[ro] |= (1 << k)
+    z, y, x = out_idx[:, 1].astype(np.int64), out_idx[:, 2].astype(np.int64), out_idx[:, 3].astype(np.int64)
+    lin = np.lexsort((x, y, z))
+    o = {"offset-mask sort (global)": np.lexsort((x, y, z, mask))}
+    for blk in (256, 1024):
+        o["linear, mask-sorted in %d-blocks" % blk] = lin[np.lexsort((mask[lin], np.arange(n) // blk))]
+    return o
+
+
 def stats(pairs, n_out, order):
     rank = np.empty(n_out, np.int64)
     rank[order] = np.arange(n_out)
@@ -113,16 +128,19 @@ def main():
             name, reps = "conv %s s%s %d->%d" % (ks, st, cin, cout), 1
             nxt = (out_idx[first], oshape)
         print("\n%s: %d -> %d sites, %d pairs" % (name, len(idx), len(out_idx), sum(len(p[0]) for p in pairs)))
-        for oname, order in orders(out_idx, first).items():
+        cand = orders(out_idx, first)
+        if kind == "subm":
+            cand.update(mask_orders(pairs, out_idx))
+        for oname, order in cand.items():
             u, e, rows, offs = stats(pairs, len(out_idx), order)
-            print("   %-28s occupancy %5.1f %%   offsets/tile %5.1f   distinct input rows/tile %6.1f" % (oname, 100.0 * u / e, offs, rows))
+            print("   %-34s occupancy %5.1f %%   offsets/tile %5.1f   distinct input rows/tile %6.1f" % (oname, 100.0 * u / e, offs, rows))
             t = tot.setdefault(oname, [0, 0])
             t[0] += u * reps * cin * cout; t[1] += e * reps * cin * cout
         if nxt is not None:
             idx, shape = nxt[0].astype(np.int32), nxt[1]
     print("\nFLOP-weighted over the 14 layers:")
     for oname, (u, e) in tot.items():
-        print("   %-28s useful / executed MFMA rows = %5.1f %%" % (oname, 100.0 * u / e))
+        print("   %-34s useful / executed MFMA rows = %5.1f %%" % (oname, 100.0 * u / e))
     print("\nRenumbering level 0 only:")
     for oname, order in orders(idx_level0, np.arange(len(idx_level0))).items():
         propagate(idx_level0[order], oname)
