@@ -126,6 +126,14 @@ int sessd_sparse_conv(const float* in_feat, int cin, const int32_t* nbr, const u
                       const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
                       float* dense_out, const int32_t* dense_dims3, int cout_split, sessd_stream_t stream);
 
+/* EXPERIMENTAL -- compiled, not yet validated on hardware. Same contract and bit-identical results as sessd_sparse_conv (same
+ * packed weights and rulebook) for the channel pairs of SpMiddleFHD, with the operands of three kernel offsets in flight
+ * while the fourth is multiplied (csrc/sparse_conv_deep.hip). */
+int sessd_sparse_conv_deep(const float* in_feat, int cin, const int32_t* nbr, const uint32_t* tile_mask, int kernel_volume,
+                           const int32_t* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
+                           const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
+                           float* dense_out, const int32_t* dense_dims3, int cout_split, sessd_stream_t stream);
+
 /* ---- engine-internal site renumbering (no reference counterpart: spconv numbers sites as they come) ---------------
  * EXPERIMENTAL -- compiled, not yet validated on hardware (round 1 ran out of GPU budget); off by default in the engine.
  * Rewrites a level's site table in (batch, z, y) grid-row order so that the 16-site tiles of sessd_sparse_conv hold spatial

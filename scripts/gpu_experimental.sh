@@ -4,7 +4,7 @@
 set -u
 mkdir -p gpurun_out
 export SESSD_EXPERIMENTAL=1
-timeout -k 5 300 python -m pytest tests/test_site_renumber_gpu.py tests/test_datapath_gpu.py -x -q > gpurun_out/experimental_tests.log 2>&1
+timeout -k 5 400 python -m pytest tests/test_site_renumber_gpu.py tests/test_datapath_gpu.py tests/test_sparse_conv_deep_gpu.py -q -s > gpurun_out/experimental_tests.log 2>&1
 echo "experimental tests exit $?" | tee -a gpurun_out/experimental_tests.log
 tail -15 gpurun_out/experimental_tests.log
 timeout -k 5 300 python - <<'PY' > gpurun_out/renumber_bench.log 2>&1
@@ -16,9 +16,9 @@ dev = torch.device("cuda:0")
 VG = configs.VOXEL_GENERATOR
 model = configs.build_synthetic_detector(dev, seed=0, max_voxels=16000, num_points=20000)
 frames = [torch.from_numpy(synth.make_frame(i, 20000)).to(dev) for i in range(8)]
-for flag in (False, True):
+for flag, deep in ((False, False), (True, False), (False, True), (True, True)):
     e = InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], 16000, configs.TEST_CFG, batch_size=1,
-                        max_points_per_frame=20000, device=dev, sort_sites=flag)
+                        max_points_per_frame=20000, device=dev, sort_sites=flag, deep_sparse=deep)
     e.set_points([frames[0]]); e.enqueue(); torch.cuda.synchronize(); e.autotune()
     st = e.stage_times(reps=20)
     e.capture()
@@ -29,6 +29,6 @@ for flag in (False, True):
     for i in range(200):
         e.set_points([frames[i % 8]]); e.replay()
     t1.record(); torch.cuda.synchronize()
-    print("sort_sites=%s  graph %.1f us/frame  eager stages %s" % (flag, t0.elapsed_time(t1) / 200 * 1e3, {k: round(v, 3) for k, v in st.items()}))
+    print("sort_sites=%s deep_sparse=%s  graph %.1f us/frame  eager stages %s" % (flag, deep, t0.elapsed_time(t1) / 200 * 1e3, {k: round(v, 3) for k, v in st.items()}))
 PY
 tail -5 gpurun_out/renumber_bench.log

@@ -49,6 +49,7 @@ SIGNATURES = {
     "sessd_sparse_renumber_workspace_bytes": (sz, [i32, vp]),
     "sessd_sparse_renumber_sites": (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, u32, vp, vp, vp, sz, vp]),
     "sessd_points_in_bodies": (i32, [vp, i32, i32, vp, i32, i32, vp, vp]),
+    "sessd_sparse_conv_deep": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
     "sessd_sparse_rulebook_transpose": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
     "sessd_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
     "sessd_sparse_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, vp, sz, vp]),
