@@ -146,6 +146,19 @@ int sessd_sparse_renumber_sites(const int32_t* indices, const int32_t* n_dev, in
                                 uint32_t hash_capacity, int32_t* out_indices, float* out_feat, void* workspace,
                                 size_t workspace_bytes, sessd_stream_t stream);
 
+/* ---- train-mode BatchNorm1d + ReLU on a sparse level's feature table --------------------------------------
+ * EXPERIMENTAL -- compiled, not yet validated on hardware, not wired into the module path.
+ * replaces torch.nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU after every sparse conv of det3d/models/backbones/scn.py:103-148
+ * in train mode (both networks of the SE-SSD step): batch statistics over the rows < *n_dev, running statistics updated in
+ * place (unbiased variance), deterministic reductions. channels must divide 256. */
+size_t sessd_bn_relu_train_workspace_bytes(int channels);
+int sessd_bn_relu_train_fwd(const float* x, const int32_t* n_dev, int n_cap, int channels, const float* gamma, const float* beta,
+                            float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,
+                            float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+int sessd_bn_relu_train_bwd(const float* dy, const float* x, const float* y, const int32_t* n_dev, int n_cap, int channels,
+                            const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                            float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+
 /* ---- training data path, point-level work -----------------------------------------------------------
  * EXPERIMENTAL -- compiled, not yet validated on hardware; the pipeline uses the numpy host stage.
  * replaces det3d/core/bbox/geometry.py:215-276 points_in_convex_polygon_3d_jit (numba) as used by

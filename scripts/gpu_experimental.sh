@@ -4,7 +4,7 @@
 set -u
 mkdir -p gpurun_out
 export SESSD_EXPERIMENTAL=1
-timeout -k 5 400 python -m pytest tests/test_site_renumber_gpu.py tests/test_datapath_gpu.py tests/test_sparse_conv_deep_gpu.py -q -s > gpurun_out/experimental_tests.log 2>&1
+timeout -k 5 400 python -m pytest tests/test_site_renumber_gpu.py tests/test_datapath_gpu.py tests/test_sparse_conv_deep_gpu.py tests/test_bn_train_gpu.py -q -s > gpurun_out/experimental_tests.log 2>&1
 echo "experimental tests exit $?" | tee -a gpurun_out/experimental_tests.log
 tail -15 gpurun_out/experimental_tests.log
 timeout -k 5 300 python - <<'PY' > gpurun_out/renumber_bench.log 2>&1

@@ -274,6 +274,50 @@ def sparse_renumber_sites(indices, n_dev, feat, site_hash, batch):
     return out_idx, out_feat
 
 
+class BnReluTrainFunction(torch.autograd.Function):
+    """EXPERIMENTAL (not yet validated on hardware): train-mode BatchNorm1d + optional ReLU over the first *n_dev rows of a
+    sparse feature table, statistics and both passes on the HIP kernels of csrc/bn_train.hip; running statistics are updated
+    in place like torch.nn.BatchNorm1d does."""
+
+    @staticmethod
+    def forward(ctx, x, n_dev, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = x.float().contiguous()
+        _req(x, torch.float32, "x")
+        cap, C = x.shape
+        dev = x.device
+        y = torch.zeros_like(x)
+        mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        ws = torch.empty(int(lib.sessd_bn_relu_train_workspace_bytes(C)), dtype=torch.uint8, device=dev)
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        check(lib.sessd_bn_relu_train_fwd(x.data_ptr(), n_dev.data_ptr(), cap, C, g.data_ptr(), b.data_ptr(), float(eps),
+                                          float(momentum), 1 if relu else 0, _p(running_mean), _p(running_var), y.data_ptr(),
+                                          mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_relu_train_fwd")
+        ctx.save_for_backward(x, y, g, mean, invstd, n_dev)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, g, mean, invstd, n_dev = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        cap, C = x.shape
+        dx = torch.zeros_like(x)
+        dg, db = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+        ws = torch.empty(int(lib.sessd_bn_relu_train_workspace_bytes(C)), dtype=torch.uint8, device=x.device)
+        check(lib.sessd_bn_relu_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), n_dev.data_ptr(), cap, C, g.data_ptr(),
+                                          mean.data_ptr(), invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), dg.data_ptr(),
+                                          db.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_relu_train_bwd")
+        return dx, None, dg, db, None, None, None, None, None
+
+
+def bn_relu_train(x, n_dev, bn, relu=True):
+    """x (cap, C) float32 on the device, rows < n_dev[0] valid; bn: a torch.nn.BatchNorm1d in train mode (its running statistics are
+    updated in place, num_batches_tracked incremented)."""
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BnReluTrainFunction.apply(x, n_dev, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+
+
 def points_in_bodies(points, planes):
     """EXPERIMENTAL (not yet validated on hardware): points (P, >=3) float32 on the device, planes (M, F, 4) float32 on the
     device [nx, ny, nz, d] with inward normals -> (P, M) bool on the device (strictly inside every face)."""

@@ -1,0 +1,56 @@
+"""sessd_bn_relu_train_fwd / _bwd (train-mode BatchNorm1d + ReLU over a sparse feature table, csrc/bn_train.hip) vs
+torch.nn.BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU on the same rows: output, running statistics, and the gradients with
+respect to the input, weight and bias. Tolerances: 2e-5 on values of O(1) (float32, different reduction order).
+
+EXPERIMENTAL: written after round 1's GPU budget was spent, not yet run on hardware -> runs only with SESSD_EXPERIMENTAL=1."""
+import os
+
+import pytest
+import torch
+
+from sessd_hip import ops
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SESSD_EXPERIMENTAL") != "1",
+                                                  reason="not yet validated on hardware; set SESSD_EXPERIMENTAL=1")]
+
+
+@pytest.mark.parametrize("C", [4, 16, 32, 64, 128])
+@pytest.mark.parametrize("n,cap", [(15000, 16000), (1, 64), (2, 2), (3001, 3001)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_matches_torch_batchnorm(dev, C, n, cap, relu):
+    g = torch.Generator().manual_seed(C * 1000 + n)
+    x = torch.zeros(cap, C)
+    x[:n] = torch.randn(n, C, generator=g) * 1.7 + 0.3
+    x[n:] = 1e6        # rows past the count must not matter
+    w, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    up = torch.randn(cap, C, generator=g)
+    ref = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    mine = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    ref.weight.data.copy_(w); ref.bias.data.copy_(b)
+    ref.running_mean.data.copy_(torch.randn(C, generator=g) * 0.1); ref.running_var.data.copy_(torch.rand(C, generator=g) + 0.5)
+    mine.load_state_dict(ref.state_dict())
+    xr = x[:n].to(dev).clone().requires_grad_(True)
+    if n > 1:
+        yr = ref(xr)
+        yr = torch.relu(yr) if relu else yr
+        (yr * up[:n].to(dev)).sum().backward()
+    xm = x.to(dev).clone().requires_grad_(True)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    ym = ops.bn_relu_train(xm, n_dev, mine, relu=relu)
+    (ym[:n] * up[:n].to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(ym[:n]).all() and float(ym[n:].abs().sum()) == 0 and float(xm.grad[n:].abs().sum()) == 0
+    if n > 1:
+        assert torch.allclose(ym[:n], yr, rtol=0, atol=2e-5 * max(1.0, float(yr.abs().max())))
+        assert torch.allclose(mine.running_mean, ref.running_mean, rtol=0, atol=1e-6)
+        assert torch.allclose(mine.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+        scale = max(1.0, float(xr.grad.abs().max()))
+        assert torch.allclose(xm.grad[:n], xr.grad, rtol=0, atol=5e-5 * scale)
+        assert torch.allclose(mine.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
+        assert torch.allclose(mine.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
+    # deterministic: a second run gives the same bits
+    mine2 = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    mine2.weight.data.copy_(w); mine2.bias.data.copy_(b)
+    y2 = ops.bn_relu_train(x.to(dev), n_dev, mine2, relu=relu)
+    assert torch.equal(y2, ym.detach())
