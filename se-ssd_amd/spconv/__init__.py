@@ -186,13 +186,29 @@ class SparseSequential(SparseModule):
     def add(self, module, name=None):
         self.add_module(str(len(self._modules)) if name is None else name, module)
 
+    # EXPERIMENTAL (not yet validated on hardware, off): in train mode run BatchNorm1d + the ReLU that follows it as the two
+    # fused HIP passes of csrc/bn_train.hip instead of the torch modules. Set `spconv.SparseSequential.FUSED_BN_TRAIN = True`.
+    FUSED_BN_TRAIN = False
+
     def forward(self, input):
-        for k, module in self._modules.items():
+        mods = list(self._modules.values())
+        skip = False
+        for pos, module in enumerate(mods):
+            if skip:
+                skip = False
+                continue
             if isinstance(module, SparseModule):
                 input = module(input)
             elif isinstance(input, SparseConvTensor):
                 if input.indices.shape[0] != 0:
-                    input.features = module(input.features)
+                    if (self.FUSED_BN_TRAIN and module.training and isinstance(module, torch.nn.BatchNorm1d)
+                            and module.track_running_stats and module.affine and input.features.is_cuda):
+                        relu = pos + 1 < len(mods) and isinstance(mods[pos + 1], torch.nn.ReLU)
+                        n_dev = torch.tensor([input.features.shape[0]], dtype=torch.int32, device=input.features.device)
+                        input.features = ops.bn_relu_train(input.features, n_dev, module, relu=relu)
+                        skip = relu
+                    else:
+                        input.features = module(input.features)
             else:
                 input = module(input)
         return input

@@ -54,3 +54,34 @@ def test_matches_torch_batchnorm(dev, C, n, cap, relu):
     mine2.weight.data.copy_(w); mine2.bias.data.copy_(b)
     y2 = ops.bn_relu_train(x.to(dev), n_dev, mine2, relu=relu)
     assert torch.equal(y2, ym.detach())
+
+
+def test_sparse_sequential_with_the_fused_pair(dev):
+    """spconv.SparseSequential.FUSED_BN_TRAIN: subm conv -> BatchNorm1d(train) -> ReLU -> strided conv, fused vs torch modules:
+    same output features, same weight / BN gradients, same running statistics."""
+    import numpy as np
+    import spconv
+    rng = np.random.RandomState(9)
+    B, shape, n = 2, [11, 40, 36], 1200
+    lin = rng.permutation(B * shape[0] * shape[1] * shape[2])[:n]
+    idx = np.stack([lin // (shape[0] * shape[1] * shape[2]), (lin // (shape[1] * shape[2])) % shape[0], (lin // shape[2]) % shape[1], lin % shape[2]], 1).astype(np.int32)
+    g = torch.Generator().manual_seed(4)
+    feat = torch.randn(n, 16, generator=g)
+    w1, w2 = torch.randn(3, 3, 3, 16, 32, generator=g) * 0.1, torch.randn(3, 3, 3, 32, 64, generator=g) * 0.1
+    results = []
+    try:
+        for fused in (False, True):
+            spconv.SparseSequential.FUSED_BN_TRAIN = fused
+            net = spconv.SparseSequential(spconv.SubMConv3d(16, 32, 3, bias=False, indice_key="s"), torch.nn.BatchNorm1d(32, eps=1e-3, momentum=0.01),
+                                          torch.nn.ReLU(), spconv.SparseConv3d(32, 64, 3, 2, padding=1, bias=False)).to(dev).train()
+            with torch.no_grad():
+                net[0].weight.copy_(w1.to(dev)); net[3].weight.copy_(w2.to(dev))
+            out = net(spconv.SparseConvTensor(feat.to(dev), torch.from_numpy(idx).to(dev), shape, B))
+            out.features.pow(2).sum().backward()
+            order = np.lexsort(out.indices.cpu().numpy().T[::-1])
+            results.append((out.features.detach().cpu()[order], net[0].weight.grad.cpu(), net[3].weight.grad.cpu(), net[1].weight.grad.cpu(),
+                            net[1].bias.grad.cpu(), net[1].running_mean.cpu(), net[1].running_var.cpu()))
+    finally:
+        spconv.SparseSequential.FUSED_BN_TRAIN = False
+    for a, b in zip(*results):
+        assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(a.abs().max()))), (a - b).abs().max()
