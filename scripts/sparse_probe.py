@@ -1,0 +1,49 @@
+"""Run the inference engine eagerly for a few frames (for rocprofv3 --kernel-trace / --pmc passes of the sparse stage).
+
+    python scripts/sparse_probe.py [--stress] [--frames N] [--sort] [--deep] [--sparse-only]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "se-ssd_amd")):
+    sys.path.insert(0, p)
+import torch
+from sessd_hip import configs, synth
+from sessd_hip.engine import InferenceEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--stress", action="store_true")
+ap.add_argument("--frames", type=int, default=4)
+ap.add_argument("--sort", action="store_true")
+ap.add_argument("--deep", action="store_true")
+ap.add_argument("--graph", action="store_true")
+a = ap.parse_args()
+dev = torch.device("cuda:0")
+VG = configs.VOXEL_GENERATOR
+pts, mv, B, ss = (200000, 64000, 8, 3) if a.stress else (20000, 16000, 1, 1)
+model = configs.build_synthetic_detector(dev, seed=0, max_voxels=mv, num_points=pts)
+frames = [torch.from_numpy(synth.make_frame(i, pts, supersample=ss)).to(dev) for i in range(B)]
+kw = {}
+if a.sort:
+    kw["sort_sites"] = True
+if a.deep:
+    kw["deep_sparse"] = True
+e = InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], mv, configs.TEST_CFG, batch_size=B,
+                    max_points_per_frame=pts, device=dev, **kw)
+e.set_points(frames)
+e.enqueue()
+torch.cuda.synchronize()
+e.autotune()
+if a.graph:
+    e.capture()
+for i in range(a.frames):
+    e.set_points(frames)
+    if a.graph:
+        e.replay()
+    else:
+        e.enqueue()
+torch.cuda.synchronize()
+print("sites", e.spmiddle_algorithmic_bytes())
+print("stages", e.stage_times(reps=5))

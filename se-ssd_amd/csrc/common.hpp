@@ -66,14 +66,17 @@ static __device__ __forceinline__ uint32_t sessd_hash_u32(uint32_t k) {
   return k;
 }
 
-// Insert-or-find. Returns the slot that holds `key`.
+// Insert-or-find. Returns the slot that holds `key`, or SESSD_HASH_FULL when every slot is taken by other keys
+// (the probe sequence is bounded by the table size: a full table is reported, never spun on).
+#define SESSD_HASH_FULL 0xFFFFFFFFu
 static __device__ __forceinline__ uint32_t sessd_hash_insert(uint32_t* keys, uint32_t mask, uint32_t key) {
   uint32_t slot = sessd_hash_u32(key) & mask;
-  while (true) {
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
     uint32_t prev = atomicCAS(&keys[slot], SESSD_HASH_EMPTY, key);
     if (prev == SESSD_HASH_EMPTY || prev == key) return slot;
     slot = (slot + 1) & mask;
   }
+  return SESSD_HASH_FULL;
 }
 
 // Lookup. Returns value or -1.
@@ -81,7 +84,7 @@ static __device__ __forceinline__ int sessd_hash_find(const uint32_t* __restrict
                                                       const int* __restrict__ vals, uint32_t mask,
                                                       uint32_t key) {
   uint32_t slot = sessd_hash_u32(key) & mask;
-  while (true) {
+  for (uint32_t probes = 0; probes <= mask; ++probes) {
     uint32_t k = keys[slot];
     if (k == key) {
       int v = vals[slot];
@@ -90,6 +93,7 @@ static __device__ __forceinline__ int sessd_hash_find(const uint32_t* __restrict
     if (k == SESSD_HASH_EMPTY) return -1;
     slot = (slot + 1) & mask;
   }
+  return -1;  // full table without the key
 }
 
 // ---- wave / block reductions ----------------------------------------------

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(NT) void hash_build_kernel(const int* __restrict__ 
   if (i >= n) return;
   const int4 c = *reinterpret_cast<const int4*>(indices + (size_t)i * 4);
   uint32_t slot = sessd_hash_insert(keys, mask, lin_key(c.x, c.y, c.z, c.w, G.in_dims));
-  vals[slot] = i;
+  if (slot != SESSD_HASH_FULL) vals[slot] = i;  // capacity >= 2 * n_cap: cannot fill up
 }
 
 // ---- strided conv output sites ------------------------------------------------------------
@@ -71,7 +71,7 @@ __device__ __forceinline__ bool cand_coord(const int* __restrict__ indices, int 
 __global__ __launch_bounds__(NT) void down_insert_kernel(const int* __restrict__ indices, const int* __restrict__ n_dev,
                                                           int n_cap, int KV, ConvGeom G, uint32_t* __restrict__ keys,
                                                           uint32_t mask, int* __restrict__ first,
-                                                          int* __restrict__ ent) {
+                                                          int* __restrict__ ent, int* __restrict__ err_flag) {
   int id = blockIdx.x * NT + threadIdx.x;
   int n = min(n_dev[0], n_cap);
   if (id >= n_cap * KV) return;
@@ -80,8 +80,12 @@ __global__ __launch_bounds__(NT) void down_insert_kernel(const int* __restrict__
     int b, o[3];
     if (cand_coord<false>(indices, id, KV, G, b, o)) {
       uint32_t slot = sessd_hash_insert(keys, mask, lin_key(b, o[0], o[1], o[2], G.out_dims));
-      atomicMin(&first[slot], id);
-      e = (int)slot;
+      if (slot != SESSD_HASH_FULL) {
+        atomicMin(&first[slot], id);
+        e = (int)slot;
+      } else {
+        atomicOr(err_flag, 1);  // more output cells than hash slots: reported like a capacity overflow
+      }
     }
   }
   ent[id] = e;
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(NT) void down_insert_unordered_kernel(const int* __
   if (active) {
     const uint32_t key = lin_key(b, o[0], o[1], o[2], G.out_dims);
     slot = sessd_hash_u32(key) & mask;
-    while (true) {
+    uint32_t probes = 0;
+    for (; probes <= mask; ++probes) {
       const uint32_t prev = atomicCAS(&keys[slot], SESSD_HASH_EMPTY, key);
       if (prev == SESSD_HASH_EMPTY) {  // this thread created the cell
         created = true;
@@ -116,6 +121,7 @@ __global__ __launch_bounds__(NT) void down_insert_unordered_kernel(const int* __
       if (prev == key) break;
       slot = (slot + 1) & mask;
     }
+    if (probes > mask) atomicOr(err_flag, 1);  // table full (a cloud far sparser than the growth factors assume)
   }
   // Row numbers for the cells this WAVE created with ONE atomic on the shared counter (a per-thread atomicAdd on one
   // address serialises: 285 k creators of the dense-scene level cost 0.5 ms).
@@ -361,7 +367,7 @@ int sessd_sparse_downsample_sites(const int* in_indices, const int* n_in_dev, in
   const int total = n_in_cap * kv;
   const int nblk = sessd_divup(total, NT);
   SESSD_LAUNCH(down_insert_kernel, dim3(nblk), dim3(NT), 0, stream, in_indices, n_in_dev, n_in_cap, kv, G, out_keys,
-                     out_capacity - 1, w.first, w.ent);
+                     out_capacity - 1, w.first, w.ent, err_flag);
   SESSD_CHECK_LAUNCH();
   SESSD_LAUNCH(down_count_kernel, dim3(nblk), dim3(NT), 0, stream, total, w.ent, w.first, w.blk_cnt);
   SESSD_CHECK_LAUNCH();

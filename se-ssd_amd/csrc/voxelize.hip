@@ -53,6 +53,10 @@ __global__ __launch_bounds__(VOX_NT) void vox_insert_kernel(const float* __restr
   }
   uint32_t key = key_base + ((uint32_t)c[2] * (uint32_t)G.g[1] + (uint32_t)c[1]) * (uint32_t)G.g[0] + (uint32_t)c[0];
   uint32_t slot = sessd_hash_insert(keys, mask, key);
+  if (slot == SESSD_HASH_FULL) {  // cannot happen with capacity >= 2 * points (checked by the entry point)
+    ent[i] = -1;
+    return;
+  }
   ent[i] = (int)slot;
   int* L = lists + (size_t)slot * MP;
   int v = i;
