@@ -120,19 +120,13 @@ int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, in
                              sessd_stream_t stream);
 /* out[o] = act((sum_k W[k]^T in[nbr[k][o]]) * scale + shift); scale/shift = folded eval BatchNorm1d (may be NULL).
  * dense_out != NULL: scatter into the pre-zeroed BEV tensor (B, cout*D, H, W), dense_dims3 = (D,H,W).
- * cout_split: 0 heuristic | 1,2,4 waves per 16-site tile (each computes cout/split channels). */
+ * tuning = cout_split + 256 * depth. cout_split: 0 heuristic | 1,2,4 waves per 16-site tile (each computes cout/split
+ * channels); depth: 0 default | 2..4 operand register sets (offsets whose rows and weights are in flight, plus the one being
+ * multiplied). Results are bit-identical for every tuning. */
 int sessd_sparse_conv(const float* in_feat, int cin, const int32_t* nbr, const uint32_t* tile_mask, int kernel_volume,
                       const int32_t* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
                       const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
-                      float* dense_out, const int32_t* dense_dims3, int cout_split, sessd_stream_t stream);
-
-/* EXPERIMENTAL -- compiled, not yet validated on hardware. Same contract and bit-identical results as sessd_sparse_conv (same
- * packed weights and rulebook) for the channel pairs of SpMiddleFHD, with the operands of three kernel offsets in flight
- * while the fourth is multiplied (csrc/sparse_conv_deep.hip). */
-int sessd_sparse_conv_deep(const float* in_feat, int cin, const int32_t* nbr, const uint32_t* tile_mask, int kernel_volume,
-                           const int32_t* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
-                           const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
-                           float* dense_out, const int32_t* dense_dims3, int cout_split, sessd_stream_t stream);
+                      float* dense_out, const int32_t* dense_dims3, int tuning, sessd_stream_t stream);
 
 /* ---- engine-internal site renumbering (no reference counterpart: spconv numbers sites as they come) ---------------
  * EXPERIMENTAL -- compiled, not yet validated on hardware (round 1 ran out of GPU budget); off by default in the engine.

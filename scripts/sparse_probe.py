@@ -1,6 +1,5 @@
 """Run the inference engine eagerly for a few frames (for rocprofv3 --kernel-trace / --pmc passes of the sparse stage).
 
-    python scripts/sparse_probe.py [--stress] [--frames N] [--sort] [--deep] [--sparse-only]
 """
 import argparse
 import os
@@ -17,7 +16,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--stress", action="store_true")
 ap.add_argument("--frames", type=int, default=4)
 ap.add_argument("--sort", action="store_true")
-ap.add_argument("--deep", action="store_true")
 ap.add_argument("--graph", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
@@ -28,8 +26,6 @@ frames = [torch.from_numpy(synth.make_frame(i, pts, supersample=ss)).to(dev) for
 kw = {}
 if a.sort:
     kw["sort_sites"] = True
-if a.deep:
-    kw["deep_sparse"] = True
 e = InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], mv, configs.TEST_CFG, batch_size=B,
                     max_points_per_frame=pts, device=dev, **kw)
 e.set_points(frames)
@@ -47,3 +43,4 @@ for i in range(a.frames):
 torch.cuda.synchronize()
 print("sites", e.spmiddle_algorithmic_bytes())
 print("stages", e.stage_times(reps=5))
+print("tuning", {k: (v[0] & 255, v[0] >> 8, round(v[1] * 1e3, 1)) for k, v in e.tune_report.items() if k.startswith("sparse")})

@@ -35,7 +35,16 @@ __device__ __forceinline__ f32x4 bufload4(rsrc_t r, unsigned voff, unsigned soff
 
 // NTW = 16-wide cout tiles per wave; blockIdx.y selects the cout group (COUT/16/NTW groups): splitting Cout over
 // more waves fills the 1024 SIMDs when a level has fewer than 1024 site tiles (batch 1).
-template <int CIN, int COUT, int NTW, bool DENSE_OUT>
+// DEPTH = operand register sets: the gathered rows and weights of DEPTH-1 offsets are in flight while one is multiplied.
+//
+// Everything that steers the walk over the tile's active offsets is WAVE-UNIFORM and kept in SGPRs (tile index and tile
+// mask through readfirstlane): the offset loop is SALU + scalar branches, and the weight loads take their per-offset base
+// as an SGPR offset. (Round 1 kept the mask in a VGPR: hipcc then wrapped every weight load in a waterfall loop and
+// ended each iteration with s_waitcnt vmcnt(0) for the rotated index registers, i.e. no load ever overlapped an MFMA of
+// the next step -- 25 us per 64->64 layer whatever the number of sites; rocprofv3 counters in profiles/r2_sparse_pmc.txt.)
+// The tile's neighbour table (<= 27 x 16 row indices) is staged once in LDS, so that the per-step index fetch is a
+// ds_read on its own counter (lgkmcnt) and never forces a wait on the operand loads (vmcnt counts in order).
+template <int CIN, int COUT, int NTW, int DEPTH, bool DENSE_OUT>
 __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restrict__ in_feat,
                                                            const int* __restrict__ nbr,
                                                            const uint32_t* __restrict__ tile_mask, int kv,
@@ -49,39 +58,65 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   constexpr int STEPS = CIN / 4;          // MFMA k-steps per offset
   constexpr int NTILE = NTW;              // 16-wide cout tiles handled by this wave
   constexpr int NTALL = COUT / 16;        // ... of all groups
-  const int tbase = blockIdx.y * NTW;
   constexpr int G = STEPS < 4 ? STEPS : 4;  // floats per vector load
   constexpr int SG = STEPS / G;
+  __shared__ int s_nbr[4][32][16];        // per wave: row index of (offset, site) -- 8 KB per workgroup
+  // 1-D grid, cout group fastest: the workgroups that have work (tiles below the live site count) are the FIRST ones of the
+  // grid, so the dispatcher deals them round-robin over all XCDs / CUs. (With the cout group in blockIdx.y the live
+  // workgroups came as COUT/16/NTW separate bursts, each landing on the same few CUs: 4 waves per SIMD there, most CUs idle.)
+  constexpr int NGRP = COUT / 16 / NTW;
+  const int tbase = (int)(blockIdx.x % NGRP) * NTW;
   const int lane = threadIdx.x & 63;
-  const int tile = (blockIdx.x * 256 + threadIdx.x) >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tile = (int)(blockIdx.x / NGRP) * 4 + wv;   // wave-uniform
   const int n = min(n_dev[0], n_cap);
-  if (tile * 16 >= n) return;
+  if (tile * 16 >= n) return;             // scalar branch; no workgroup barrier below (every wave is independent)
   const int i = lane & 15, kq = lane >> 4;
-  const uint32_t tmask = tile_mask[tile];
+  const uint32_t tmask = __builtin_amdgcn_readfirstlane(tile_mask[tile]);
 
   f32x4 acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // Software pipeline over the ACTIVE offsets of this tile (bits of tmask), three stages deep:
-  //   stage 1  neighbour row index of offset i+2        (4-byte load from the rulebook)
-  //   stage 2  A (gathered quarter row) and B (packed weights) of offset i+1 into the other register set
-  //   stage 3  MFMAs of offset i
-  // All loads are unconditional (exhausted lists re-load the last offset, missing neighbours load row 0 and are
-  // zeroed at the use) so that hipcc's vmcnt accounting stays exact and loads stay in flight under the MFMAs.
-  // Buffer loads (SGPR resource + 32-bit lane offset + SGPR offset): no 64-bit VALU address arithmetic in the
-  // loop (the f32 MFMA shares the SIMD lanes with the VALU); a missing neighbour gets an out-of-range offset and
-  // the hardware returns zeros for its row.
-  const rsrc_t fr = make_rsrc(in_feat, 0x7FFFFFFFu);
-  const rsrc_t wrs = make_rsrc(wpk, (unsigned)kv * NTALL * STEPS * 64u * 4u);
-  float a[2][STEPS], bw[2][NTILE][STEPS];
-  uint32_t rest = tmask;
-  int remaining = __builtin_popcount(tmask);
+  // stage the tile's neighbour table: lane (i, kq) fetches offsets kq, kq+4, ... of site i (64-byte segments).
   // lanes of the last tile whose site is >= n read the tile's first site instead (their results are discarded below):
   // with a capacity that is not a multiple of 16 their own column would lie past the end of the last rulebook row
-  const int* nb = nbr + tile * 16 + (tile * 16 + i < n ? i : 0);
-  int klast = 0;
-#define SESSD_NEXTK() (rest ? (klast = __builtin_ctz(rest), rest &= rest - 1, klast) : klast)
+  {
+    const int* nb = nbr + tile * 16 + (tile * 16 + i < n ? i : 0);
+    int r[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int k = p * 4 + kq;
+      r[p] = (k < kv && ((tmask >> k) & 1u)) ? nb[(size_t)k * n_cap] : -1;
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s_nbr[wv][p * 4 + kq][i] = r[p];
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // Software pipeline over the ACTIVE offsets of this tile (bits of tmask). All operand loads are unconditional
+  // (an exhausted list re-loads its last offset, a missing neighbour gets an out-of-range buffer offset and the hardware
+  // returns zeros for its row), so the vmcnt of every wait is a compile-time constant. Buffer loads (SGPR resource +
+  // 32-bit lane offset + SGPR offset): no 64-bit VALU address arithmetic in the loop (the f32 MFMA shares the SIMD
+  // lanes with the VALU).
+  const rsrc_t fr = make_rsrc(in_feat, 0x7FFFFFFFu);
+  const rsrc_t wrs = make_rsrc(wpk, (unsigned)kv * NTALL * STEPS * 64u * 4u);
+  float a[DEPTH][STEPS], bw[DEPTH][NTILE][STEPS];
+  uint32_t rest = tmask;                        // SGPR
+  const int remaining = __builtin_popcount(tmask);
+  int kn = 0, rn = -1;
+  // next active offset and this lane's input row for it; past the end of the list: the last offset again with "no
+  // neighbour" (zeros), which the counted loop below multiplies harmlessly
+#define SESSD_FETCH()                                        \
+  {                                                          \
+    const bool more = rest != 0u;                            \
+    if (more) {                                              \
+      kn = __builtin_ctz(rest);                              \
+      rest &= rest - 1;                                      \
+    }                                                        \
+    const int rr = s_nbr[wv][kn][i];                         \
+    rn = more ? rr : -1;                                     \
+  }
 #define SESSD_LOADAB(SET, K, ROW)                                                                  \
   {                                                                                                \
     const unsigned ao = (ROW) >= 0 ? (unsigned)(((ROW)*CIN + kq * STEPS) * 4) : SESSD_OOB;          \
@@ -110,32 +145,37 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SET][s2], bw[SET][t][s2], acc[t], 0, 0, 0); \
   }
   if (remaining > 0) {
-    const int kcur = SESSD_NEXTK();
-    int knext = SESSD_NEXTK();
-    int knn = SESSD_NEXTK();
-    const int rcur = nb[(size_t)kcur * n_cap];
-    int rnext = nb[(size_t)knext * n_cap];
-    int rnn = nb[(size_t)knn * n_cap];
-    SESSD_LOADAB(0, kcur, rcur)
-    while (true) {
-      SESSD_LOADAB(1, knext, rnext)
-      const int k3 = SESSD_NEXTK();
-      const int r3 = nb[(size_t)k3 * n_cap];
-      __builtin_amdgcn_sched_barrier(0);
-      SESSD_MMA(0)
-      __builtin_amdgcn_sched_barrier(0);
-      if (--remaining == 0) break;
-      SESSD_LOADAB(0, knn, rnn)
-      const int k4 = SESSD_NEXTK();
-      const int r4 = nb[(size_t)k4 * n_cap];
-      __builtin_amdgcn_sched_barrier(0);
-      SESSD_MMA(1)
-      __builtin_amdgcn_sched_barrier(0);
-      if (--remaining == 0) break;
-      knext = k3; rnext = r3; knn = k4; rnn = r4;
+    // fill DEPTH-1 sets, keep the (offset, row) of the next refill at hand
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) {
+      SESSD_FETCH()
+      SESSD_LOADAB(d, kn, rn)
+      __builtin_amdgcn_sched_barrier(0);  // keep the sets in issue order: the loop's wait counts assume it
     }
+    SESSD_FETCH()
+    __builtin_amdgcn_sched_barrier(0);
+    // one step: refill the set multiplied in the previous step with the offset at hand, fetch the next (offset, row),
+    // multiply set CUR. The loop is COUNTED in whole rotations (the list is padded with zero rows to a multiple of DEPTH):
+    // a straight-line body with one back edge is what keeps hipcc's s_waitcnt placement exact -- with early exits inside
+    // the rotation it either waited for vmcnt(0) at the loop head or re-ordered the steps.
+#define SESSD_STEP(CUR)                                                                            \
+  {                                                                                                \
+    SESSD_LOADAB((CUR + DEPTH - 1) % DEPTH, kn, rn)                                                \
+    SESSD_FETCH()                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_MMA(CUR)                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
   }
-#undef SESSD_NEXTK
+    const int iters = (remaining + DEPTH - 1) / DEPTH;
+    for (int it = 0; it < iters; ++it) {
+      SESSD_STEP(0)
+      SESSD_STEP(1)
+      if constexpr (DEPTH >= 3) SESSD_STEP(2)
+      if constexpr (DEPTH >= 4) SESSD_STEP(3)
+    }
+#undef SESSD_STEP
+  }
+#undef SESSD_FETCH
 #undef SESSD_LOADAB
 #undef SESSD_MMA
 
@@ -178,29 +218,52 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin,
   wpk[idx] = w[((size_t)k * cin + ci) * cout + co];
 }
 
-template <int CIN, int COUT, int NTW>
-int launch_ntw(bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
-               int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
-               const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
+template <int CIN, int COUT, int NTW, int DEPTH>
+int launch_depth(bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
+                 int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
+                 const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
   const int tiles = sessd_divup(n_cap, 16);
-  dim3 grid(sessd_divup(tiles, 4), COUT / 16 / NTW), block(256);
+  dim3 grid(sessd_divup(tiles, 4) * (COUT / 16 / NTW)), block(256);
   if (dense)
-    SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
+    SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, DEPTH, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
                        n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2]);
   else
-    SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, false>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
+    SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, DEPTH, false>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
                        n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
 
+// operand sets (A: CIN/4 registers, B: NTW * CIN/4) of `depth` offsets must fit the 512-entry register file with room
+// for the accumulators and addresses; deeper than that is clamped
+template <int CIN, int COUT, int NTW>
+int launch_ntw(int depth, bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv,
+               const int* n_dev, int n_cap, const float* wpk, const float* scale, const float* shift, int relu,
+               float* out_feat, const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
+  constexpr int SET = (CIN / 4) * (1 + NTW);
+  constexpr int DMAX = SET * 4 <= 400 ? 4 : (SET * 3 <= 400 ? 3 : 2);
+  if (depth <= 0) depth = 3;
+  if (depth > DMAX) depth = DMAX;
+#define SESSD_ARGS2 dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
+  if constexpr (DMAX >= 4) {
+    if (depth >= 4) return launch_depth<CIN, COUT, NTW, 4>(SESSD_ARGS2);
+  }
+  if constexpr (DMAX >= 3) {
+    if (depth == 3) return launch_depth<CIN, COUT, NTW, 3>(SESSD_ARGS2);
+  }
+  return launch_depth<CIN, COUT, NTW, 2>(SESSD_ARGS2);
+#undef SESSD_ARGS2
+}
+
 template <int CIN, int COUT>
-int launch(int split, bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
+int launch(int tuning, bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
            int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
            const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
   constexpr int NT = COUT / 16;
+  int split = tuning & 0xFF;
+  const int depth = (tuning >> 8) & 0xFF;
   if (split <= 0) split = (n_cap / 16 < 4096) ? (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1)) : 1;  // fill 1024 SIMDs on small levels
-#define SESSD_ARGS dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
+#define SESSD_ARGS depth, dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
   if constexpr (NT % 4 == 0) {
     if (split >= 4) return launch_ntw<CIN, COUT, NT / 4>(SESSD_ARGS);
   }
@@ -227,21 +290,23 @@ int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, in
   return SESSD_OK;
 }
 
-// cout_split: 0 = heuristic, 1/2/4 = number of waves that share one 16-site tile (each takes Cout/split channels).
+// tuning = cout_split + 256 * depth. cout_split: 0 = heuristic, 1/2/4 = number of waves that share one 16-site tile (each
+// takes Cout/split channels); depth: 0 = default (3), 2..4 = operand register sets (offsets in flight + the one multiplied).
+// Results do not depend on either.
 // out[o] = act( (sum_k W[k]^T in[nbr[k][o]]) * scale + shift ). If dense_out != NULL the result is
 // scattered instead into the dense BEV tensor (B, cout*D, H, W) with dense_dims3 = (D,H,W) (pre-zeroed
 // by the caller) and out_feat may be NULL.
 int sessd_sparse_conv(const float* in_feat, int cin, const int* nbr, const uint32_t* tile_mask, int kernel_volume,
                       const int* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
                       const float* shift, int relu, float* out_feat, int cout, const int* out_indices,
-                      float* dense_out, const int* dense_dims3, int cout_split, hipStream_t stream) {
+                      float* dense_out, const int* dense_dims3, int tuning, hipStream_t stream) {
   if (n_out_cap <= 0 || kernel_volume <= 0 || kernel_volume > 32) return SESSD_EINVAL;
   const bool dense = dense_out != nullptr;
   if (dense && (!out_indices || !dense_dims3)) return SESSD_EINVAL;
   if (!dense && !out_feat) return SESSD_EINVAL;
 #define SESSD_SC(CI, CO)                                                                                              \
   if (cin == CI && cout == CO)                                                                                        \
-    return launch<CI, CO>(cout_split, dense, in_feat, nbr, tile_mask, kernel_volume, n_out_dev, n_out_cap, packed_weight, scale,  \
+    return launch<CI, CO>(tuning, dense, in_feat, nbr, tile_mask, kernel_volume, n_out_dev, n_out_cap, packed_weight, scale,  \
                           shift, relu, out_feat, out_indices, dense_out, dense_dims3, stream);
   SESSD_SC(4, 16)
   SESSD_SC(16, 16)

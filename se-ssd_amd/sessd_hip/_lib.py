@@ -49,7 +49,6 @@ SIGNATURES = {
     "sessd_sparse_renumber_workspace_bytes": (sz, [i32, vp]),
     "sessd_sparse_renumber_sites": (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, u32, vp, vp, vp, sz, vp]),
     "sessd_points_in_bodies": (i32, [vp, i32, i32, vp, i32, i32, vp, vp]),
-    "sessd_sparse_conv_deep": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
     "sessd_bn_relu_train_workspace_bytes": (sz, [i32]),
     "sessd_bn_relu_train_fwd": (i32, [vp, vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_bn_relu_train_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),

@@ -98,12 +98,11 @@ class DensePlan:
 class InferenceEngine:
     def __init__(self, model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, batch_size=1,
                  max_points_per_frame=32768, device=None, growth=(1.5, 1.0, 0.75, 0.75), anchors=None,
-                 use_frustum=False, allow_winograd=True, sort_sites=False, deep_sparse=False):
+                 use_frustum=False, allow_winograd=True, sort_sites=False):
         """growth[i]: capacity of sparse level i+1 relative to level i (observed ratios on KITTI-like scans are
         ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results().
         sort_sites (EXPERIMENTAL, not yet validated on hardware): renumber the voxels by grid row between the voxelizer and
-        the first sparse conv (sessd_sparse_renumber_sites); results do not depend on it.
-        deep_sparse (EXPERIMENTAL, same status): sparse convs through sessd_sparse_conv_deep (bit-identical results)."""
+        the first sparse conv (sessd_sparse_renumber_sites); results do not depend on it."""
         self.dev = torch.device("cuda:0") if device is None else device
         dev = self.dev
         self.B = int(batch_size)
@@ -216,7 +215,6 @@ class InferenceEngine:
         self.pred_ws = torch.empty(int(lib.sessd_predict_workspace_bytes(B, 2 * H * W, self.pre_max, self.post_max)),
                                    dtype=torch.uint8, device=dev)
         self.sort_sites = bool(sort_sites)
-        self._sparse_conv_fn = lib.sessd_sparse_conv_deep if deep_sparse else lib.sessd_sparse_conv
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
             self.levels[0]["indices"] = self.coors_s
@@ -272,7 +270,7 @@ class InferenceEngine:
         kv = lay["ks"][0] * lay["ks"][1] * lay["ks"][2]
         # nbr buffers are allocated [27][cap]; a (3,1,1) kernel uses the first 3 rows
         dd = self._i3(Lo["shape"]).data_ptr() if dense else 0
-        check(self._sparse_conv_fn(in_feat.data_ptr(), lay["cin"], nbr.data_ptr(), tm.data_ptr(), kv, self._n(out_li),
+        check(lib.sessd_sparse_conv(in_feat.data_ptr(), lay["cin"], nbr.data_ptr(), tm.data_ptr(), kv, self._n(out_li),
                                     Lo["cap"], lay["wpk"].data_ptr(), lay["scale"].data_ptr(), lay["shift"].data_ptr(), 1,
                                     0 if dense else out_feat.data_ptr(), lay["cout"],
                                     Lo["indices"].data_ptr() if dense else 0, self.bev.data_ptr() if dense else 0, dd,
@@ -296,24 +294,24 @@ class InferenceEngine:
         todo_sp, self._tuning_sparse = self._tuning_sparse, None
         st = torch.cuda.current_stream().cuda_stream
         for idx, lay, in_feat, nbr, tm, out_li, out_feat in todo_sp:
-            if lay["cout"] < 32:
-                continue
+            # sparse_split[idx] = cout_split + 256 * depth (sessd_sparse_conv's `tuning`; results do not depend on it)
             best = (None, 1e30)
             for split in (1, 2, 4):
                 if (lay["cout"] // 16) % split:
                     continue
-                self.sparse_split[idx] = split
-                for _ in range(2):
-                    self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, idx=idx)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(reps):
-                    self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, idx=idx)
-                e1.record()
-                torch.cuda.synchronize()
-                t = e0.elapsed_time(e1) / reps
-                if t < best[1]:
-                    best = (split, t)
+                for depth in (2, 3, 4):
+                    self.sparse_split[idx] = split + 256 * depth
+                    for _ in range(2):
+                        self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, idx=idx)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(reps):
+                        self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, idx=idx)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    t = e0.elapsed_time(e1) / reps
+                    if t < best[1]:
+                        best = (split + 256 * depth, t)
             self.sparse_split[idx] = best[0]
             self.tune_report["sparse%d" % idx] = best
         for name, x, layer, out, relu, residual in todo:

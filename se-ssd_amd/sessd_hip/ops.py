@@ -240,8 +240,9 @@ def sparse_pack_weight(weight):
 
 
 def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, scale=None, shift=None, relu=True,
-                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, deep=False):
-    """deep=True (EXPERIMENTAL, not yet validated on hardware): the four-deep operand ring of sparse_conv_deep.hip."""
+                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0):
+    """cout_split (0 heuristic | 1, 2, 4) and depth (0 default | 2..4 operand sets in flight) only tune the launch: results are
+    bit-identical for every choice."""
     _req(in_feat, torch.float32, "in_feat")
     kv, cap = nbr.shape
     dd = None
@@ -250,10 +251,9 @@ def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, sc
             out = torch.empty((cap, cout), dtype=torch.float32, device=in_feat.device)
     else:
         dd = _i3(dense_dims)
-    fn = lib.sessd_sparse_conv_deep if deep else lib.sessd_sparse_conv
-    check(fn(in_feat.data_ptr(), cin, nbr.data_ptr(), tile_mask.data_ptr(), kv, n_out_dev.data_ptr(),
+    check(lib.sessd_sparse_conv(in_feat.data_ptr(), cin, nbr.data_ptr(), tile_mask.data_ptr(), kv, n_out_dev.data_ptr(),
                                 cap, packed_weight.data_ptr(), _p(scale), _p(shift), 1 if relu else 0, _p(out), cout,
-                                _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), int(cout_split),
+                                _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), int(cout_split) + 256 * int(depth),
                                 _stream()),
           "sparse_conv")
     return out if dense_out is None else dense_out

@@ -112,3 +112,48 @@ def test_empty_input(dev):
     out = ops.sparse_conv(torch.zeros(cap, 16, device=dev), nbr, tm, n_out,
                           ops.sparse_pack_weight(torch.zeros(3, 3, 3, 16, 32, device=dev)), 16, 32)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("cin,cout", [(4, 16), (16, 16), (16, 32), (32, 32), (32, 64), (64, 64)])
+@pytest.mark.parametrize("n,cap", [(1500, 2048), (1501, 1501), (7, 64), (16, 16)])
+def test_every_tuning_is_bit_identical(dev, cin, cout, n, cap):
+    """cout split x operand depth only tune the launch (sparse_conv.hip): every combination must give the SAME bits
+    (fixed (offset, cin) accumulation order), incl. partial last tiles, tiny levels, strided rulebooks and the dense output."""
+    rng = np.random.RandomState(cin + cout + n)
+    B, shape = 2, [9, 24, 20]
+    idx = _random_sites(rng, B, shape, n)
+    d_idx = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    d_idx[:n] = torch.from_numpy(idx).to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    feat = torch.zeros((cap, cin), device=dev)
+    feat[:n] = torch.randn(n, cin, generator=torch.Generator().manual_seed(1)).to(dev)
+    w = (torch.randn(3, 3, 3, cin, cout, generator=torch.Generator().manual_seed(2)) * 0.2).to(dev)
+    wpk = ops.sparse_pack_weight(w)
+    scale, shift = (torch.rand(cout) + 0.5).to(dev), (torch.randn(cout) * 0.1).to(dev)
+    h = ops.sparse_hash_build(d_idx, n_dev, shape)
+    nbr, tm = ops.sparse_rulebook(d_idx, n_dev, 3, 1, 1, h)
+    ref = ops.sparse_conv(feat, nbr, tm, n_dev, wpk, cin, cout, scale, shift, True, cout_split=1, depth=2).clone()
+    assert float(ref[:n].abs().max()) > 0
+    want, _, _, _ = osc.sparse_conv(feat[:n].cpu(), idx, shape, w.cpu(), 3, 1, 0, True)
+    want = torch.relu(want * scale.cpu() + shift.cpu())
+    assert float((ref[:n].cpu() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    out_idx, n_out, out_hash, err = ops.sparse_downsample_sites(d_idx, n_dev, 3, 2, 1, [5, 12, 10], 4096)
+    nbr2, tm2 = ops.sparse_rulebook(out_idx, n_out, 3, 2, 1, h)
+    m = int(n_out.item())
+    ref2 = ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, False, cout_split=1, depth=2).clone()
+    dref = torch.zeros((B, cout * 5, 12, 10), device=dev)
+    ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, True, dense_out=dref, out_indices=out_idx,
+                    dense_dims=[5, 12, 10], cout_split=1, depth=2)
+    assert m > 0 and float(dref.abs().max()) > 0
+    for split in (0, 1, 2, 4):
+        if split > 1 and (cout // 16) % split:
+            continue
+        for depth in (0, 2, 3, 4):
+            a = ops.sparse_conv(feat, nbr, tm, n_dev, wpk, cin, cout, scale, shift, True, cout_split=split, depth=depth)
+            assert torch.equal(a[:n], ref[:n]), (cin, cout, split, depth)
+            b = ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, False, cout_split=split, depth=depth)
+            assert torch.equal(b[:m], ref2[:m]), (cin, cout, split, depth)
+            d = torch.zeros_like(dref)
+            ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, True, dense_out=d, out_indices=out_idx,
+                            dense_dims=[5, 12, 10], cout_split=split, depth=depth)
+            assert torch.equal(d, dref), (cin, cout, split, depth)
