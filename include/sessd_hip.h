@@ -15,6 +15,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "sessd_hip_types.h"
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -115,6 +117,25 @@ int sessd_sparse_downsample_sites_unordered(const int32_t* in_indices, const int
                                             const int32_t* out_dims3, uint32_t* out_keys, int32_t* out_vals,
                                             uint32_t out_capacity, int32_t* out_indices, int n_out_cap,
                                             int32_t* n_out_dev, int32_t* err_flag, sessd_stream_t stream);
+/* ---- the whole strided chain at once (csrc/sparse_sites.hip) ---------------------------------------------------------
+ * replaces the per-layer spconv.ops.get_indice_pairs calls behind det3d/models/backbones/scn.py:106-148 (four SparseConv3d,
+ * four SubMConv3d groups): the site sets of ALL levels follow from the level-0 sites alone, so three launches (mark the
+ * reachable cells of every level in per-level occupancy bit maps; popcount per block; prefix scan + site table) give every
+ * level's rows, numbered in ascending (b,z,y,x) order (deterministic; 16 consecutive rows are spatial neighbours), and ONE
+ * more launch builds every neighbour table of the chain. `workspace` holds the occupancy maps (rank-annotated after the
+ * call; sessd_sparse_chain_rulebooks reads them); clear != 0: the call zeroes it, clear == 0: the caller did (one arena
+ * fill per frame). err_flag |= 1 when a level has more active cells than `cap` (rows beyond cap are dropped, as absent). */
+size_t sessd_sparse_chain_workspace_bytes(int batch, int n_levels, const sessd_chain_level_t* levels);
+int sessd_sparse_chain_sites(const int32_t* indices0, const int32_t* n0_dev, int n0_cap, int batch, int n_levels,
+                             const sessd_chain_level_t* levels, void* workspace, size_t workspace_bytes, int clear,
+                             int32_t* err_flag, sessd_stream_t stream);
+/* level 0 is looked up through its hash (keys0 / vals0 / capacity0, key dims dims0 = (D,H,W) as built by the voxelizer or
+ * sessd_sparse_hash_build); deeper levels through the occupancy maps in `workspace`. Same nbr / tile_mask layout as
+ * sessd_sparse_rulebook. */
+int sessd_sparse_chain_rulebooks(const int32_t* indices0, const int32_t* n0_dev, int n0_cap, const uint32_t* keys0,
+                                 const int32_t* vals0, uint32_t capacity0, const int32_t* dims0, int batch, int n_levels,
+                                 const sessd_chain_level_t* levels, const void* workspace, int n_jobs,
+                                 const sessd_rulebook_job_t* jobs, sessd_stream_t stream);
 /* weight (kernel_volume, cin, cout) row-major == spconv's [kz,ky,kx,Cin,Cout] flattened -> MFMA fragment order */
 int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, int cout, float* packed,
                              sessd_stream_t stream);

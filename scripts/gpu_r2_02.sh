@@ -4,7 +4,7 @@ set -u
 R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out
 cd $R
-timeout -k 5 500 python -m pytest tests/test_sparse_conv_gpu.py tests/test_sparse_grad_gpu.py tests/test_pipeline_gpu.py -q -x --timeout 200 > gpurun_out/r2_02_tests.log 2>&1
+timeout -k 5 500 python -m pytest tests/test_sparse_sites_gpu.py tests/test_sparse_conv_gpu.py tests/test_site_renumber_gpu.py tests/test_pipeline_gpu.py -q -x --timeout 200 > gpurun_out/r2_02_tests.log 2>&1
 echo "tests exit $?"; tail -5 gpurun_out/r2_02_tests.log
 cd /tmp && export TMPDIR=/tmp
 for cfg in b1 stress; do

@@ -35,7 +35,7 @@ def build(verbose=True, force=False):
     os.makedirs(OBJDIR, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")]
-    hdrs += [os.path.join(os.path.dirname(HERE), "include", "sessd_hip.h")]
+    hdrs += [os.path.join(os.path.dirname(HERE), "include", h) for h in ("sessd_hip.h", "sessd_hip_types.h")]
     hdrs = [h for h in hdrs if os.path.exists(h)]
     jobs = []
     objs = []

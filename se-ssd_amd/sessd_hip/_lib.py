@@ -11,6 +11,20 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsessd_hip.so")
 
 vp, i32, u32, f32, sz, i64, f64 = C.c_void_p, C.c_int, C.c_uint32, C.c_float, C.c_size_t, C.c_longlong, C.c_double
 
+
+
+class ChainLevel(C.Structure):
+    """sessd_chain_level_t (include/sessd_hip_types.h)"""
+    _fields_ = [("ksize", i32 * 3), ("stride", i32 * 3), ("pad", i32 * 3), ("out_dims", i32 * 3), ("cap", i32),
+                ("indices", vp), ("n_dev", vp)]
+
+
+class RulebookJob(C.Structure):
+    """sessd_rulebook_job_t (include/sessd_hip_types.h)"""
+    _fields_ = [("in_level", i32), ("out_level", i32), ("ksize", i32 * 3), ("stride", i32 * 3), ("pad", i32 * 3),
+                ("nbr", vp), ("tile_mask", vp)]
+
+
 # name -> (restype, argtypes). Kept in step with include/sessd_hip.h (tests/test_abi.py checks it).
 SIGNATURES = {
     "sessd_version": (C.c_char_p, []),
@@ -44,6 +58,9 @@ SIGNATURES = {
     "sessd_sparse_rulebook": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
     "sessd_sparse_rulebook_pair": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
     "sessd_sparse_downsample_sites_unordered": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, u32, vp, i32, vp, vp, vp]),
+    "sessd_sparse_chain_workspace_bytes": (sz, [i32, i32, vp]),
+    "sessd_sparse_chain_sites": (i32, [vp, vp, i32, i32, i32, vp, vp, sz, i32, vp, vp]),
+    "sessd_sparse_chain_rulebooks": (i32, [vp, vp, i32, vp, vp, u32, vp, i32, i32, vp, vp, i32, vp, vp]),
     "sessd_sparse_pack_weight": (i32, [vp, i32, i32, i32, vp, vp]),
     "sessd_sparse_conv": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
     "sessd_sparse_renumber_workspace_bytes": (sz, [i32, vp]),

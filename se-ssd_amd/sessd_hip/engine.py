@@ -156,12 +156,30 @@ class InferenceEngine:
         self.coors = E(cap0, 4, dt=i32)
         self.nump = E(cap0, dt=i32)
         self.vfeat = E(cap0, 4)
-        # control words cleared to 0 by ONE fill per frame: prefix[B+1] | err
-        nlv = len(self.levels)
-        self.ctrl = torch.zeros((B + 2 + nlv,), dtype=i32, device=dev)
+        # ---- sites and rulebooks of the whole strided chain (csrc/sparse_sites.hip): levels 1.. numbered in (b,z,y,x) order
+        steps = [(lay[3], lay[4], lay[5]) for lay in SPMIDDLE_LAYERS if lay[0] == "conv"]
+        jobs, li = [], 0
+        self._job_of = {}  # layer index -> job index
+        for idx, (kind, cin, cout, ks, st, pd, key) in enumerate(SPMIDDLE_LAYERS):
+            if kind == "subm":
+                if ("subm", li) not in self._job_of:
+                    self._job_of[("subm", li)] = len(jobs)
+                    jobs.append((li, li, ks, 1, [k // 2 for k in _t3(ks)]))
+                self._job_of[idx] = self._job_of[("subm", li)]
+            else:
+                self._job_of[idx] = len(jobs)
+                jobs.append((li, li + 1, ks, st, pd))
+                li += 1
+        chain_bytes = ops.SparseChain.workspace_bytes(self.sparse_shape, steps, [L["cap"] for L in self.levels[1:]], B)
+        # control words + the chain's occupancy maps, cleared to 0 by ONE fill per frame: prefix[B+1] | err | maps
+        n_ctrl = (B + 2 + 63) // 64 * 64
+        self.zero_arena = torch.zeros((n_ctrl + (chain_bytes + 3) // 4,), dtype=i32, device=dev)
+        self.ctrl = self.zero_arena[:n_ctrl]
         self.prefix = self.ctrl[:B + 1]
         self.err = self.ctrl[B + 1:B + 2]
-        self._lvl_n = [self.ctrl[B + 2 + i:B + 3 + i] for i in range(nlv)]  # atomic row counters of levels 1..
+        self.chain = ops.SparseChain(self.sparse_shape, steps, [L["cap"] for L in self.levels[1:]], B, jobs, dev,
+                                     workspace_tensor=self.zero_arena[n_ctrl:].view(torch.uint8))
+        self.chain.bind_tables(cap0)
         # ---- one contiguous arena for everything that must read 0x7F7F7F7F at the start of a frame (hash tables,
         # per-cell point lists, first-touch words): cleared by ONE fill instead of ~17 small ones
         cap0h = int(lib.sessd_hash_capacity(self.P_cap * B))
@@ -175,32 +193,19 @@ class InferenceEngine:
             return (o, int(nbytes))
 
         p_k0, p_v0, p_vox = take(cap0h * 4), take(cap0h * 4), take(vox_bytes)
-        lvl_parts = []
-        for li in range(1, len(self.levels)):
-            hc = int(lib.sessd_hash_capacity(self.levels[li]["cap"]))
-            wsb = int(lib.sessd_sparse_downsample_workspace_bytes(self.levels[li - 1]["cap"], 27, hc))
-            lvl_parts.append((hc, take(hc * 4), take(hc * 4), take(wsb)))
         self.arena = torch.empty(off, dtype=torch.uint8, device=dev)
         view_i32 = lambda pr: self.arena[pr[0]:pr[0] + pr[1]].view(torch.int32)
         self.hash0 = ops.VoxelHash(self.P_cap * B, dev, view_i32(p_k0), view_i32(p_v0))
         self.vox_ws = self.arena[p_vox[0]:p_vox[0] + p_vox[1]]
         for li, L in enumerate(self.levels):
             c = L["cap"]
-            L["nbr_subm"] = E(27, c, dt=i32)
-            L["tm_subm"] = E((c + 15) // 16, dt=i32)
             L["feat_a"] = E(c, 64)
             L["feat_b"] = E(c, 64)
             if li == 0:
                 L["indices"], L["n"] = self.coors, None  # n = prefix[B]
                 L["hash"] = ops.SiteHash(self.hash0.capacity, L["hash_dims"], dev, self.hash0.keys, self.hash0.vals)
             else:
-                hc, pk, pv, pw = lvl_parts[li - 1]
-                L["indices"] = E(c, 4, dt=i32)
-                L["n"] = self._lvl_n[li]
-                L["hash"] = ops.SiteHash(hc, L["hash_dims"], dev, view_i32(pk), view_i32(pv))
-                L["down_ws"] = self.arena[pw[0]:pw[0] + pw[1]]
-                L["nbr_down"] = E(27, c, dt=i32)
-                L["tm_down"] = E((c + 15) // 16, dt=i32)
+                L["indices"], L["n"] = self.chain.indices[li - 1], self.chain.n_dev[li - 1]
         self.bev = torch.zeros((B, self.bev_c, H, W), dtype=f32, device=dev)
         self.t = {k: E(B, 128, H, W) for k in ("a", "b", "x0", "tr0", "mid0", "mid1", "o0", "o1", "out")}
         self.h = {k: E(B, 256, H // 2, W // 2) for k in ("a", "b", "x1", "tr1")}
@@ -258,17 +263,9 @@ class InferenceEngine:
         L = self.levels[li]
         return self.prefix.data_ptr() + 4 * self.B if li == 0 else L["n"].data_ptr()
 
-    def _rulebook(self, out_li, ks, st, pd, in_li, nbr, tm, s):
-        Lo, Li = self.levels[out_li], self.levels[in_li]
-        check(lib.sessd_sparse_rulebook(Lo["indices"].data_ptr(), self._n(out_li), Lo["cap"], self._i3(ks).data_ptr(),
-                                        self._i3(st).data_ptr(), self._i3(pd).data_ptr(), Li["hash"].keys.data_ptr(),
-                                        Li["hash"].vals.data_ptr(), Li["hash"].capacity, Li["hash"]._dims_t.data_ptr(),
-                                        nbr.data_ptr(), tm.data_ptr(), s), "sparse_rulebook")
-
     def _sconv(self, lay, in_feat, nbr, tm, out_li, out_feat, s, dense=False, idx=None):
         Lo = self.levels[out_li]
         kv = lay["ks"][0] * lay["ks"][1] * lay["ks"][2]
-        # nbr buffers are allocated [27][cap]; a (3,1,1) kernel uses the first 3 rows
         dd = self._i3(Lo["shape"]).data_ptr() if dense else 0
         check(lib.sessd_sparse_conv(in_feat.data_ptr(), lay["cin"], nbr.data_ptr(), tm.data_ptr(), kv, self._n(out_li),
                                     Lo["cap"], lay["wpk"].data_ptr(), lay["scale"].data_ptr(), lay["shift"].data_ptr(), 1,
@@ -352,7 +349,7 @@ class InferenceEngine:
         s = torch.cuda.current_stream().cuda_stream
         B = self.B
         # ---- voxelize (a1-a3)
-        check(lib.sessd_fill_u32(self.ctrl.data_ptr(), 0, self.ctrl.numel(), s), "fill")
+        check(lib.sessd_fill_u32(self.zero_arena.data_ptr(), 0, self.zero_arena.numel(), s), "fill")
         check(lib.sessd_fill_u32(self.arena.data_ptr(), 0x7F7F7F7F, self.arena.numel() // 4, s), "fill")
         lib.sessd_set_external_clear(1)  # the arena fill above replaces the per-call scratch clears
         try:
@@ -378,51 +375,29 @@ class InferenceEngine:
                                                   self.renum_ws.numel(), s), "sparse_renumber_sites")
             feat = self.vfeat_s
         self._mark("voxelize")
-        # ---- SpMiddleFHD (a4-a8)
+        # ---- SpMiddleFHD (a4-a8): every level's sites and every rulebook first (4 launches), then the 14 convolutions
+        L0 = self.levels[0]
+        self.chain.run(L0["indices"], self._n(0), L0["cap"], L0["hash"], self.err, clear=False, stream=s)
         li = 0
-        have_subm = False
         n_layers = len(self.sp.layers)
         for idx, lay in enumerate(self.sp.layers):
             last = idx == n_layers - 1
+            j = self._job_of[idx]
+            nbr, tm = self.chain.nbr[j], self.chain.tile_mask[j]
             if lay["kind"] == "subm":
                 L = self.levels[li]
-                if not have_subm:
-                    self._rulebook(li, lay["ks"], 1, [k // 2 for k in lay["ks"]], li, L["nbr_subm"], L["tm_subm"], s)
-                    have_subm = True
                 out = L["feat_a"] if feat is not L["feat_a"] else L["feat_b"]
-                self._sconv(lay, feat, L["nbr_subm"], L["tm_subm"], li, out, s, idx=idx)
+                self._sconv(lay, feat, nbr, tm, li, out, s, idx=idx)
                 feat = out
             else:
-                Li, Lo = self.levels[li], self.levels[li + 1]
-                # output sites in ONE launch (atomic row numbering; hash / counter pre-cleared by the arena + ctrl fills)
-                check(lib.sessd_sparse_downsample_sites_unordered(
-                    Li["indices"].data_ptr(), self._n(li), Li["cap"], self._i3(lay["ks"]).data_ptr(),
-                    self._i3(lay["st"]).data_ptr(), self._i3(lay["pd"]).data_ptr(), self._i3(Lo["shape"]).data_ptr(),
-                    Lo["hash"].keys.data_ptr(), Lo["hash"].vals.data_ptr(), Lo["hash"].capacity, Lo["indices"].data_ptr(),
-                    Lo["cap"], Lo["n"].data_ptr(), self.err.data_ptr(), s), "sparse_downsample_sites_unordered")
-                nxt = self.sp.layers[idx + 1] if idx + 1 < n_layers else None
-                if nxt is not None and nxt["kind"] == "subm":
-                    # rulebook of this strided conv AND of the submanifold convs on the new level: one launch
-                    Hi, Ho = Li["hash"], Lo["hash"]
-                    check(lib.sessd_sparse_rulebook_pair(
-                        Lo["indices"].data_ptr(), self._n(li + 1), Lo["cap"], self._i3(lay["ks"]).data_ptr(),
-                        self._i3(lay["st"]).data_ptr(), self._i3(lay["pd"]).data_ptr(), Hi.keys.data_ptr(), Hi.vals.data_ptr(),
-                        Hi.capacity, Hi._dims_t.data_ptr(), Lo["nbr_down"].data_ptr(), Lo["tm_down"].data_ptr(),
-                        self._i3(nxt["ks"]).data_ptr(), self._i3(1).data_ptr(), self._i3([k // 2 for k in nxt["ks"]]).data_ptr(),
-                        Ho.keys.data_ptr(), Ho.vals.data_ptr(), Ho.capacity, Ho._dims_t.data_ptr(), Lo["nbr_subm"].data_ptr(),
-                        Lo["tm_subm"].data_ptr(), s), "sparse_rulebook_pair")
-                    subm_ready = True
-                else:
-                    self._rulebook(li + 1, lay["ks"], lay["st"], lay["pd"], li, Lo["nbr_down"], Lo["tm_down"], s)
-                    subm_ready = False
+                Lo = self.levels[li + 1]
                 if last:
                     check(lib.sessd_fill_u32(self.bev.data_ptr(), 0, self.bev.numel(), s), "fill")
-                    self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, None, s, dense=True, idx=idx)
+                    self._sconv(lay, feat, nbr, tm, li + 1, None, s, dense=True, idx=idx)
                 else:
-                    self._sconv(lay, feat, Lo["nbr_down"], Lo["tm_down"], li + 1, Lo["feat_a"], s, idx=idx)
+                    self._sconv(lay, feat, nbr, tm, li + 1, Lo["feat_a"], s, idx=idx)
                     feat = Lo["feat_a"]
                 li += 1
-                have_subm = subm_ready
         self._mark("spmiddle")
         # ---- SSFA (a9) rpn_v1.py:220-235
         t, h, d = self.t, self.h, self.dn

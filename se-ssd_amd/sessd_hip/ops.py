@@ -227,6 +227,88 @@ def sparse_rulebook(out_indices, n_out_dev, ksize, stride, pad, in_hash):
     return nbr, tmask
 
 
+class SparseChain:
+    """Sites and rulebooks of a chain of strided sparse convs in four launches (csrc/sparse_sites.hip).
+
+    steps: list of (ksize, stride, pad) of the SparseConv3d layers, level l-1 -> level l; shape0: spatial shape of level 0;
+    caps: row capacity per deeper level. jobs: list of (in_level, out_level, ksize, stride, pad) neighbour tables to build.
+    Buffers are allocated once; `run()` enqueues on the current stream (no synchronisation, no allocation)."""
+
+    def __init__(self, shape0, steps, caps, batch, jobs, device, workspace_tensor=None):
+        from ._lib import ChainLevel, RulebookJob
+        self.batch, self.dev = int(batch), device
+        self.shapes = [[int(v) for v in shape0]]
+        self.levels = (ChainLevel * len(steps))()
+        self.indices, self.n_dev, self.caps = [], [], [int(c) for c in caps]
+        counters = torch.zeros((len(steps),), dtype=torch.int32, device=device)
+        for l, ((ks, st, pd), cap) in enumerate(zip(steps, caps)):
+            ks, st, pd = _t3(ks), _t3(st), _t3(pd)
+            shp = [(d + 2 * p - k) // s + 1 for d, k, s, p in zip(self.shapes[-1], ks, st, pd)]
+            self.shapes.append(shp)
+            idx = torch.empty((int(cap), 4), dtype=torch.int32, device=device)
+            self.indices.append(idx)
+            self.n_dev.append(counters[l:l + 1])
+            L = self.levels[l]
+            for d in range(3):
+                L.ksize[d], L.stride[d], L.pad[d], L.out_dims[d] = ks[d], st[d], pd[d], shp[d]
+            L.cap, L.indices, L.n_dev = int(cap), idx.data_ptr(), self.n_dev[l].data_ptr()
+        self.ws_bytes = int(lib.sessd_sparse_chain_workspace_bytes(self.batch, len(steps), self.levels))
+        if self.ws_bytes == 0:
+            raise ValueError("invalid sparse chain (kernel < stride, empty level or more than 2^31 cells)")
+        self.ws = workspace_tensor if workspace_tensor is not None else torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        assert self.ws.numel() >= self.ws_bytes
+        self.jobs = (RulebookJob * len(jobs))()
+        self.nbr, self.tile_mask = [], []
+        for j, (li, lo, ks, st, pd) in enumerate(jobs):
+            ks, st, pd = _t3(ks), _t3(st), _t3(pd)
+            cap = None if lo == 0 else self.caps[lo - 1]
+            self.nbr.append(None)
+            self.tile_mask.append(None)
+            J = self.jobs[j]
+            J.in_level, J.out_level = int(li), int(lo)
+            for d in range(3):
+                J.ksize[d], J.stride[d], J.pad[d] = ks[d], st[d], pd[d]
+        self._job_spec = [(int(li), int(lo), _t3(ks)) for (li, lo, ks, st, pd) in jobs]
+
+    @staticmethod
+    def workspace_bytes(shape0, steps, caps, batch):
+        from ._lib import ChainLevel
+        lv = (ChainLevel * len(steps))()
+        shp = [int(v) for v in shape0]
+        for l, ((ks, st, pd), cap) in enumerate(zip(steps, caps)):
+            ks, st, pd = _t3(ks), _t3(st), _t3(pd)
+            shp = [(d + 2 * p - k) // s + 1 for d, k, s, p in zip(shp, ks, st, pd)]
+            for d in range(3):
+                lv[l].ksize[d], lv[l].stride[d], lv[l].pad[d], lv[l].out_dims[d] = ks[d], st[d], pd[d], shp[d]
+            lv[l].cap = int(cap)
+        return int(lib.sessd_sparse_chain_workspace_bytes(int(batch), len(steps), lv))
+
+    def bind_tables(self, n0_cap):
+        """allocate nbr / tile_mask of every job (level-0 capacity is only known to the caller)"""
+        for j, (li, lo, ks) in enumerate(self._job_spec):
+            cap = int(n0_cap) if lo == 0 else self.caps[lo - 1]
+            kv = ks[0] * ks[1] * ks[2]
+            self.nbr[j] = torch.empty((kv, cap), dtype=torch.int32, device=self.dev)
+            self.tile_mask[j] = torch.empty(((cap + 15) // 16,), dtype=torch.int32, device=self.dev)
+            self.jobs[j].nbr, self.jobs[j].tile_mask = self.nbr[j].data_ptr(), self.tile_mask[j].data_ptr()
+
+    def run(self, indices0, n0_dev_ptr, n0_cap, hash0, err_flag, clear=True, stream=None):
+        s = _stream() if stream is None else stream
+        if self.nbr and self.nbr[0] is None:
+            self.bind_tables(n0_cap)
+        check(lib.sessd_sparse_chain_sites(indices0.data_ptr(), n0_dev_ptr, int(n0_cap), self.batch, len(self.levels),
+                                           self.levels, self.ws.data_ptr(), self.ws.numel(), 1 if clear else 0,
+                                           err_flag.data_ptr(), s), "sparse_chain_sites")
+        check(lib.sessd_sparse_chain_rulebooks(indices0.data_ptr(), n0_dev_ptr, int(n0_cap), hash0.keys.data_ptr(),
+                                               hash0.vals.data_ptr(), hash0.capacity, hash0._dims_t.data_ptr(), self.batch,
+                                               len(self.levels), self.levels, self.ws.data_ptr(), len(self.jobs), self.jobs,
+                                               s), "sparse_chain_rulebooks")
+
+
+def _t3(v):
+    return [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
+
+
 def sparse_pack_weight(weight):
     """weight (kz,ky,kx,Cin,Cout) (spconv v1 layout) on the device -> packed MFMA-fragment order."""
     w = weight.detach().to(torch.float32).contiguous()

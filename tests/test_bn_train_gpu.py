@@ -1,8 +1,6 @@
 """sessd_bn_relu_train_fwd / _bwd (train-mode BatchNorm1d + ReLU over a sparse feature table, csrc/bn_train.hip) vs
 torch.nn.BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU on the same rows: output, running statistics, and the gradients with
-respect to the input, weight and bias. Tolerances: 2e-5 on values of O(1) (float32, different reduction order).
-
-EXPERIMENTAL: written after round 1's GPU budget was spent, not yet run on hardware -> runs only with SESSD_EXPERIMENTAL=1."""
+respect to the input, weight and bias. Tolerances: 2e-5 on values of O(1) (float32, different reduction order)."""
 import os
 
 import pytest
@@ -10,8 +8,7 @@ import torch
 
 from sessd_hip import ops
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SESSD_EXPERIMENTAL") != "1",
-                                                  reason="not yet validated on hardware; set SESSD_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("C", [4, 16, 32, 64, 128])

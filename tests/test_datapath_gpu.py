@@ -1,7 +1,4 @@
 """sessd_points_in_bodies (device membership test of the training data path).
-
-EXPERIMENTAL: written after round 1's GPU budget was spent, not yet run on hardware -> runs only with SESSD_EXPERIMENTAL=1
-(    SESSD_EXPERIMENTAL=1 python -m pytest tests/test_datapath_gpu.py -x -q ).
 The masks must be IDENTICAL to the reference's numba loop: golden A_in_rbbox of tests/golden/datapath_ref.npz (the reference run
 from source) and the host mirror on boxes, pyramids and a body count that needs more than one mask word."""
 import os
@@ -13,8 +10,7 @@ import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SESSD_EXPERIMENTAL") != "1",
-                                                  reason="not yet validated on hardware; set SESSD_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
 
 
 def _planes(surfaces):

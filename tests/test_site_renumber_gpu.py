@@ -1,10 +1,8 @@
-"""sessd_sparse_renumber_sites (engine-internal grid-row numbering of the voxels).
+"""sessd_sparse_renumber_sites (engine-internal grid-row numbering of the voxels, optional: `InferenceEngine(sort_sites=True)`).
 
-EXPERIMENTAL: the kernels were written after round 1's GPU budget was spent and have not run on hardware yet, so this file only
-runs with SESSD_EXPERIMENTAL=1 (first thing to do on the next GPU box:
-    SESSD_EXPERIMENTAL=1 python -m pytest tests/test_site_renumber_gpu.py -x -q ).
 What must hold: the output is a permutation of the input sites with their features, rows are ordered by (batch, z, y), the
-level's hash points at the new rows, and the whole engine produces bit-identical detections and BEV map with the option on."""
+level's hash points at the new rows, and the whole engine produces bit-identical detections and BEV map with the option on.
+(First run on hardware in round 2: green.)"""
 import os
 
 import numpy as np
@@ -13,8 +11,7 @@ import torch
 
 from sessd_hip import ops
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("SESSD_EXPERIMENTAL") != "1",
-                                                  reason="not yet validated on hardware; set SESSD_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
 
 
 def _sites(rng, B, shape, n):
