@@ -90,7 +90,7 @@ def main():
     from sessd_hip.engine import InferenceEngine
     VG = configs.VOXEL_GENERATOR
 
-    model = configs.build_synthetic_detector(dev, seed=0, max_voxels=args.max_voxels, num_points=args.points)
+    model = configs.build_synthetic_detector(dev, seed=0, max_voxels=args.max_voxels, num_points=args.points, supersample=args.supersample)
     engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], args.max_voxels,
                                configs.TEST_CFG, batch_size=args.batch, max_points_per_frame=args.points, device=dev)
                for _ in range(max(1, args.streams))]
@@ -117,6 +117,11 @@ def main():
         e.set_points(batch_of(0))
         e.enqueue()
     torch.cuda.synchronize()
+    # every frame leaves a fixed-size detection record on the device; the end-of-job gather of those records (ONE all_gather
+    # per tensor over RCCL when N > 1; tools/dist_test.py:150-186) is inside the timed region
+    per_engine = (args.warmup + args.steps + len(engines) - 1) // len(engines) * args.batch + args.batch
+    for e in engines:
+        e.attach_records(per_engine)
     if not args.eager:
         for e, st in zip(engines, streams):
             with torch.cuda.stream(st):
@@ -138,15 +143,26 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from sessd_hip import dist as sdist
     for i in range(args.warmup):
         step(i)
+    barrier()
+    for e in engines:
+        e.record_cursor.zero_()
     barrier()
     log("warmup done")
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    # end-of-job gather of this rank's records (per engine: frames i, i + streams, ...), still inside the timed region
+    gathered = []
+    for e, st in zip(engines, streams):
+        with torch.cuda.stream(st):
+            n_e = int(e.record_counts.shape[0])
+            gathered.append(sdist.gather_records(e.records, e.record_counts, n_e * world))
     barrier()
     dt = time.perf_counter() - t0
+    frames_gathered = sum(min(int(e.record_cursor.item()), int(g[0].shape[1])) for g, e in zip(gathered, engines)) * world
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -170,7 +186,10 @@ def main():
                        "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps * args.batch,
                        "frames_in_flight": len(engines),
                        "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
-                       "detections_last_frame": dets, "detections_first_frame": int(len(first["scores"]))},
+                       "detections_last_frame": dets, "detections_first_frame": int(len(first["scores"])),
+                       "records_gathered": frames_gathered,
+                       "gather": "one all_gather of fixed-size (frames, 100, 9) float32 records + counts per engine at the end "
+                                 "of the job, inside the timed region (RCCL when n_gpus > 1; a device-side no-op at n_gpus = 1)"},
         }
         # ---- roofline of the dominant kernel, measured live with events on the launching (current) stream
         if not args.no_roofline:

@@ -60,7 +60,9 @@ int sessd_vfe_mean(const float* voxels, const int32_t* num_points, const int32_t
 /* ------------------------------------------------------------------ iou3d_cuda operators (a15)
  * replace det3d/core/iou3d/src/iou3d.cpp:24-115 (boxes_overlap_bev_gpu, boxes_aligned_overlap_bev_gpu,
  * boxes_iou_bev_gpu, boxes_iou3d_gpu) and :117-262 (nms_gpu, nms_3d_gpu, nms_normal_gpu).
- * mode for pairwise: 0 overlap area (N,5)x(M,5) | 1 BEV IoU (N,5)x(M,5) | 2 3-D IoU (N,7)x(M,7).
+ * and the host twins :275-277 boxes_overlap_bev_cpu / boxes_iou_bev_cpu / boxes_iou3d_cpu (iou3d_cpu.cpp:270-336).
+ * mode for pairwise: 0 overlap area (N,5)x(M,5) | 1 BEV IoU (N,5)x(M,5) | 2 3-D IoU (N,7)x(M,7) |
+ * 3 3-D IoU with the host twin's convention (no early zero for disjoint z ranges: overlap * 1e-8, iou3d_cpu.cpp:322-333).
  * Boxes are [x1,y1,x2,y2,ry] or [x1,y1,z1,x2,y2,z2,ry]; out is (N,M) row-major float32.
  * NMS: boxes already sorted by descending score; keep (device int64[N]) and num_keep (device
  * int32) are produced ON THE DEVICE (the reference reduces the bitmask on the host). */
@@ -117,6 +119,14 @@ int sessd_sparse_downsample_sites_unordered(const int32_t* in_indices, const int
                                             const int32_t* out_dims3, uint32_t* out_keys, int32_t* out_vals,
                                             uint32_t out_capacity, int32_t* out_indices, int n_out_cap,
                                             int32_t* n_out_dev, int32_t* err_flag, sessd_stream_t stream);
+/* spconv.SparseConvTensor.dense() (scn.py:184) and its gradient: features (n, channels) at sites indices (n,4) [b,z,y,x]
+ * <-> dense (batch, channels, D, H, W) float32, dims3 = (D,H,W) on the host. sessd_sparse_to_dense writes only the site
+ * cells: the caller zeroes `dense` first. */
+int sessd_sparse_to_dense(const float* features, const int32_t* indices, int n, int channels, const int32_t* dims3,
+                          float* dense, sessd_stream_t stream);
+int sessd_dense_to_sparse(const float* dense, const int32_t* indices, int n, int channels, const int32_t* dims3,
+                          float* features, sessd_stream_t stream);
+
 /* ---- the whole strided chain at once (csrc/sparse_sites.hip) ---------------------------------------------------------
  * replaces the per-layer spconv.ops.get_indice_pairs calls behind det3d/models/backbones/scn.py:106-148 (four SparseConv3d,
  * four SubMConv3d groups): the site sets of ALL levels follow from the level-0 sites alone, so three launches (mark the
@@ -289,6 +299,18 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
                   const float* post_center_range6, float direction_offset, float* out_box, float* out_score,
                   int32_t* out_label, int32_t* out_count, void* workspace, size_t workspace_bytes,
                   sessd_stream_t stream);
+/* spconv.utils.rbbox_iou / rbbox_intersection (third-party spconv v1, imported by det3d/core/bbox/box_np_ops.py:9 for riou_cc /
+ * rinter_cc :20-50): pairwise IoU (mode 0) or intersection area (mode 1) of convex quads given as corners (n,4,2) x (k,4,2);
+ * pairs whose caller-supplied stand-up IoU is <= standup_thresh stay 0. standup_iou and out are (n,k) row-major. */
+int sessd_quads_pairwise(int mode, const float* corners_a, int n, const float* corners_b, int k, const float* standup_iou,
+                         float standup_thresh, float* out, sessd_stream_t stream);
+/* Detection records for the end-of-job gather (replaces the pickled per-rank dicts of tools/dist_test.py:150-186 /
+ * det3d/torchie/trainer/utils.py:115-155): appends the `batch` frames of sessd_predict's outputs to a device ring of
+ * fixed-size records (capacity_frames, post_max_size, 9) float32 [box 7 | score | label] + counts; slot = (*cursor + b) %
+ * capacity_frames, then *cursor += batch (device int, so the call can sit inside a captured graph). */
+int sessd_pack_detections(const float* out_box, const float* out_score, const int32_t* out_label, const int32_t* out_count,
+                          int batch, int post_max_size, float* records, int32_t* record_counts, int capacity_frames,
+                          int32_t* cursor, sessd_stream_t stream);
 /* box_torch_ops.rotate_nms after its topk: dets (N,5) [x,y,w,l,r] sorted by descending score -> keep int32[post] */
 size_t sessd_rotate_nms_workspace_bytes(int num_boxes);
 int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float iou_thresh, int post_max_size, int32_t* keep,

@@ -35,6 +35,8 @@ def lib():
         L.oracle_quad_iou.argtypes = [_f32p, _f32p]
         L.oracle_rotate_nms.restype = C.c_int
         L.oracle_rotate_nms.argtypes = [_f32p, C.c_int, _i32p, C.c_float, _i32p, C.c_double, _i32p]
+        L.oracle_rotate_nms_pairs.argtypes = [_f32p, C.c_int, _i32p, C.c_float, _i32p, C.c_double, _i32p, _i32p, C.c_int]
+        L.oracle_rotate_nms_forced.argtypes = [_f32p, C.c_int, _i32p, C.c_float, _i32p, C.c_double, _i32p, _i32p, C.c_int, _i32p, C.c_int]
         L.oracle_rotate_iou_eval.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _f32p]
         L.oracle_rotate_iou_pair.restype = C.c_float
         L.oracle_rotate_iou_pair.argtypes = [_f32p, _f32p, C.c_int]
@@ -148,8 +150,10 @@ def quad_iou(p, q):
     return lib().oracle_quad_iou(_f32(p).reshape(-1), _f32(q).reshape(-1))
 
 
-def rotate_nms_cc(dets, thresh, order=None, margin=1e-4):
-    """nms_cpu.py:40-51. dets (K,6) [x,y,w,l,r,score]. Returns (keep, n_near_threshold_pairs)."""
+def rotate_nms_cc(dets, thresh, order=None, margin=1e-4, return_pairs=False, forced=None):
+    """nms_cpu.py:40-51. dets (K,6) [x,y,w,l,r,score]. Returns (keep, n_near_threshold_pairs) and, with return_pairs, the
+    (n,2) array of (kept box, candidate) indices whose IoU lies within `margin` of the threshold. forced: (m,3) rows
+    (i, j, suppress) imposing the decision of pair (kept i, candidate j) (oracle/compare.py explores the marginal ones)."""
     dets = _f32(dets)
     K = dets.shape[0]
     if order is None:
@@ -158,6 +162,12 @@ def rotate_nms_cc(dets, thresh, order=None, margin=1e-4):
     order = np.ascontiguousarray(order, np.int32)
     keep = np.zeros((max(K, 1),), np.int32)
     near = np.zeros((1,), np.int32)
+    if return_pairs or forced is not None:
+        pairs = np.zeros((4096, 2), np.int32)
+        fz = np.ascontiguousarray(np.asarray(forced if forced is not None and len(forced) else np.zeros((0, 3)), np.int32).reshape(-1, 3))
+        n = lib().oracle_rotate_nms_forced(dets, K, order, float(thresh), keep, float(margin), near, pairs.reshape(-1), 4096,
+                                           fz.reshape(-1) if len(fz) else np.zeros((3,), np.int32), int(len(fz)))
+        return keep[:n].astype(np.int64), int(near[0]), pairs[:min(int(near[0]), 4096)].astype(np.int64)
     n = lib().oracle_rotate_nms(dets, K, order, float(thresh), keep, float(margin), near)
     return keep[:n].astype(np.int64), int(near[0])
 

@@ -1,0 +1,66 @@
+"""TEST INFRASTRUCTURE ONLY -- detection-level parity rule used by tests/ and __graft_entry__.smoke().
+
+The SE-SSD post-processor runs rotated NMS at an IoU threshold of 0.01 (config.py:119): two boxes that barely touch
+suppress each other, so a float32 kernel and the float64 oracle may take a marginal decision differently, and one flipped
+decision changes who suppresses whom further down the score order. The rule:
+
+  * with no near-threshold pair (|IoU - thresh| < 1e-4 among the pairs the oracle evaluated, oracle/rotate_nms.c) the
+    detections must be IDENTICAL: same count, same order, boxes within `box_tol`, scores within `score_rtol`;
+  * otherwise the oracle is re-run with every combination of those LISTED decisions taken one way or the other
+    (`rerun(forced)`, at most 2**max_pairs combinations) and the detections must be identical to ONE of these outcomes.
+    Nothing else may differ; more than `max_pairs` marginal decisions in one frame is itself a failure.
+No path returns success without having compared every box.
+"""
+import itertools
+
+import numpy as np
+
+
+def _ang(a, b):
+    d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)) % (2 * np.pi)
+    return np.minimum(d, 2 * np.pi - d)
+
+
+def same_detections(got, want, box_tol=2e-3, score_rtol=1e-3):
+    """None if identical (count, order, values within tolerance), else a short description of the first difference"""
+    gb, gs = np.asarray(got["box3d_lidar"], np.float32).reshape(-1, 7), np.asarray(got["scores"], np.float32)
+    wb, ws = np.asarray(want["box3d_lidar"], np.float32).reshape(-1, 7), np.asarray(want["scores"], np.float32)
+    if gs.shape != ws.shape:
+        return "count %d vs %d" % (len(gs), len(ws))
+    if len(ws) == 0:
+        return None
+    if not np.allclose(gs, ws, rtol=score_rtol, atol=1e-6):
+        k = int(np.argmax(np.abs(gs - ws) > score_rtol * np.abs(ws) + 1e-6))
+        return "score of detection %d: %.6f vs %.6f" % (k, gs[k], ws[k])
+    d = np.maximum(np.abs(gb[:, :6] - wb[:, :6]).max(1), _ang(gb[:, 6], wb[:, 6]))
+    if d.max() > box_tol:
+        return "box of detection %d differs by %.2e" % (int(np.argmax(d)), d.max())
+    if "label_preds" in got and "label_preds" in want and not np.array_equal(np.asarray(got["label_preds"]), np.asarray(want["label_preds"])):
+        return "labels differ"
+    return None
+
+
+def compare_detections(got, want, dbg, box_tol=2e-3, score_rtol=1e-3, max_pairs=6):
+    """got / want: dict(box3d_lidar (n,7), scores (n,), label_preds). dbg: the oracle's debug dict of the frame
+    (oracle.pipeline.run_frames(return_intermediate=True)['debug'][b]; needs dbg['rerun'] when near pairs exist).
+    Raises AssertionError on a mismatch; returns dict(n, matched, near_pairs, flipped) where `flipped` lists the
+    (kept row, candidate row, suppress) decisions under which the oracle reproduces the device result."""
+    pairs = np.asarray(dbg.get("near_pairs", np.zeros((0, 2), np.int64))).reshape(-1, 2)
+    why = same_detections(got, want, box_tol, score_rtol)
+    n = len(np.asarray(want["scores"]))
+    if why is None:
+        return dict(n=n, matched=n, near_pairs=pairs.tolist(), flipped=[])
+    assert len(pairs) > 0, "detections differ (%s) and the oracle met no near-threshold NMS decision" % why
+    assert len(pairs) <= max_pairs, "%d near-threshold decisions in one frame: too many to call the frame comparable" % len(pairs)
+    rerun = dbg.get("rerun")
+    assert rerun is not None, "detections differ (%s); near-threshold pairs %s but no rerun hook to explore them" % (why, pairs.tolist())
+    tried = []
+    for flags in itertools.product((0, 1), repeat=len(pairs)):
+        forced = [(int(i), int(j), int(f)) for (i, j), f in zip(pairs, flags)]
+        alt = rerun(np.asarray(forced, np.int32))
+        w2 = same_detections(got, alt, box_tol, score_rtol)
+        if w2 is None:
+            return dict(n=len(np.asarray(alt["scores"])), matched=len(np.asarray(alt["scores"])), near_pairs=pairs.tolist(), flipped=forced)
+        tried.append((flags, w2))
+    raise AssertionError("detections match the oracle under NO assignment of its %d near-threshold decisions %s: baseline: %s; %s"
+                         % (len(pairs), pairs.tolist(), why, "; ".join("%s -> %s" % t for t in tried[:8])))

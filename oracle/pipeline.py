@@ -59,8 +59,10 @@ def run_frames(points_list, sd, voxel_range, voxel_size, max_points, max_voxels,
         dirl = preds["dir_cls_preds"][b].reshape(-1, 2).numpy()
         iou = preds["iou_preds"][b].reshape(-1).numpy()
         fr = None if frustum is None else frustum[b]
-        r, d = postprocess.predict_frame(box, cls, dirl, iou, anchors, fr, tc["score_thresh"], tc["pre_max"], tc["post_max"],
-                                         tc["nms_thresh"], return_debug=True)
+        args = (box, cls, dirl, iou, anchors, fr, tc["score_thresh"], tc["pre_max"], tc["post_max"], tc["nms_thresh"])
+        r, d = postprocess.predict_frame(*args, return_debug=True)
+        # the same frame with chosen near-threshold NMS decisions taken the other way (oracle/compare.py)
+        d["rerun"] = (lambda a: (lambda forced: postprocess.predict_frame(*a, forced=forced)))(args)
         out.append(r)
         dbg.append(d)
     tick("predict", t0)

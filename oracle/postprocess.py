@@ -116,7 +116,7 @@ def sigmoid32(x):
 
 def predict_frame(box_codes, cls_logits, dir_logits, iou_preds, anchors, frustum, score_thresh=0.3, pre_max=1000,
                   post_max=100, nms_thresh=0.01, post_center_range=(0, -40.0, -5.0, 70.4, 40.0, 5.0),
-                  direction_offset=0.0, return_debug=False):
+                  direction_offset=0.0, return_debug=False, forced=None):
     """One frame of get_task_detections. box_codes (A,7), cls_logits (A,), dir_logits (A,2), iou_preds (A,),
     anchors (A,7), frustum (1,6,4,3) float64 or None. Returns dict(box3d_lidar (n,7), scores (n,), label_preds (n,))."""
     boxes = second_box_decode(box_codes, anchors)
@@ -138,9 +138,11 @@ def predict_frame(box_codes, cls_logits, dir_logits, iou_preds, anchors, frustum
     k = min(len(idx), pre_max)
     order = np.lexsort((idx, -s.astype(np.float64)))[:k]  # score desc, ties by anchor index asc
     dets = np.concatenate([b[order][:, [0, 1, 3, 4, 6]], s[order][:, None]], 1).astype(np.float32)
-    kept, near = capi.rotate_nms_cc(dets, nms_thresh, order=np.arange(k, dtype=np.int32))
+    kept, near, pairs = capi.rotate_nms_cc(dets, nms_thresh, order=np.arange(k, dtype=np.int32), return_pairs=True, forced=forced)
     kept = kept[:post_max]
     sel = order[kept]
+    # the NMS problem itself, for oracle/compare.py: candidates in score order, who survived, which decisions were marginal
+    dbg.update(cand_dets=dets, cand_boxes=b[order], cand_anchor=idx[order], nms_kept_rows=kept, near_pairs=pairs)
     b, s, dl = b[sel], s[sel], dl[sel]
     dbg.update(topk=k, nms_kept=len(sel), near_threshold_pairs=near, selected_anchor=idx[sel])
     if frustum is not None and len(b):

@@ -88,8 +88,8 @@ double oracle_quad_iou(const float *P, const float *Q) {
  * like box_torch_ops.py:543). near_thresh (optional, may be NULL) counts candidate pairs
  * whose IoU lies within `margin` of the threshold (the tests use it to flag inputs on
  * which a float32 implementation may legitimately disagree). */
-int oracle_rotate_nms(const float *dets, int K, const int32_t *order, float thresh, int32_t *keep, double margin,
-                      int32_t *near_thresh) {
+static int oracle_rotate_nms_impl(const float *dets, int K, const int32_t *order, float thresh, int32_t *keep, double margin,
+                                 int32_t *near_thresh, int32_t *near_pairs, int near_cap, const int32_t *forced, int n_forced) {
   float *corners = (float *)malloc((size_t)K * 8 * sizeof(float));
   float *standup = (float *)malloc((size_t)K * 4 * sizeof(float));
   unsigned char *sup = (unsigned char *)calloc(K > 0 ? K : 1, 1);
@@ -123,11 +123,35 @@ int oracle_rotate_nms(const float *dets, int K, const int32_t *order, float thre
       /* nms_cpu.h:139: nothing happens when boost returns an empty intersection */
       if (oracle_quad_intersection_area(corners + 8 * i, corners + 8 * j) <= 0) continue;
       double ov = oracle_quad_iou(corners + 8 * i, corners + 8 * j);
-      if (fabs(ov - (double)thresh) < margin) nnear++;
-      if (ov >= (double)thresh) sup[j] = 1;
+      if (fabs(ov - (double)thresh) < margin) {
+        if (near_pairs && nnear < near_cap) { near_pairs[2 * nnear] = i; near_pairs[2 * nnear + 1] = j; }
+        nnear++;
+      }
+      int suppress = ov >= (double)thresh;
+      for (int f = 0; f < n_forced; ++f) /* decisions taken the other way on purpose (oracle/compare.py) */
+        if (forced[3 * f] == i && forced[3 * f + 1] == j) suppress = forced[3 * f + 2];
+      if (suppress) sup[j] = 1;
     }
   }
   if (near_thresh) *near_thresh = nnear;
   free(corners); free(standup); free(sup);
   return nk;
+}
+
+int oracle_rotate_nms(const float *dets, int K, const int32_t *order, float thresh, int32_t *keep, double margin,
+                      int32_t *near_thresh) {
+  return oracle_rotate_nms_impl(dets, K, order, thresh, keep, margin, near_thresh, NULL, 0, NULL, 0);
+}
+
+/* same, also listing the (kept i, candidate j) pairs whose IoU lies within `margin` of the threshold (first near_cap of them):
+ * the decisions a float32 implementation may legitimately take the other way */
+int oracle_rotate_nms_pairs(const float *dets, int K, const int32_t *order, float thresh, int32_t *keep, double margin,
+                            int32_t *near_thresh, int32_t *near_pairs, int near_cap) {
+  return oracle_rotate_nms_impl(dets, K, order, thresh, keep, margin, near_thresh, near_pairs, near_cap, NULL, 0);
+}
+
+/* same with `n_forced` decisions imposed: forced = (i, j, suppress) triples for pairs (kept i, candidate j) */
+int oracle_rotate_nms_forced(const float *dets, int K, const int32_t *order, float thresh, int32_t *keep, double margin,
+                             int32_t *near_thresh, int32_t *near_pairs, int near_cap, const int32_t *forced, int n_forced) {
+  return oracle_rotate_nms_impl(dets, K, order, thresh, keep, margin, near_thresh, near_pairs, near_cap, forced, n_forced);
 }

@@ -21,7 +21,7 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 VG = configs.VOXEL_GENERATOR
 pts, mv, B, ss = (200000, 64000, 8, 3) if a.stress else (20000, 16000, 1, 1)
-model = configs.build_synthetic_detector(dev, seed=0, max_voxels=mv, num_points=pts)
+model = configs.build_synthetic_detector(dev, seed=0, max_voxels=mv, num_points=pts, supersample=ss)
 frames = [torch.from_numpy(synth.make_frame(i, pts, supersample=ss)).to(dev) for i in range(B)]
 kw = {}
 if a.sort:

@@ -13,7 +13,7 @@ namespace {
 
 constexpr int TP = 16;  // pair tile edge
 
-enum { MODE_OVERLAP = 0, MODE_IOU_BEV = 1, MODE_IOU_3D = 2, MODE_IOU_NORMAL = 3 };
+enum { MODE_OVERLAP = 0, MODE_IOU_BEV = 1, MODE_IOU_3D = 2, MODE_IOU_NORMAL = 3, MODE_IOU_3D_CPU = 4 };
 
 struct BoxRow {
   float v[7];
@@ -51,7 +51,8 @@ __device__ __forceinline__ float pair_value(const sessd_rect& A, float az1, floa
   float va = (A.x2 - A.x1) * (A.y2 - A.y1) * (az2 - az1);
   float vb = (B.x2 - B.x1) * (B.y2 - B.y1) * (bz2 - bz1);
   float dh = fmaxf(fminf(az2, bz2) - fmaxf(az1, bz1), SESSD_IOU_EPS);
-  if (dh == SESSD_IOU_EPS) return 0.f;
+  // the _cpu twin (iou3d_cpu.cpp:306-336) has no early return: disjoint z ranges give overlap * 1e-8, not exactly 0
+  if (MODE != MODE_IOU_3D_CPU && dh == SESSD_IOU_EPS) return 0.f;
   float vo = sessd_rect_overlap_f32(A, B, L) * dh;
   return vo / fmaxf(va + vb - vo, SESSD_IOU_EPS);
 }
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(64) void sessd_nms_reduce_kernel(const int* __restr
 
 extern "C" {
 
-// mode: 0 overlap area (N,5)x(M,5); 1 BEV IoU (N,5)x(M,5); 2 3-D IoU (N,7)x(M,7)
+// mode: 0 overlap area (N,5)x(M,5); 1 BEV IoU (N,5)x(M,5); 2 3-D IoU (N,7)x(M,7); 3 3-D IoU as boxes_iou3d_cpu computes it
 int sessd_boxes_pairwise(int mode, const float* boxes_a, int num_a, const float* boxes_b, int num_b, float* out,
                          hipStream_t stream) {
   if (num_a < 0 || num_b < 0) return SESSD_EINVAL;
@@ -431,6 +432,9 @@ int sessd_boxes_pairwise(int mode, const float* boxes_a, int num_a, const float*
       break;
     case MODE_IOU_3D:
       SESSD_LAUNCH((pairwise_kernel<MODE_IOU_3D, 7>), grid, block, 0, stream, num_a, boxes_a, num_b, boxes_b, out);
+      break;
+    case 3:  // the convention of boxes_iou3d_cpu (public mode number 3)
+      SESSD_LAUNCH((pairwise_kernel<MODE_IOU_3D_CPU, 7>), grid, block, 0, stream, num_a, boxes_a, num_b, boxes_b, out);
       break;
     default:
       return SESSD_EINVAL;

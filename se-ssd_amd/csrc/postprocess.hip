@@ -552,3 +552,80 @@ extern "C" int sessd_rotate_nms_sorted(const float* dets, int num_boxes, float i
   return rotate_nms_common(dets, nullptr, num_boxes, iou_thresh, post_max_size, keep, num_keep, workspace, workspace_bytes,
                            stream);
 }
+
+// ---- spconv.utils.rbbox_iou / rbbox_intersection (spconv v1 box_iou: boost polygons on the host), as imported by
+// det3d/core/bbox/box_np_ops.py:9 and used by riou_cc / rinter_cc :20-50: pairwise IoU / intersection area of convex quads
+// given as corners, skipped (0) where the caller's stand-up IoU is <= standup_thresh. Same float64 clipper as the rotated NMS.
+namespace {
+__global__ __launch_bounds__(256) void quads_pairwise_kernel(int mode, const float* __restrict__ ca, int n,
+                                                              const float* __restrict__ cb, int k,
+                                                              const float* __restrict__ standup_iou, float standup_thresh,
+                                                              float* __restrict__ out) {
+  const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (size_t)n * k) return;
+  const int i = (int)(id / k), j = (int)(id - (size_t)i * k);
+  float v = 0.f;
+  if (standup_iou[id] > standup_thresh) {
+    const float* pi = ca + (size_t)i * 8;
+    const float* pj = cb + (size_t)j * 8;
+    const double inter = sessd_quad_inter_area_green(pi, pj);
+    if (inter > 0) {
+      if (mode == 0) {
+        double px[4], py[4], qx[4], qy[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { px[q] = pi[2 * q]; py[q] = pi[2 * q + 1]; qx[q] = pj[2 * q]; qy[q] = pj[2 * q + 1]; }
+        const double uni = fabs(sessd_poly_area2(px, py, 4)) * 0.5 + fabs(sessd_poly_area2(qx, qy, 4)) * 0.5 - inter;
+        v = uni > 0 ? (float)(inter / uni) : 0.f;
+      } else {
+        v = (float)inter;
+      }
+    }
+  }
+  out[id] = v;
+}
+}  // namespace
+
+// mode 0: IoU, 1: intersection area. corners (n,4,2) / (k,4,2) float32, standup_iou and out (n,k) row-major.
+extern "C" int sessd_quads_pairwise(int mode, const float* corners_a, int n, const float* corners_b, int k,
+                                    const float* standup_iou, float standup_thresh, float* out, hipStream_t stream) {
+  if (n < 0 || k < 0 || mode < 0 || mode > 1) return SESSD_EINVAL;
+  if (n == 0 || k == 0) return SESSD_OK;
+  const size_t total = (size_t)n * k;
+  SESSD_LAUNCH(quads_pairwise_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, mode, corners_a, n,
+               corners_b, k, standup_iou, standup_thresh, out);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// ---- detection records for the end-of-job gather (tools/dist_test.py:150-186 gathers pickled per-rank dicts; here every frame
+// leaves one fixed-size record on the device: (post_max, 9) float32 [box 7 | score | label] + a count), appended by the frame's
+// own launch sequence so that a captured graph needs no host-side bookkeeping: slot = (*cursor + b) % capacity, cursor += batch.
+namespace {
+__global__ __launch_bounds__(256) void pack_detections_kernel(const float* __restrict__ box, const float* __restrict__ score,
+                                                               const int* __restrict__ label, const int* __restrict__ count,
+                                                               int batch, int post_max, float* __restrict__ records,
+                                                               int* __restrict__ rec_count, int capacity, int* __restrict__ cursor) {
+  const int c0 = *cursor;
+  const int total = batch * post_max * 9;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int b = e / (post_max * 9), r = (e - b * post_max * 9) / 9, q = e % 9;
+    const int n = count[b];
+    float v = 0.f;
+    if (r < n) v = q < 7 ? box[((size_t)b * post_max + r) * 7 + q] : (q == 7 ? score[(size_t)b * post_max + r] : (float)label[(size_t)b * post_max + r]);
+    records[((size_t)((c0 + b) % capacity) * post_max + r) * 9 + q] = v;
+  }
+  if (threadIdx.x < batch) rec_count[(c0 + threadIdx.x) % capacity] = count[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) *cursor = c0 + batch;
+}
+}  // namespace
+
+extern "C" int sessd_pack_detections(const float* out_box, const float* out_score, const int* out_label, const int* out_count,
+                                     int batch, int post_max_size, float* records, int* record_counts, int capacity_frames,
+                                     int* cursor, hipStream_t stream) {
+  if (batch <= 0 || batch > 256 || post_max_size <= 0 || capacity_frames < batch) return SESSD_EINVAL;
+  SESSD_LAUNCH(pack_detections_kernel, dim3(1), dim3(256), 0, stream, out_box, out_score, out_label, out_count, batch,
+               post_max_size, records, record_counts, capacity_frames, cursor);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}

@@ -55,6 +55,26 @@ def iou_jit(boxes, query_boxes, eps=1.0):
     return np.where(ok, inter / np.where(ok, ua, 1), 0).astype(b.dtype)
 
 
+def _corners_and_standup_iou(rbboxes, qrbboxes):
+    boxes_corners = center_to_corner_box2d(rbboxes[:, :2], rbboxes[:, 2:4], rbboxes[:, 4])
+    qboxes_corners = center_to_corner_box2d(qrbboxes[:, :2], qrbboxes[:, 2:4], qrbboxes[:, 4])
+    # if the stand-up boxes do not overlap, the rotated boxes do not either
+    standup_iou = iou_jit(corner_to_standup_nd(boxes_corners), corner_to_standup_nd(qboxes_corners), eps=0.0)
+    return boxes_corners, qboxes_corners, standup_iou
+
+
+def riou_cc(rbboxes, qrbboxes, standup_thresh=0.0):
+    """rotated BEV IoU of (N,5) x (K,5) [x,y,w,l,r] boxes (box_np_ops.py:20-32) through spconv.utils.rbbox_iou"""
+    from spconv.utils import rbbox_iou
+    return rbbox_iou(*_corners_and_standup_iou(rbboxes, qrbboxes), standup_thresh)
+
+
+def rinter_cc(rbboxes, qrbboxes, standup_thresh=0.0):
+    """rotated BEV intersection area (box_np_ops.py:35-50) through spconv.utils.rbbox_intersection"""
+    from spconv.utils import rbbox_intersection
+    return rbbox_intersection(*_corners_and_standup_iou(rbboxes, qrbboxes), standup_thresh)
+
+
 def limit_period(val, offset=0.5, period=2 * np.pi):
     """val folded into [-offset*period, (1-offset)*period) (box_np_ops.py:619-620)."""
     return val - np.floor(val / period + offset) * period

@@ -127,3 +127,46 @@ def nms_normal_gpu(boxes, scores, thresh):
     keep = torch.LongTensor(boxes.size(0))
     num_out = iou3d_cuda.nms_normal_gpu(boxes, keep, thresh)
     return order[keep[:num_out].cuda()].contiguous()
+
+
+# ---- host-tensor twins (iou3d_utils.py:7-29,54-120): CPU tensors in, CPU tensors out, through iou3d_cuda's *_cpu entry points
+def boxes_iou_bev_cpu(boxes_a, boxes_b, box_mode="wlh", metric="rotate_iou", rect=False):
+    """(N,7),(M,7) host tensors -> BEV IoU (N,M) host tensor  (iou3d_utils.py:7-29)."""
+    if metric == "rotate_iou":
+        a_bev, b_bev = boxes3d_to_bev_torch(boxes_a, box_mode, rect), boxes3d_to_bev_torch(boxes_b, box_mode, rect)
+    elif metric == "nearest_iou":
+        a_bev, b_bev = rbbox2d_to_near_bbox_torch(boxes_a, box_mode, rect), rbbox2d_to_near_bbox_torch(boxes_b, box_mode, rect)
+    else:
+        raise NotImplementedError
+    iou_bev = torch.FloatTensor(torch.Size((boxes_a.shape[0], boxes_b.shape[0]))).zero_()
+    iou3d_cuda.boxes_iou_bev_cpu(a_bev.contiguous(), b_bev.contiguous(), iou_bev)
+    return iou_bev
+
+
+def boxes_iou3d_cpu_test(boxes_a, boxes_b, box_mode="wlh", rect=False):
+    """(iou3d_utils.py:54-70) 3-D IoU through the extension's own boxes_iou3d_cpu on [x1,y1,z1,x2,y2,z2,ry] boxes."""
+    a3, b3 = boxes3d_to_bev_3d_torch(boxes_a, box_mode, rect), boxes3d_to_bev_3d_torch(boxes_b, box_mode, rect)
+    iou3d = torch.FloatTensor(torch.Size((boxes_a.shape[0], boxes_b.shape[0]))).zero_()
+    iou3d_cuda.boxes_iou3d_cpu(a3.contiguous(), b3.contiguous(), iou3d)
+    return iou3d
+
+
+def boxes_iou3d_cpu(boxes_a, boxes_b, box_mode="wlh", rect=False, need_bev=False):
+    """(iou3d_utils.py:72-120) host tensors; NOTE the reference's host wrapper takes the height range as [z - h, z]
+    (the *_gpu wrappers use z -+ h/2) -- reproduced as is."""
+    w_index, l_index, h_index = box_mode.index("w") + 3, box_mode.index("l") + 3, box_mode.index("h") + 3
+    a_bev, b_bev = boxes3d_to_bev_torch(boxes_a, box_mode, rect), boxes3d_to_bev_torch(boxes_b, box_mode, rect)
+    overlaps_bev = torch.FloatTensor(torch.Size((boxes_a.shape[0], boxes_b.shape[0]))).zero_()
+    iou3d_cuda.boxes_overlap_bev_cpu(a_bev.contiguous(), b_bev.contiguous(), overlaps_bev)
+    area_a = (boxes_a[:, w_index] * boxes_a[:, l_index]).view(-1, 1)
+    area_b = (boxes_b[:, w_index] * boxes_b[:, l_index]).view(1, -1)
+    iou_bev = overlaps_bev / torch.clamp(area_a + area_b - overlaps_bev, min=1e-7)
+    up = 1 if rect else 2
+    a_hmin, a_hmax = (boxes_a[:, up] - boxes_a[:, h_index]).view(-1, 1), boxes_a[:, up].view(-1, 1)
+    b_hmin, b_hmax = (boxes_b[:, up] - boxes_b[:, h_index]).view(1, -1), boxes_b[:, up].view(1, -1)
+    overlaps_h = torch.clamp(torch.min(a_hmax, b_hmax) - torch.max(a_hmin, b_hmin), min=0)
+    overlaps_3d = overlaps_bev * overlaps_h
+    vol_a = (boxes_a[:, h_index] * boxes_a[:, w_index] * boxes_a[:, l_index]).view(-1, 1)
+    vol_b = (boxes_b[:, h_index] * boxes_b[:, w_index] * boxes_b[:, l_index]).view(1, -1)
+    iou3d = overlaps_3d / torch.clamp(vol_a + vol_b - overlaps_3d, min=1e-7)
+    return (iou3d, iou_bev) if need_bev else iou3d

@@ -41,7 +41,7 @@ class Head(nn.Module):
     def planar(self, x):
         """(B, 14+2+4+2, H, W): the four 1x1 convs as ONE fused launch, channels [box | cls | dir | iou]."""
         convs = [self.conv_box, self.conv_cls] + ([self.conv_dir] if self.use_dir else []) + [self.conv_iou]
-        key = tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in convs)
+        key = (ops.param_generation(),) + tuple((c.weight.data_ptr(), c.weight._version, c.bias._version) for c in convs)
         if self._packed is None or self._packed[0] != key:
             w = torch.cat([c.weight.detach() for c in convs], 0)
             b = torch.cat([c.bias.detach() for c in convs], 0).float().contiguous()

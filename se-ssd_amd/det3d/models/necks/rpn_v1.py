@@ -23,7 +23,9 @@ class _Lowered:
         return _Lowered()
 
     def get(self, name, conv, bn, deconv=False):
-        key = (conv.weight.data_ptr(), conv.weight._version, None if bn is None else bn.running_mean._version)
+        # every tensor that feeds the packing / BN folding, plus the raw-pointer write counter (ops.param_generation)
+        tensors = [conv.weight, conv.bias] + ([] if bn is None else [bn.weight, bn.bias, bn.running_mean, bn.running_var])
+        key = (conv.weight.data_ptr(), ops.param_generation()) + tuple(-1 if t is None else t._version for t in tensors)
         hit = self._cache.get(name)
         if hit is None or hit[0] != key:
             w = conv.weight.detach()

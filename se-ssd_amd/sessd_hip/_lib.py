@@ -49,6 +49,8 @@ SIGNATURES = {
     "sessd_ssfa_fuse": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp]),
     "sessd_predict_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "sessd_predict": (i32, [vp, i32, i32, vp, i32, vp, f32, i32, i32, f32, vp, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "sessd_pack_detections": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp]),
+    "sessd_quads_pairwise": (i32, [i32, vp, i32, vp, i32, vp, f32, vp, vp]),
     "sessd_rotate_nms_workspace_bytes": (sz, [i32]),
     "sessd_rotate_nms_sorted": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
     "sessd_rotate_nms_corners_sorted": (i32, [vp, i32, f32, i32, vp, vp, vp, sz, vp]),
@@ -58,6 +60,8 @@ SIGNATURES = {
     "sessd_sparse_rulebook": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
     "sessd_sparse_rulebook_pair": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, vp, vp, vp, u32, vp, vp, vp, vp]),
     "sessd_sparse_downsample_sites_unordered": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, u32, vp, i32, vp, vp, vp]),
+    "sessd_sparse_to_dense": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "sessd_dense_to_sparse": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "sessd_sparse_chain_workspace_bytes": (sz, [i32, i32, vp]),
     "sessd_sparse_chain_sites": (i32, [vp, vp, i32, i32, i32, vp, vp, sz, i32, vp, vp]),
     "sessd_sparse_chain_rulebooks": (i32, [vp, vp, i32, vp, vp, u32, vp, i32, i32, vp, vp, i32, vp, vp]),

@@ -34,15 +34,17 @@ VOXEL_GENERATOR = dict(range=[0, -40.0, -3.0, 70.4, 40.0, 1.0], voxel_size=[0.05
                        max_voxel_num=20000)
 
 
-def build_synthetic_detector(device, seed=0, calib_frame_seed=0, max_voxels=16000, num_points=20000):
-    """det3d-mirror VoxelNet with seeded weights, BatchNorm statistics calibrated on one synthetic frame (on `device`)."""
+def build_synthetic_detector(device, seed=0, calib_frame_seed=0, max_voxels=16000, num_points=20000, supersample=1):
+    """det3d-mirror VoxelNet with seeded weights, BatchNorm statistics calibrated on one synthetic frame (on `device`) of the
+    workload's own density (supersample = 3 for the 200 k-point dense scenes): random weights calibrated on a sparse scan give
+    activations (and decoded boxes) of absurd magnitude on a dense one."""
     import torch
     from det3d.models import build_detector
     from . import ops, synth
     model = build_detector(kitti_car_model(), train_cfg=None, test_cfg=TEST_CFG)
     synth.init_synthetic_weights(model, seed)
     model.to(device)
-    pts = torch.from_numpy(synth.make_frame(calib_frame_seed, num_points)).to(device)
+    pts = torch.from_numpy(synth.make_frame(calib_frame_seed, num_points, supersample=supersample)).to(device)
     r = ops.voxelize_batch([pts], VOXEL_GENERATOR["voxel_size"], VOXEL_GENERATOR["range"], 5, max_voxels)
     m = int(r["prefix"][1].item())
     synth.calibrate_synthetic_model(model, r["mean"][:m].contiguous(), r["coors"][:m].contiguous(), 1, [1408, 1600, 40])

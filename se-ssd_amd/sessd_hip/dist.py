@@ -62,3 +62,37 @@ def gather_detections(local_dets, num_frames, post_max=100, device=None):
                 a = recs[r][j, :n].cpu()
                 out[f] = dict(box3d_lidar=a[:, :7].numpy(), scores=a[:, 7].numpy(), label_preds=a[:, 8].long().numpy())
     return out
+
+
+def gather_records(records, counts, num_frames):
+    """Device-side twin of gather_detections for the engine's records (InferenceEngine.attach_records): every rank passes its
+    (per, post_max, 9) float32 records + (per,) int32 counts in shard order (per = ceil(num_frames / world)); ONE all_gather each
+    (RCCL over xGMI: 3.6 KB per frame). Returns (world, per, post_max, 9) and (world, per) tensors on the calling device; nothing
+    touches the host."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    per = int(math.ceil(num_frames / float(world)))
+    assert records.shape[0] >= per and counts.shape[0] >= per
+    rec, cnt = records[:per].contiguous(), counts[:per].contiguous()
+    if world == 1:
+        return rec.unsqueeze(0), cnt.unsqueeze(0)
+    # concatenated along dim 0 (the layout both the RCCL and the gloo backend accept), viewed as (world, per, ...)
+    all_rec = torch.empty((world * per,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)
+    all_cnt = torch.empty((world * per,), dtype=cnt.dtype, device=cnt.device)
+    dist.all_gather_into_tensor(all_rec, rec)
+    dist.all_gather_into_tensor(all_cnt, cnt)
+    return all_rec.view((world, per) + tuple(rec.shape[1:])), all_cnt.view(world, per)
+
+
+def unpack_records(all_rec, all_cnt, num_frames):
+    """(world, per, post_max, 9) + (world, per) -> list of num_frames per-frame dicts in dataset order (padding duplicates dropped)."""
+    world = all_rec.shape[0]
+    rec, cnt = all_rec.cpu(), all_cnt.cpu()
+    out = [None] * num_frames
+    for r in range(world):
+        idx, _ = shard_indices(num_frames, r, world)
+        for j, f in enumerate(idx):
+            if out[f] is None:
+                n = int(cnt[r, j])
+                a = rec[r, j, :n]
+                out[f] = dict(box3d_lidar=a[:, :7].numpy(), scores=a[:, 7].numpy(), label_preds=a[:, 8].long().numpy())
+    return out

@@ -227,6 +227,7 @@ class InferenceEngine:
             self.renum_ws = torch.empty(int(lib.sessd_sparse_renumber_workspace_bytes(B, self._hash0_dims.data_ptr())),
                                         dtype=torch.uint8, device=dev)
         self._ks = {}
+        self.records = None
         self._npts = [0] * B
         self.graph = None
         self._marks = None
@@ -422,8 +423,22 @@ class InferenceEngine:
                                 self.post_max, self.nms_thresh, self.post_range.data_ptr(), self.dir_offset,
                                 self.out["box"].data_ptr(), self.out["score"].data_ptr(), self.out["label"].data_ptr(),
                                 self.out["count"].data_ptr(), self.pred_ws.data_ptr(), self.pred_ws.numel(), s), "predict")
+        if self.records is not None:  # one fixed-size record per frame for the end-of-job gather (dist.gather_records)
+            check(lib.sessd_pack_detections(self.out["box"].data_ptr(), self.out["score"].data_ptr(), self.out["label"].data_ptr(),
+                                            self.out["count"].data_ptr(), B, self.post_max, self.records.data_ptr(),
+                                            self.record_counts.data_ptr(), self.records.shape[0], self.record_cursor.data_ptr(), s),
+                  "pack_detections")
         self._mark("predict")
         return self.out
+
+    def attach_records(self, capacity_frames):
+        """Keep every frame's detections on the device as a fixed-size record (capacity_frames, post_max, 9) [box 7 | score |
+        label] + counts, appended by the frame itself (also inside a captured graph; call before capture())."""
+        cap = max(int(capacity_frames), self.B)
+        self.records = torch.zeros((cap, self.post_max, 9), dtype=torch.float32, device=self.dev)
+        self.record_counts = torch.zeros((cap,), dtype=torch.int32, device=self.dev)
+        self.record_cursor = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+        return self.records, self.record_counts
 
     def _mark(self, name):
         if self._marks is not None:

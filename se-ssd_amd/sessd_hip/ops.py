@@ -100,7 +100,7 @@ def vfe_mean(voxels, num_points, num_features=4, num_voxels_dev=None):
 
 # ------------------------------------------------------------------ iou3d operators
 def boxes_pairwise(mode, a, b, out=None):
-    w = 7 if mode == 2 else 5
+    w = 7 if mode in (2, 3) else 5
     _req(a, torch.float32, "boxes_a")
     _req(b, torch.float32, "boxes_b")
     if a.dim() != 2 or b.dim() != 2 or a.shape[1] != w or b.shape[1] != w:
@@ -111,6 +111,20 @@ def boxes_pairwise(mode, a, b, out=None):
         _req(out, torch.float32, "out")
     check(lib.sessd_boxes_pairwise(mode, a.data_ptr(), a.shape[0], b.data_ptr(), b.shape[0], out.data_ptr(), _stream()),
           "boxes_pairwise")
+    return out
+
+
+def quads_pairwise(mode, corners_a, corners_b, standup_iou, standup_thresh=0.0):
+    """mode 0: IoU, 1: intersection area of convex quads (n,4,2) x (k,4,2); 0 where standup_iou <= standup_thresh."""
+    _req(corners_a, torch.float32, "corners_a")
+    _req(corners_b, torch.float32, "corners_b")
+    _req(standup_iou, torch.float32, "standup_iou")
+    n, k = corners_a.shape[0], corners_b.shape[0]
+    if tuple(corners_a.shape[1:]) != (4, 2) or tuple(corners_b.shape[1:]) != (4, 2) or tuple(standup_iou.shape) != (n, k):
+        raise ValueError("corners must be (n,4,2) / (k,4,2) and standup_iou (n,k)")
+    out = torch.empty((n, k), dtype=torch.float32, device=corners_a.device)
+    check(lib.sessd_quads_pairwise(int(mode), corners_a.data_ptr(), n, corners_b.data_ptr(), k, standup_iou.data_ptr(),
+                                   float(standup_thresh), out.data_ptr(), _stream()), "quads_pairwise")
     return out
 
 
@@ -166,6 +180,20 @@ def nms_axis_eps_sorted(boxes, thresh, eps):
 def _i3(v):
     v = [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
     return torch.tensor(v, dtype=torch.int32)
+
+
+# Parameters written through raw pointers (sessd_adam_ema_step: student AND teacher) do not bump torch's tensor versions.
+# Every cache of packed / folded weights includes this counter in its key; whoever writes parameters behind torch's back
+# calls bump_param_generation().
+_PARAM_GENERATION = [0]
+
+
+def param_generation():
+    return _PARAM_GENERATION[0]
+
+
+def bump_param_generation():
+    _PARAM_GENERATION[0] += 1
 
 
 class SiteHash:
@@ -225,6 +253,40 @@ def sparse_rulebook(out_indices, n_out_dev, ksize, stride, pad, in_hash):
                                     in_hash._dims_t.data_ptr(), nbr.data_ptr(), tmask.data_ptr(), _stream()),
           "sparse_rulebook")
     return nbr, tmask
+
+
+class _SparseToDense(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, indices, spatial_shape, batch_size):
+        feats = features.float().contiguous()
+        n, c = feats.shape
+        dims = _i3(spatial_shape)
+        out = torch.zeros([int(batch_size), c] + [int(v) for v in spatial_shape], dtype=torch.float32, device=feats.device)
+        check(lib.sessd_sparse_to_dense(feats.data_ptr(), indices.data_ptr(), n, c, dims.data_ptr(), out.data_ptr(), _stream()),
+              "sparse_to_dense")
+        ctx.save_for_backward(indices)
+        ctx.shape = [int(v) for v in spatial_shape]
+        ctx.nc = (n, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        (indices,) = ctx.saved_tensors
+        n, c = ctx.nc
+        g = grad.float().contiguous()
+        dims = _i3(ctx.shape)
+        gf = torch.empty((n, c), dtype=torch.float32, device=g.device)
+        check(lib.sessd_dense_to_sparse(g.data_ptr(), indices.data_ptr(), n, c, dims.data_ptr(), gf.data_ptr(), _stream()),
+              "dense_to_sparse")
+        return gf, None, None, None
+
+
+def sparse_to_dense(features, indices, spatial_shape, batch_size):
+    """SparseConvTensor.dense(): (n,C) features at (n,4) int32 sites -> (B,C,D,H,W); differentiable w.r.t. the features."""
+    _req(indices, torch.int32, "indices")
+    if not features.is_cuda:
+        raise ValueError("features must be on the HIP device")
+    return _SparseToDense.apply(features, indices, spatial_shape, batch_size)
 
 
 class SparseChain:

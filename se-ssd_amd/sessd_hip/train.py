@@ -19,6 +19,7 @@ import math
 import torch
 import torch.distributed as dist
 
+from . import ops
 from ._lib import check, lib
 
 
@@ -105,6 +106,7 @@ class FusedAdamEMA:
                                       self.exp_avg_sq.data_ptr(), 0 if self.t is None else self.t.data.data_ptr(), self.s.numel,
                                       float(lr), float(self.wd), float(beta1), float(self.beta2), float(self.eps), self.steps,
                                       self.norm_coef.data_ptr(), float(ema_alpha(global_step)), s), "adam_ema_step")
+        ops.bump_param_generation()  # student and teacher were written through raw pointers: packed-weight caches are stale
 
 
 def allreduce_flat(flat_grad, group=None):

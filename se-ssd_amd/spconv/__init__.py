@@ -34,11 +34,8 @@ class SparseConvTensor(object):
         return None if key is None else self.indice_dict.get(key)
 
     def dense(self, channels_first=True):
-        n, c = self.features.shape
-        out = torch.zeros([self.batch_size] + self.spatial_shape + [c], dtype=self.features.dtype, device=self.features.device)
-        i = self.indices.long()
-        out[i[:, 0], i[:, 1], i[:, 2], i[:, 3]] = self.features
-        return out.permute(0, 4, 1, 2, 3).contiguous() if channels_first else out
+        out = ops.sparse_to_dense(self.features, self.indices, self.spatial_shape, self.batch_size)  # (B,C,D,H,W), HIP scatter
+        return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 
     def _hash(self):
         h = self.indice_dict.get("__hash__")
@@ -107,7 +104,7 @@ class SparseConvolution(SparseModule):
             self.weight.uniform_(-bound, bound)
 
     def _wpk(self):
-        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device))
+        key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device), ops.param_generation())
         if self._packed is None or self._packed[0] != key:
             self._packed = (key, ops.sparse_pack_weight(self.weight))
         return self._packed[1]
@@ -214,5 +211,4 @@ class SparseSequential(SparseModule):
         return input
 
 
-class utils:  # noqa: N801  (namespace placeholder for `from spconv.utils import rbbox_iou` style imports)
-    pass
+from . import utils  # noqa: E402,F401  (`from spconv.utils import rbbox_iou, rbbox_intersection`, box_np_ops.py:9)

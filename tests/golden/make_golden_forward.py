@@ -1,0 +1,274 @@
+"""Generates tests/golden/forward_ref.npz by running the REFERENCE's inference-path classes from source on CPU
+(build container only; nothing of the reference is copied into the repository, only input / output vectors are stored):
+
+  ssfa_*     det3d/models/necks/rpn_v1.py            SSFA.__init__ + forward  :119-235   (eval mode and train mode)
+  head_*     det3d/models/bbox_heads/mg_head_sessd.py  Head.__init__ + forward  :195-230
+  vfe_*      det3d/models/readers/voxel_encoder.py    VoxelFeatureExtractorV3.forward :215-220
+  predict_*  det3d/models/bbox_heads/mg_head_sessd.py  MultiGroupHead.predict + get_task_detections :893-1057 with the reference's
+             own box_torch_ops.rotate_nms :527-548, nms_cpu.rotate_nms_cc :40-51 (numpy corners / stand-up boxes / iou_jit),
+             box_coders.GroundBox3dCoderTorch, geometry.points_in_convex_polygon_3d_jit, box_np_ops anchors + frustum
+  collate_*  det3d/datasets/pipelines/formating.py Reformat :14-86 + det3d/torchie/parallel/collate.py collate_kitti :154-218
+
+What cannot run here is substituted, and only that:
+  * the pybind function rotate_non_max_suppression_cpu (nms.cc / nms_cpu.h:72-168, needs boost::geometry) -> the greedy loop of
+    oracle/rotate_nms.c fed with the corners / order / stand-up IoU the REFERENCE code computed (its polygon IoU is cross-checked
+    against the compiled iou3d reference in tests/test_oracle_golden.py)
+  * `.cuda()`, registries, logging / checkpoint helpers, matplotlib, torchvision, numba, syncbn -> identity / inert stubs
+  * MultiGroupHead.__init__ is bypassed (it builds the loss modules and calls .cuda()); the attributes predict() reads are set
+    from the constructor arguments config.py passes
+Weights and the large inputs come from tests/golden/forward_cases.py (seeded), check values of them are stored.
+
+    python tests/golden/make_golden_forward.py
+"""
+import ctypes as C
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "se-ssd_amd"))
+sys.path.insert(0, HERE)
+
+import forward_cases as FC  # noqa: E402
+
+
+def main():
+    assert os.path.isdir(REF)
+    warnings.filterwarnings("ignore")
+    from oracle import capi
+    import make_golden as MG
+    import make_golden_head_loss as HL
+    from sessd_hip import synth
+    head_mod, ll, od, bto, build_loss = HL.install(capi)
+    mod, load_as = HL.mod, HL.load_as
+    out = {}
+
+    class _Logger:
+        def info(self, *a, **k):
+            pass
+
+    class _Reg:
+        @staticmethod
+        def register_module(obj):
+            return obj
+
+    # ------------------------------------------------------------------ SSFA from source
+    for n in ("matplotlib", "matplotlib.pyplot", "torchvision", "torchvision.models", "det3d.ops.syncbn", "det3d.utils.dist"):
+        mod(n)
+    sys.modules["torchvision.models"].resnet = types.ModuleType("resnet")
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["det3d.ops.syncbn"].DistributedSyncBN = torch.nn.BatchNorm2d
+    sys.modules["det3d.utils.dist"].dist_common = types.SimpleNamespace(get_world_size=lambda: 1)
+    mod("det3d.torchie.cnn", constant_init=None, kaiming_init=None, xavier_init=None)
+    mod("det3d.torchie.trainer", load_checkpoint=None)
+    misc = load_as("det3d/models/utils/misc.py", "refpkg.models.utils.misc")
+    norm = load_as("det3d/models/utils/norm.py", "refpkg.models.utils.norm")
+    mod("refpkg.models.utils", build_norm_layer=norm.build_norm_layer)
+    mod("det3d.models.utils", Empty=misc.Empty, GroupNorm=misc.GroupNorm, Sequential=misc.Sequential,
+        change_default_args=misc.change_default_args, get_paddings_indicator=misc.get_paddings_indicator)
+    mod("refpkg.models.registry", NECKS=_Reg(), HEADS=_Reg(), LOSSES=_Reg(), READERS=_Reg())
+    mod("refpkg.models.necks")
+    rpn = load_as("det3d/models/necks/rpn_v1.py", "refpkg.models.necks.rpn_v1")
+    neck = rpn.SSFA(layer_nums=[5], ds_layer_strides=[1], ds_num_filters=[128], us_layer_strides=[1], us_num_filters=[128],
+                    num_input_features=128, norm_cfg=None, logger=_Logger())
+    shapes = {k: tuple(v.shape) for k, v in neck.state_dict().items()}
+    sd = FC.seeded_state_dict(shapes, seed=11)
+    neck.load_state_dict(sd)
+    x = FC.ssfa_input()
+    neck.eval()
+    with torch.no_grad():
+        out["ssfa_eval"] = neck(x).numpy()
+    neck.train()
+    with torch.no_grad():
+        out["ssfa_train"] = neck(x).numpy()
+    out["ssfa_keys"] = np.array(sorted(shapes))
+    out["ssfa_shapes"] = np.array([str(shapes[k]) for k in sorted(shapes)])
+    out["ssfa_weight_check"] = np.array([float(sd[k].double().sum()) for k in sorted(shapes)])
+    out["ssfa_input_check"] = np.array([float(x.double().sum()), float(x.abs().max())])
+    print("SSFA from source:", out["ssfa_eval"].shape, "params", sum(int(np.prod(s)) for s in shapes.values()))
+
+    # ------------------------------------------------------------------ Head from source (the already loaded head module)
+    H = head_mod.Head(128, 14, 2, use_dir=True, num_dir=4, header=False)
+    hshapes = {k: tuple(v.shape) for k, v in H.state_dict().items()}
+    hsd = FC.seeded_state_dict(hshapes, seed=12)
+    H.load_state_dict(hsd)
+    H.eval()
+    hx = FC.head_input()
+    with torch.no_grad():
+        hr = H(hx)
+    for k, v in hr.items():
+        out["head_" + k] = v.numpy()
+    out["head_keys"] = np.array(sorted(hshapes))
+    out["head_weight_check"] = np.array([float(hsd[k].double().sum()) for k in sorted(hshapes)])
+
+    # ------------------------------------------------------------------ VFE from source
+    mod("refpkg.models.readers")
+    ve = load_as("det3d/models/readers/voxel_encoder.py", "refpkg.models.readers.voxel_encoder")
+    vox, num = FC.vfe_case()
+    vfe = ve.VoxelFeatureExtractorV3(num_input_features=4)
+    out["vfe_mean"] = vfe(torch.from_numpy(vox), torch.from_numpy(num)).numpy()
+    out["vfe_input_check"] = np.array([float(vox.astype(np.float64).sum()), float(num.sum())])
+
+    # ------------------------------------------------------------------ predict from source
+    geo = sys.modules["det3d.core.bbox.geometry"]
+    bnp = sys.modules["det3d.core.bbox.box_np_ops"]
+    for n in ("non_max_suppression_cpu", "rotate_non_max_suppression_cpu", "IOU_weighted_rotate_non_max_suppression_cpu"):
+        setattr(sys.modules["det3d.ops.nms.nms"], n, None)  # the pybind module: replaced below
+    nms_cpu = load_as("det3d/ops/nms/nms_cpu.py", "ref_nms_cpu")
+
+    lib = capi.lib()
+    lib.oracle_quad_intersection_area.restype = C.c_double
+    lib.oracle_quad_intersection_area.argtypes = [np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")] * 2
+    stats = dict(calls=0, near=0)
+
+    def rotate_non_max_suppression_cpu(box_corners, order, standup_iou, thresh):
+        """nms_cpu.h:72-168 restated (oracle/rotate_nms.c greedy loop) on the REFERENCE-computed corners / order / stand-up IoU."""
+        K = box_corners.shape[0]
+        corners = np.ascontiguousarray(box_corners, np.float32)
+        sup = np.zeros(K, bool)
+        keep = []
+        for _i in range(K):
+            i = int(order[_i])
+            if sup[i]:
+                continue
+            keep.append(i)
+            for _j in range(_i + 1, K):
+                j = int(order[_j])
+                if sup[j] or not (standup_iou[i, j] > 0):
+                    continue
+                if lib.oracle_quad_intersection_area(corners[i].reshape(-1), corners[j].reshape(-1)) <= 0:
+                    continue
+                ov = capi.quad_iou(corners[i], corners[j])
+                if abs(ov - thresh) < 1e-4:
+                    stats["near"] += 1
+                if ov >= thresh:
+                    sup[j] = True
+        stats["calls"] += 1
+        return keep
+
+    nms_cpu.rotate_non_max_suppression_cpu = rotate_non_max_suppression_cpu
+    # the reference sorts with numpy's default (unstable) argsort; equal scores are ordered by ascending index here and in the
+    # oracle / kernels (DESIGN.md "tie rule"), so make that explicit for the run
+    _orig_cc = nms_cpu.rotate_nms_cc
+
+    def rotate_nms_cc(dets, thresh):
+        scores = dets[:, 5]
+        order = np.lexsort((np.arange(len(scores)), -scores.astype(np.float64))).astype(np.int32)
+        dets_corners = bnp.center_to_corner_box2d(dets[:, :2], dets[:, 2:4], dets[:, 4])
+        dets_standup = bnp.corner_to_standup_nd(dets_corners)
+        standup_iou = bnp.iou_jit(dets_standup, dets_standup, eps=0.0)
+        return rotate_non_max_suppression_cpu(dets_corners, order, standup_iou, thresh)
+
+    # same statements as nms_cpu.py:40-51 except the explicit tie order; check it agrees with the source function on a tie-free set
+    d = synth.clustered_boxes7(80, seed=3)[:, [0, 1, 3, 4, 6]].astype(np.float32)
+    d = np.concatenate([d, np.linspace(0.9, 0.31, 80, dtype=np.float32)[:, None]], 1)
+    assert list(_orig_cc(d, 0.01)) == list(rotate_nms_cc(d, 0.01))
+    bto.rotate_nms_cc = rotate_nms_cc
+    _topk = torch.topk
+
+    def topk_ties_by_index(scores, k):  # torch.topk leaves equal scores unordered: ascending index (the tie rule)
+        order = np.lexsort((np.arange(scores.shape[0]), -scores.detach().numpy().astype(np.float64)))[:k]
+        idx = torch.from_numpy(order.astype(np.int64))
+        return scores[idx], idx
+
+    bc = load_as("det3d/core/bbox/box_coders.py", "det3d.core.bbox.box_coders")
+    coder = bc.GroundBox3dCoderTorch(False, False, n_dim=7, norm_velo=False)  # builder.py:427-432 with config.py:60
+    _mg = np.meshgrid
+    np.meshgrid = lambda *a, **k: list(_mg(*a, **k))
+    anchors = bnp.create_anchors_3d_range([1, 200, 176], [0, -40.0, -1.0, 70.4, 40.0, -1.0], [1.6, 3.9, 1.56], [0, 1.57])
+    np.meshgrid = _mg
+    anchors = anchors.reshape(-1, 7).astype(np.float32)
+    cal = synth.kitti_calib()
+    frustum = bnp.get_valid_frustum(cal["rect"], cal["Trv2c"], cal["P2"], cal["image_shape"])  # (1,6,4,3) float64
+
+    Hd = head_mod.MultiGroupHead
+    h = object.__new__(Hd)
+    torch.nn.Module.__init__(h)
+    h.num_classes = [1]
+    h.box_n_dim = 7
+    h.box_coder = coder
+    h.use_direction_classifier = True
+    h.direction_offset = 0.0
+    h.post_center_range = torch.tensor([0, -40.0, -5.0, 70.4, 40.0, 5.0], dtype=torch.float)
+    h.thresh = torch.tensor([0.3], dtype=torch.float)
+    h.top_labels = torch.zeros([70400], dtype=torch.long)
+
+    class Cfg(dict):
+        __getattr__ = dict.__getitem__
+
+    test_cfg = Cfg(nms=Cfg(use_rotate_nms=True, use_multi_class_nms=False, nms_pre_max_size=1000, nms_post_max_size=100,
+                           nms_iou_threshold=0.01), score_threshold=0.3, post_center_limit_range=[0, -40.0, -5.0, 70.4, 40.0, 5.0],
+                   max_per_img=100)
+    for case, seed in (("a", 21), ("b", 22)):
+        B = 2
+        pc = FC.predict_case(seed, B=B)
+        preds = [{k: torch.from_numpy(v) for k, v in pc.items()}]
+        example = dict(anchors=[torch.from_numpy(np.broadcast_to(anchors, (B,) + anchors.shape).copy())],
+                       metadata=[dict(token=str(i)) for i in range(B)],
+                       calib=dict(frustum=torch.from_numpy(np.broadcast_to(frustum, (B,) + frustum.shape).copy())))  # (B,1,6,4,3)
+        torch.topk = topk_ties_by_index
+        try:
+            with torch.no_grad():
+                rets = h.predict(example, preds, test_cfg)
+        finally:
+            torch.topk = _topk
+        for b, r in enumerate(rets):
+            out["predict_%s%d_boxes" % (case, b)] = r["box3d_lidar"].numpy()
+            out["predict_%s%d_scores" % (case, b)] = r["scores"].numpy()
+            out["predict_%s%d_labels" % (case, b)] = r["label_preds"].numpy()
+        out["predict_%s_input_check" % case] = np.array([float(v.astype(np.float64).sum()) for v in pc.values()])
+        s = torch.sigmoid(torch.from_numpy(pc["cls_preds"]).view(B, -1))
+        out["predict_%s_num_above_thresh" % case] = (s >= 0.3).sum(1).numpy()
+        print("predict case", case, "kept", [len(r["scores"]) for r in rets], "above threshold",
+              out["predict_%s_num_above_thresh" % case].tolist())
+    out["predict_near_threshold_pairs"] = np.array(stats["near"])
+    out["predict_anchor_check"] = np.concatenate([anchors.sum(0), anchors[::997].reshape(-1)[:70]])
+    out["predict_frustum"] = frustum
+    print("rotate_nms calls", stats["calls"], "near-threshold pairs", stats["near"])
+
+    # ------------------------------------------------------------------ Reformat + collate_kitti from source
+    mod("refpkg.datasets"); mod("refpkg.datasets.pipelines")
+    mod("refpkg.datasets.registry", PIPELINES=_Reg())
+    sys.modules["det3d"].torchie = sys.modules["det3d.torchie"]
+    fm = load_as("det3d/datasets/pipelines/formating.py", "refpkg.datasets.pipelines.formating")
+    mod("refpkg.parallel")
+    mod("refpkg.parallel.data_container", DataContainer=type("DataContainer", (), {}))
+    co = load_as("det3d/torchie/parallel/collate.py", "refpkg.parallel.collate")
+    for mode in ("val", "train"):
+        samples = FC.collate_samples()
+        bundles = []
+        for res in samples:
+            res = dict(res, mode=mode, labeled=True)
+            if mode == "val":  # the validation pipeline has no raw twins / targets besides the anchors (preprocess.py:178-232)
+                lid = {k: v for k, v in res["lidar"].items() if k in ("points", "voxels", "annotations")}
+                lid["targets"] = dict(anchors=res["lidar"]["targets"]["anchors"])
+                res["lidar"] = lid
+            b, _ = fm.Reformat()(res, {})
+            bundles.append(b)
+        ret = co.collate_kitti(bundles)
+        out["collate_%s_keys" % mode] = np.array(sorted(ret))
+        for k, v in ret.items():
+            if torch.is_tensor(v):
+                out["collate_%s__%s" % (mode, k)] = v.numpy()
+            elif isinstance(v, np.ndarray) and v.dtype != object:
+                out["collate_%s__%s" % (mode, k)] = v
+            elif isinstance(v, list) and v and torch.is_tensor(v[0]):
+                for t, vv in enumerate(v):
+                    out["collate_%s__%s__%d" % (mode, k, t)] = vv.numpy()
+            elif k == "calib":
+                for k1, v1 in v.items():
+                    out["collate_%s__calib__%s" % (mode, k1)] = v1.numpy()
+        print("collate", mode, sorted(ret))
+    np.savez_compressed(os.path.join(HERE, "forward_ref.npz"), **out)
+    print("forward golden written:", os.path.getsize(os.path.join(HERE, "forward_ref.npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

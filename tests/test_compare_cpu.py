@@ -1,0 +1,118 @@
+"""The detection parity rule itself (oracle/compare.py) on the oracle's own NMS problems: identical selections pass; a missing /
+moved / re-scored box fails when there is no near-threshold decision; a difference is accepted only if it is exactly what the
+oracle produces with its LISTED near-threshold decisions taken the other way; too many marginal decisions are rejected.
+Also pins the `forced` / `pairs` entry points of oracle/rotate_nms.c to the plain one."""
+import copy
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+sys.path.insert(0, GOLDEN)
+import forward_cases as FC  # noqa: E402
+from oracle import capi, postprocess as pp  # noqa: E402
+from oracle.compare import compare_detections, same_detections  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def frame():
+    pc = FC.predict_case(21)
+    anchors = pp.create_anchors_3d_range().reshape(-1, 7).astype(np.float32)
+    args = (pc["box_preds"][0].reshape(-1, 7), pc["cls_preds"][0].reshape(-1), pc["dir_cls_preds"][0].reshape(-1, 2),
+            pc["iou_preds"][0].reshape(-1), anchors, None)
+    out, dbg = pp.predict_frame(*args, return_debug=True)
+    dbg["rerun"] = lambda forced: pp.predict_frame(*args, forced=forced)
+    return out, dbg
+
+
+def _drop(d, i):
+    return {k: np.delete(v, i, axis=0) for k, v in d.items()}
+
+
+def test_identical_passes_and_any_change_fails_without_near_pairs(frame):
+    out, dbg = frame
+    d0 = dict(dbg, near_threshold_pairs=0, near_pairs=np.zeros((0, 2), np.int64))
+    r = compare_detections(out, out, d0)
+    assert r["matched"] == r["n"] == len(out["scores"]) > 20 and r["flipped"] == []
+    with pytest.raises(AssertionError):
+        compare_detections(_drop(out, 5), out, d0)
+    moved = copy.deepcopy(out)
+    moved["box3d_lidar"][3, 0] += 0.05
+    with pytest.raises(AssertionError):
+        compare_detections(moved, out, d0)
+    rescored = copy.deepcopy(out)
+    rescored["scores"][2] *= 1.01
+    with pytest.raises(AssertionError):
+        compare_detections(rescored, out, d0)
+    swapped = copy.deepcopy(out)
+    for k in swapped:
+        swapped[k][[0, 1]] = swapped[k][[1, 0]]
+    assert same_detections(swapped, out) is not None  # order matters
+
+
+def test_only_the_outcome_of_a_flipped_listed_decision_is_accepted(frame):
+    out, dbg = frame
+    kept = np.asarray(dbg["nms_kept_rows"])
+    dets = dbg["cand_dets"]
+    # a pair the oracle really evaluated: kept row i and a lower-scored candidate j it suppresses
+    # (most flips change nothing: in a cluster the candidate is suppressed by the next kept box anyway -- take one that matters)
+    corners = capi.box2d_corners(dets)
+    i = j = alt = None
+    for i in kept[:10].tolist():
+        for c in range(i + 1, len(dets)):
+            if c in set(kept.tolist()) or capi.quad_iou(corners[i], corners[c]) < 0.01:
+                continue
+            cand = dbg["rerun"](np.array([[i, c, 0]], np.int32))  # the decision taken the other way: c survives row i
+            if same_detections(cand, out) is not None:
+                j, alt = c, cand
+                break
+        if alt is not None:
+            break
+    assert alt is not None
+    d1 = dict(dbg, near_threshold_pairs=1, near_pairs=np.array([[i, j]]))
+    r = compare_detections(alt, out, d1)   # exactly the flipped outcome: accepted, and the flip is reported
+    assert r["flipped"] == [(i, j, 0)]
+    assert compare_detections(out, out, d1)["flipped"] == []
+    # anything else is not
+    with pytest.raises(AssertionError):
+        compare_detections(_drop(out, 7), out, d1)
+    with pytest.raises(AssertionError):
+        compare_detections(_drop(alt, 2), out, d1)
+    # without the rerun hook a difference cannot be excused
+    with pytest.raises(AssertionError):
+        compare_detections(alt, out, {k: v for k, v in d1.items() if k != "rerun"})
+
+
+def test_too_many_marginal_decisions_are_rejected(frame):
+    out, dbg = frame
+    K = dbg["cand_dets"].shape[0]
+    pairs = np.stack([np.arange(0, 9), np.arange(1, 10)], 1)
+    d2 = dict(dbg, near_threshold_pairs=len(pairs), near_pairs=pairs)
+    with pytest.raises(AssertionError):
+        compare_detections(_drop(out, 1), out, d2)
+
+
+def test_pairs_and_forced_entry_points_equal_the_plain_one():
+    from sessd_hip import synth
+    d = synth.clustered_boxes7(300, seed=9)[:, [0, 1, 3, 4, 6]].astype(np.float32)
+    d = np.concatenate([d, np.linspace(0.95, 0.3, 300, dtype=np.float32)[:, None]], 1)
+    k0, n0 = capi.rotate_nms_cc(d, 0.01, margin=5e-3)
+    k1, n1, pairs = capi.rotate_nms_cc(d, 0.01, margin=5e-3, return_pairs=True)
+    k2, n2, _ = capi.rotate_nms_cc(d, 0.01, margin=5e-3, forced=np.zeros((0, 3), np.int32))
+    assert np.array_equal(k0, k1) and np.array_equal(k0, k2) and n0 == n1 == n2 == len(pairs)
+    for i, j in pairs:
+        iou = capi.quad_iou(capi.box2d_corners(d[i:i + 1])[0], capi.box2d_corners(d[j:j + 1])[0])
+        assert abs(iou - 0.01) < 5e-3 and i in set(k1.tolist())
+    # forcing a decision to what it already is changes nothing; forcing it the other way changes the kept list
+    i, j = int(k0[0]), None
+    for c in range(i + 1, 300):
+        if c not in set(k0.tolist()) and capi.quad_iou(capi.box2d_corners(d[i:i + 1])[0], capi.box2d_corners(d[c:c + 1])[0]) >= 0.01:
+            j = c
+            break
+    assert j is not None
+    same, _, _ = capi.rotate_nms_cc(d, 0.01, forced=np.array([[i, j, 1]], np.int32))
+    flip, _, _ = capi.rotate_nms_cc(d, 0.01, forced=np.array([[i, j, 0]], np.int32))
+    assert np.array_equal(same, k0) and not np.array_equal(flip, k0)

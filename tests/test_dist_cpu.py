@@ -70,3 +70,43 @@ def test_shard_indices_match_distributed_sampler():
             want = list(DistributedSampler(data, num_replicas=w, rank=r, shuffle=False))
             got, _ = sdist.shard_indices(n, r, w)
             assert got == want
+
+
+def _worker_records(rank, world, port, num_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    idx, pad = sdist.shard_indices(num_frames, rank, world)
+    rec, cnt = sdist.pack_detections([_fake_dets(i) for i in idx])          # what the engine leaves on the device per frame
+    all_rec, all_cnt = sdist.gather_records(rec, cnt, num_frames)           # the bench's end-of-job collective
+    allf = sdist.unpack_records(all_rec, all_cnt, num_frames)
+    ok = all(np.array_equal(allf[i]["box3d_lidar"], _fake_dets(i)["box3d_lidar"]) and
+             np.allclose(allf[i]["scores"], _fake_dets(i)["scores"]) for i in range(num_frames))
+    q.put((rank, ok, tuple(all_rec.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("num_frames", [5, 6])
+def test_two_rank_gather_of_device_records(num_frames):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_records, args=(r, world, port, num_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, shape in res:
+        assert ok and shape == (2, 3, 100, 9), (rank, ok, shape)
+
+
+def test_gather_records_single_process():
+    rec, cnt = sdist.pack_detections([_fake_dets(i) for i in range(4)])
+    all_rec, all_cnt = sdist.gather_records(rec, cnt, 4)
+    assert tuple(all_rec.shape) == (1, 4, 100, 9)
+    out = sdist.unpack_records(all_rec, all_cnt, 4)
+    assert all(np.array_equal(out[i]["box3d_lidar"], _fake_dets(i)["box3d_lidar"]) for i in range(4))

@@ -2,13 +2,15 @@
 (oracle/pipeline.py) on the same seeded weights and synthetic KITTI-shaped frames.
 
 Tolerances: BEV / SSFA feature maps 2e-4 * max|ref| (float32 sums in another order through 14 + 14 layers);
-detections: same count and order, boxes within 2e-3 m / rad, scores within 1e-4 relative -- unless the oracle
-reports a pair within 1e-4 of the NMS threshold or a score within 1e-5 of 0.3 (selection may then differ)."""
+detections: same count and order, boxes within 2e-3 m / rad, scores within 1e-3 relative. When the oracle reports NMS
+decisions within 1e-4 of the 0.01 IoU threshold, the detections must equal the oracle's under SOME assignment of those listed
+decisions (at most 6 per frame; oracle/compare.py); no path returns success without comparing every box."""
 import numpy as np
 import pytest
 import torch
 
 from oracle import pipeline, postprocess as pp
+from oracle.compare import compare_detections
 from sessd_hip import configs, synth
 from sessd_hip.engine import InferenceEngine
 
@@ -27,13 +29,12 @@ def state(model):
 
 
 def _compare_dets(got, want, dbg):
-    near = dbg.get("near_threshold_pairs", 0)
-    if len(got["scores"]) != len(want["scores"]) or not np.allclose(got["scores"], want["scores"], rtol=1e-3, atol=1e-6):
-        assert near > 0, ("selection differs without near-threshold pairs", len(got["scores"]), len(want["scores"]))
-        return False
-    if len(want["scores"]):
-        assert np.allclose(got["box3d_lidar"], want["box3d_lidar"], rtol=1e-3, atol=2e-3)
-    return True
+    """oracle/compare.py: identical detections, or identical to the oracle re-run with some of its LISTED near-threshold NMS
+    decisions (|IoU - 0.01| < 1e-4, at most 6) taken the other way. Never returns without having compared every box."""
+    r = compare_detections(got, want, dbg)
+    if r["flipped"]:
+        print("device == oracle with near-threshold decisions (kept row, candidate row, suppress):", r["flipped"])
+    return r
 
 
 @pytest.mark.parametrize("batch,seeds,max_voxels", [(1, (0,), 16000), (2, (3, 4), 20000)])
@@ -58,8 +59,8 @@ def test_engine_vs_oracle(dev, model, state, batch, seeds, max_voxels):
     assert float((bev - inter["bev"]).abs().max()) < 2e-4 * max(1.0, float(inter["bev"].abs().max()))
     ssfa = eng.t["out"].cpu()
     assert float((ssfa - inter["ssfa"]).abs().max()) < 5e-4 * max(1.0, float(inter["ssfa"].abs().max()))
-    ok = [_compare_dets(g, w, d) for g, w, d in zip(got, want, inter["debug"])]
-    assert any(ok), "every frame fell into the near-threshold escape hatch"
+    res = [_compare_dets(g, w, d) for g, w, d in zip(got, want, inter["debug"])]
+    assert all(r["matched"] == r["n"] for r in res)
     print("detections per frame", [len(g["scores"]) for g in got], "candidates", [d["num_candidates"] for d in inter["debug"]])
 
 
@@ -144,12 +145,16 @@ def test_data_pipeline_contract_to_detections(dev, model):
     assert [d["metadata"]["token"] for d in dets] == ["0", "1"]
 
 
-def test_stress_config_dense_scene(dev, model, state):
+def test_stress_config_dense_scene(dev):
     """BASELINE.json configs[4] (dense-scene stress): 200k points per frame, max 64000 voxels, batch 8 on one GPU.
     (a) frame 0 against the CPU oracle pipeline at full size; (b) size-independent properties: a frame's detections do
     not depend on its batch slot or on the batch size (bit-identical), voxel counts equal the oracle voxelizer's."""
     from oracle import capi
     B, P, MV = 8, 200000, 64000
+    # BatchNorm calibrated on a dense scene (as bench.py --stress does): with the sparse-scan calibration the dense frames decode
+    # to boxes hundreds of kilometres long, on which float32 corner geometry -- and so any NMS comparison -- is meaningless
+    model = configs.build_synthetic_detector(dev, seed=0, calib_frame_seed=99, max_voxels=MV, num_points=P, supersample=3)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     distinct = [synth.make_frame(100 + i, P, supersample=3) for i in range(3)]
     frames = [distinct[i % 3] for i in range(B)]
     anchors = pp.create_anchors_3d_range().reshape(-1, 7)
@@ -178,7 +183,9 @@ def test_stress_config_dense_scene(dev, model, state):
     # (a) full-size oracle comparison of one frame
     want, inter = pipeline.run_frames([distinct[0]], state, VG["range"], VG["voxel_size"], 5, MV, anchors, None,
                                       return_intermediate=True)
-    assert _compare_dets(got[0], want[0], inter["debug"][0]) or inter["debug"][0].get("near_threshold_pairs", 0) > 0
+    r = _compare_dets(got[0], want[0], inter["debug"][0])
+    assert r["matched"] == r["n"]
+    assert float(np.abs(want[0]["box3d_lidar"][:, 3:6]).max(initial=0)) < 50.0  # car-sized boxes, not the degenerate regime
 
 
 def test_engine_voxelizer_mixed_cap_batch(dev, model):
@@ -204,3 +211,26 @@ def test_engine_voxelizer_mixed_cap_batch(dev, model):
         assert np.array_equal(eng.voxels[lo:hi].cpu().numpy(), v)
         hit.append(c.shape[0] == MV)
     assert hit[0] and not hit[1] and not hit[2], hit  # the case the regression needs: capped frame, then uncapped ones
+
+
+def test_detection_records_follow_the_frames(dev, model):
+    """InferenceEngine.attach_records: every enqueue / graph replay appends one fixed-size record per frame on the device
+    (what bench.py gathers at the end of the job); unpacked, they equal results() of the same frames."""
+    from sessd_hip import dist as sdist
+    eng = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 2, 20480, dev)
+    rec, cnt = eng.attach_records(8)
+    frames = [torch.from_numpy(synth.make_frame(40 + i, 20000 - 500 * i)).to(dev) for i in range(6)]
+    want = []
+    eng.set_points(frames[0:2]); eng.enqueue(); want += eng.results()
+    eng.capture()
+    eng.record_cursor.zero_()
+    want = []
+    for k in range(3):
+        eng.set_points(frames[2 * k:2 * k + 2]); eng.replay(); want += eng.results()
+    assert int(eng.record_cursor.item()) == 6
+    all_rec, all_cnt = sdist.gather_records(rec, cnt, 6)
+    got = sdist.unpack_records(all_rec, all_cnt, 6)
+    for g, w in zip(got, want):
+        assert np.array_equal(g["box3d_lidar"], w["box3d_lidar"]) and np.array_equal(g["scores"], w["scores"])
+        assert np.array_equal(g["label_preds"], w["label_preds"])
+    assert sum(len(w["scores"]) for w in want) > 20
