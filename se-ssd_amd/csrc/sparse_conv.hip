@@ -61,15 +61,27 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   constexpr int G = STEPS < 4 ? STEPS : 4;  // floats per vector load
   constexpr int SG = STEPS / G;
   __shared__ int s_nbr[4][32][16];        // per wave: row index of (offset, site) -- 8 KB per workgroup
-  // 1-D grid, cout group fastest: the workgroups that have work (tiles below the live site count) are the FIRST ones of the
-  // grid, so the dispatcher deals them round-robin over all XCDs / CUs. (With the cout group in blockIdx.y the live
-  // workgroups came as COUT/16/NTW separate bursts, each landing on the same few CUs: 4 waves per SIMD there, most CUs idle.)
+  // 1-D grid. Workgroup b runs on XCD b % 8 (observed dispatch order; only speed depends on it). The live 64-site tile
+  // groups are dealt to the XCDs in runs of C consecutive groups: rows are numbered in (b,z,y,x) order, so a run is a
+  // spatial neighbourhood whose gathered rows are mostly its own -- each XCD's L2 fetches its share of the feature table
+  // instead of most of it (FETCH_SIZE of a 64->64 layer: 4.7 -> 2.9 MB at batch 1, profiles/) -- while runs, not whole
+  // slabs, per XCD keep the dense regions of a scene from landing on one XCD (contiguous eighths: +25 % time at batch 1).
+  // C grows with the level (1 below 512 groups: plain round robin, 8 from 4096 groups). Inside an XCD the cout groups of
+  // a tile group are adjacent workgroups (they share the gathered rows) and the live workgroups come first, so the
+  // dispatcher spreads them over all CUs. (With the cout group in blockIdx.y the live workgroups came as separate
+  // bursts, each landing on the same few CUs: 4 waves per SIMD there, most CUs idle.)
   constexpr int NGRP = COUT / 16 / NTW;
-  const int tbase = (int)(blockIdx.x % NGRP) * NTW;
+  const int n = min(n_dev[0], n_cap);
+  const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+  const int groups = (n + 63) >> 6;
+  const int lg = groups >= 4096 ? 3 : (groups >= 2048 ? 2 : (groups >= 512 ? 1 : 0));  // C = 1 << lg
+  const int t_local = j / NGRP;
+  const int group = ((((t_local >> lg) << 3) + xcd) << lg) + (t_local & ((1 << lg) - 1));
+  if (group >= groups) return;
+  const int tbase = (j - t_local * NGRP) * NTW;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int tile = (int)(blockIdx.x / NGRP) * 4 + wv;   // wave-uniform
-  const int n = min(n_dev[0], n_cap);
+  const int tile = group * 4 + wv;   // wave-uniform
   if (tile * 16 >= n) return;             // scalar branch; no workgroup barrier below (every wave is independent)
   const int i = lane & 15, kq = lane >> 4;
   const uint32_t tmask = __builtin_amdgcn_readfirstlane(tile_mask[tile]);
@@ -223,7 +235,8 @@ int launch_depth(bool dense, const float* in_feat, const int* nbr, const uint32_
                  int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
                  const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
   const int tiles = sessd_divup(n_cap, 16);
-  dim3 grid(sessd_divup(tiles, 4) * (COUT / 16 / NTW)), block(256);
+  // per XCD: ceil(groups / 8C) runs of C groups; C <= 8, so ceil(groups / 8) + 8 positions always suffice
+  dim3 grid(8 * (sessd_divup(sessd_divup(tiles, 4), 8) + 8) * (COUT / 16 / NTW)), block(256);
   if (dense)
     SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, DEPTH, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
                        n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2]);

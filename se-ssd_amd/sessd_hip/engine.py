@@ -234,6 +234,7 @@ class InferenceEngine:
         self.tile_cfg = {}
         self.tune_report = {}
         self._tuning = None
+        self._kmarks = None
         self.sparse_split = {}
         self._tuning_sparse = None
 
@@ -280,6 +281,13 @@ class InferenceEngine:
         pc, scale, shift = layer
         if self._tuning is not None:
             self._tuning.append((name, x, layer, out, relu, residual))
+        if self._kmarks is not None:  # per-launch HIP events inside a whole eager frame (dense_layer_times)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name))
+            e1.record()
+            self._kmarks.append((name, e0, e1))
+            return r
         return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name))
 
     def autotune(self, candidates=(1, 2, 3, 4, 6, 11, 12), reps=5):
@@ -481,6 +489,69 @@ class InferenceEngine:
         total -= ns[-1] * self.sp.layers[-1]["cout"] * 4  # the last layer writes the dense map instead of a feature table
         total += self.bev.numel() * 4
         return total, ns
+
+    def dense_layer_times(self, reps=10):
+        """In-frame duration (ms) of every dense conv launch: whole frames are enqueued eagerly with a HIP event before and after
+        each launch on the launching stream (the launches are 10-80 us long and the host runs ahead of the device, so the events
+        bracket the kernel, in the cache / clock state the frame really gives it). dict name -> mean ms."""
+        acc = {}
+        for _ in range(2):
+            self.enqueue()
+        for _ in range(reps):
+            self._kmarks = []
+            self.enqueue()
+            marks, self._kmarks = self._kmarks, None
+            torch.cuda.synchronize()
+            for name, e0, e1 in marks:
+                acc[name] = acc.get(name, 0.0) + e0.elapsed_time(e1) / reps
+        return acc
+
+    def spmiddle_mfma_report(self, reps=10):
+        """Per sparse conv layer of the staged batch: HIP-event time of the launch alone, rulebook pairs (useful work) and active
+        (16-site tile, offset) steps (executed work: every step multiplies 16 rows whatever the number of pairs in it).
+        Returns dict(layers=[...], conv_ms, useful_gflop, executed_gflop, executed_tflops, executed_frac_of_f32_mfma_peak)."""
+        self._tuning_sparse = []
+        self.enqueue()
+        torch.cuda.synchronize()
+        todo, self._tuning_sparse = self._tuning_sparse, None
+        ns = [int(self.prefix[self.B].item())] + [int(L["n"].item()) for L in self.levels[1:]]
+        st = torch.cuda.current_stream().cuda_stream
+        rows, tot_ms, tot_use, tot_exe = [], 0.0, 0.0, 0.0
+        # the dense-output layer is not in the tuning list: time it with its own arguments
+        last_idx = len(self.sp.layers) - 1
+        jl = self._job_of[last_idx]
+        todo = list(todo) + [(last_idx, self.sp.layers[last_idx], None, self.chain.nbr[jl], self.chain.tile_mask[jl], len(self.levels) - 1, None)]
+        feat_last = None
+        for idx, lay, in_feat, nbr, tm, out_li, out_feat in todo:
+            n = ns[out_li]
+            kv = lay["ks"][0] * lay["ks"][1] * lay["ks"][2]
+            pairs = int((nbr[:kv, :n] >= 0).sum().item())
+            masks = tm[:(n + 15) // 16]
+            steps = int(sum(int(((masks >> k) & 1).sum().item()) for k in range(kv)))
+            if in_feat is None:  # last layer: input = output of the previous one
+                in_feat, dense = feat_last, True
+            else:
+                dense = False
+            for _ in range(2):
+                self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, dense=dense, idx=idx)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, dense=dense, idx=idx)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            use, exe = 2.0 * pairs * lay["cin"] * lay["cout"] / 1e9, 2.0 * steps * 16 * lay["cin"] * lay["cout"] / 1e9
+            rows.append(dict(layer=idx, kind=lay["kind"], cin=lay["cin"], cout=lay["cout"], sites=n, pairs=pairs, tile_steps=steps,
+                             ms=round(ms, 5), useful_gflop=round(use, 4), executed_gflop=round(exe, 4),
+                             executed_tflops=round(exe / ms, 2) if ms > 0 else 0.0))
+            tot_ms, tot_use, tot_exe = tot_ms + ms, tot_use + use, tot_exe + exe
+            feat_last = out_feat if out_feat is not None else feat_last
+        self.enqueue()  # leave the buffers consistent
+        torch.cuda.synchronize()
+        return dict(layers=rows, conv_ms=round(tot_ms, 5), useful_gflop=round(tot_use, 3), executed_gflop=round(tot_exe, 3),
+                    executed_tflops=round(tot_exe / tot_ms, 2), executed_frac_of_f32_mfma_peak=round(tot_exe / tot_ms / 157.3, 4),
+                    useful_row_fraction=round(tot_use / tot_exe, 4))
 
     # ------------------------------------------------------------------ hipGraph
     def capture(self, warmup=2):
