@@ -75,6 +75,27 @@ int sessd_boxes_aligned_overlap_bev(const float* boxes_a, const float* boxes_b, 
  * criterion -1 IoU | 0 inter/area(query) | 1 inter/area(box) | 2 intersection area. */
 int sessd_rotate_iou_eval(const float* boxes, int num_boxes, const float* query, int num_query, int criterion, float* out,
                           sessd_stream_t stream);
+/* det3d/datasets/utils/eval.py:324-367 box3d_overlap (rotate_iou_gpu_eval criterion 2 + the numba loop d3_box_overlap_kernel) in
+ * one launch: boxes (N,7), query (K,7) rows [loc 3, dims 3, rot], z_axis = height axis among the three (KITTI camera: 1),
+ * z_center = position of the location in the height (camera: 1.0); criterion -1 IoU | 0 / box volume | 1 / query volume | 2 raw.
+ * float64 rows as the annotations hold them: the rotated BEV part is computed in float32 (as rotate_iou_gpu_eval casts), the
+ * height / volume arithmetic in float64 (as the numba loop does). */
+int sessd_box3d_overlap_eval(const double* boxes, int num_boxes, const double* query, int num_query, int criterion, int z_axis,
+                             double z_center, double* out, sessd_stream_t stream);
+/* KITTI AP accumulation (det3d/datasets/kitti/eval.py:121-171,174-319, utils/eval.py:144-278): frames flattened CSR style --
+ * overlaps = per frame a (n_det, n_gt) float64 block at ov_off[f]; gt_off / dt_off / dc_off (F+1) row offsets into gt_data (.,5)
+ * [bbox 4, alpha], dt_data (.,6) [bbox 4, alpha, score], dc_boxes (.,4), ignored_gt / ignored_det (0 counts | 1 neutral | -1 other).
+ * compute_fp == 0: tp_scores (sum n_gt) = score of the detection matched to each ground truth, NaN where none (first pass);
+ * compute_fp != 0: stats (F, num_thresholds, 4) = tp, fp, fn, orientation similarity per frame and score threshold.
+ * sessd_kitti_thresholds = get_thresholds on scores sorted descending; sessd_kitti_reduce = ordered sum over the frames. */
+int sessd_kitti_statistics(const double* overlaps, const long long* ov_off, const int32_t* gt_off, const int32_t* dt_off,
+                           const int32_t* dc_off, const double* gt_data, const double* dt_data, const int32_t* ignored_gt,
+                           const int32_t* ignored_det, const double* dc_boxes, int num_frames, int metric, double min_overlap,
+                           const double* thresholds, int num_thresholds, int compute_fp, int compute_aos, double* tp_scores,
+                           double* stats, int32_t* err_flag, sessd_stream_t stream);
+int sessd_kitti_reduce(const double* stats, int num_frames, int num_thresholds, double* pr, sessd_stream_t stream);
+int sessd_kitti_thresholds(const double* sorted_scores_desc, int num_scores, int num_gt, int num_sample_pts, double* thresholds,
+                           int32_t* num_thresholds, sessd_stream_t stream);
 /* sessd_nms_sorted modes 3 / 4 = numba rotate_nms_gpu (nms_gpu.py:422-499) / nms_gpu (+1 convention, :36-169) */
 size_t sessd_nms_workspace_bytes(int num_boxes);
 int sessd_nms_sorted(int mode, const float* boxes, int num_boxes, float thresh, long long* keep, int32_t* num_keep,
@@ -185,7 +206,6 @@ int sessd_bn_relu_train_bwd(const float* dy, const float* x, const float* y, con
                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 
 /* ---- training data path, point-level work -----------------------------------------------------------
- * EXPERIMENTAL -- compiled, not yet validated on hardware; the pipeline uses the numpy host stage.
  * replaces det3d/core/bbox/geometry.py:215-276 points_in_convex_polygon_3d_jit (numba) as used by
  * box_np_ops.points_in_rbbox :1152, sampler/preprocess.py:645 (per-object noise) and sa_da_v2.py:65-74 (pyramids).
  * points (num_points, point_stride) float32; planes (num_bodies, faces, 4) float32 [nx,ny,nz,d], inward normals, from the host
@@ -193,6 +213,22 @@ int sessd_bn_relu_train_bwd(const float* dy, const float* x, const float* y, con
  * (x*nx + y*ny + z*nz + d < 0 for every face, float32, left to right, no contraction: identical to the numba loop). */
 int sessd_points_in_bodies(const float* points, int num_points, int point_stride, const float* planes, int num_bodies,
                            int faces, uint32_t* out_mask, sessd_stream_t stream);
+/* det3d/core/sampler/preprocess.py:544-560 points_transform_ (the point side of noise_per_object_v4_): in place, every point takes
+ * the rigid motion of the FIRST valid box that contains it (membership fused: same planes and comparison as above) -- rotation
+ * about the box centre, then the translation, rounded step by step like the reference's in-place float32 row updates with
+ * float64 operands. planes (num_boxes, 6, 4), centers / loc (num_boxes, 3) float64, sincos (num_boxes, 2) [sin, cos], valid
+ * (num_boxes) bytes; num_boxes <= 128. */
+int sessd_points_rigid_moves(float* points, int num_points, int point_stride, const float* planes, const double* centers,
+                             const double* loc, const float* sincos, const uint8_t* valid, int num_boxes, sessd_stream_t stream);
+/* preprocess.py:896-945 random_flip_v2 + global_rotation_v3 + global_scaling_v3 applied to the points in one pass (the draws
+ * themselves stay on the host); raw_copy != NULL: the cloud as it was before (points_raw, pipelines/preprocess.py:130-134). */
+int sessd_points_global_transform(float* points, int num_points, int point_stride, int flip, float sin_angle, float cos_angle,
+                                  float scale, float* raw_copy, sessd_stream_t stream);
+/* order-preserving compaction by a keep byte per point (GT-AUG removal of covered points pipelines/preprocess.py:102-105,
+ * shape-aware dropout): out rows + *n_out on the device, ready for sessd_voxelize_frame. */
+size_t sessd_points_compact_workspace_bytes(int num_points);
+int sessd_points_compact(const float* points, const uint8_t* keep, int num_points, int point_stride, float* out,
+                         int out_capacity, int32_t* n_out, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 
 /* ---- sparse conv backward (spconv's indice_conv backward as differentiated by the SE-SSD training
  * step, det3d/torchie/trainer/trainer_sessd.py:250-275 through det3d/models/backbones/scn.py:106-148) -------------

@@ -271,6 +271,50 @@ __global__ __launch_bounds__(256) void rotate_iou_eval_kernel(const float* __res
   out[(size_t)n * K + k] = rot_iou_crit(rq, rb, criterion, &S.px[0][t], &S.py[0][t], &S.vs[0][t], 256);
 }
 
+// det3d/datasets/utils/eval.py:324-367 box3d_overlap = d3_box_overlap_kernel over rotate_iou_gpu_eval(criterion 2): the rotated
+// BEV intersection area times the overlap of the height ranges, normalised by union (-1) / volume(box) (0) / volume(query) (1).
+// boxes (N,7), query (K,7) rows [loc 3, dims 3, rot]; z_axis = index of the height axis among the three (KITTI camera: 1),
+// z_center = where the location sits in the height (camera: 1.0 = bottom face). One launch instead of a device call for the
+// intersections plus a numba loop for the rest. The BEV box of a row is what remains after dropping the height axis
+// (eval.py:359-364), in the reference's [c0, c1, d0, d1, rot] order.
+__global__ __launch_bounds__(256) void box3d_overlap_eval_kernel(const double* __restrict__ boxes, int N,
+                                                                  const double* __restrict__ query, int K, int criterion,
+                                                                  int z_axis, double z_center, double* __restrict__ out) {
+  __shared__ RotLds S;
+  const int k = blockIdx.x * 16 + (threadIdx.x & 15), n = blockIdx.y * 16 + (threadIdx.x >> 4);
+  if (n >= N || k >= K) return;
+  const double* b = boxes + (size_t)n * 7;
+  const double* q = query + (size_t)k * 7;
+  // the rotated part runs in float32 like rotate_iou_gpu_eval (nms_gpu.py:655-657 casts its inputs), the height / volume part in
+  // the annotation dtype (float64) like the numba loop
+  float rb[5], rq[5];
+  int w = 0;
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+    if (a != z_axis) {
+      rb[w] = (float)b[a]; rb[w + 2] = (float)b[a + 3];
+      rq[w] = (float)q[a]; rq[w + 2] = (float)q[a + 3];
+      ++w;
+    }
+  rb[4] = (float)b[6]; rq[4] = (float)q[6];
+  const int t = threadIdx.x;
+  double rinc = (double)rot_iou_crit(rq, rb, 2, &S.px[0][t], &S.py[0][t], &S.vs[0][t], 256);
+  if (rinc > 0.0) {
+    const double min_z = fmin(b[z_axis] + b[z_axis + 3] * (1.0 - z_center), q[z_axis] + q[z_axis + 3] * (1.0 - z_center));
+    const double max_z = fmax(b[z_axis] - b[z_axis + 3] * z_center, q[z_axis] - q[z_axis + 3] * z_center);
+    const double iw = min_z - max_z;
+    if (iw > 0.0) {
+      const double area1 = b[3] * b[4] * b[5], area2 = q[3] * q[4] * q[5];
+      const double inc = iw * rinc;
+      const double ua = criterion == -1 ? (area1 + area2 - inc) : (criterion == 0 ? area1 : (criterion == 1 ? area2 : 1.0));
+      rinc = inc / ua;
+    } else {
+      rinc = 0.0;
+    }
+  }
+  out[(size_t)n * K + k] = rinc;
+}
+
 // rotate_nms_kernel (nms_gpu.py:422-458): suppress when devRotateIoU(row, col) > thresh; boxes (N,5) sorted
 __global__ __launch_bounds__(64) void rotate_nms_numba_mask_kernel(int n, float thresh, const float* __restrict__ boxes,
                                                                     unsigned long long* __restrict__ mask) {
@@ -517,6 +561,17 @@ int sessd_rotate_iou_eval(const float* boxes, int num_boxes, const float* query,
   if (num_boxes == 0 || num_query == 0) return SESSD_OK;
   SESSD_LAUNCH(rotate_iou_eval_kernel, dim3(sessd_divup(num_query, 16), sessd_divup(num_boxes, 16)), dim3(256), 0, stream,
                      boxes, num_boxes, query, num_query, criterion, out);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// det3d/datasets/utils/eval.py:324-367 box3d_overlap on the device (see box3d_overlap_eval_kernel)
+int sessd_box3d_overlap_eval(const double* boxes, int num_boxes, const double* query, int num_query, int criterion, int z_axis,
+                             double z_center, double* out, hipStream_t stream) {
+  if (num_boxes < 0 || num_query < 0 || z_axis < 0 || z_axis > 2 || criterion < -1 || criterion > 2) return SESSD_EINVAL;
+  if (num_boxes == 0 || num_query == 0) return SESSD_OK;
+  SESSD_LAUNCH(box3d_overlap_eval_kernel, dim3(sessd_divup(num_query, 16), sessd_divup(num_boxes, 16)), dim3(256), 0, stream,
+               boxes, num_boxes, query, num_query, criterion, z_axis, z_center, out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -1,8 +1,10 @@
 """mirrors det3d/datasets/kitti/eval.py: KITTI average precision (2-D bbox / BEV / 3-D / orientation) as the reference
 computes it for the "car 3D AP@0.7" headline of SE-SSD -- get_official_eval_result :467-569, do_eval_v3 :395-421,
 eval_class_v3 :174-319, fused_compute_statistics :121-171, clean_data :40-108, get_thresholds :18-37, get_mAP :330-340.
-The rotated-box overlaps run on the device (det3d.datasets.utils.eval); difficulty filtering, the greedy matching and the
-precision / recall accumulation are host code as in the reference. Pinned by tests/golden/kitti_eval_ref.npz."""
+The rotated-box overlaps (det3d.datasets.utils.eval), the greedy matching of every (frame, score threshold), the recall
+thresholds and the tp / fp / fn / similarity sums run on the device (sessd_kitti_* in csrc/kitti_eval.hip); difficulty
+filtering (strings, a few boxes per frame) and the final 41-point table arithmetic stay on the host. The host loops of the
+reference's structure remain as the second implementation (on_device=False). Pinned by tests/golden/kitti_eval_ref.npz."""
 import io as sysio
 
 import numpy as np
@@ -85,10 +87,18 @@ def fused_compute_statistics(overlaps, pr, gt_nums, dt_nums, dc_nums, gt_datas, 
         g, d, c = g + gt_nums[i], d + dt_nums[i], c + dc_nums[i]
 
 
+ACCUMULATE_ON_DEVICE = True  # False: the host loops below (the reference's structure; what the CPU tests pin to the golden)
+
+
 def eval_class_v3(gt_annos, dt_annos, current_classes, difficultys, metric, min_overlaps, compute_aos=False, z_axis=1,
-                  z_center=1.0, num_parts=50):
+                  z_center=1.0, num_parts=50, on_device=None):
     """Precision at 41 recall levels per (class, difficulty, overlap threshold) (:174-319). metric 0 bbox / 1 BEV / 2 3-D;
-    min_overlaps [num_minoverlap, metric, class]."""
+    min_overlaps [num_minoverlap, metric, class]. on_device (default: ACCUMULATE_ON_DEVICE and a GPU is present): the greedy
+    matching of every (frame, score threshold) and the tp / fp / fn / similarity sums run on the MI355X
+    (sessd_kitti_statistics / _thresholds / _reduce), only the (<= 41, 4) table per configuration comes back."""
+    if on_device is None:
+        import torch
+        on_device = ACCUMULATE_ON_DEVICE and torch.cuda.is_available()
     assert len(gt_annos) == len(dt_annos)
     parts = [p for p in get_split_parts(len(gt_annos), num_parts) if p != 0]
     overlaps, parted, n_dt, n_gt = calculate_iou_partly(dt_annos, gt_annos, metric, num_parts, z_axis=z_axis, z_center=z_center)
@@ -99,7 +109,26 @@ def eval_class_v3(gt_annos, dt_annos, current_classes, difficultys, metric, min_
         for l, diff in enumerate(difficultys):
             gt_datas, dt_datas, ign_gts, ign_dets, dontcares, n_dc, n_valid = prepare_data(gt_annos, dt_annos, cls, difficulty=diff,
                                                                                          clean_data=clean_data)
+            stat = None
+            if on_device:
+                import torch
+                from sessd_hip import ops
+                stat = ops.KittiStatistics(overlaps, gt_datas, dt_datas, ign_gts, ign_dets, dontcares,
+                                           torch.device("cuda", torch.cuda.current_device()))
             for k, min_overlap in enumerate(min_overlaps[:, metric, m]):
+                if stat is not None:
+                    thresholds, pr = stat.precision_table(metric, float(min_overlap), int(n_valid), compute_aos, PTS)
+                    n = len(thresholds)
+                    all_thr[m, l, k, :n] = thresholds
+                    with np.errstate(invalid="ignore", divide="ignore"):
+                        precision[m, l, k, :n] = pr[:, 0] / (pr[:, 0] + pr[:, 1])
+                        if compute_aos:
+                            aos[m, l, k, :n] = pr[:, 3] / (pr[:, 0] + pr[:, 1])
+                    for i in range(n):
+                        precision[m, l, k, i] = np.max(precision[m, l, k, i:], axis=-1)
+                        if compute_aos:
+                            aos[m, l, k, i] = np.max(aos[m, l, k, i:], axis=-1)
+                    continue
                 tp_scores = []
                 for i in range(len(gt_annos)):
                     tp_scores += compute_statistics_jit(overlaps[i], gt_datas[i], dt_datas[i], ign_gts[i], ign_dets[i], dontcares[i],
@@ -123,6 +152,7 @@ def eval_class_v3(gt_annos, dt_annos, current_classes, difficultys, metric, min_
                     precision[m, l, k, i] = np.max(precision[m, l, k, i:], axis=-1)
                     if compute_aos:
                         aos[m, l, k, i] = np.max(aos[m, l, k, i:], axis=-1)
+    # `recall` stays zero as in the reference (:292 is commented out there)
     return {"recall": recall, "precision": precision, "orientation": aos, "thresholds": all_thr, "min_overlaps": min_overlaps}
 
 

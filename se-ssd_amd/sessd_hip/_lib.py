@@ -39,6 +39,10 @@ SIGNATURES = {
     "sessd_boxes_pairwise": (i32, [i32, vp, i32, vp, i32, vp, vp]),
     "sessd_boxes_aligned_overlap_bev": (i32, [vp, vp, i32, vp, vp]),
     "sessd_rotate_iou_eval": (i32, [vp, i32, vp, i32, i32, vp, vp]),
+    "sessd_box3d_overlap_eval": (i32, [vp, i32, vp, i32, i32, i32, f64, vp, vp]),
+    "sessd_kitti_statistics": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "sessd_kitti_reduce": (i32, [vp, i32, i32, vp, vp]),
+    "sessd_kitti_thresholds": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "sessd_nms_workspace_bytes": (sz, [i32]),
     "sessd_nms_sorted": (i32, [i32, vp, i32, f32, vp, vp, vp, sz, vp]),
     "sessd_nms_axis_eps_sorted": (i32, [vp, i32, i32, f32, f32, vp, vp, vp, sz, vp]),
@@ -70,6 +74,10 @@ SIGNATURES = {
     "sessd_sparse_renumber_workspace_bytes": (sz, [i32, vp]),
     "sessd_sparse_renumber_sites": (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, u32, vp, vp, vp, sz, vp]),
     "sessd_points_in_bodies": (i32, [vp, i32, i32, vp, i32, i32, vp, vp]),
+    "sessd_points_rigid_moves": (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, vp]),
+    "sessd_points_global_transform": (i32, [vp, i32, i32, i32, f32, f32, f32, vp, vp]),
+    "sessd_points_compact_workspace_bytes": (sz, [i32]),
+    "sessd_points_compact": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
     "sessd_bn_relu_train_workspace_bytes": (sz, [i32]),
     "sessd_bn_relu_train_fwd": (i32, [vp, vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_bn_relu_train_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),

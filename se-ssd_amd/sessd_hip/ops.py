@@ -5,7 +5,7 @@ tensors of the stated dtype; nothing here copies to the host or synchronises.
 """
 import torch
 
-from ._lib import lib, check
+from ._lib import lib, check, SessdError
 
 
 def _stream():
@@ -463,8 +463,8 @@ def bn_relu_train(x, n_dev, bn, relu=True):
 
 
 def points_in_bodies(points, planes):
-    """EXPERIMENTAL (not yet validated on hardware): points (P, >=3) float32 on the device, planes (M, F, 4) float32 on the
-    device [nx, ny, nz, d] with inward normals -> (P, M) bool on the device (strictly inside every face)."""
+    """points (P, >=3) float32 on the device, planes (M, F, 4) float32 on the device [nx, ny, nz, d] with inward normals ->
+    (P, M) bool on the device (strictly inside every face)."""
     _req(points, torch.float32, "points")
     _req(planes, torch.float32, "planes")
     P, M, F = points.shape[0], planes.shape[0], planes.shape[1]
@@ -474,6 +474,126 @@ def points_in_bodies(points, planes):
           "points_in_bodies")
     bit = torch.arange(M, device=points.device)
     return ((mask[:, bit // 32] >> (bit % 32)) & 1).bool()
+
+
+def box3d_overlap_eval(boxes, qboxes, criterion=-1, z_axis=1, z_center=1.0):
+    """det3d/datasets/utils/eval.py:324-367 on the device: boxes (N,7), qboxes (K,7) float64 device tensors -> (N,K) float64."""
+    _req(boxes, torch.float64, "boxes")
+    _req(qboxes, torch.float64, "qboxes")
+    out = torch.empty((boxes.shape[0], qboxes.shape[0]), dtype=torch.float64, device=boxes.device)
+    check(lib.sessd_box3d_overlap_eval(boxes.data_ptr(), boxes.shape[0], qboxes.data_ptr(), qboxes.shape[0], int(criterion),
+                                       int(z_axis), float(z_center), out.data_ptr(), _stream()), "box3d_overlap_eval")
+    return out
+
+
+class KittiStatistics:
+    """Device side of eval_class_v3 (det3d/datasets/kitti/eval.py:174-319) for one (class, difficulty): the frames' overlap
+    matrices and cleaned annotations uploaded once (CSR layout), then per overlap threshold: first matching pass -> recall
+    thresholds -> second pass over (frame, threshold) -> ordered reduction. Only the final (T,4) table returns to the host."""
+
+    def __init__(self, overlaps, gt_datas, dt_datas, ign_gts, ign_dets, dontcares, device):
+        import numpy as np
+        F = len(overlaps)
+        self.F, self.dev = F, device
+        n_gt = np.array([g.shape[0] for g in gt_datas], np.int64)
+        n_dt = np.array([d.shape[0] for d in dt_datas], np.int64)
+        n_dc = np.array([c.shape[0] for c in dontcares], np.int64)
+        off = lambda n: np.concatenate([[0], np.cumsum(n)]).astype(np.int32)
+        self.gt_off_h, self.dt_off_h = off(n_gt), off(n_dt)
+        ov_sizes = n_gt * n_dt
+        ov_off = np.concatenate([[0], np.cumsum(ov_sizes)[:-1]]).astype(np.int64) if F else np.zeros((0,), np.int64)
+        # overlaps[i] is (n_det, n_gt) (calculate_iou_partly(dt, gt)), float64 as the host code carries them
+        flat = np.concatenate([np.ascontiguousarray(o, np.float64).reshape(-1) for o in overlaps]) if F else np.zeros((0,), np.float64)
+        cat = lambda lst, w, dt: (np.concatenate(lst, 0) if len(lst) and sum(x.shape[0] for x in lst) else np.zeros((0, w), dt)).astype(dt)
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+        self.ov, self.ov_off = t(flat if flat.size else np.zeros((1,), np.float64)), t(ov_off if F else np.zeros((1,), np.int64))
+        self.gt_off, self.dt_off, self.dc_off = t(self.gt_off_h), t(self.dt_off_h), t(off(n_dc))
+        pad = lambda a, w, dt: a if a.shape[0] else np.zeros((1, w), dt)
+        self.gt = t(pad(cat(gt_datas, 5, np.float64), 5, np.float64))
+        self.dt = t(pad(cat(dt_datas, 6, np.float64), 6, np.float64))
+        self.dc = t(pad(cat(dontcares, 4, np.float64), 4, np.float64))
+        ig = np.concatenate(ign_gts).astype(np.int32) if F else np.zeros((0,), np.int32)
+        idt = np.concatenate(ign_dets).astype(np.int32) if F else np.zeros((0,), np.int32)
+        self.ig, self.idt = t(ig if ig.size else np.zeros((1,), np.int32)), t(idt if idt.size else np.zeros((1,), np.int32))
+        self.n_gt_total = int(n_gt.sum())
+        self.err = torch.zeros((1,), dtype=torch.int32, device=device)
+
+    def _run(self, metric, min_overlap, thresholds, compute_fp, compute_aos, tp_scores, stats):
+        check(lib.sessd_kitti_statistics(self.ov.data_ptr(), self.ov_off.data_ptr(), self.gt_off.data_ptr(), self.dt_off.data_ptr(),
+                                         self.dc_off.data_ptr(), self.gt.data_ptr(), self.dt.data_ptr(), self.ig.data_ptr(),
+                                         self.idt.data_ptr(), self.dc.data_ptr(), self.F, int(metric), float(min_overlap),
+                                         _p(thresholds), 0 if thresholds is None else int(thresholds.shape[0]),
+                                         1 if compute_fp else 0, 1 if compute_aos else 0, _p(tp_scores), _p(stats),
+                                         self.err.data_ptr(), _stream()), "kitti_statistics")
+
+    def precision_table(self, metric, min_overlap, num_valid_gt, compute_aos=False, num_pts=41):
+        """-> (thresholds (n,), pr (n,4) [tp, fp, fn, similarity]) as numpy float64, n <= num_pts."""
+        import numpy as np
+        tp_scores = torch.empty((max(self.n_gt_total, 1),), dtype=torch.float64, device=self.dev)
+        self._run(metric, min_overlap, None, False, False, tp_scores, None)
+        sc = tp_scores[:self.n_gt_total]
+        sc = sc[~torch.isnan(sc)]
+        if sc.numel() == 0 or num_valid_gt <= 0:
+            return np.zeros((0,)), np.zeros((0, 4))
+        sc, _ = torch.sort(sc, descending=True)
+        thr = torch.zeros((num_pts,), dtype=torch.float64, device=self.dev)
+        n_thr = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+        check(lib.sessd_kitti_thresholds(sc.data_ptr(), int(sc.numel()), int(num_valid_gt), int(num_pts), thr.data_ptr(),
+                                         n_thr.data_ptr(), _stream()), "kitti_thresholds")
+        n = int(n_thr.item())
+        thr = thr[:n].contiguous()
+        stats = torch.empty((self.F, n, 4), dtype=torch.float64, device=self.dev)
+        self._run(metric, min_overlap, thr, True, compute_aos, None, stats)
+        pr = torch.empty((n, 4), dtype=torch.float64, device=self.dev)
+        check(lib.sessd_kitti_reduce(stats.data_ptr(), self.F, n, pr.data_ptr(), _stream()), "kitti_reduce")
+        if int(self.err.item()):
+            raise SessdError("a frame has more than 256 detections: not supported by the device evaluation")
+        return thr.cpu().numpy(), pr.cpu().numpy()
+
+
+def points_rigid_moves_(points, planes, centers, loc, rot, valid):
+    """In place on the device: preprocess.py:544-560 points_transform_. points (P, >=3) f32 device; planes (M,6,4) f32 device;
+    centers / loc (M,3), rot (M,) yaw changes and valid (M,) given as host arrays (float64 as the sampler draws them)."""
+    import numpy as np
+    _req(points, torch.float32, "points")
+    _req(planes, torch.float32, "planes")
+    M = planes.shape[0]
+    dev = points.device
+    rot = np.asarray(rot, np.float64)
+    sc = np.stack([np.sin(rot), np.cos(rot)], 1).astype(np.float32)  # numpy casts sin / cos of the float64 angle to the point dtype
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a).astype(dt))).to(dev)
+    c, l, r, v = t(centers, np.float64), t(loc, np.float64), t(sc, np.float32), t(np.asarray(valid).astype(np.uint8), np.uint8)
+    check(lib.sessd_points_rigid_moves(points.data_ptr(), points.shape[0], points.shape[1], planes.data_ptr(), c.data_ptr(),
+                                       l.data_ptr(), r.data_ptr(), v.data_ptr(), M, _stream()), "points_rigid_moves")
+    return points
+
+
+def points_global_transform_(points, flip, angle, scale, raw_copy=None):
+    """In place on the device: random_flip_v2 + global_rotation_v3 + global_scaling_v3 (preprocess.py:896-945) with the host's
+    draws; raw_copy (same shape, device) optionally receives the untransformed cloud."""
+    import numpy as np
+    _req(points, torch.float32, "points")
+    if raw_copy is not None:
+        _req(raw_copy, torch.float32, "raw_copy")
+    check(lib.sessd_points_global_transform(points.data_ptr(), points.shape[0], points.shape[1], 1 if flip else 0,
+                                            float(np.float32(np.sin(angle))), float(np.float32(np.cos(angle))),
+                                            float(np.float32(scale)), _p(raw_copy), _stream()), "points_global_transform")
+    return points
+
+
+def points_compact(points, keep, out=None):
+    """Order-preserving compaction on the device: rows of points (P, C) whose keep flag (P,) bool / uint8 is set.
+    Returns (out (cap, C), n_out device int32 (1,)); nothing synchronises."""
+    _req(points, torch.float32, "points")
+    k = keep.to(torch.uint8).contiguous()
+    P, C = points.shape
+    if out is None:
+        out = torch.empty((max(P, 1), C), dtype=torch.float32, device=points.device)
+    n_out = torch.zeros((1,), dtype=torch.int32, device=points.device)
+    ws = workspace(lib.sessd_points_compact_workspace_bytes(P), points.device, "compact")
+    check(lib.sessd_points_compact(points.data_ptr(), k.data_ptr(), P, C, out.data_ptr(), out.shape[0], n_out.data_ptr(),
+                                   ws.data_ptr(), ws.numel(), _stream()), "points_compact")
+    return out, n_out
 
 
 def sparse_rulebook_transpose(nbr, n_out_dev, n_in_cap):
