@@ -58,6 +58,9 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight: independent batch-1 engines on separate HIP streams (1 = strictly one frame at a time)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--sk-workgroups", type=int, default=-1,
+                    help="persistent workgroups of the stream-K Winograd launches (multiple of 8; 0 = the kernel's default, all CUs; "
+                         "-1 = 0 with one frame in flight, 224 with several: the free CUs take the other stream's small kernels)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     return ap.parse_args()
 
@@ -111,9 +114,14 @@ def main():
     if not args.no_autotune:
         rep = eng.autotune()
         log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
+    if args.sk_workgroups < 0:
+        args.sk_workgroups = 224 if len(engines) > 1 else 0
+    for e in engines:
+        e.sk_workgroups = args.sk_workgroups
     for e in engines[1:]:
         e.tile_cfg = dict(eng.tile_cfg)
         e.sparse_split = dict(eng.sparse_split)
+        e.sk_ws = torch.zeros_like(eng.sk_ws) if eng.sk_ws is not None else None  # one stream-K workspace per stream
         e.set_points(batch_of(0))
         e.enqueue()
     torch.cuda.synchronize()
@@ -184,7 +192,7 @@ def main():
                                    "seeded random weights, BatchNorm calibrated"
                                    % (args.batch, args.points, args.max_voxels, args.batch, 4 if args.stress else 1),
                        "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps * args.batch,
-                       "frames_in_flight": len(engines),
+                       "frames_in_flight": len(engines), "streamk_workgroups": args.sk_workgroups,
                        "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                        "detections_last_frame": dets, "detections_first_frame": int(len(first["scores"])),
                        "records_gathered": frames_gathered,
@@ -201,14 +209,17 @@ def main():
             # the set the rocprofv3 kernel trace averages under this kernel's name
             names = ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2")
             cfgs = [eng.tile_cfg.get(nm) for nm in names]
-            wino = all(c in (20, 21) or (c is None and ops.USE_WINOGRAD) for c in cfgs)
+            wino = all(c in (20, 21, 22, 23) or (c is None and ops.USE_WINOGRAD) for c in cfgs)
+            streamk = sum(1 for c in cfgs if c in (22, 23))
+            log("dense tile_cfg:", {k: v for k, v in eng.tile_cfg.items()})
             eng.set_points(batch_of(0))
             lt = eng.dense_layer_times(reps=20)
             kms = sum(lt[nm] for nm in names) / len(names)
             flops = CONV_FLOPS * args.batch
             ach = flops / (kms * 1e-3) / 1e12
             log("roofline kernel: %.3f ms per launch in sequence" % kms)
-            kname = ("conv3x3s1_winograd_kernel (fused Winograd F(2x2,3x3) on f32 MFMA)" if wino
+            kname = (("conv3x3s1_winograd_sk_kernel / conv3x3s1_winograd_kernel (fused Winograd F(2x2,3x3) on f32 MFMA; %d of the 7 "
+                      "launches are the stream-K kernel, as the per-layer autotune chose)" % streamk) if wino
                      else "conv2d_mfma_kernel<9 taps> (direct implicit GEMM on f32 MFMA)")
             exe = ach * (16.0 / 36.0 if wino else 1.0)  # Winograd F(2x2,3x3) multiplies 16 of the 36 products of direct convolution
             out["roofline"] = {"bound": "mfma", "kernel": kname + ": Conv2d 3x3 128->128 @200x176 (5 launches per frame) and "
@@ -220,6 +231,7 @@ def main():
                                "avg_launch_source": "HIP events before / after each of the kernel's 7 launches inside 20 whole frames "
                                                     "(eager enqueue; same stream as the kernels)",
                                "dense_launch_ms": {k: round(v, 5) for k, v in lt.items()},
+                               "dense_tile_cfg": {k: eng.tile_cfg.get(k) for k in lt},
                                "flops_per_launch_executed": flops * (16.0 / 36.0 if wino else 1.0),
                                "flops_per_launch_algorithmic": flops,
                                "achieved_algorithmic": ach, "frac_algorithmic": ach / F32_MFMA_PEAK_TFLOPS,

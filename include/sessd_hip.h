@@ -310,6 +310,17 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
 int sessd_conv3x3_winograd(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
                            const float* scale, const float* shift, int relu, const float* residual, int variant,
                            sessd_stream_t stream);
+/* Second generation of the above (csrc/dense_wino_sk.hip): a workgroup handles 32 tiles x ALL couts of a unit (the patch
+ * transform runs once per tile block instead of once per 32-cout block) and the rounds of all units are dealt out "stream-K" in
+ * equal shares to `workgroups` persistent workgroups (a multiple of 8; 0 = the shape's default), units cut by a share boundary
+ * being finished by whichever part arrives last. shape 0: 8 waves x 128 couts per workgroup, one per CU; shape 1: 4 waves x 64
+ * couts, two per CU. upk = U = G g G^T packed [ceil(cout / C)][cin/2][NW][2][32][C/32][16/NW], (NW, C) = (8, 128) / (4, 64);
+ * cin % (2 NW) == 0, even H and W. workspace: sessd_conv3x3_winograd_sk_workspace_bytes(...) bytes, zeroed ONCE by the caller
+ * (the kernel leaves its counters zero), not shared between launches that may run concurrently. */
+size_t sessd_conv3x3_winograd_sk_workspace_bytes(int batch, int h, int w, int cout, int shape, int workgroups);
+int sessd_conv3x3_winograd_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
+                              const float* scale, const float* shift, int relu, const float* residual, void* workspace,
+                              size_t workspace_bytes, int shape, int workgroups, sessd_stream_t stream);
 /* ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
  * classes (py,px) = (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps: wpk4[c] packed like above, taps_dy4/taps_dx4 are
  * 4 rows of 4 ints. input (B,cin,hin,win) -> output (B,cout,2*hin,2*win); cin % 8 == 0. */

@@ -20,7 +20,7 @@ FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-
          "-I", os.path.join(os.path.dirname(HERE), "include"), "-I", CSRC]
 # Geometry / index kernels must round like the reference's scalar CPU code: no FMA contraction.
 # The MFMA / FMA-chain kernels (sparse and dense convolutions) contract freely.
-CONTRACT_FAST = {"dense_conv.hip", "sparse_conv.hip"}
+CONTRACT_FAST = {"dense_conv.hip", "dense_wino_sk.hip", "sparse_conv.hip"}
 
 
 def _newer(src_list, target):

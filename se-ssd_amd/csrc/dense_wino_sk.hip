@@ -1,0 +1,496 @@
+// 3x3 stride-1 BEV convolutions (the seven of the SSFA neck, det3d/models/necks/rpn_v1.py:135-210) as fused Winograd
+// F(2x2,3x3) on the f32 matrix cores, decomposed "stream-K": second generation of conv3x3s1_winograd_kernel
+// (dense_conv.hip), written after its counters (profiles/r2_wino_pmc.txt): f32 MFMA and VALU never co-execute on gfx950
+// (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so the 3.4 VALU instructions per MFMA of the patch transform -- repeated by each of
+// the four 32-cout workgroups of a tile block -- cost a quarter of the SIMD time, 1100 workgroups over 256 CUs leave 16 %
+// of the CU time idle in the last wave of workgroups, and operands arrive at 0.5 KB-loads per MFMA.
+//
+//   unit      = 32 consecutive 2x2-output tiles x (CBN x 32) couts x all input channels; 16 GEMMs M_xi = U_xi V_xi
+//   workgroup = NW waves; wave w owns the 16/NW transform points xi = XW w .. XW w + XW-1 for ALL couts of the unit
+//               (XW x CBN = 8 accumulators of 32x32). Two shapes: <8 waves, 128 couts> (one workgroup per CU) and
+//               <4 waves, 64 couts> (two per CU: one's epilogue and pipeline refill hide behind the other's MFMAs).
+//   round     = NW k-steps (2 NW input channels): wave w loads the 4x4 patches of k-step w (lane = tile, channel parity;
+//               4 x 16-B buffer loads, out-of-image rows by out-of-range offsets), transforms them in registers and writes
+//               V[k-step w][16 xi] of the NEXT round into the other LDS buffer -- once per unit, not once per 32 couts;
+//               its 8 NW MFMAs of THIS round take B (V) from LDS and A (U = G g G^T, host-packed so the 8 operands of a
+//               lane and k-step are two 16-B loads) through a register ring of NW sets, loaded NW - 1 k-steps ahead with
+//               exact vmcnt. One barrier per round.
+//   stream-K  : the launch has a fixed number of persistent workgroups (a multiple of 8); the list of all rounds of all
+//               units is cut into equal contiguous shares, so every CU runs the same number of rounds (275 units on 256 CUs
+//               would otherwise take two passes). A unit cut by a share boundary is finished by whichever of its parts
+//               arrives last: a part that finds all others already counted adds their partial outputs (prefetched while
+//               it transforms its own) and finishes; otherwise it applies the (linear) output transform to its partial
+//               sums, writes them to its scratch slot with system-scope write-through stores and bumps the unit's counter
+//               -- if that made it the last after all, it re-reads all parts in share order. No workgroup ever waits for
+//               another. Summation order is fixed (share order), so results do not depend on arrival order.
+// Numerics: Winograd rounding (1e-6 of the output scale); the bits depend on (shape, number of workgroups), not on timing.
+#include "common.hpp"
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+using f32x2v = __attribute__((ext_vector_type(2))) float;
+typedef unsigned int u32x4g __attribute__((__vector_size__(16)));  // the b128 buffer builtins' own type
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+#define SESSD_OOB 0x80000000u
+// Workgroup barrier that orders LDS traffic only. __syncthreads() is a workgroup-scope fence: with global stores in flight
+// hipcc emits s_waitcnt vmcnt(0) in front of it, i.e. every barrier of the epilogue would wait for the previous pass's output
+// stores to be acknowledged by memory (measured: 3 us per pass).
+#define SESSD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#define SESSD_SYSTEM_SCOPE 17  // sc0 | sc1: write-through to / read from memory, past the per-XCD L2
+
+struct WinoArgs {
+  const float* in;        // (B, cin, H, W)
+  const float* upk;       // [cout groups][cin/2][wave NW][h 2][j 32][cb CBN][xi_local XW]
+  float* out;             // (B, cout, H, W)
+  const float* scale;
+  const float* shift;
+  const float* residual;
+  float* scratch;         // [2 * workgroups][CBN*32 couts][32 tiles][4]
+  unsigned* counters;     // [units], zero between launches
+  int cin, hin, win, cout, relu;
+  int tw, ntiles, tblocks, ngroups, rpu, total_rounds;
+};
+
+template <int NW, int CBN>
+__global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(WinoArgs A) {
+  constexpr int XW = 16 / NW;                          // transform points per wave
+  static_assert(XW * CBN == 8, "8 accumulators per wave");
+  constexpr int NT = NW * 64;
+  constexpr unsigned WSTEP = NW * 2u * 32u * 32u;      // bytes of packed U per k-step
+  constexpr int VBUF = NW * 1024;                      // floats of one V buffer: [ks NW][xi 16][h 2][tile 32]
+  constexpr int SLOT = CBN * 32 * 32 * 4;              // floats of one scratch slot
+  constexpr int NPT = 1024 / NT;                       // (cout, tile) pairs per thread and 32-cout pass
+  constexpr int RING = NW;                             // U operand sets in flight (one round's worth)
+  __shared__ __attribute__((aligned(16))) float lds[16384];  // 64 KB: V double buffer, then the M exchange of the epilogue
+  __shared__ int s_last, s_pend;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int j = lane & 31, h = lane >> 5;
+  const int G = gridDim.x;
+  // share w of the round list; consecutive shares on one XCD (workgroup b runs on XCD b % 8): neighbouring units share
+  // input rows through that XCD's L2
+  const int w = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+  const long long R = A.total_rounds;
+  int r = (int)((long long)w * R / G);
+  const int r_stop = (int)((long long)(w + 1) * R / G);
+  const int in_plane = A.hin * A.win;
+  const size_t out_plane = (size_t)in_plane;
+  const unsigned xstep = 2u * (unsigned)in_plane * 4u;  // bytes per k-step (2 channels)
+  const unsigned wo = (unsigned)(((wave * 2 + h) * 32 + j) * 32);
+
+  // A cut unit this workgroup has written a part of but not finished: 0 none, 1 part stored, 2 part counted and found to be
+  // the last one (this workgroup finishes the unit after its last segment)
+  int pend_state = 0, pend_u = 0, pend_first = 0, pend_last = 0, pend_tbase = 0, pend_mbase = 0, pend_b = 0;
+  // Every vector-memory operation issued before this point has completed in every thread (vmcnt returns in order; called right
+  // after a wait that covers younger loads, or with an explicit wait) -> count the stored part.
+#define SESSD_SK_SIGNAL()                                                                          \
+  {                                                                                                \
+    __builtin_amdgcn_s_waitcnt(0);                                                                 \
+    __syncthreads();                                                                               \
+    if (tid == 0) {                                                                                \
+      const unsigned old = __hip_atomic_fetch_add(A.counters + pend_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+      s_pend = (old == (unsigned)(pend_last - pend_first)) ? 1 : 0;                                \
+    }                                                                                              \
+    __syncthreads();                                                                               \
+    pend_state = s_pend ? 2 : 0;                                                                   \
+  }
+
+#define SESSD_SK_FINALIZE(Y, CO, SC, SH)                                                            \
+  if (tok && (CO) < e_cout) {                                                                       \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                 \
+      const size_t o = (size_t)(CO) * out_plane + pix + (size_t)a * e_win;                          \
+      float v0 = fmaf((Y)[2 * a], (SC), (SH)), v1 = fmaf((Y)[2 * a + 1], (SC), (SH));              \
+      if (e_relu & 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }                                 \
+      if (resb) { v0 += resb[o]; v1 += resb[o + 1]; }                                               \
+      *reinterpret_cast<float2*>(outb + o) = make_float2(v0, v1);                                   \
+    }                                                                                               \
+  }
+// Finish the cut unit this workgroup turned out to be the last part of: all parts (its own included) from the scratch slots,
+// added in share order, then BatchNorm / ReLU / residual and the stores.
+#define SESSD_SK_FINISH_PENDING()                                                                  \
+  {                                                                                                \
+    const __attribute__((address_space(4))) WinoArgs* Fp =                                         \
+        (const __attribute__((address_space(4))) WinoArgs*)__builtin_amdgcn_kernarg_segment_ptr(); \
+    asm volatile("" : "+s"(Fp));                                                                   \
+    const float* f_scale = Fp->scale;                                                              \
+    const float* f_shift = Fp->shift;                                                              \
+    const int e_cout = Fp->cout, e_relu = Fp->relu, e_win = Fp->win, f_tw = Fp->tw;                \
+    const rsrc_t fr = make_rsrc(Fp->scratch, (unsigned)(2 * G) * SLOT * 4u);                       \
+    float* outb = Fp->out + (size_t)pend_b * e_cout * out_plane;                                   \
+    const float* resb = Fp->residual ? Fp->residual + (size_t)pend_b * e_cout * out_plane : nullptr; \
+    const int tl = tid & 31, col0 = tid >> 5;                                                      \
+    const int tt = pend_tbase + tl;                                                                \
+    const bool tok = tt < Fp->ntiles;                                                              \
+    const int oty = tok ? tt / f_tw : 0, otx = tok ? tt - (tt / f_tw) * f_tw : 0;                  \
+    const size_t pix = (size_t)(2 * oty) * e_win + 2 * otx;                                        \
+    _Pragma("unroll 1") for (int cb = 0; cb < CBN; ++cb) {                                         \
+      f32x4v ysum[NPT];                                                                            \
+      _Pragma("unroll") for (int n = 0; n < NPT; ++n) ysum[n] = 0.f;                               \
+      for (int wq = pend_first; wq <= pend_last; ++wq) {                                           \
+        const unsigned slot = (unsigned)(2 * wq + (wq == pend_first ? 1 : 0)) * (unsigned)(SLOT * 4); \
+        f32x4v p[NPT];                                                                             \
+        _Pragma("unroll") for (int n = 0; n < NPT; ++n)                                            \
+          p[n] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(                 \
+              fr, (int)(slot + (unsigned)(((cb * 32 + col0 + (NT / 32) * n) * 32 + tl) * 16)), 0, SESSD_SYSTEM_SCOPE)); \
+        _Pragma("unroll") for (int n = 0; n < NPT; ++n) ysum[n] += p[n];                           \
+      }                                                                                            \
+      _Pragma("unroll") for (int n = 0; n < NPT; ++n) {                                            \
+        const int co = pend_mbase + cb * 32 + col0 + (NT / 32) * n;                                \
+        const float scv = (f_scale && co < e_cout) ? f_scale[co] : 1.f, shv = (f_shift && co < e_cout) ? f_shift[co] : 0.f; \
+        const float z[4] = {ysum[n].x, ysum[n].y, ysum[n].z, ysum[n].w};                           \
+        SESSD_SK_FINALIZE(z, co, scv, shv)                                                         \
+      }                                                                                            \
+    }                                                                                              \
+    if (tid == 0) __hip_atomic_store(Fp->counters + pend_u, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+    pend_state = 0;                                                                                \
+  }
+
+  while (r < r_stop) {
+    // everything that shapes a buffer resource or an SGPR offset is forced wave-uniform (otherwise hipcc wraps every
+    // buffer load in a readfirstlane waterfall loop; integer division runs on the VALU)
+    const int u = __builtin_amdgcn_readfirstlane(r / A.rpu);
+    const int r0 = __builtin_amdgcn_readfirstlane(r - u * A.rpu);
+    const int r1 = __builtin_amdgcn_readfirstlane(min(r_stop - u * A.rpu, A.rpu));
+    r = u * A.rpu + r1;
+    const int cg = __builtin_amdgcn_readfirstlane(u % A.ngroups), ub = u / A.ngroups;
+    const int tb = __builtin_amdgcn_readfirstlane(ub % A.tblocks), b = __builtin_amdgcn_readfirstlane(ub / A.tblocks);
+    const int t_base = tb * 32, m_base = cg * (CBN * 32);
+    const rsrc_t xr = make_rsrc(A.in + (size_t)b * A.cin * in_plane, (unsigned)A.cin * in_plane * 4u);
+    const rsrc_t wr = make_rsrc(A.upk + (size_t)cg * (A.cin >> 1) * (WSTEP / 4), (unsigned)(A.cin >> 1) * WSTEP);
+
+    // ---- transform role: lane = (tile j, channel parity h)
+    const int t = t_base + j;
+    const bool tlive = t < A.ntiles;
+    const int ty = tlive ? t / A.tw : 0, tx = tlive ? t - (t / A.tw) * A.tw : 0;
+    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
+    unsigned ro[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int y = y0 + q;
+      ro[q] = (tlive && y >= 0 && y < A.hin) ? (unsigned)((h * in_plane + y * A.win + max(x0, 0)) * 4) : SESSD_OOB;
+    }
+    const bool mask_l = (tx == 0), mask_r = (tx == A.tw - 1);
+    const bool edge = __builtin_amdgcn_ballot_w64(tlive && (mask_l || mask_r)) != 0;
+    const int klast = r1 * NW - 1;
+
+    f32x16 acc[XW][CBN];
+#pragma unroll
+    for (int x = 0; x < XW; ++x)
+#pragma unroll
+      for (int c = 0; c < CBN; ++c)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[x][c][q] = 0.f;
+    f32x4v pr[4];
+    f32x4v ua[RING][2];
+    float bv[2][XW];
+
+#define SESSD_SK_LOADP(ROUND)                                                                      \
+  {                                                                                                \
+    const unsigned xs = (unsigned)(min((ROUND), r1 - 1) * NW + wave) * xstep;                      \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                  \
+      pr[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)ro[q], (int)xs, 0)); \
+  }
+#define SESSD_SK_LOADU(SET, KG)                                                                    \
+  {                                                                                                \
+    const unsigned ws = (unsigned)min((KG), klast) * WSTEP;                                        \
+    ua[SET][0] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)wo, (int)ws, 0));        \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    ua[SET][1] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(wr, (int)(wo + 16u), (int)ws, 0)); \
+  }
+#define SESSD_SK_TRANSFORM(VOFF)                                                                   \
+  {                                                                                                \
+    if (edge) {                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                              \
+        const f32x4v p = pr[q];                                                                    \
+        pr[q].x = mask_l ? 0.f : p.x; pr[q].y = mask_l ? p.x : p.y;                                \
+        pr[q].z = mask_l ? p.y : p.z; pr[q].w = mask_l ? p.z : (mask_r ? 0.f : p.w);               \
+      }                                                                                            \
+    }                                                                                              \
+    f32x2v tl[4], tr[4];                                                                           \
+    tl[0] = pr[0].xy - pr[2].xy; tr[0] = pr[0].zw - pr[2].zw;                                      \
+    tl[1] = pr[1].xy + pr[2].xy; tr[1] = pr[1].zw + pr[2].zw;                                      \
+    tl[2] = pr[2].xy - pr[1].xy; tr[2] = pr[2].zw - pr[1].zw;                                      \
+    tl[3] = pr[1].xy - pr[3].xy; tr[3] = pr[1].zw - pr[3].zw;                                      \
+    float* dst = &lds[(VOFF) + wave * 1024 + h * 32 + j];                                          \
+    _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                \
+      dst[(a * 4 + 0) * 64] = tl[a].x - tr[a].x;                                                   \
+      dst[(a * 4 + 1) * 64] = tl[a].y + tr[a].x;                                                   \
+      dst[(a * 4 + 2) * 64] = tr[a].x - tl[a].y;                                                   \
+      dst[(a * 4 + 3) * 64] = tl[a].y - tr[a].y;                                                   \
+    }                                                                                              \
+  }
+#define SESSD_SK_READV(P, KS, VOFF)                                                                \
+  {                                                                                                \
+    const float* vb = &lds[(VOFF) + (KS)*1024 + wave * (XW * 64) + h * 32 + j];                    \
+    _Pragma("unroll") for (int x = 0; x < XW; ++x) bv[P][x] = vb[x * 64];                          \
+  }
+#define SESSD_SK_MMA(SET, P)                                                                       \
+  {                                                                                                \
+    _Pragma("unroll") for (int c = 0; c < CBN; ++c)                                                \
+      _Pragma("unroll") for (int x = 0; x < XW; ++x)                                               \
+        acc[x][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[SET][(c * XW + x) >> 2][(c * XW + x) & 3], bv[P][x], acc[x][c], 0, 0, 0); \
+  }
+  // step KS of a round: k-step kg0 + KS from ring set KS; the set freed by the previous step receives k-step + RING - 1
+#define SESSD_SK_STEP(KS)                                                                          \
+  {                                                                                                \
+    SESSD_SK_LOADU(((KS) + RING - 1) & (RING - 1), kg0 + (KS) + RING - 1)                          \
+    if ((KS) < NW - 1) SESSD_SK_READV(((KS) + 1) & 1, (KS) + 1, voff)                              \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_SK_MMA((KS) & (RING - 1), (KS) & 1)                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+#define SESSD_SK_ROUND()                                                                           \
+  {                                                                                                \
+    const int kg0 = rr * NW;                                                                       \
+    SESSD_SK_LOADP(rr + 1)                                                                         \
+    SESSD_SK_READV(0, 0, voff)                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_SK_STEP(0)                                                                               \
+    SESSD_SK_STEP(1)                                                                               \
+    SESSD_SK_STEP(2)                                                                               \
+    SESSD_SK_STEP(3)                                                                               \
+    if constexpr (NW == 8) {                                                                       \
+      SESSD_SK_STEP(4)                                                                             \
+      SESSD_SK_STEP(5)                                                                             \
+      SESSD_SK_STEP(6)                                                                             \
+      SESSD_SK_STEP(7)                                                                             \
+    }                                                                                              \
+    SESSD_SK_TRANSFORM(voff ^ VBUF)                                                                \
+    __syncthreads();                                                                               \
+    voff ^= VBUF;                                                                                  \
+    ++rr;                                                                                          \
+  }
+
+    SESSD_SK_LOADP(r0)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < RING - 1; ++s) {  // in ring order: the in-loop vmcnt ladder assumes it
+      SESSD_SK_LOADU(s, r0 * NW + s)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    SESSD_SK_TRANSFORM(0)
+    __syncthreads();
+    if (pend_state == 1) {
+      // the previous segment's part: its stores are older than the patch loads every thread has just consumed
+      if (tid == 0) {
+        const unsigned old = __hip_atomic_fetch_add(A.counters + pend_u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_pend = (old == (unsigned)(pend_last - pend_first)) ? 1 : 0;
+      }
+      pend_state = 3;  // counted; the answer is read at this segment's epilogue
+    }
+    int voff = 0;
+    int rr = (A.relu & 4) ? r1 : r0;  // DEBUG bit 4: skip the main loop
+    while (rr < r1) SESSD_SK_ROUND()
+#undef SESSD_SK_LOADP
+#undef SESSD_SK_LOADU
+#undef SESSD_SK_TRANSFORM
+#undef SESSD_SK_READV
+#undef SESSD_SK_MMA
+#undef SESSD_SK_STEP
+#undef SESSD_SK_ROUND
+
+    // ---- epilogue: per 32-cout block, M_xi of all 16 xi through LDS, Y = A^T M A per (cout, tile)
+    // The arguments only the epilogue needs are re-read from the kernel-argument segment HERE (through an opaque pointer):
+    // kept live across the main loop they exhaust the SGPRs, and hipcc then parks a buffer resource in VGPRs and wraps
+    // its loads in waterfall loops.
+    if (pend_state == 3) {
+      SESSD_LDS_BARRIER();
+      pend_state = s_pend ? 2 : 0;
+    }
+    const __attribute__((address_space(4))) WinoArgs* Ep =
+        (const __attribute__((address_space(4))) WinoArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(Ep));
+    const float* e_scale = Ep->scale;
+    const float* e_shift = Ep->shift;
+    const int e_cout = Ep->cout, e_relu = Ep->relu, e_win = Ep->win, e_tw = Ep->tw, e_ntiles = Ep->ntiles;
+    unsigned* e_counter = Ep->counters + u;
+    const rsrc_t sr = make_rsrc(Ep->scratch, (unsigned)(2 * G) * SLOT * 4u);
+    const bool full = (r0 == 0 && r1 == Ep->rpu);
+    float* outb = Ep->out + (size_t)b * e_cout * out_plane;
+    const float* resb = Ep->residual ? Ep->residual + (size_t)b * e_cout * out_plane : nullptr;
+    // this thread's (cout, tile) pairs: tile tl = tid & 31 in every pass, cout = m_base + cb * 32 + (tid >> 5) + (NT / 32) * n
+    const int tl = tid & 31, col0 = tid >> 5;
+    const int tt = t_base + tl;
+    const bool tok = tt < e_ntiles;
+    const int oty = tok ? tt / e_tw : 0, otx = tok ? tt - (tt / e_tw) * e_tw : 0;
+    const size_t pix = (size_t)(2 * oty) * e_win + 2 * otx;
+    // parts of unit u = the shares that intersect its rounds; share of round q = ((q + 1) G - 1) / R
+    const int w_first = (int)((((long long)u * Ep->rpu + 1) * G - 1) / R);
+    const int w_last = (int)((((long long)u * Ep->rpu + Ep->rpu) * G - 1) / R);
+    const unsigned my_slot = (unsigned)(2 * w + (r0 == 0 ? 1 : 0)) * (unsigned)(SLOT * 4);
+    // A part that finds every other part already counted is the last one for certain: it neither writes nor counts, it
+    // fetches the (single) other part now and adds it on the fly.
+    bool certain = false;
+    unsigned oslot = 0;
+    if (!full && w_last == w_first + 1 && !(e_relu & 8)) {
+      // one reader: every thread of the workgroup must take the same path
+      if (tid == 0) s_last = __hip_atomic_load(e_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1 : 0;
+      __syncthreads();
+      certain = s_last != 0;
+      const int wq = (w == w_first) ? w_last : w_first;
+      oslot = (unsigned)(2 * wq + (wq == w_first ? 1 : 0)) * (unsigned)(SLOT * 4);
+    }
+    const bool writes_out = full || certain;
+    // other-part values and BatchNorm constants of a pass are fetched one pass ahead, into the registers the previous pass's
+    // accumulators have just left (fetching all passes up front spills; fetching a pass at its own start exposes one memory
+    // latency per pass)
+    f32x4v onext[NPT];
+    float scn[NPT], shn[NPT];
+#define SESSD_SK_FETCH(CB)                                                                          \
+  _Pragma("unroll") for (int n = 0; n < NPT; ++n) {                                                 \
+    const int co_ = m_base + (CB)*32 + col0 + (NT / 32) * n;                                        \
+    if (certain)                                                                                    \
+      onext[n] = __builtin_bit_cast(                                                                \
+          f32x4v, __builtin_amdgcn_raw_buffer_load_b128(                                            \
+                      sr, (int)(oslot + (unsigned)((((CB)*32 + col0 + (NT / 32) * n) * 32 + tl) * 16)), 0, SESSD_SYSTEM_SCOPE)); \
+    else                                                                                            \
+      onext[n] = 0.f;                                                                               \
+    scn[n] = (writes_out && e_scale && co_ < e_cout) ? e_scale[co_] : 1.f;                          \
+    shn[n] = (writes_out && e_shift && co_ < e_cout) ? e_shift[co_] : 0.f;                          \
+  }
+    SESSD_SK_FETCH(0)
+#pragma unroll
+    for (int cb = 0; cb < CBN; ++cb) {
+      if (e_relu & 2) break;  // DEBUG bit 2: skip the epilogue passes
+      if (cb) SESSD_LDS_BARRIER();
+#pragma unroll
+      for (int x = 0; x < XW; ++x)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const int co = (q & 3) + 8 * (q >> 2) + 4 * h;
+          lds[((wave * XW + x) * 32 + co) * 32 + j] = acc[x][cb][q];
+        }
+      f32x4v other[NPT];
+      float sc[NPT], sh[NPT];
+#pragma unroll
+      for (int n = 0; n < NPT; ++n) { other[n] = onext[n]; sc[n] = scn[n]; sh[n] = shn[n]; }
+      if (cb + 1 < CBN) { SESSD_SK_FETCH(cb + 1) }
+      SESSD_LDS_BARRIER();
+#pragma unroll
+      for (int n = 0; n < NPT; ++n) {
+        const int col = col0 + (NT / 32) * n;
+        float m[16];
+#pragma unroll
+        for (int x = 0; x < 16; ++x) m[x] = lds[(x * 32 + col) * 32 + tl];
+        float q0[4], q1[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          q0[c] = m[0 * 4 + c] + m[1 * 4 + c] + m[2 * 4 + c];
+          q1[c] = m[1 * 4 + c] - m[2 * 4 + c] - m[3 * 4 + c];
+        }
+        float y[4];
+        y[0] = q0[0] + q0[1] + q0[2]; y[1] = q0[1] - q0[2] - q0[3];
+        y[2] = q1[0] + q1[1] + q1[2]; y[3] = q1[1] - q1[2] - q1[3];
+        const int co = m_base + cb * 32 + col;
+        if (full) {
+          SESSD_SK_FINALIZE(y, co, sc[n], sh[n])
+        } else if (certain) {
+          // share order: the part of the lower share first (a + b is commutative; written out for the general rule)
+          const f32x4v o4 = other[n];
+          const bool mine_first = (w == w_first);
+          float z[4];
+          z[0] = mine_first ? (0.f + y[0]) + o4.x : (0.f + o4.x) + y[0];
+          z[1] = mine_first ? (0.f + y[1]) + o4.y : (0.f + o4.y) + y[1];
+          z[2] = mine_first ? (0.f + y[2]) + o4.z : (0.f + o4.z) + y[2];
+          z[3] = mine_first ? (0.f + y[3]) + o4.w : (0.f + o4.w) + y[3];
+          SESSD_SK_FINALIZE(z, co, sc[n], sh[n])
+        } else {
+          f32x4v v;
+          v.x = y[0]; v.y = y[1]; v.z = y[2]; v.w = y[3];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4g, v), sr,
+                                                 (int)(my_slot + (unsigned)(((cb * 32 + col) * 32 + tl) * 16)), 0, SESSD_SYSTEM_SCOPE);
+        }
+      }
+    }
+    if (certain) {
+      if (tid == 0) __hip_atomic_store(e_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else if (!full && !(e_relu & 8)) {  // DEBUG bit 8: skip the partial-unit protocol
+      // My partial outputs are on their way to memory. Counting this part needs them acknowledged: if more work follows, that
+      // wait is folded into the next segment's prologue (SESSD_SK_SIGNAL below), and the (unlikely) duty of finishing the unit
+      // is carried out after the last segment.
+      if (pend_state == 2) SESSD_SK_FINISH_PENDING()
+      pend_u = u; pend_first = w_first; pend_last = w_last; pend_tbase = t_base; pend_mbase = m_base; pend_b = b;
+      pend_state = 1;  // stores issued, not yet counted
+    }
+#undef SESSD_SK_FETCH
+    SESSD_LDS_BARRIER();  // the next segment's prologue overwrites the LDS the epilogue read
+  }
+  if (pend_state == 1) SESSD_SK_SIGNAL()
+  if (pend_state == 2) SESSD_SK_FINISH_PENDING()
+#undef SESSD_SK_FINALIZE
+#undef SESSD_SK_SIGNAL
+#undef SESSD_SK_FINISH_PENDING
+}
+
+template <int NW, int CBN>
+int launch_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout, const float* scale,
+              const float* shift, int relu, const float* residual, void* workspace, size_t workspace_bytes, int workgroups,
+              hipStream_t stream) {
+  constexpr int SLOT = CBN * 32 * 32 * 4;
+  if (cin % (2 * NW)) return SESSD_EINVAL;
+  WinoArgs A;
+  A.in = in; A.upk = upk; A.out = out; A.scale = scale; A.shift = shift; A.residual = residual;
+  A.cin = cin; A.hin = h; A.win = w; A.cout = cout; A.relu = relu;
+  A.tw = w / 2; A.ntiles = (h / 2) * (w / 2); A.tblocks = sessd_divup(A.ntiles, 32); A.ngroups = sessd_divup(cout, CBN * 32);
+  A.rpu = cin / (2 * NW);
+  const long long units = (long long)batch * A.tblocks * A.ngroups;
+  if (units * A.rpu > 0x7fffffffLL) return SESSD_EINVAL;
+  A.total_rounds = (int)(units * A.rpu);
+  const size_t need = sessd_align((size_t)units * 4, 256) + (size_t)2 * workgroups * SLOT * 4;
+  if (need > workspace_bytes) return SESSD_EWORKSPACE;
+  // every share must hold at least one round (the part count of a cut unit is a difference of share indices)
+  if (workgroups > A.total_rounds) workgroups = A.total_rounds >= 8 ? (A.total_rounds & ~7) : A.total_rounds;
+  A.counters = (unsigned*)workspace;
+  A.scratch = (float*)((char*)workspace + sessd_align((size_t)units * 4, 256));
+  SESSD_LAUNCH((conv3x3s1_winograd_sk_kernel<NW, CBN>), dim3(workgroups), dim3(NW * 64), 0, stream, A);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+int default_workgroups(int shape, int* out) {
+  int dev = 0, cus = 0;
+  SESSD_TRY(hipGetDevice(&dev));
+  SESSD_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  *out = ((shape == 1 ? 2 : 1) * cus) & ~7;
+  return *out >= 8 ? SESSD_OK : SESSD_EINVAL;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Scratch + counters of sessd_conv3x3_winograd_sk. shape 0: 8 waves x 128 couts per workgroup (one per CU), shape 1: 4 waves x
+// 64 couts (two per CU); workgroups 0 = that default. The caller zeroes the workspace ONCE (the kernel leaves the counters
+// zero) and must not share it between launches that may run concurrently.
+size_t sessd_conv3x3_winograd_sk_workspace_bytes(int batch, int h, int w, int cout, int shape, int workgroups) {
+  if (batch < 1 || h < 2 || w < 2 || cout < 1 || workgroups < 0 || shape < 0 || shape > 1) return 0;
+  if (workgroups == 0 && default_workgroups(shape, &workgroups) != SESSD_OK) return 0;
+  const int cpu = shape == 1 ? 64 : 128;
+  const size_t units = (size_t)batch * sessd_divup((h / 2) * (w / 2), 32) * sessd_divup(cout, cpu);
+  return sessd_align(units * 4, 256) + (size_t)2 * workgroups * (cpu * 32 * 4) * 4;
+}
+
+// Conv2d(cin, cout, 3, stride 1, padding 1) + folded BatchNorm + ReLU + residual, fused Winograd F(2x2,3x3), stream-K over
+// `workgroups` persistent workgroups (a multiple of 8; 0 = the shape's default).
+// upk = U = G g G^T packed [ceil(cout / C)][cin/2][NW][2][32][C/32][16/NW] with (NW, C) = (8, 128) for shape 0, (4, 64) for
+// shape 1 (ops.pack_winograd_sk); even H, W; cin % (2 NW) == 0.
+int sessd_conv3x3_winograd_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
+                              const float* scale, const float* shift, int relu, const float* residual, void* workspace,
+                              size_t workspace_bytes, int shape, int workgroups, hipStream_t stream) {
+  if ((h & 1) || (w & 1) || batch < 1 || cout < 1 || workgroups < 0 || (workgroups & 7) || shape < 0 || shape > 1) return SESSD_EINVAL;
+  if (workgroups == 0) {
+    const int rc = default_workgroups(shape, &workgroups);
+    if (rc != SESSD_OK) return rc;
+  }
+  if (shape == 1)
+    return launch_sk<4, 2>(in, batch, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream);
+  return launch_sk<8, 4>(in, batch, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream);
+}
+
+}  // extern "C"

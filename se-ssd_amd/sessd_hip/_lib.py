@@ -49,6 +49,8 @@ SIGNATURES = {
     "sessd_conv2d_mfma": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32,
                                 vp, vp, i32, vp, i32, vp]),
     "sessd_conv3x3_winograd": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
+    "sessd_conv3x3_winograd_sk_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "sessd_conv3x3_winograd_sk": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, sz, i32, i32, vp]),
     "sessd_deconv2d_s2_mfma": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
     "sessd_ssfa_fuse": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp]),
     "sessd_predict_workspace_bytes": (sz, [i32, i32, i32, i32]),

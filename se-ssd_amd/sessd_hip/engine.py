@@ -232,6 +232,8 @@ class InferenceEngine:
         self.graph = None
         self._marks = None
         self.tile_cfg = {}
+        self.sk_ws = None  # workspace of the stream-K Winograd launches (autotune allocates it)
+        self.sk_workgroups = 0  # persistent workgroups of those launches (0 = one or two per CU; fewer leaves CUs to a second stream)
         self.tune_report = {}
         self._tuning = None
         self._kmarks = None
@@ -284,11 +286,11 @@ class InferenceEngine:
         if self._kmarks is not None:  # per-launch HIP events inside a whole eager frame (dense_layer_times)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name))
+            r = ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name), workspace=self.sk_ws, workgroups=self.sk_workgroups)
             e1.record()
             self._kmarks.append((name, e0, e1))
             return r
-        return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name))
+        return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name), workspace=self.sk_ws, workgroups=self.sk_workgroups)
 
     def autotune(self, candidates=(1, 2, 3, 4, 6, 11, 12), reps=5):
         """Pick the wave/workgroup tiling of every dense conv launch by timing it on this device (one-off, ~0.1 s).
@@ -330,17 +332,25 @@ class InferenceEngine:
                     cands.append(20)  # fused Winograd F(2x2,3x3)
                     if pc.cin % 32 == 0:
                         cands.append(21)  # same, operands fetched two rounds ahead
+                    # stream-K Winograd (all couts of a unit in one workgroup, equal shares of rounds per CU): 8 waves x 128
+                    # couts / 4 waves x 64 couts. One workspace per engine: its launches are serialised on the engine's stream.
+                    for cfg, shape in ((22, 0), (23, 1)):
+                        if pc.upk_sk[shape] is not None:
+                            need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(x.shape[0], x.shape[2], x.shape[3], pc.cout, shape, 0))
+                            if self.sk_ws is None or self.sk_ws.numel() < need:
+                                self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=x.device)
+                            cands.append(cfg)
             for cfg in cands:
                 if pc.cout <= 32 and cfg != 4:
                     continue
                 if cfg in (11, 12, 13) and pc.kind != "conv":
                     continue
                 for _ in range(2):
-                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg)
+                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg, workspace=self.sk_ws, workgroups=self.sk_workgroups)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
-                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg)
+                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg, workspace=self.sk_ws, workgroups=self.sk_workgroups)
                 e1.record()
                 torch.cuda.synchronize()
                 t = e0.elapsed_time(e1) / reps

@@ -653,7 +653,46 @@ def pack_conv2d(weight, stride=1, padding=None):
               out_mul=1, py=0, px=0, ntaps=kh * kw)
     pc = PackedConv([la], ci, co, "conv", stride)
     pc.upk = pack_winograd(w) if (kh == 3 and stride == 1 and ci % 8 == 0) else None  # tile_cfg 20
+    sk = kh == 3 and stride == 1
+    pc.upk_sk = [pack_winograd_sk(w, 0) if (sk and ci % 16 == 0) else None,   # tile_cfg 22
+                 pack_winograd_sk(w, 1) if (sk and ci % 8 == 0) else None]    # tile_cfg 23
     return pc
+
+
+def winograd_u(weight):
+    """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) -> (Cout, Cin, 16) float32, xi = 4 * row + col."""
+    w = weight.detach().to(torch.float64)
+    co, ci, kh, kw = w.shape
+    assert kh == 3 and kw == 3
+    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
+    return torch.einsum("ia,ocab,jb->ocij", G, w, G).to(torch.float32).reshape(co, ci, 16)
+
+
+def pack_winograd_sk(weight, shape=0):
+    """U for sessd_conv3x3_winograd_sk: [ceil(Cout/C)][Cin/2][wave NW][channel parity 2][cout%32][(cout/32)%(C/32)][xi%(16/NW)]
+    with xi = (16/NW) * wave + xi%(16/NW) and (NW, C) = (8, 128) for shape 0, (4, 64) for shape 1 -- the 8 A operands of a lane
+    and k-step are 32 contiguous bytes."""
+    nw, c = ((8, 128), (4, 64))[shape]
+    xw, cbn = 16 // nw, c // 32
+    U = winograd_u(weight)
+    co, ci, _ = U.shape
+    ng = (co + c - 1) // c
+    Up = torch.zeros((ng * c, ci, 16), dtype=torch.float32, device=U.device)
+    Up[:co] = U
+    # (group, cb, j, ks, h, wave, xl) -> (group, ks, wave, h, j, cb, xl)
+    return Up.view(ng, cbn, 32, ci // 2, 2, nw, xw).permute(0, 3, 5, 4, 2, 1, 6).contiguous()
+
+
+_SK_WS = {}
+
+
+def winograd_sk_workspace(batch, h, w, cout, device, workgroups=0, shape=0):
+    """Zeroed workspace of sessd_conv3x3_winograd_sk (partial-unit scratch + counters)."""
+    with torch.cuda.device(device):
+        n = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(batch, h, w, cout, shape, workgroups))
+    if n == 0:
+        raise ValueError("winograd_sk_workspace: bad arguments")
+    return torch.zeros(n, dtype=torch.uint8, device=device)
 
 
 def pack_winograd(weight):
@@ -699,8 +738,9 @@ def pack_deconv2d_s2(weight):
     return pc
 
 
-def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, tile_cfg=None):
-    """x (B,Cin,H,W) NCHW float32 on the device. Returns (B,Cout,Ho,Wo)."""
+def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, tile_cfg=None, workspace=None, workgroups=0):
+    """x (B,Cin,H,W) NCHW float32 on the device. Returns (B,Cout,Ho,Wo). tile_cfg 22 = stream-K Winograd: `workspace` from
+    winograd_sk_workspace (one per concurrently running stream); without one a per-(device, stream) cache is used."""
     _req(x, torch.float32, "x")
     B, ci, H, W = x.shape
     assert ci == pc.cin
@@ -712,6 +752,21 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         th, tw = H, W
     if out is None:
         out = torch.empty((B, pc.cout, Ho, Wo), dtype=torch.float32, device=x.device)
+    if tile_cfg in (22, 23):
+        shape = tile_cfg - 22
+        upk = getattr(pc, "upk_sk", None)
+        if upk is None or upk[shape] is None or (H & 1) or (W & 1):
+            raise ValueError("tile_cfg 22/23 (stream-K Winograd) needs a 3x3 stride-1 conv with cin % 16 (22) / 8 (23) == 0 and even H, W")
+        if workspace is None:
+            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, shape, workgroups)
+            need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(B, H, W, pc.cout, shape, workgroups))
+            workspace = _SK_WS.get(key)
+            if workspace is None or workspace.numel() < need:
+                workspace = _SK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=x.device)
+        check(lib.sessd_conv3x3_winograd_sk(x.data_ptr(), B, ci, H, W, upk[shape].data_ptr(), out.data_ptr(), pc.cout, _p(scale),
+                                            _p(shift), 1 if relu else 0, _p(residual), workspace.data_ptr(), workspace.numel(),
+                                            shape, workgroups, _stream()), "conv3x3_winograd_sk")
+        return out
     if tile_cfg in (20, 21):
         if getattr(pc, "upk", None) is None or (H & 1) or (W & 1):
             raise ValueError("tile_cfg 20/21 (Winograd) needs a 3x3 stride-1 conv with cin % 8 == 0 and even H, W")

@@ -71,6 +71,41 @@ def test_winograd_variant(dev, cin, cout, H, W, B):
     assert e_w < 8 * e_d + 1e-6
 
 
+@pytest.mark.parametrize("cin,cout,H,W,B,wgs", [(128, 128, 24, 40, 2, 0), (256, 256, 14, 18, 1, 0), (16, 40, 10, 66, 3, 8), (128, 128, 200, 176, 1, 0),
+                                                 (128, 128, 200, 176, 1, 104), (64, 300, 12, 16, 1, 64), (32, 128, 8, 8, 1, 16), (256, 256, 100, 88, 2, 0)])
+@pytest.mark.parametrize("cfg", [22, 23])
+def test_winograd_stream_k(dev, cin, cout, H, W, B, wgs, cfg):
+    """tile_cfg 22 / 23: 128 / 64 couts per workgroup of 8 / 4 waves, rounds dealt out in equal shares (stream-K). Same bound as the first-generation
+    Winograd kernel; covers whole units, units cut in two and (few rounds per share) units cut in three or more parts; the
+    second and third launch reuse the workspace (the counters must be back at zero) and must give the same bits."""
+    g = torch.Generator().manual_seed(cin + H + W + wgs)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    res = torch.randn(B, cout, H, W, generator=g)
+    ref = (torch.relu(F.conv2d(x.double(), w.double(), padding=1) * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1))
+           + res.double())
+    pc = ops.pack_conv2d(w.to(dev), 1)
+    args = (x.to(dev), pc, scale.to(dev), shift.to(dev), True)
+    ws = ops.winograd_sk_workspace(B, H, W, cout, dev, wgs, cfg - 22)
+    a = ops.conv2d(*args, residual=res.to(dev), tile_cfg=cfg, workspace=ws, workgroups=wgs)
+    b = ops.conv2d(*args, residual=res.to(dev), tile_cfg=cfg, workspace=ws, workgroups=wgs)
+    c = ops.conv2d(*args, residual=res.to(dev), tile_cfg=cfg, workspace=ws, workgroups=wgs)
+    torch.cuda.synchronize()
+    units = B * (((H // 2) * (W // 2) + 31) // 32) * ((cout + 127) // 128 if cfg == 22 else (cout + 63) // 64)
+    assert int(ws[:units * 4].view(torch.int32).abs().sum().item()) == 0       # counters left at zero
+    assert torch.equal(a, b) and torch.equal(a, c)
+    direct = ops.conv2d(*args, residual=res.to(dev), tile_cfg=3).cpu().double()
+    e_w, e_d = float((a.cpu().double() - ref).abs().max()), float((direct - ref).abs().max())
+    print("stream-K winograd err %.2e  direct err %.2e  (max|ref| %.2f)" % (e_w, e_d, float(ref.abs().max())))
+    assert e_w < 2e-4 * max(1.0, float(ref.abs().max()))
+    assert e_w < 8 * e_d + 1e-6
+    # no ReLU / BatchNorm / residual
+    plain = ops.conv2d(x.to(dev), pc, None, None, False, tile_cfg=cfg, workspace=ws, workgroups=wgs).cpu().double()
+    assert float((plain - F.conv2d(x.double(), w.double(), padding=1)).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("cfg", [1, 3])
 def test_deconv_s2_with_residual(dev, cfg):
     g = torch.Generator().manual_seed(9)
