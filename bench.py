@@ -213,7 +213,9 @@ def main():
             streamk = sum(1 for c in cfgs if c in (22, 23))
             log("dense tile_cfg:", {k: v for k, v in eng.tile_cfg.items()})
             eng.set_points(batch_of(0))
+            skw, eng.sk_workgroups = eng.sk_workgroups, 0   # the kernel on all CUs, one frame in flight (what the single-stream run times)
             lt = eng.dense_layer_times(reps=20)
+            eng.sk_workgroups = skw
             kms = sum(lt[nm] for nm in names) / len(names)
             flops = CONV_FLOPS * args.batch
             ach = flops / (kms * 1e-3) / 1e12
@@ -229,7 +231,10 @@ def main():
                                                   "convolution count for the Winograd kernel) / launch time / dense f32 MFMA peak",
                                "avg_launch_ms": kms,
                                "avg_launch_source": "HIP events before / after each of the kernel's 7 launches inside 20 whole frames "
-                                                    "(eager enqueue; same stream as the kernels)",
+                                                    "(eager enqueue; same stream as the kernels; one frame in flight, stream-K "
+                                                    "launches on all CUs -- with two frames in flight the timed region launches them "
+                                                    "with config.streamk_workgroups workgroups and leaves the other CUs to the other "
+                                                    "stream)",
                                "dense_launch_ms": {k: round(v, 5) for k, v in lt.items()},
                                "dense_tile_cfg": {k: eng.tile_cfg.get(k) for k in lt},
                                "flops_per_launch_executed": flops * (16.0 / 36.0 if wino else 1.0),

@@ -15,25 +15,6 @@ for c in cfgs:   # "22" or "22:248" = stream-K with 248 workgroups; "22:64:100x8
     if len(f) > 2 and f[2]:
         hh, ww = [int(v) for v in f[2].split("x")]
         x = torch.randn(1, 128, hh, ww, generator=g).to(dev)
-    dbg = int(f[3]) if len(f) > 3 else 0   # debug bits passed through the relu argument (see dense_wino_sk.hip)
-    if dbg:
-        from sessd_hip._lib import lib
-        ws = ops.winograd_sk_workspace(1, x.shape[2], x.shape[3], 128, dev, wg, cfg - 22)
-        o2 = torch.empty_like(x)
-        def run():
-            lib.sessd_conv3x3_winograd_sk(x.data_ptr(), 1, 128, x.shape[2], x.shape[3], pc.upk_sk[cfg - 22].data_ptr(), o2.data_ptr(), 128, None, None,
-                                          dbg, None, ws.data_ptr(), ws.numel(), cfg - 22, wg, torch.cuda.current_stream().cuda_stream)
-        for _ in range(5):
-            run()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(50):
-            run()
-        e1.record()
-        torch.cuda.synchronize()
-        print("cfg %s: %.1f us per launch (debug bits %d)" % (c, e0.elapsed_time(e1) * 1000 / 50, dbg))
-        continue
     out = ops.conv2d(x, pc, None, None, False, tile_cfg=cfg, workgroups=wg)
     for _ in range(10):
         ops.conv2d(x, pc, None, None, False, out=out, tile_cfg=cfg, workgroups=wg)

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                 \
       const size_t o = (size_t)(CO) * out_plane + pix + (size_t)a * e_win;                          \
       float v0 = fmaf((Y)[2 * a], (SC), (SH)), v1 = fmaf((Y)[2 * a + 1], (SC), (SH));              \
-      if (e_relu & 1) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }                                 \
+      if (e_relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); }                                 \
       if (resb) { v0 += resb[o]; v1 += resb[o + 1]; }                                               \
       *reinterpret_cast<float2*>(outb + o) = make_float2(v0, v1);                                   \
     }                                                                                               \
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
       pend_state = 3;  // counted; the answer is read at this segment's epilogue
     }
     int voff = 0;
-    int rr = (A.relu & 4) ? r1 : r0;  // DEBUG bit 4: skip the main loop
+    int rr = r0;
     while (rr < r1) SESSD_SK_ROUND()
 #undef SESSD_SK_LOADP
 #undef SESSD_SK_LOADU
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     // fetches the (single) other part now and adds it on the fly.
     bool certain = false;
     unsigned oslot = 0;
-    if (!full && w_last == w_first + 1 && !(e_relu & 8)) {
+    if (!full && w_last == w_first + 1) {
       // one reader: every thread of the workgroup must take the same path
       if (tid == 0) s_last = __hip_atomic_load(e_counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 1u ? 1 : 0;
       __syncthreads();
@@ -357,7 +357,6 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     SESSD_SK_FETCH(0)
 #pragma unroll
     for (int cb = 0; cb < CBN; ++cb) {
-      if (e_relu & 2) break;  // DEBUG bit 2: skip the epilogue passes
       if (cb) SESSD_LDS_BARRIER();
 #pragma unroll
       for (int x = 0; x < XW; ++x)
@@ -410,7 +409,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     }
     if (certain) {
       if (tid == 0) __hip_atomic_store(e_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (!full && !(e_relu & 8)) {  // DEBUG bit 8: skip the partial-unit protocol
+    } else if (!full) {
       // My partial outputs are on their way to memory. Counting this part needs them acknowledged: if more work follows, that
       // wait is folded into the next segment's prologue (SESSD_SK_SIGNAL below), and the (unlikely) duty of finishing the unit
       // is carried out after the last segment.

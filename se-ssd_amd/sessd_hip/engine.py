@@ -335,7 +335,7 @@ class InferenceEngine:
                     # stream-K Winograd (all couts of a unit in one workgroup, equal shares of rounds per CU): 8 waves x 128
                     # couts / 4 waves x 64 couts. One workspace per engine: its launches are serialised on the engine's stream.
                     for cfg, shape in ((22, 0), (23, 1)):
-                        if pc.upk_sk[shape] is not None:
+                        if pc.upk_sk(shape) is not None:
                             need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(x.shape[0], x.shape[2], x.shape[3], pc.cout, shape, 0))
                             if self.sk_ws is None or self.sk_ws.numel() < need:
                                 self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=x.device)

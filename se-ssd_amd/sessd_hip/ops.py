@@ -628,6 +628,22 @@ class PackedConv:
     def __init__(self, launches, cin, cout, kind, stride):
         self.launches = launches  # list of dict(wpk, dy, dx, in_mul, out_mul, py, px, ntaps)
         self.cin, self.cout, self.kind, self.stride = cin, cout, kind, stride
+        self._w3 = None      # the 3x3 stride-1 weight the Winograd packings are made from, on demand
+        self._upk = None
+        self._upk_sk = [None, None]
+
+    @property
+    def upk(self):
+        """U = G g G^T packed for sessd_conv3x3_winograd (tile_cfg 20 / 21); None if the layer is not eligible."""
+        if self._upk is None and self._w3 is not None and self.cin % 8 == 0:
+            self._upk = pack_winograd(self._w3)
+        return self._upk
+
+    def upk_sk(self, shape):
+        """U packed for sessd_conv3x3_winograd_sk (tile_cfg 22 / 23 = shape 0 / 1); None if not eligible."""
+        if self._upk_sk[shape] is None and self._w3 is not None and self.cin % (16, 8)[shape] == 0:
+            self._upk_sk[shape] = pack_winograd_sk(self._w3, shape)
+        return self._upk_sk[shape]
 
 
 def _pack_taps(w_co_ci_t, cout):
@@ -652,10 +668,8 @@ def pack_conv2d(weight, stride=1, padding=None):
     la = dict(wpk=wpk, dy=torch.tensor(dy, dtype=torch.int32), dx=torch.tensor(dx, dtype=torch.int32), in_mul=stride,
               out_mul=1, py=0, px=0, ntaps=kh * kw)
     pc = PackedConv([la], ci, co, "conv", stride)
-    pc.upk = pack_winograd(w) if (kh == 3 and stride == 1 and ci % 8 == 0) else None  # tile_cfg 20
-    sk = kh == 3 and stride == 1
-    pc.upk_sk = [pack_winograd_sk(w, 0) if (sk and ci % 16 == 0) else None,   # tile_cfg 22
-                 pack_winograd_sk(w, 1) if (sk and ci % 8 == 0) else None]    # tile_cfg 23
+    if kh == 3 and stride == 1:
+        pc._w3 = w  # Winograd packings (tile_cfg 20-23) are made when first asked for
     return pc
 
 
@@ -754,8 +768,8 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         out = torch.empty((B, pc.cout, Ho, Wo), dtype=torch.float32, device=x.device)
     if tile_cfg in (22, 23):
         shape = tile_cfg - 22
-        upk = getattr(pc, "upk_sk", None)
-        if upk is None or upk[shape] is None or (H & 1) or (W & 1):
+        upk = pc.upk_sk(shape) if pc.kind == "conv" else None
+        if upk is None or (H & 1) or (W & 1):
             raise ValueError("tile_cfg 22/23 (stream-K Winograd) needs a 3x3 stride-1 conv with cin % 16 (22) / 8 (23) == 0 and even H, W")
         if workspace is None:
             key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, shape, workgroups)
@@ -763,7 +777,7 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
             workspace = _SK_WS.get(key)
             if workspace is None or workspace.numel() < need:
                 workspace = _SK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=x.device)
-        check(lib.sessd_conv3x3_winograd_sk(x.data_ptr(), B, ci, H, W, upk[shape].data_ptr(), out.data_ptr(), pc.cout, _p(scale),
+        check(lib.sessd_conv3x3_winograd_sk(x.data_ptr(), B, ci, H, W, upk.data_ptr(), out.data_ptr(), pc.cout, _p(scale),
                                             _p(shift), 1 if relu else 0, _p(residual), workspace.data_ptr(), workspace.numel(),
                                             shape, workgroups, _stream()), "conv3x3_winograd_sk")
         return out
@@ -782,8 +796,12 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
                                          pc.cout, _p(scale), _p(shift), 1 if relu else 0, _p(residual), cfg, _stream()),
               "deconv2d_s2_mfma")
         return out
-    if tile_cfg is None and USE_WINOGRAD and getattr(pc, "upk", None) is not None and not (H & 1) and not (W & 1) \
-            and H * W >= 4096:
+    if tile_cfg is None and USE_WINOGRAD and pc.kind == "conv" and pc._w3 is not None and not (H & 1) and not (W & 1) \
+            and H * W >= 4096 and ci % 8 == 0:
+        # The first-generation kernel: every tile block is computed by one workgroup from start to end, so a frame's bits do not
+        # depend on its batch slot or on the batch size. The stream-K kernel (tile_cfg 22 / 23, 20 % faster) is deterministic
+        # for a fixed (shape, batch, workgroup count) only -- a unit cut between two workgroups adds two partial sums -- and is
+        # chosen explicitly: engine.autotune(), the training path.
         return conv2d(x, pc, scale, shift, relu, residual, out, 20)
     for la in pc.launches:
         cfg = tile_cfg
@@ -864,6 +882,13 @@ def conv2d_wgrad(inp, grad_out, ksize, stride):
     return gw
 
 
+def _train_cfg(pc, x):
+    """tile_cfg of the training path: the stream-K Winograd kernel for the 3x3 stride-1 layers it covers, else the default."""
+    ok = (USE_WINOGRAD and pc.kind == "conv" and pc._w3 is not None and pc.cin % 16 == 0 and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0
+          and x.shape[2] * x.shape[3] >= 4096)
+    return 22 if ok else None
+
+
 class Conv2dFunction(torch.autograd.Function):
     """Differentiable Conv2d(k in {1,3}, stride in {1,2}, padding k//2) / ConvTranspose2d(3, s2, p1, op1) on the HIP kernels.
     forward: sessd_conv2d_mfma / sessd_conv3x3_winograd / sessd_deconv2d_s2_mfma (no BatchNorm fold, no ReLU);
@@ -875,7 +900,7 @@ class Conv2dFunction(torch.autograd.Function):
         pc = pack_deconv2d_s2(weight) if transposed else pack_conv2d(weight, stride)
         ctx.save_for_backward(x, weight)
         ctx.cfg = (bool(transposed), int(stride), bias is not None)
-        return conv2d(x, pc, None, None if bias is None else bias.detach().float().contiguous(), False)
+        return conv2d(x, pc, None, None if bias is None else bias.detach().float().contiguous(), False, tile_cfg=_train_cfg(pc, x))
 
     @staticmethod
     def backward(ctx, grad):
@@ -892,7 +917,8 @@ class Conv2dFunction(torch.autograd.Function):
                 gx = conv2d(g, pack_deconv2d_s2(w), None, None, False)
             else:               # stride 1: correlation with the flipped kernel, channels swapped
                 wd = (w.flip(2, 3) if k == 3 else w).transpose(0, 1).contiguous()
-                gx = conv2d(g, pack_conv2d(wd, 1), None, None, False)
+                pcd = pack_conv2d(wd, 1)
+                gx = conv2d(g, pcd, None, None, False, tile_cfg=_train_cfg(pcd, g))
         if ctx.needs_input_grad[1]:
             gw = conv2d_wgrad(g, x, 3, 2) if transposed else conv2d_wgrad(x, g, k, stride)
         if has_bias and ctx.needs_input_grad[2]:

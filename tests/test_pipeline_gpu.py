@@ -11,7 +11,7 @@ import torch
 
 from oracle import pipeline, postprocess as pp
 from oracle.compare import compare_detections
-from sessd_hip import configs, synth
+from sessd_hip import configs, ops, synth
 from sessd_hip.engine import InferenceEngine
 
 pytestmark = pytest.mark.gpu
@@ -62,6 +62,37 @@ def test_engine_vs_oracle(dev, model, state, batch, seeds, max_voxels):
     res = [_compare_dets(g, w, d) for g, w, d in zip(got, want, inter["debug"])]
     assert all(r["matched"] == r["n"] for r in res)
     print("detections per frame", [len(g["scores"]) for g in got], "candidates", [d["num_candidates"] for d in inter["debug"]])
+
+
+@pytest.mark.parametrize("cfg,wgs", [(22, 0), (23, 0), (22, 224)])
+def test_engine_with_stream_k_dense_layers_vs_oracle(dev, model, state, cfg, wgs):
+    """The configuration bench.py times: the seven 3x3 stride-1 SSFA layers on the stream-K Winograd kernel (what
+    engine.autotune() selects on MI355X), eagerly and through a captured graph replayed twice -- same oracle comparison as the
+    default engine, and the replays must reproduce the eager bits (fixed shape and workgroup count => fixed summation order)."""
+    frames = [synth.make_frame(s, 20000) for s in (21, 22)]
+    anchors = pp.create_anchors_3d_range().reshape(-1, 7)
+    want, inter = pipeline.run_frames(frames, state, VG["range"], VG["voxel_size"], 5, 16000, anchors, None, return_intermediate=True)
+    eng = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, batch_size=2, max_points_per_frame=20480,
+                          device=dev)
+    for name in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):
+        eng.tile_cfg[name] = cfg
+    eng.sk_workgroups = wgs
+    eng.sk_ws = ops.winograd_sk_workspace(2, 200, 176, 256, dev, 0, cfg - 22)
+    eng.set_points([torch.from_numpy(f).to(dev) for f in frames])
+    eng.enqueue()
+    got = eng.results()
+    ssfa = eng.t["out"].cpu()
+    assert float((ssfa - inter["ssfa"]).abs().max()) < 5e-4 * max(1.0, float(inter["ssfa"].abs().max()))
+    res = [_compare_dets(g, w, d) for g, w, d in zip(got, want, inter["debug"])]
+    assert all(r["matched"] == r["n"] for r in res) and sum(r["n"] for r in res) > 20
+    eng.capture()
+    for _ in range(2):
+        eng.replay()
+        again = eng.results()
+        for a, b in zip(got, again):
+            for k in ("box3d_lidar", "scores", "label_preds"):
+                assert np.array_equal(a[k], b[k]), k
+    assert int(eng.sk_ws[:4096].view(torch.int32).abs().sum().item()) == 0   # unit counters back at zero
 
 
 def test_graph_replay_is_bit_identical_and_idempotent(dev, model):
