@@ -62,6 +62,8 @@ def parse():
                     help="persistent workgroups of the stream-K Winograd launches (multiple of 8; 0 = the kernel's default, all CUs; "
                          "-1 = 0 with one frame in flight, 224 with several: the free CUs take the other stream's small kernels)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
+    ap.add_argument("--no-offset-split", action="store_true", help="autotune without the offset-split sparse conv variants")
+    ap.add_argument("--no-streamk", action="store_true", help="autotune without the stream-K Winograd variants")
     return ap.parse_args()
 
 
@@ -112,6 +114,8 @@ def main():
     first = eng.results()[0]
     log("first frame done:", len(first["scores"]), "detections")
     if not args.no_autotune:
+        eng.allow_offset_split = not args.no_offset_split
+        eng.allow_streamk = not args.no_streamk
         rep = eng.autotune()
         log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
     if args.sk_workgroups < 0:

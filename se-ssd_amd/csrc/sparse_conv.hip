@@ -44,7 +44,13 @@ __device__ __forceinline__ f32x4 bufload4(rsrc_t r, unsigned voff, unsigned soff
 // the next step -- 25 us per 64->64 layer whatever the number of sites; rocprofv3 counters in profiles/r2_sparse_pmc.txt.)
 // The tile's neighbour table (<= 27 x 16 row indices) is staged once in LDS, so that the per-step index fetch is a
 // ds_read on its own counter (lgkmcnt) and never forces a wait on the operand loads (vmcnt counts in order).
-template <int CIN, int COUT, int NTW, int DEPTH, bool DENSE_OUT>
+//
+// KSPLIT (offset split, for levels with fewer 16-site tiles than SIMDs): the four waves of a workgroup share ONE tile, wave w
+// walks the active offsets k with k % 4 == w (at most 7 of 27 instead of up to 27 in sequence), the four partial tiles are added
+// through LDS in wave order and wave w finishes rows 4 q + w. The per-site summation order is then
+// ((S0 + S1) + S2) + S3 with S_w = the fmaf chain over the offsets of class w -- fixed by the offset index alone, so it does
+// not depend on how sites fall into tiles, but it is NOT the single chain of the unsplit kernel (last-bit differences).
+template <int CIN, int COUT, int NTW, int DEPTH, bool DENSE_OUT, bool KSPLIT = false>
 __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restrict__ in_feat,
                                                            const int* __restrict__ nbr,
                                                            const uint32_t* __restrict__ tile_mask, int kv,
@@ -73,7 +79,7 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   constexpr int NGRP = COUT / 16 / NTW;
   const int n = min(n_dev[0], n_cap);
   const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
-  const int groups = (n + 63) >> 6;
+  const int groups = KSPLIT ? ((n + 15) >> 4) : ((n + 63) >> 6);  // unit of the XCD mapping: a workgroup's sites
   const int lg = groups >= 4096 ? 3 : (groups >= 2048 ? 2 : (groups >= 512 ? 1 : 0));  // C = 1 << lg
   const int t_local = j / NGRP;
   const int group = ((((t_local >> lg) << 3) + xcd) << lg) + (t_local & ((1 << lg) - 1));
@@ -81,10 +87,12 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   const int tbase = (j - t_local * NGRP) * NTW;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int tile = group * 4 + wv;   // wave-uniform
-  if (tile * 16 >= n) return;             // scalar branch; no workgroup barrier below (every wave is independent)
+  const int tile = KSPLIT ? group : group * 4 + wv;   // wave-uniform
+  if (tile * 16 >= n) return;             // scalar branch; without KSPLIT every wave is independent (no workgroup barrier
+                                          // below), with it the four waves of a workgroup leave together
   const int i = lane & 15, kq = lane >> 4;
-  const uint32_t tmask = __builtin_amdgcn_readfirstlane(tile_mask[tile]);
+  const uint32_t tmask_all = __builtin_amdgcn_readfirstlane(tile_mask[tile]);
+  const uint32_t tmask = KSPLIT ? (tmask_all & (0x11111111u << wv)) : tmask_all;
 
   f32x4 acc[NTILE];
 #pragma unroll
@@ -192,13 +200,27 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
 #undef SESSD_MMA
 
   // C/D layout: column (cout) = lane & 15, rows (sites) = (lane >> 4) * 4 + r
+  constexpr int RS = NTILE * 16 + 4;      // row stride of the partial tiles in LDS: the four row groups of a wave on distinct banks
+  __shared__ float s_red[KSPLIT ? 4 * 16 * RS : 1];
+  if constexpr (KSPLIT) {
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_red[(wv * 16 + kq * 4 + r) * RS + t * 16 + i] = acc[t][r];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const float* p = &s_red[(kq * 4 + wv) * RS + t * 16 + i];
+      acc[t][0] = ((p[0] + p[16 * RS]) + p[32 * RS]) + p[48 * RS];
+    }
+  }
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) {
     const int co = (tbase + t) * 16 + i;
     const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int site = tile * 16 + kq * 4 + r;
+    for (int r = 0; r < (KSPLIT ? 1 : 4); ++r) {
+      const int site = tile * 16 + kq * 4 + (KSPLIT ? wv : r);
       if (site >= n) continue;
       float v = fmaf(acc[t][r], sc, sh);
       if (relu) v = fmaxf(v, 0.f);
@@ -230,13 +252,19 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin,
   wpk[idx] = w[((size_t)k * cin + ci) * cout + co];
 }
 
-template <int CIN, int COUT, int NTW, int DEPTH>
+template <int CIN, int COUT, int NTW, int DEPTH, bool KS = false>
 int launch_depth(bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
                  int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
                  const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
   const int tiles = sessd_divup(n_cap, 16);
   // per XCD: ceil(groups / 8C) runs of C groups; C <= 8, so ceil(groups / 8) + 8 positions always suffice
-  dim3 grid(8 * (sessd_divup(sessd_divup(tiles, 4), 8) + 8) * (COUT / 16 / NTW)), block(256);
+  dim3 grid(8 * (sessd_divup(KS ? tiles : sessd_divup(tiles, 4), 8) + 8) * (COUT / 16 / NTW)), block(256);
+  if constexpr (KS) {
+    SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, DEPTH, false, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
+                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0);
+    SESSD_CHECK_LAUNCH();
+    return SESSD_OK;
+  }
   if (dense)
     SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, DEPTH, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
                        n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2]);
@@ -249,7 +277,7 @@ int launch_depth(bool dense, const float* in_feat, const int* nbr, const uint32_
 
 // operand sets (A: CIN/4 registers, B: NTW * CIN/4) of `depth` offsets must fit the 512-entry register file with room
 // for the accumulators and addresses; deeper than that is clamped
-template <int CIN, int COUT, int NTW>
+template <int CIN, int COUT, int NTW, bool KS = false>
 int launch_ntw(int depth, bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv,
                const int* n_dev, int n_cap, const float* wpk, const float* scale, const float* shift, int relu,
                float* out_feat, const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
@@ -258,6 +286,12 @@ int launch_ntw(int depth, bool dense, const float* in_feat, const int* nbr, cons
   if (depth <= 0) depth = 3;
   if (depth > DMAX) depth = DMAX;
 #define SESSD_ARGS2 dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
+  if constexpr (KS) {  // offset split: at most 7 offsets per wave -- two or three operand sets
+    if constexpr (DMAX >= 3) {
+      if (depth >= 3) return launch_depth<CIN, COUT, NTW, 3, true>(SESSD_ARGS2);
+    }
+    return launch_depth<CIN, COUT, NTW, 2, true>(SESSD_ARGS2);
+  }
   if constexpr (DMAX >= 4) {
     if (depth >= 4) return launch_depth<CIN, COUT, NTW, 4>(SESSD_ARGS2);
   }
@@ -276,7 +310,17 @@ int launch(int tuning, bool dense, const float* in_feat, const int* nbr, const u
   int split = tuning & 0xFF;
   const int depth = (tuning >> 8) & 0xFF;
   if (split <= 0) split = (n_cap / 16 < 4096) ? (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1)) : 1;  // fill 1024 SIMDs on small levels
+  const bool ksplit = ((tuning >> 16) & 1) && !dense;
 #define SESSD_ARGS depth, dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
+  if (ksplit) {
+    if constexpr (NT % 4 == 0) {
+      if (split >= 4) return launch_ntw<CIN, COUT, NT / 4, true>(SESSD_ARGS);
+    }
+    if constexpr (NT % 2 == 0) {
+      if (split >= 2) return launch_ntw<CIN, COUT, NT / 2, true>(SESSD_ARGS);
+    }
+    return launch_ntw<CIN, COUT, NT, true>(SESSD_ARGS);
+  }
   if constexpr (NT % 4 == 0) {
     if (split >= 4) return launch_ntw<CIN, COUT, NT / 4>(SESSD_ARGS);
   }
@@ -303,9 +347,12 @@ int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, in
   return SESSD_OK;
 }
 
-// tuning = cout_split + 256 * depth. cout_split: 0 = heuristic, 1/2/4 = number of waves that share one 16-site tile (each
-// takes Cout/split channels); depth: 0 = default (3), 2..4 = operand register sets (offsets in flight + the one multiplied).
-// Results do not depend on either.
+// tuning = cout_split + 256 * depth + 65536 * offset_split. cout_split: 0 = heuristic, 1/2/4 = number of waves that share one
+// 16-site tile (each takes Cout/split channels); depth: 0 = default (3), 2..4 = operand register sets (offsets in flight + the
+// one multiplied). Results do not depend on either. offset_split = 1 (ignored with dense_out): the four waves of a workgroup
+// split the kernel offsets of one tile by k % 4 and add their partial tiles -- for levels with fewer tiles than SIMDs; its
+// results are the same for every cout_split / depth but differ in the last bits from offset_split = 0 (four partial chains
+// added instead of one chain).
 // out[o] = act( (sum_k W[k]^T in[nbr[k][o]]) * scale + shift ). If dense_out != NULL the result is
 // scattered instead into the dense BEV tensor (B, cout*D, H, W) with dense_dims3 = (D,H,W) (pre-zeroed
 // by the caller) and out_feat may be NULL.

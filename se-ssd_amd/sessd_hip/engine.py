@@ -233,6 +233,8 @@ class InferenceEngine:
         self._marks = None
         self.tile_cfg = {}
         self.sk_ws = None  # workspace of the stream-K Winograd launches (autotune allocates it)
+        self.allow_streamk = True  # autotune may choose the stream-K Winograd kernel (tile_cfg 22 / 23)
+        self.allow_offset_split = True  # autotune may choose the offset-split sparse conv (see sessd_sparse_conv)
         self.sk_workgroups = 0  # persistent workgroups of those launches (0 = one or two per CU; fewer leaves CUs to a second stream)
         self.tune_report = {}
         self._tuning = None
@@ -302,13 +304,15 @@ class InferenceEngine:
         todo_sp, self._tuning_sparse = self._tuning_sparse, None
         st = torch.cuda.current_stream().cuda_stream
         for idx, lay, in_feat, nbr, tm, out_li, out_feat in todo_sp:
-            # sparse_split[idx] = cout_split + 256 * depth (sessd_sparse_conv's `tuning`; results do not depend on it)
+            # sparse_split[idx] = cout_split + 256 * depth + 65536 * offset_split (sessd_sparse_conv's `tuning`). cout split and
+            # depth do not change the results; the offset split (allow_offset_split; four waves per tile, for levels with fewer
+            # tiles than SIMDs) has one summation order of its own (last-bit differences)
             best = (None, 1e30)
-            for split in (1, 2, 4):
-                if (lay["cout"] // 16) % split:
+            for split, depth, ks in [(a, b, c) for c in ((0, 1) if self.allow_offset_split else (0,)) for a in (1, 2, 4) for b in (2, 3, 4)]:
+                if (lay["cout"] // 16) % split or (ks and depth == 4):
                     continue
-                for depth in (2, 3, 4):
-                    self.sparse_split[idx] = split + 256 * depth
+                if True:
+                    self.sparse_split[idx] = split + 256 * depth + 65536 * ks
                     for _ in range(2):
                         self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, idx=idx)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -319,7 +323,7 @@ class InferenceEngine:
                     torch.cuda.synchronize()
                     t = e0.elapsed_time(e1) / reps
                     if t < best[1]:
-                        best = (split + 256 * depth, t)
+                        best = (split + 256 * depth + 65536 * ks, t)
             self.sparse_split[idx] = best[0]
             self.tune_report["sparse%d" % idx] = best
         for name, x, layer, out, relu, residual in todo:
@@ -334,7 +338,7 @@ class InferenceEngine:
                         cands.append(21)  # same, operands fetched two rounds ahead
                     # stream-K Winograd (all couts of a unit in one workgroup, equal shares of rounds per CU): 8 waves x 128
                     # couts / 4 waves x 64 couts. One workspace per engine: its launches are serialised on the engine's stream.
-                    for cfg, shape in ((22, 0), (23, 1)):
+                    for cfg, shape in ((22, 0), (23, 1)) if self.allow_streamk else ():
                         if pc.upk_sk(shape) is not None:
                             need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(x.shape[0], x.shape[2], x.shape[3], pc.cout, shape, 0))
                             if self.sk_ws is None or self.sk_ws.numel() < need:

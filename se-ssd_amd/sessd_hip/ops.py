@@ -384,9 +384,10 @@ def sparse_pack_weight(weight):
 
 
 def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, scale=None, shift=None, relu=True,
-                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0):
+                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0, offset_split=0):
     """cout_split (0 heuristic | 1, 2, 4) and depth (0 default | 2..4 operand sets in flight) only tune the launch: results are
-    bit-identical for every choice."""
+    bit-identical for every choice. offset_split = 1 (small levels; ignored with dense_out): the four waves of a workgroup split
+    the kernel offsets of a tile by k % 4 -- the same bits for every cout_split / depth, last-bit differences from offset_split 0."""
     _req(in_feat, torch.float32, "in_feat")
     kv, cap = nbr.shape
     dd = None
@@ -397,7 +398,7 @@ def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, sc
         dd = _i3(dense_dims)
     check(lib.sessd_sparse_conv(in_feat.data_ptr(), cin, nbr.data_ptr(), tile_mask.data_ptr(), kv, n_out_dev.data_ptr(),
                                 cap, packed_weight.data_ptr(), _p(scale), _p(shift), 1 if relu else 0, _p(out), cout,
-                                _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), int(cout_split) + 256 * int(depth),
+                                _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), int(cout_split) + 256 * int(depth) + 65536 * int(bool(offset_split)),
                                 _stream()),
           "sparse_conv")
     return out if dense_out is None else dense_out

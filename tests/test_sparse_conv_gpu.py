@@ -157,3 +157,21 @@ def test_every_tuning_is_bit_identical(dev, cin, cout, n, cap):
             ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, True, dense_out=d, out_indices=out_idx,
                             dense_dims=[5, 12, 10], cout_split=split, depth=depth)
             assert torch.equal(d, dref), (cin, cout, split, depth)
+    # offset split (four waves share a tile, offsets dealt out by k % 4): one summation order of its own -- the same bits for
+    # every cout split / depth, the oracle's tolerance against the unsplit chain; with dense_out the flag is ignored
+    kref = ops.sparse_conv(feat, nbr, tm, n_dev, wpk, cin, cout, scale, shift, True, cout_split=1, depth=2, offset_split=1).clone()
+    kref2 = ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, False, cout_split=1, depth=2, offset_split=1).clone()
+    assert float((kref[:n].cpu() - want).abs().max()) < 1e-4 * max(1.0, float(want.abs().max()))
+    assert float((kref2[:m] - ref2[:m]).abs().max()) < 1e-4 * max(1.0, float(ref2[:m].abs().max()))
+    for split in (0, 1, 2, 4):
+        if split > 1 and (cout // 16) % split:
+            continue
+        for depth in (0, 2, 3, 4):
+            a = ops.sparse_conv(feat, nbr, tm, n_dev, wpk, cin, cout, scale, shift, True, cout_split=split, depth=depth, offset_split=1)
+            assert torch.equal(a[:n], kref[:n]), (cin, cout, split, depth)
+            b = ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, False, cout_split=split, depth=depth, offset_split=1)
+            assert torch.equal(b[:m], kref2[:m]), (cin, cout, split, depth)
+    d = torch.zeros_like(dref)
+    ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, True, dense_out=d, out_indices=out_idx,
+                    dense_dims=[5, 12, 10], cout_split=1, depth=2, offset_split=1)
+    assert torch.equal(d, dref)
