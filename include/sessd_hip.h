@@ -351,6 +351,18 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
  * pairs whose caller-supplied stand-up IoU is <= standup_thresh stay 0. standup_iou and out are (n,k) row-major. */
 int sessd_quads_pairwise(int mode, const float* corners_a, int n, const float* corners_b, int k, const float* standup_iou,
                          float standup_thresh, float* out, sessd_stream_t stream);
+/* DI-NMS: det3d/ops/nms/nms_cpu.h:173-384 IOU_weighted_rotate_non_max_suppression_cpu (the pybind core of
+ * det3d/core/bbox/box_torch_ops.py:552-621 rotate_weighted_nms; nms_cpu.py:52-93 prepares its inputs). All arrays are device
+ * pointers except sigma_dist_interval / sigma_square (host, n_interval <= 8 / n_interval - 1 used). boxes (n,7), corners (n,4,2),
+ * standup_iou (n,n), scores / iou_preds (n), labels / dirs (n) int32, anchors (n, anchor_stride) or NULL with centerness_c = 0;
+ * n <= 1024. Outputs (capacity n): weighted-average boxes (k,7), scores, labels, directions, kept input indices; *n_keep = k.
+ * Like the reference, `thresh` of the Python signature does not exist here (the core never reads it). */
+size_t sessd_di_nms_workspace_bytes(int n);
+int sessd_di_nms(const float* boxes, const float* corners, const float* standup_iou, int n, const float* scores,
+                 const float* iou_preds, const int* labels, const int* dirs, const float* anchors, int anchor_stride,
+                 float cnt_thresh, const float* sigma_dist_interval, int n_interval, const float* sigma_square,
+                 float suppressed_thresh, int centerness_c, float* boxes_ret, float* scores_ret, int* labels_ret, int* dirs_ret,
+                 int* keep, int* n_keep, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 /* Detection records for the end-of-job gather (replaces the pickled per-rank dicts of tools/dist_test.py:150-186 /
  * det3d/torchie/trainer/utils.py:115-155): appends the `batch` frames of sessd_predict's outputs to a device ring of
  * fixed-size records (capacity_frames, post_max_size, 9) float32 [box 7 | score | label] + counts; slot = (*cursor + b) %

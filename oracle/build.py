@@ -16,7 +16,7 @@ LIB = os.path.join(HERE, "liboracle.so")
 REF_DIR = os.path.join(HERE, "_ref")
 REF_LIB = os.path.join(REF_DIR, "libref_iou3d.so")
 REF_SRC = "/root/reference/det3d/core/iou3d/src/iou3d_cpu.cpp"
-C_SRCS = ["voxelize.c", "iou3d.c", "rotate_nms.c", "rotate_iou_eval.c"]
+C_SRCS = ["voxelize.c", "iou3d.c", "rotate_nms.c", "rotate_iou_eval.c", "di_nms.c"]
 
 
 def _newer(srcs, target):

@@ -40,6 +40,9 @@ def lib():
         L.oracle_rotate_iou_eval.argtypes = [_f32p, C.c_int, _f32p, C.c_int, C.c_int, _f32p]
         L.oracle_rotate_iou_pair.restype = C.c_float
         L.oracle_rotate_iou_pair.argtypes = [_f32p, _f32p, C.c_int]
+        L.oracle_di_nms.restype = C.c_int
+        L.oracle_di_nms.argtypes = [_f32p, _f32p, _f32p, C.c_int, _f32p, _f32p, _i32p, _i32p, C.c_void_p, C.c_int, C.c_float, _f32p, C.c_int,
+                                    _f32p, C.c_float, C.c_int, _f32p, _f32p, _i32p, _i32p, _i32p]
     return _lib
 
 
@@ -170,6 +173,27 @@ def rotate_nms_cc(dets, thresh, order=None, margin=1e-4, return_pairs=False, for
         return keep[:n].astype(np.int64), int(near[0]), pairs[:min(int(near[0]), 4096)].astype(np.int64)
     n = lib().oracle_rotate_nms(dets, K, order, float(thresh), keep, float(margin), near)
     return keep[:n].astype(np.int64), int(near[0])
+
+
+def di_nms_core(boxes, box_corners, standup_iou, thresh, scores, iou_preds, labels, dirs, anchors, cnt_thresh,
+                nms_sigma_dist_interval, nms_sigma_square, suppressed_thresh, centerness_c):
+    """Stand-in for the pybind IOU_weighted_rotate_non_max_suppression_cpu (nms_cpu.h:173-384), same argument list and the same
+    [boxes, scores, labels, dirs, keep] list-of-lists return (`thresh` is unused by the reference as well)."""
+    b = _f32(boxes).reshape(-1, 7)
+    n = b.shape[0]
+    co = _f32(box_corners).reshape(n, 8)
+    su = _f32(standup_iou).reshape(n, n)
+    an = _f32(anchors) if int(centerness_c) == 1 else None
+    if an is not None:
+        an = np.ascontiguousarray(an.reshape(n, -1))
+    iv, sg = _f32(np.asarray(nms_sigma_dist_interval, np.float32)), _f32(np.asarray(nms_sigma_square, np.float32))
+    bo, so = np.zeros((max(n, 1), 7), np.float32), np.zeros((max(n, 1),), np.float32)
+    lo, do, ke = np.zeros((max(n, 1),), np.int32), np.zeros((max(n, 1),), np.int32), np.zeros((max(n, 1),), np.int32)
+    k = lib().oracle_di_nms(b, co, su, n, _f32(scores), _f32(iou_preds), np.ascontiguousarray(labels, np.int32),
+                            np.ascontiguousarray(dirs, np.int32), None if an is None else an.ctypes.data_as(C.c_void_p),
+                            0 if an is None else an.shape[1], float(cnt_thresh), iv, int(iv.shape[0]), sg, float(suppressed_thresh),
+                            int(centerness_c), bo, so, lo, do, ke)
+    return [bo[:k].tolist(), so[:k].tolist(), lo[:k].tolist(), do[:k].tolist(), ke[:k].tolist()]
 
 
 # ---------------------------------------------------------------- numba-convention rotated IoU (AP evaluation family)

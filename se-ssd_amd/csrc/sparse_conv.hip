@@ -235,6 +235,150 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   }
 }
 
+// Variant for levels with many tiles (tuning bit 17): the four site tiles of a workgroup walk the UNION of their active offsets in
+// step and share W[k] through LDS. Without it every wave streams its own copy of W[k] (Cin x Cout/split floats per 16-site tile
+// and offset: 2/3 of the operand bytes), and at scale the kernel is bound by that L1/L2 traffic, not by the matrix cores
+// (45 % of the f32 MFMA peak on the dense-scene batch). Per step: all threads fetch W[k_next] (16-byte loads, the packed fragment
+// order is kept) and each wave the rows of its own tile for k_next, the MFMAs of offset k take B from the LDS copy staged during
+// the previous step, then the fetched W goes to the other LDS buffer; one barrier per offset. A wave whose tile has no
+// neighbour at offset k multiplies zero rows in that step (it waits for the others at the barrier anyway; a branch around the
+// MFMAs makes hipcc shuttle the accumulators between AGPRs and VGPRs). Same (offset, cin) fmaf chain per site as the plain
+// kernel: identical bits.
+template <int CIN, int COUT, int NTW>
+__global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __restrict__ in_feat, const int* __restrict__ nbr,
+                                                                  const uint32_t* __restrict__ tile_mask, int kv,
+                                                                  const int* __restrict__ n_dev, int n_cap,
+                                                                  const float* __restrict__ wpk, const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int relu,
+                                                                  float* __restrict__ out_feat) {
+  constexpr int STEPS = CIN / 4, NTILE = NTW, NTALL = COUT / 16, SG = STEPS / 4;
+  static_assert(CIN % 16 == 0, "16-byte operand loads");
+  constexpr int WFLOATS = NTILE * CIN * 16;   // W[k] of this workgroup's couts, in fragment order
+  constexpr int WVEC = WFLOATS / 1024;        // 16-byte loads per thread and offset
+  static_assert(WVEC >= 1, "at least one 16-byte load per thread");
+  constexpr int NGRP = COUT / 16 / NTW;
+  __shared__ __attribute__((aligned(16))) float s_w[2][WFLOATS];
+  __shared__ int s_nbr[4][32][16];
+  const int n = min(n_dev[0], n_cap);
+  const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+  const int groups = (n + 63) >> 6;
+  const int lg = groups >= 4096 ? 3 : (groups >= 2048 ? 2 : (groups >= 512 ? 1 : 0));
+  const int t_local = j / NGRP;
+  const int group = ((((t_local >> lg) << 3) + xcd) << lg) + (t_local & ((1 << lg) - 1));
+  if (group >= groups) return;
+  const int tbase = (j - t_local * NGRP) * NTW;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int tile = group * 4 + wv;
+  const bool live = tile * 16 < n;          // wave-uniform; dead waves still take part in the staging and the barriers
+  const int i = lane & 15, kq = lane >> 4;
+  const int ntiles = (n + 15) >> 4;
+  uint32_t un = 0, mine = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const uint32_t m = (group * 4 + q < ntiles) ? __builtin_amdgcn_readfirstlane(tile_mask[group * 4 + q]) : 0u;
+    un |= m;
+    if (q == wv) mine = m;
+  }
+  mine = __builtin_amdgcn_readfirstlane(mine);
+  f32x4 acc[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const int* nb = nbr + tile * 16 + (tile * 16 + i < n ? i : 0);
+    int r[8];
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int k = p * 4 + kq;
+      r[p] = (k < kv && ((mine >> k) & 1u)) ? nb[(size_t)k * n_cap] : -1;
+    }
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s_nbr[wv][p * 4 + kq][i] = r[p];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const rsrc_t fr = make_rsrc(in_feat, 0x7FFFFFFFu);
+  const rsrc_t wrs = make_rsrc(wpk, (unsigned)kv * NTALL * STEPS * 64u * 4u);
+  const unsigned wlane = (unsigned)tid * 16u + (unsigned)(tbase * SG) * 1024u;  // this thread's 16 bytes of the W[k] block
+  f32x4 wreg[WVEC];
+  float a[2][STEPS];
+#define SESSD_WS_LOADW(K)                                                                          \
+  _Pragma("unroll") for (int p = 0; p < WVEC; ++p)                                                 \
+    wreg[p] = bufload4(wrs, wlane + 4096u * p, (unsigned)(K) * (NTALL * STEPS * 64 * 4));
+#define SESSD_WS_LOADA(SET, K)                                                                     \
+  {                                                                                                \
+    const int row = (live && ((mine >> (K)) & 1u)) ? s_nbr[wv][(K)][i] : -1;                       \
+    const unsigned ao = row >= 0 ? (unsigned)((row * CIN + kq * STEPS) * 4) : SESSD_OOB;           \
+    _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                               \
+      const f32x4 v = bufload4(fr, ao + 16u * g, 0);                                               \
+      a[SET][4 * g] = v.x; a[SET][4 * g + 1] = v.y; a[SET][4 * g + 2] = v.z; a[SET][4 * g + 3] = v.w; \
+    }                                                                                              \
+  }
+#define SESSD_WS_STAGE(BUF)                                                                        \
+  _Pragma("unroll") for (int p = 0; p < WVEC; ++p)                                                 \
+    *reinterpret_cast<f32x4*>(&s_w[BUF][(p * 256 + tid) * 4]) = wreg[p];
+#define SESSD_WS_MMA(SET, BUF, K)                                                                  \
+  {                                                                                                \
+    _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                               \
+      f32x4 b[NTILE];                                                                              \
+      _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
+        b[t] = *reinterpret_cast<const f32x4*>(&s_w[BUF][((t * SG + g) * 64 + lane) * 4]);         \
+      /* cout tiles innermost: consecutive MFMAs go to different accumulators (same order per accumulator) */ \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                \
+        _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                          \
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SET][4 * g + e], b[t][e], acc[t], 0, 0, 0); \
+    }                                                                                              \
+  }
+  // one step: fetch the operands of the next offset, multiply the current one, publish the fetched W
+#define SESSD_WS_STEP(SET)                                                                         \
+  {                                                                                                \
+    const bool more = rest != 0u;                                                                  \
+    const int kn = more ? __builtin_ctz(rest) : k;                                                 \
+    rest &= rest - 1;                                                                              \
+    SESSD_WS_LOADW(kn)                                                                             \
+    SESSD_WS_LOADA((SET) ^ 1, kn)                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_WS_MMA(SET, SET, k)                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_WS_STAGE((SET) ^ 1)                                                                      \
+    __syncthreads();                                                                               \
+    k = kn;                                                                                        \
+  }
+  if (un != 0u) {
+    uint32_t rest = un;
+    int k = __builtin_ctz(rest);
+    rest &= rest - 1;
+    const int steps = __builtin_popcount(un);
+    SESSD_WS_LOADW(k)
+    SESSD_WS_LOADA(0, k)
+    SESSD_WS_STAGE(0)
+    __syncthreads();
+    for (int it = 0; it < steps; it += 2) {
+      SESSD_WS_STEP(0)
+      if (it + 1 >= steps) break;
+      SESSD_WS_STEP(1)
+    }
+  }
+#undef SESSD_WS_LOADW
+#undef SESSD_WS_LOADA
+#undef SESSD_WS_STAGE
+#undef SESSD_WS_MMA
+#undef SESSD_WS_STEP
+  if (!live) return;
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int co = (tbase + t) * 16 + i;
+    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int site = tile * 16 + kq * 4 + r;
+      if (site >= n) continue;
+      float v = fmaf(acc[t][r], sc, sh);
+      if (relu) v = fmaxf(v, 0.f);
+      out_feat[(size_t)site * COUT + co] = v;
+    }
+  }
+}
+
 // W (kv, cin, cout) row-major [the flattened spconv layout (kz,ky,kx,Cin,Cout)] -> fragment order
 //   wpk[(((k*NTILE + t)*SG + g)*64 + lane)*G + e] = W[k][ (lane>>4)*STEPS + g*G + e ][ t*16 + (lane&15) ]
 __global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin, int cout, float* __restrict__ wpk) {
@@ -311,6 +455,27 @@ int launch(int tuning, bool dense, const float* in_feat, const int* nbr, const u
   const int depth = (tuning >> 8) & 0xFF;
   if (split <= 0) split = (n_cap / 16 < 4096) ? (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1)) : 1;  // fill 1024 SIMDs on small levels
   const bool ksplit = ((tuning >> 16) & 1) && !dense;
+  if (((tuning >> 17) & 1) && !dense) {
+    // shared-W variant: needs 16-byte A loads and at least one 16-byte W load per thread
+    const int tiles = sessd_divup(n_cap, 16);
+#define SESSD_WSHARE(NTW_)                                                                                            \
+    if constexpr (CIN % 16 == 0 && (NTW_) * CIN >= 64) {                                                              \
+      dim3 grid(8 * (sessd_divup(sessd_divup(tiles, 4), 8) + 8) * (NT / (NTW_))), block(256);                          \
+      SESSD_LAUNCH((sparse_conv_wshare_kernel<CIN, COUT, (NTW_)>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv, \
+                   n_dev, n_cap, wpk, scale, shift, relu, out_feat);                                                  \
+      SESSD_CHECK_LAUNCH();                                                                                           \
+      return SESSD_OK;                                                                                                \
+    }
+    if constexpr (NT % 4 == 0) {
+      if (split >= 4) { SESSD_WSHARE(NT / 4) }
+    }
+    if constexpr (NT % 2 == 0) {
+      if (split >= 2) { SESSD_WSHARE(NT / 2) }
+    }
+    { SESSD_WSHARE(NT) }
+#undef SESSD_WSHARE
+    // not instantiable for this channel pair / split: the plain kernel (same bits)
+  }
 #define SESSD_ARGS depth, dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
   if (ksplit) {
     if constexpr (NT % 4 == 0) {
@@ -352,7 +517,8 @@ int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, in
 // one multiplied). Results do not depend on either. offset_split = 1 (ignored with dense_out): the four waves of a workgroup
 // split the kernel offsets of one tile by k % 4 and add their partial tiles -- for levels with fewer tiles than SIMDs; its
 // results are the same for every cout_split / depth but differ in the last bits from offset_split = 0 (four partial chains
-// added instead of one chain).
+// added instead of one chain). Bit 17 (131072; ignored with dense_out and where the shape does not allow it): the four tiles of a
+// workgroup walk the union of their offsets and share W[k] through LDS -- for levels with many tiles; same bits as the plain kernel.
 // out[o] = act( (sum_k W[k]^T in[nbr[k][o]]) * scale + shift ). If dense_out != NULL the result is
 // scattered instead into the dense BEV tensor (B, cout*D, H, W) with dense_dims3 = (D,H,W) (pre-zeroed
 // by the caller) and out_feat may be NULL.

@@ -78,6 +78,43 @@ def rotate_nms(rbboxes, scores, pre_max_size=None, post_max_size=None, iou_thres
     return indices[keep]
 
 
+def rotate_weighted_nms(box_preds, rbboxes, dir_labels, labels_preds, scores, iou_preds, anchors, enable_centerness=True,
+                        centerness_pow=1, centerness_c=False, pre_max_size=None, post_max_size=None, iou_threshold=0.5,
+                        nms_cnt_thresh=2.6, nms_sigma_dist_interval=(0, 20, 40, 60), nms_sigma_square=(0.0009, 0.009, 0.1, 1),
+                        suppressed_thresh=0.3):
+    """DI-NMS (box_torch_ops.py:552-621): confidence-aware, IoU-weighted box averaging instead of plain suppression. box_preds
+    (K,7), rbboxes (K,5) [x,y,w,l,r], dir_labels / labels_preds (K,), scores / iou_preds (K,), anchors (K,7). Returns (boxes (k,7),
+    dirs (k,), labels (k,), scores (k,), kept indices into the input) on the input's device. Like the reference, the input
+    `scores` tensor is damped in place when enable_centerness is set without centerness_c, and an empty input returns None.
+    (Without pre_max_size the reference fails on an unbound `indices`; here the indices are then simply 0..K-1.)"""
+    indices = torch.arange(scores.shape[0], device=scores.device)
+    if pre_max_size is not None:
+        k = min(scores.shape[0], pre_max_size)
+        scores, indices = torch.topk(scores, k=k)
+        rbboxes, iou_preds, dir_labels = rbboxes[indices], iou_preds[indices], dir_labels[indices]
+        labels_preds, box_preds, anchors = labels_preds[indices], box_preds[indices], anchors[indices]
+    if enable_centerness and not centerness_c:
+        dist = torch.abs(box_preds - anchors)
+        metric = torch.softmax(torch.pow(torch.pow(dist[:, 0:2], 2).sum(-1), 0.5), dim=0)
+        scores *= torch.pow(torch.ones_like(metric) - metric, centerness_pow)
+    import numpy as np
+    from det3d.ops.nms.nms_cpu import rotate_weighted_nms_cc
+    if rbboxes.shape[0] == 0:
+        return None   # the reference's empty branch falls off the end of the function (box_torch_ops.py:598-599)
+    dev = rbboxes.device
+    # as in the reference the footprints, stand-up boxes and their IoU are prepared in numpy (nms_cpu.py:65-72); the selection
+    # loop itself -- the O(K^2) polygon work -- runs on the device
+    dets_np = torch.cat([rbboxes, scores.unsqueeze(-1)], dim=1).data.cpu().numpy()
+    res = rotate_weighted_nms_cc(box_preds.data.cpu().numpy(), dets_np, iou_threshold, iou_preds.data.cpu().numpy().reshape(-1),
+                                 labels_preds.cpu().numpy().reshape(-1), dir_labels.cpu().numpy().reshape(-1),
+                                 anchors.cpu().numpy() if (enable_centerness and centerness_c) else None,
+                                 nms_cnt_thresh=nms_cnt_thresh, nms_sigma_dist_interval=nms_sigma_dist_interval,
+                                 nms_sigma_square=nms_sigma_square, suppressed_thresh=suppressed_thresh)
+    keep = torch.from_numpy(np.array(res[4], dtype=np.int64)).to(dev)
+    return (torch.from_numpy(np.array(res[0], dtype=np.float32).reshape(-1, 7)).to(dev), torch.from_numpy(np.array(res[3], dtype=np.int64)).to(dev),
+            torch.from_numpy(np.array(res[2], dtype=np.int64)).to(dev), torch.from_numpy(np.array(res[1], dtype=np.float32)).to(dev), indices[keep])
+
+
 def nms(bboxes, scores, pre_max_size=None, post_max_size=None, iou_threshold=0.5):
     """axis-aligned NMS (box_torch_ops.py:505-524 -> nms_gpu, numba kernel with the +1 pixel convention); boxes (K,4)."""
     if bboxes.shape[0] == 0:

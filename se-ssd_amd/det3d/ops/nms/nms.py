@@ -5,7 +5,7 @@ int out); the work runs on the HIP kernels of libsessd_hip.so -- there is no hos
   non_max_suppression(boxes, keep_out, thresh, device_id) -> int            nms_kernel.cu.cc (+1 pixel convention)
   non_max_suppression_cpu(boxes, order, thresh, eps=0) -> list[int]         nms_cpu.h:24-70
   rotate_non_max_suppression_cpu(box_corners, order, standup_iou, thresh)   nms_cpu.h:72-168
-  IOU_weighted_rotate_non_max_suppression_cpu(...)                          nms_cpu.h:173-384 (DI-NMS: SURVEY 8f row 4, not built)
+  IOU_weighted_rotate_non_max_suppression_cpu(... 14 args) -> 5 lists       nms_cpu.h:173-384 (DI-NMS, sessd_di_nms)
 """
 import numpy as np
 import torch
@@ -52,6 +52,20 @@ def rotate_non_max_suppression_cpu(box_corners, order, standup_iou, thresh):
     return [int(v) for v in order[keep[:n].cpu().numpy().astype(np.int64)]]
 
 
-def IOU_weighted_rotate_non_max_suppression_cpu(*args, **kwargs):
-    raise NotImplementedError("DI-NMS (nms_cpu.h:173-384) is a 'next' row of the scope table (SURVEY 8f-4) and is not built; "
-                              "SE-SSD's config.py test_cfg uses plain rotate_nms")
+def IOU_weighted_rotate_non_max_suppression_cpu(boxes, box_corners, standup_iou, thresh, scores, IOU_preds, labels, dirs, anchors,
+                                                cnt_thresh, nms_sigma_dist_interval, nms_sigma_square, suppressed_thresh, centerness_c):
+    """nms.cc:19-29 / nms_cpu.h:173-384 (DI-NMS core), same 14 arguments and the same [boxes, scores, labels, dirs, keep] list return;
+    numpy in, the selection runs on the device (sessd_di_nms). `thresh` is accepted and unused, as in the reference."""
+    boxes = np.asarray(boxes, np.float32).reshape(-1, 7)
+    n = boxes.shape[0]
+    if n == 0:
+        return [[], [], [], [], []]
+    dev = _dev()
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(np.asarray(a), dt)).to(dev)
+    an = t(np.asarray(anchors).reshape(n, -1), np.float32) if int(centerness_c) == 1 else None
+    b, s, l, d, k = ops.di_nms(t(boxes, np.float32), t(np.asarray(box_corners).reshape(n, 4, 2), np.float32),
+                               t(np.asarray(standup_iou).reshape(n, n), np.float32), t(scores, np.float32), t(IOU_preds, np.float32),
+                               t(labels, np.int32), t(dirs, np.int32), an, cnt_thresh, nms_sigma_dist_interval, nms_sigma_square,
+                               suppressed_thresh)
+    return [b.cpu().numpy().tolist(), s.cpu().numpy().tolist(), l.cpu().numpy().tolist(), d.cpu().numpy().tolist(),
+            k.cpu().numpy().tolist()]

@@ -28,5 +28,18 @@ def nms_jit(dets, thresh, eps=0.0):
     return non_max_suppression_cpu(dets, order, thresh, eps)
 
 
-def rotate_weighted_nms_cc(*args, **kwargs):
-    return IOU_weighted_rotate_non_max_suppression_cpu(*args, **kwargs)
+def rotate_weighted_nms_cc(box, dets, thresh, iou_preds, labels, dirs, anchors=None, nms_cnt_thresh=2.6,
+                           nms_sigma_dist_interval=(0, 20, 40, 60), nms_sigma_square=(0.0009, 0.009, 0.1, 1), suppressed_thresh=0.3):
+    """DI-NMS on numpy inputs (nms_cpu.py:52-93): box (N,7) predictions, dets (N,6) [x,y,w,l,r,score]; anchors given => centerness
+    damping inside the core. Returns the core's [boxes, scores, labels, dirs, keep] lists."""
+    scores = dets[:, 5]
+    corners = box_np_ops.center_to_corner_box2d(dets[:, :2], dets[:, 2:4], dets[:, 4])
+    standup = box_np_ops.corner_to_standup_nd(corners)
+    standup_iou = box_np_ops.iou_jit(standup, standup, eps=0.0)
+    if anchors is None:
+        centerness_c, anchors = 0, np.zeros((1, 1))
+    else:
+        centerness_c = 1
+    return IOU_weighted_rotate_non_max_suppression_cpu(box, corners, standup_iou, thresh, scores, iou_preds, labels, dirs, anchors,
+                                                       nms_cnt_thresh, nms_sigma_dist_interval, nms_sigma_square, suppressed_thresh,
+                                                       centerness_c)

@@ -55,6 +55,8 @@ SIGNATURES = {
     "sessd_ssfa_fuse": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp]),
     "sessd_predict_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "sessd_predict": (i32, [vp, i32, i32, vp, i32, vp, f32, i32, i32, f32, vp, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "sessd_di_nms_workspace_bytes": (sz, [i32]),
+    "sessd_di_nms": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, vp, i32, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_pack_detections": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp]),
     "sessd_quads_pairwise": (i32, [i32, vp, i32, vp, i32, vp, f32, vp, vp]),
     "sessd_rotate_nms_workspace_bytes": (sz, [i32]),

@@ -308,8 +308,10 @@ class InferenceEngine:
             # depth do not change the results; the offset split (allow_offset_split; four waves per tile, for levels with fewer
             # tiles than SIMDs) has one summation order of its own (last-bit differences)
             best = (None, 1e30)
-            for split, depth, ks in [(a, b, c) for c in ((0, 1) if self.allow_offset_split else (0,)) for a in (1, 2, 4) for b in (2, 3, 4)]:
-                if (lay["cout"] // 16) % split or (ks and depth == 4):
+            cands = [(a, b, c) for c in ((0, 1) if self.allow_offset_split else (0,)) for a in (1, 2, 4) for b in (2, 3, 4)]
+            cands += [(a, 2, 2) for a in (1, 2, 4)]  # mode 2: W[k] shared through LDS by the four tiles of a workgroup (same bits)
+            for split, depth, ks in cands:
+                if (lay["cout"] // 16) % split or (ks == 1 and depth == 4):
                     continue
                 if True:
                     self.sparse_split[idx] = split + 256 * depth + 65536 * ks

@@ -114,6 +114,44 @@ def boxes_pairwise(mode, a, b, out=None):
     return out
 
 
+def di_nms(boxes, corners, standup_iou, scores, iou_preds, labels, dirs, anchors=None, cnt_thresh=2.6,
+           sigma_dist_interval=(0, 20, 40, 60), sigma_square=(0.0009, 0.009, 0.1, 1), suppressed_thresh=0.3):
+    """DI-NMS core (nms_cpu.h:173-384) on the device: boxes (n,7), corners (n,4,2), standup_iou (n,n), scores / iou_preds (n) float32,
+    labels / dirs (n) int32, anchors (n,>=2) or None. Returns (boxes (k,7), scores (k,), labels (k,), dirs (k,), keep (k,) int64)."""
+    import ctypes
+    import numpy as np
+    for t, nm in ((boxes, "boxes"), (corners, "corners"), (standup_iou, "standup_iou"), (scores, "scores"), (iou_preds, "iou_preds")):
+        _req(t, torch.float32, nm)
+    n = boxes.shape[0]
+    dev = boxes.device
+    if n > 1024:
+        raise ValueError("di_nms handles at most 1024 boxes (the post-processor's pre_max_size)")
+    labels = labels.to(torch.int32).contiguous()
+    dirs = dirs.to(torch.int32).contiguous()
+    if anchors is not None:
+        _req(anchors, torch.float32, "anchors")
+    iv = np.ascontiguousarray(np.asarray(sigma_dist_interval, np.float32))
+    sg = np.ascontiguousarray(np.asarray(sigma_square, np.float32))
+    if sg.shape[0] < iv.shape[0] - 1:
+        raise ValueError("sigma_square needs one entry per distance interval")
+    cap = max(n, 1)
+    out_b = torch.empty((cap, 7), dtype=torch.float32, device=dev)
+    out_s = torch.empty((cap,), dtype=torch.float32, device=dev)
+    out_l = torch.empty((cap,), dtype=torch.int32, device=dev)
+    out_d = torch.empty((cap,), dtype=torch.int32, device=dev)
+    keep = torch.empty((cap,), dtype=torch.int32, device=dev)
+    nk = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws = torch.empty(int(lib.sessd_di_nms_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+    check(lib.sessd_di_nms(boxes.data_ptr(), corners.data_ptr(), standup_iou.data_ptr(), n, scores.data_ptr(), iou_preds.data_ptr(),
+                           labels.data_ptr(), dirs.data_ptr(), _p(anchors), 0 if anchors is None else anchors.shape[1],
+                           float(cnt_thresh), iv.ctypes.data_as(ctypes.c_void_p), int(iv.shape[0]), sg.ctypes.data_as(ctypes.c_void_p),
+                           float(suppressed_thresh), 0 if anchors is None else 1, out_b.data_ptr(), out_s.data_ptr(),
+                           out_l.data_ptr(), out_d.data_ptr(), keep.data_ptr(), nk.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "di_nms")
+    k = int(nk.item())
+    return out_b[:k], out_s[:k], out_l[:k], out_d[:k], keep[:k].long()
+
+
 def quads_pairwise(mode, corners_a, corners_b, standup_iou, standup_thresh=0.0):
     """mode 0: IoU, 1: intersection area of convex quads (n,4,2) x (k,4,2); 0 where standup_iou <= standup_thresh."""
     _req(corners_a, torch.float32, "corners_a")
@@ -384,10 +422,12 @@ def sparse_pack_weight(weight):
 
 
 def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, scale=None, shift=None, relu=True,
-                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0, offset_split=0):
+                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0, offset_split=0, share_w=0):
     """cout_split (0 heuristic | 1, 2, 4) and depth (0 default | 2..4 operand sets in flight) only tune the launch: results are
     bit-identical for every choice. offset_split = 1 (small levels; ignored with dense_out): the four waves of a workgroup split
-    the kernel offsets of a tile by k % 4 -- the same bits for every cout_split / depth, last-bit differences from offset_split 0."""
+    the kernel offsets of a tile by k % 4 -- the same bits for every cout_split / depth, last-bit differences from offset_split 0.
+    share_w = 1 (large levels; ignored with dense_out or where cin % 16 != 0): the four tiles of a workgroup share W[k] through LDS --
+    the same bits as the plain kernel."""
     _req(in_feat, torch.float32, "in_feat")
     kv, cap = nbr.shape
     dd = None
@@ -398,7 +438,7 @@ def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, sc
         dd = _i3(dense_dims)
     check(lib.sessd_sparse_conv(in_feat.data_ptr(), cin, nbr.data_ptr(), tile_mask.data_ptr(), kv, n_out_dev.data_ptr(),
                                 cap, packed_weight.data_ptr(), _p(scale), _p(shift), 1 if relu else 0, _p(out), cout,
-                                _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), int(cout_split) + 256 * int(depth) + 65536 * int(bool(offset_split)),
+                                _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), int(cout_split) + 256 * int(depth) + 65536 * int(bool(offset_split)) + 131072 * int(bool(share_w)),
                                 _stream()),
           "sparse_conv")
     return out if dense_out is None else dense_out

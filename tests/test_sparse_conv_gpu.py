@@ -157,6 +157,14 @@ def test_every_tuning_is_bit_identical(dev, cin, cout, n, cap):
             ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, True, dense_out=d, out_indices=out_idx,
                             dense_dims=[5, 12, 10], cout_split=split, depth=depth)
             assert torch.equal(d, dref), (cin, cout, split, depth)
+    # shared-W variant (the four tiles of a workgroup walk the union of their offsets): the plain kernel's bits
+    for split in (0, 1, 2, 4):
+        if split > 1 and (cout // 16) % split:
+            continue
+        a = ops.sparse_conv(feat, nbr, tm, n_dev, wpk, cin, cout, scale, shift, True, cout_split=split, share_w=1)
+        assert torch.equal(a[:n], ref[:n]), (cin, cout, split, "share_w")
+        b = ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, False, cout_split=split, share_w=1)
+        assert torch.equal(b[:m], ref2[:m]), (cin, cout, split, "share_w")
     # offset split (four waves share a tile, offsets dealt out by k % 4): one summation order of its own -- the same bits for
     # every cout split / depth, the oracle's tolerance against the unsplit chain; with dense_out the flag is ignored
     kref = ops.sparse_conv(feat, nbr, tm, n_dev, wpk, cin, cout, scale, shift, True, cout_split=1, depth=2, offset_split=1).clone()
