@@ -249,7 +249,8 @@ def main():
                                "traffic": None}
             # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
             # under profiles/; it cannot be collected inside this process
-            tpath = os.path.join(ROOT, "profiles", "r1_winograd_traffic.json" if wino else "r1_conv_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", ("r2_wino_sk_traffic.json" if streamk else "r1_winograd_traffic.json") if wino
+                                 else "r1_conv_traffic.json")
             if os.path.exists(tpath) and args.batch == 1:
                 tj = json.load(open(tpath))
                 out["roofline"]["traffic"] = tj["traffic_bytes"]
