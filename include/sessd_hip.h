@@ -112,7 +112,9 @@ int sessd_nms_axis_eps_sorted(const float* boxes, int stride, int num_boxes, flo
  * Sites are (N,4) int32 [b,z,y,x]; live counts stay on the device (n_*_dev), arrays are sized by
  * capacity. A rulebook is output-stationary: nbr[k][o] = input row (or -1), k = (kz*KY+ky)*KX+kx,
  * stored [kernel_volume][n_out_cap]; tile_mask[o/16] has bit k set when any of the 16 sites of the
- * tile has a neighbour through offset k. */
+ * tile has a neighbour through offset k.  The linear key ((b*D + z)*H + y)*W + x is 32 bit: batch * D * H * W must stay below 2^32 - 1
+ * (KITTI grid [41,1600,1408]: batch <= 46); the batch size is not an argument, so this is the caller's contract. The fused chain
+ * (sessd_sparse_chain_*) checks its own limits. */
 int sessd_sparse_hash_build(const int32_t* indices, const int32_t* n_dev, int n_cap, const int32_t* dims3,
                             uint32_t* keys, int32_t* vals, uint32_t capacity, sessd_stream_t stream);
 size_t sessd_sparse_downsample_workspace_bytes(int n_in_cap, int kernel_volume, uint32_t out_hash_capacity);

@@ -203,8 +203,13 @@ def noise_per_object_v4_(gt_boxes, points=None, valid_mask=None, rotation_pertur
                                                 origin=[0.5, 0.5, 0.5], axis=2)
     chosen = noise_per_box(gt_boxes[:, [0, 1, 3, 4, 6]] + offset, valid_mask, loc_noises, rot_noises)
     loc_t, rot_t = _select_transform(loc_noises, chosen), _select_transform(rot_noises, chosen)
-    if points is not None:
-        masks = points_in_convex_polygon_3d_jit(points[:, :3], box_np_ops.corner_to_surfaces_3d_jit(corners))
+    surfaces = box_np_ops.corner_to_surfaces_3d_jit(corners)
+    if callable(points):
+        # device mode of the pipeline stage: the caller moves the points (sessd_points_rigid_moves) given the faces of the boxes
+        # BEFORE the move, their centres and the chosen transforms -- same random draws, same box updates
+        points(surfaces, gt_boxes[:, :3].copy(), loc_t, rot_t, valid_mask)
+    elif points is not None:
+        masks = points_in_convex_polygon_3d_jit(points[:, :3], surfaces)
         points_transform_(points, gt_boxes[:, :3], masks, loc_t, rot_t, valid_mask)
     box3d_transform_(gt_boxes, loc_t, rot_t, valid_mask)
 

@@ -28,6 +28,7 @@ class Preprocess(object):
     reference. Labeled training frames: drop DontCare, paste database objects (GT-AUG) and remove the scene points they
     cover, per-object noise, snapshot (`points_raw`, `annotations_raw`: the teacher's view), then global flip / rotation /
     scaling recorded in `transformation` (what MultiGroupHead.consistency_loss undoes), shape-aware augmentation, point shuffle.
+    With a CUDA tensor as `points` the point-level work of the same stage runs on the device (`_call_device`).
     Unlabeled training frames only get the global transformation. Options the SE-SSD configuration leaves off
     (remove_environment, remove_unknown, min_points_in_gt, rgb, reference detections, random_crop, npoints) are not mirrored."""
 
@@ -60,6 +61,88 @@ class Preprocess(object):
             self.data_aug_random_drop = _get(cfg, "data_aug_random_drop", -1)
             self.sa_da = dict(enable_sa_dropout=0.25, enable_sa_sparsity=[0.05, 50], enable_sa_swap=[0.1, 50])  # cars (:134-138)
 
+    def _global_device(self, gt_boxes, points, snapshot):
+        """The three global draws in the host stage's order, applied to the boxes on the host and to the DEVICE cloud in one launch
+        (sessd_points_global_transform), which also leaves the untransformed cloud in `snapshot` (points_raw)."""
+        from det3d.core.sampler import preprocess as prep
+        from sessd_hip import ops
+        none = np.zeros((0, 4), np.float32)
+        gt_boxes, _, flipped = prep.random_flip_v2(gt_boxes, none)
+        gt_boxes, _, rot = prep.global_rotation_v3(gt_boxes, none, self.global_rotation_noise)
+        gt_boxes, _, scale = prep.global_scaling_v3(gt_boxes, none, *self.global_scaling_noise)
+        ops.points_global_transform_(points, bool(flipped), float(rot), float(scale), raw_copy=snapshot)
+        return gt_boxes, {"flipped": flipped, "noise_rotation": rot, "noise_scale": scale}
+
+    def _call_device(self, res, info):
+        """The stage with the point cloud resident on the device (res["lidar"]["points"] is a CUDA tensor): box-level decisions and
+        every random draw are the host stage's, in its order (a seed gives the same augmentation); the point-level work runs on
+        sessd_points_in_bodies / _compact (GT-AUG removal), _rigid_moves (per-object noise), _global_transform (+ the points_raw
+        snapshot) and a device gather (shuffle). The shape-aware augmentation takes the cloud through the host once (its thinning
+        and pyramid swapping are not ported)."""
+        import torch
+        from det3d.core.bbox import box_np_ops
+        from det3d.core.bbox.geometry import surface_equ_3d_jitv2
+        from det3d.core.sampler import preprocess as prep
+        from det3d.datasets.kitti import kitti_common as kitti
+        from det3d.datasets.utils import sa_da_v2
+        from sessd_hip import ops
+        res["mode"] = self.mode
+        points = res["lidar"]["points"].float().contiguous()
+        dev = points.device
+
+        def planes_of(surfaces):
+            nrm, d = surface_equ_3d_jitv2(surfaces[:, :, :3, :])
+            return torch.from_numpy(np.ascontiguousarray(np.concatenate([nrm, d[..., None]], axis=-1).astype(np.float32))).to(dev)
+
+        labeled = self.mode == "train" and res["labeled"]
+        if labeled:
+            anno = res["lidar"]["annotations"]
+            gt_dict = {"gt_boxes": anno["boxes"], "gt_names": np.array(anno["names"]).reshape(-1)}
+            _dict_select(gt_dict, kitti.drop_arrays_by_name(gt_dict["gt_names"], ["DontCare", "ignore"]))
+            target = np.array([n in self.class_names for n in gt_dict["gt_names"]], dtype=np.bool_)
+            if self.db_sampler:
+                pasted = self.db_sampler.sample_all(res["metadata"]["image_prefix"], gt_dict["gt_boxes"], gt_dict["gt_names"],
+                                                    res["metadata"]["num_point_features"], False, gt_group_ids=None,
+                                                    calib=res["calib"] if "calib" in res else None,
+                                                    targeted_class_names=self.class_names)
+                if pasted is not None:
+                    gt_dict["gt_names"] = np.concatenate([gt_dict["gt_names"], pasted["gt_names"]], axis=0)
+                    gt_dict["gt_boxes"] = np.concatenate([gt_dict["gt_boxes"], pasted["gt_boxes"]])
+                    target = np.concatenate([target, pasted["gt_masks"]], axis=0)
+                    if self.remove_points_after_sample and pasted["gt_boxes"].shape[0] and points.shape[0]:
+                        pb = pasted["gt_boxes"]
+                        corners = box_np_ops.center_to_corner_box3d(pb[:, :3], pb[:, 3:6], pb[:, 6], origin=(0.5, 0.5, 0.5), axis=2)
+                        inside = ops.points_in_bodies(points, planes_of(box_np_ops.corner_to_surfaces_3d(corners)))
+                        kept, n_kept = ops.points_compact(points, ~inside.any(-1))
+                        points = kept[: int(n_kept.item())]
+                    points = torch.cat([torch.from_numpy(np.ascontiguousarray(pasted["points"], np.float32)).to(dev), points], dim=0).contiguous()
+
+            def move(surfaces, centers, loc_t, rot_t, valid):
+                if points.shape[0] and surfaces.shape[0]:
+                    ops.points_rigid_moves_(points, planes_of(surfaces), centers, loc_t, rot_t, valid)
+
+            prep.noise_per_object_v4_(gt_dict["gt_boxes"], move, target, rotation_perturb=self.gt_rotation_noise,
+                                      center_noise_std=self.gt_loc_noise_std, global_random_rot_range=self.global_random_rot_range,
+                                      group_ids=None, num_try=100, data_aug_with_context=self.data_aug_with_context,
+                                      data_aug_random_drop=self.data_aug_random_drop)
+            _dict_select(gt_dict, target)
+            gt_dict["gt_classes"] = np.array([self.class_names.index(n) + 1 for n in gt_dict["gt_names"]], dtype=np.int32)
+            raw = torch.empty_like(points)
+            res["lidar"]["annotations_raw"] = {k: v.copy() for k, v in gt_dict.items()}
+            gt_dict["gt_boxes"], res["lidar"]["transformation"] = self._global_device(gt_dict["gt_boxes"], points, raw)
+            res["lidar"]["points_raw"] = raw
+            points = torch.from_numpy(sa_da_v2.pyramid_augment_v0(gt_dict["gt_boxes"], points.cpu().numpy(), **self.sa_da)).to(dev)
+        if self.shuffle_points:
+            perm = np.random.choice(np.arange(points.shape[0]), points.shape[0], replace=False)
+            points = points[torch.from_numpy(perm).to(dev)]
+        if self.mode == "train" and not res["labeled"]:
+            points = points.contiguous()
+            _, res["lidar"]["transformation"] = self._global_device(None, points, None)
+        res["lidar"]["points"] = points
+        if labeled:
+            res["lidar"]["annotations"] = gt_dict
+        return res, info
+
     def _global(self, gt_boxes, points):
         from det3d.core.sampler import preprocess as prep
         gt_boxes, points, flipped = prep.random_flip_v2(gt_boxes, points)
@@ -72,8 +155,10 @@ class Preprocess(object):
         from det3d.core.sampler import preprocess as prep
         from det3d.datasets.kitti import kitti_common as kitti
         from det3d.datasets.utils import sa_da_v2
-        res["mode"] = self.mode
         points = res["lidar"]["points"]
+        if not isinstance(points, np.ndarray) and getattr(points, "is_cuda", False):
+            return self._call_device(res, info)
+        res["mode"] = self.mode
         labeled = self.mode == "train" and res["labeled"]
         if labeled:
             anno = res["lidar"]["annotations"]

@@ -500,7 +500,10 @@ def bn_relu_train(x, n_dev, bn, relu=True):
     updated in place, num_batches_tracked incremented)."""
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return BnReluTrainFunction.apply(x, n_dev, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, bn.momentum, relu)
+    mom = bn.momentum
+    if mom is None:  # BatchNorm(momentum=None): cumulative moving average, factor 1 / number of batches seen (torch semantics)
+        mom = 1.0 / float(bn.num_batches_tracked.item()) if bn.num_batches_tracked is not None else 0.0
+    return BnReluTrainFunction.apply(x, n_dev, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
 
 
 def points_in_bodies(points, planes):

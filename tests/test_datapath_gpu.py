@@ -134,3 +134,75 @@ def test_compaction_feeds_the_voxelizer(dev):
     e, ne = ops.points_compact(d_pts, torch.zeros(pts.shape[0], dtype=torch.bool, device=dev))
     a, na = ops.points_compact(d_pts[:1001], torch.ones(1001, dtype=torch.bool, device=dev))
     assert int(ne.item()) == 0 and int(na.item()) == 1001 and np.array_equal(a[:1001].cpu().numpy(), pts[:1001])
+
+
+def _same_point_set(a, b, atol=3e-4):
+    """equal as multisets of rows (the stage ends with a shuffle; rows compared after a lexicographic sort)"""
+    if a.shape != b.shape:
+        return False
+    ka, kb = np.lexsort(np.round(a, 3).T[::-1]), np.lexsort(np.round(b, 3).T[::-1])
+    return bool(np.allclose(a[ka], b[kb], rtol=0, atol=atol))
+
+
+def test_preprocess_stage_with_the_cloud_on_the_device(dev, golden_dir):
+    """det3d.datasets.pipelines.Preprocess given a CUDA point tensor: GT-AUG removal of covered points, per-object
+    noise, the points_raw snapshot + global flip / rotation / scaling and the shuffle run on the device kernels with the host
+    stage's random draws -- same seed => the reference run's boxes, names, transformation and point sets (tests/golden/
+    datapath_ref.npz F*: the reference's Preprocess from source), and the host stage's on the same frames."""
+    import tempfile
+    from make_golden_datapath import SAMPLER_CFG, make_database, make_scene, train_cfg
+    from det3d.builder import build_dbsampler
+    from det3d.datasets.pipelines import Preprocess
+    G = np.load(os.path.join(golden_dir, "datapath_ref.npz"))
+    with tempfile.TemporaryDirectory() as tmp:
+        db = make_database(tmp)
+        out = {}
+        for mode in ("device", "host"):
+            cfg = train_cfg(); cfg["db_sampler"] = dict(SAMPLER_CFG)
+            np.random.seed(500)
+            stage = Preprocess(cfg=cfg, db_sampler=build_dbsampler(cfg["db_sampler"], db_infos=db))
+            frames = []
+            for k in range(2):
+                p, b, n = make_scene(30 + k)
+                pts = torch.from_numpy(p).to(dev) if mode == "device" else p
+                res, _ = stage(dict(labeled=True, metadata=dict(image_prefix=tmp, num_point_features=4),
+                                    lidar=dict(points=pts, annotations=dict(boxes=b, names=n))), None)
+                frames.append(res)
+            p, b, n = make_scene(40)
+            pts = torch.from_numpy(p).to(dev) if mode == "device" else p
+            res, _ = stage(dict(labeled=False, metadata=dict(image_prefix=tmp, num_point_features=4), lidar=dict(points=pts)), None)
+            frames.append(res)
+            out[mode] = frames
+    host = lambda t: t.cpu().numpy() if torch.is_tensor(t) else t
+    for k in range(2):
+        d, h = out["device"][k]["lidar"], out["host"][k]["lidar"]
+        assert d["points"].is_cuda and d["points_raw"].is_cuda
+        assert list(d["annotations"]["gt_names"]) == list(G["F%d_names" % k]) == list(h["annotations"]["gt_names"])
+        assert np.array_equal(d["annotations"]["gt_classes"], G["F%d_classes" % k])
+        t = d["transformation"]
+        assert np.allclose([float(t["flipped"]), t["noise_rotation"], t["noise_scale"]], G["F%d_t" % k], rtol=0, atol=1e-12)
+        assert np.allclose(d["annotations"]["gt_boxes"], G["F%d_boxes" % k], rtol=0, atol=2e-5)
+        assert np.allclose(d["annotations_raw"]["gt_boxes"], G["F%d_boxes_raw" % k], rtol=0, atol=2e-5)
+        assert np.array_equal(d["annotations"]["gt_boxes"], h["annotations"]["gt_boxes"])
+        assert _same_point_set(host(d["points_raw"]), G["F%d_points_raw" % k]) and _same_point_set(host(d["points"]), G["F%d_points" % k])
+        assert _same_point_set(host(d["points_raw"]), h["points_raw"], atol=1e-5) and host(d["points"]).shape == h["points"].shape
+        # same shuffle: row order identical to the host stage
+        assert np.allclose(host(d["points"]), h["points"], rtol=0, atol=3e-4)
+    d, h = out["device"][2]["lidar"], out["host"][2]["lidar"]
+    assert "annotations" not in d and _same_point_set(host(d["points"]), G["F_unlabeled_points"])
+    assert np.allclose(host(d["points"]), h["points"], rtol=0, atol=3e-4)
+    t = d["transformation"]
+    assert np.allclose([float(t["flipped"]), t["noise_rotation"], t["noise_scale"]], G["F_unlabeled_t"], rtol=0, atol=1e-12)
+    # the next stage takes the device cloud as it is: voxels of the student's and the teacher's view without a host copy
+    from det3d.datasets.pipelines import Voxelization
+    vcfg = dict(range=[0, -40.0, -3.0, 70.4, 40.0, 1.0], voxel_size=[0.05, 0.05, 0.1], max_points_in_voxel=5, max_voxel_num=20000)
+    rd, _ = Voxelization(cfg=vcfg)(out["device"][0], None)
+    rh, _ = Voxelization(cfg=vcfg)(out["host"][0], None)
+    for key in ("voxels", "voxels_raw"):
+        vd, vh = rd["lidar"][key], rh["lidar"][key]
+        assert torch.is_tensor(vd["voxels"]) and vd["voxels"].is_cuda
+        assert abs(int(vd["voxels"].shape[0]) - int(vh["voxels"].shape[0])) <= max(2, int(vh["voxels"].shape[0]) // 200)
+    # validation mode passes the device tensor through
+    val = Preprocess(cfg=dict(mode="val", shuffle_points=False, remove_environment=False, remove_unknown_examples=False))
+    res, _ = val(dict(labeled=False, lidar=dict(points=torch.from_numpy(p).to(dev))), None)
+    assert res["mode"] == "val" and res["lidar"]["points"].is_cuda and np.array_equal(res["lidar"]["points"].cpu().numpy(), p)
