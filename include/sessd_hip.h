@@ -206,6 +206,16 @@ int sessd_bn_relu_train_fwd(const float* x, const int32_t* n_dev, int n_cap, int
 int sessd_bn_relu_train_bwd(const float* dy, const float* x, const float* y, const int32_t* n_dev, int n_cap, int channels,
                             const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+/* The same for the dense BEV layout: torch.nn.BatchNorm2d (train mode) + optional ReLU on x (batch, channels, plane = H * W,
+ * plane % 4 == 0) -- det3d/models/necks/rpn_v1.py:131-210 in the training step (BatchNorm2d(eps 1e-3, momentum 0.01) + ReLU after
+ * each SSFA convolution). Statistics in float64 partial sums with a fixed reduction order. */
+size_t sessd_bn2d_relu_train_workspace_bytes(int channels);
+int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane, const float* gamma, const float* beta, float eps,
+                              float momentum, int relu, float* running_mean, float* running_var, float* y, float* save_mean,
+                              float* save_invstd, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
+                              const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                              float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 
 /* ---- training data path, point-level work -----------------------------------------------------------
  * replaces det3d/core/bbox/geometry.py:215-276 points_in_convex_polygon_3d_jit (numba) as used by
@@ -312,6 +322,17 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
 int sessd_conv3x3_winograd(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
                            const float* scale, const float* shift, int relu, const float* residual, int variant,
                            sessd_stream_t stream);
+/* Weight packing on the device, one launch each (ops.pack_conv2d / pack_deconv2d_s2 / pack_winograd*; the training step re-packs every
+ * dense conv weight for the teacher forward, the student forward and the student data gradient of every iteration).
+ * sessd_conv2d_pack_taps: out [cin/2][ntaps][2][cout_pad32], out[kp][t][h][o] = w[o * out_stride + (2 kp + h) * in_stride +
+ * tap_offsets[t]] (element strides / offsets, ntaps <= 16, tap_offsets a HOST array): a transposed, flipped or tap-selected view
+ * of the stored weight without an intermediate tensor. sessd_conv3x3_winograd_pack: U = G g G^T of the 3x3 filters of the same
+ * kind of view (flip != 0: the adjoint layer), written in the layout of sessd_conv3x3_winograd (layout 0) or of
+ * sessd_conv3x3_winograd_sk shape 0 / 1 (layout 1 / 2), padding included. */
+int sessd_conv2d_pack_taps(const float* w, long long out_stride, long long in_stride, const int* tap_offsets, int ntaps, int cout,
+                           int cin, float* out, sessd_stream_t stream);
+int sessd_conv3x3_winograd_pack(const float* w, long long out_stride, long long in_stride, int flip, int cout, int cin, int layout,
+                                float* out, sessd_stream_t stream);
 /* Second generation of the above (csrc/dense_wino_sk.hip): a workgroup handles 32 tiles x ALL couts of a unit (the patch
  * transform runs once per tile block instead of once per 32-cout block) and the rounds of all units are dealt out "stream-K" in
  * equal shares to `workgroups` persistent workgroups (a multiple of 8; 0 = the shape's default), units cut by a share boundary

@@ -706,6 +706,109 @@ int sessd_conv3x3_winograd(const float* in, int batch, int cin, int h, int w, co
   return SESSD_OK;
 }
 
+// ---- weight packing on the device (the training step re-packs every dense conv weight three times per iteration: teacher
+// forward, student forward, student data gradient; as torch permute / stack / einsum chains that was ~2 ms of small launches)
+}  // extern "C"
+namespace {
+struct PackArgs {
+  const float* w;
+  long long so, sc;     // element strides of the (virtual) output / input channel in w
+  int tap_off[16];      // element offset of tap t inside a (channel, channel) filter
+  int co, ci, nt, cp;
+};
+// out [ci/2][nt][2][cp]: out[((kp*nt + t)*2 + h)*cp + o] = w[o*so + (2kp+h)*sc + tap_off[t]], zero for o >= co
+__global__ __launch_bounds__(256) void pack_taps_kernel(PackArgs A, float* __restrict__ out) {
+  const size_t total = (size_t)(A.ci >> 1) * A.nt * 2 * A.cp;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int o = (int)(idx % A.cp);
+  size_t r = idx / A.cp;
+  const int h = (int)(r & 1); r >>= 1;
+  const int t = (int)(r % A.nt);
+  const int kp = (int)(r / A.nt);
+  out[idx] = o < A.co ? A.w[(long long)o * A.so + (long long)(2 * kp + h) * A.sc + A.tap_off[t]] : 0.f;
+}
+// U = G g G^T (float64 arithmetic, rounded once) of the 3x3 filter of (o, c), flipped when flip != 0, written in
+// layout 0: sessd_conv3x3_winograd      [ci/2][xi/4][h][cp32][xi%4]
+// layout 1: sessd_conv3x3_winograd_sk shape 0  [ceil(co/128)][ci/2][8][2][32][4][2]
+// layout 2: sessd_conv3x3_winograd_sk shape 1  [ceil(co/64)][ci/2][4][2][32][2][4]
+__global__ __launch_bounds__(256) void winograd_pack_kernel(PackArgs A, int flip, int layout, float* __restrict__ out) {
+  const int cpad = layout == 0 ? A.cp : (layout == 1 ? (A.co + 127) / 128 * 128 : (A.co + 63) / 64 * 64);
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (size_t)cpad * A.ci) return;
+  const int o = (int)(idx % cpad), c = (int)(idx / cpad);
+  double g[3][3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int t = flip ? 8 - (3 * a + b) : 3 * a + b;
+      g[a][b] = o < A.co ? (double)A.w[(long long)o * A.so + (long long)c * A.sc + t] : 0.0;
+    }
+  // rows of G: [1,0,0], [.5,.5,.5], [.5,-.5,.5], [0,0,1]
+  double t0[4][3];
+#pragma unroll
+  for (int b = 0; b < 3; ++b) {
+    t0[0][b] = g[0][b];
+    t0[1][b] = 0.5 * g[0][b] + 0.5 * g[1][b] + 0.5 * g[2][b];
+    t0[2][b] = 0.5 * g[0][b] - 0.5 * g[1][b] + 0.5 * g[2][b];
+    t0[3][b] = g[2][b];
+  }
+  const int kp = c >> 1, h = c & 1;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const double u[4] = {t0[a][0], 0.5 * t0[a][0] + 0.5 * t0[a][1] + 0.5 * t0[a][2], 0.5 * t0[a][0] - 0.5 * t0[a][1] + 0.5 * t0[a][2],
+                         t0[a][2]};
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int xi = a * 4 + b;
+      size_t dst;
+      if (layout == 0) {
+        dst = ((((size_t)kp * 4 + (xi >> 2)) * 2 + h) * cpad + o) * 4 + (xi & 3);
+      } else if (layout == 1) {
+        const int grp = o >> 7, cb = (o >> 5) & 3, j = o & 31, wave = xi >> 1, xl = xi & 1;
+        dst = ((((((size_t)grp * (A.ci >> 1) + kp) * 8 + wave) * 2 + h) * 32 + j) * 4 + cb) * 2 + xl;
+      } else {
+        const int grp = o >> 6, cb = (o >> 5) & 1, j = o & 31, wave = xi >> 2, xl = xi & 3;
+        dst = ((((((size_t)grp * (A.ci >> 1) + kp) * 4 + wave) * 2 + h) * 32 + j) * 2 + cb) * 4 + xl;
+      }
+      out[dst] = (float)u[b];
+    }
+  }
+}
+}  // namespace
+extern "C" {
+
+// Pack a conv weight for sessd_conv2d_mfma / sessd_deconv2d_s2_mfma: out [cin/2][ntaps][2][cout_pad32] with
+// out[kp][t][h][o] = w[o * out_stride + (2 kp + h) * in_stride + tap_offsets[t]] (element strides / offsets into w, so that a
+// transposed, flipped or tap-selected view of the stored weight needs no intermediate tensor). ntaps <= 16.
+int sessd_conv2d_pack_taps(const float* w, long long out_stride, long long in_stride, const int* tap_offsets, int ntaps, int cout,
+                           int cin, float* out, hipStream_t stream) {
+  if (ntaps < 1 || ntaps > 16 || cout < 1 || cin < 2 || (cin & 1)) return SESSD_EINVAL;
+  PackArgs A;
+  A.w = w; A.so = out_stride; A.sc = in_stride; A.co = cout; A.ci = cin; A.nt = ntaps; A.cp = sessd_divup(cout, 32) * 32;
+  for (int t = 0; t < 16; ++t) A.tap_off[t] = t < ntaps ? tap_offsets[t] : 0;
+  const size_t total = (size_t)(cin >> 1) * ntaps * 2 * A.cp;
+  SESSD_LAUNCH(pack_taps_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, A, out);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// U = G g G^T of a 3x3 weight viewed through (out_stride, in_stride, flip) as above, in the layout of sessd_conv3x3_winograd
+// (layout 0) or sessd_conv3x3_winograd_sk shape 0 / 1 (layout 1 / 2); `out` must hold the padded layout (all of it is written).
+int sessd_conv3x3_winograd_pack(const float* w, long long out_stride, long long in_stride, int flip, int cout, int cin, int layout,
+                                float* out, hipStream_t stream) {
+  if (cout < 1 || cin < 2 || (cin & 1) || layout < 0 || layout > 2) return SESSD_EINVAL;
+  PackArgs A;
+  A.w = w; A.so = out_stride; A.sc = in_stride; A.co = cout; A.ci = cin; A.nt = 9; A.cp = sessd_divup(cout, 32) * 32;
+  for (int t = 0; t < 16; ++t) A.tap_off[t] = 0;
+  const int cpad = layout == 0 ? A.cp : (layout == 1 ? sessd_divup(cout, 128) * 128 : sessd_divup(cout, 64) * 64);
+  const size_t total = (size_t)cpad * cin;
+  SESSD_LAUNCH(winograd_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, A, flip, layout, out);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
 // ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
 // classes. wpk4[c], ntaps4[c], taps_dy4/taps_dx4 (4 x 4 ints, row c = class c) in class order (py,px) =
 // (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps; input (B,cin,hin,win) -> output (B,cout,2*hin,2*win).

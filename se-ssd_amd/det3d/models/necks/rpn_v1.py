@@ -93,6 +93,7 @@ class SSFA(nn.Module):
         self.w_1 = Sequential(nn.Conv2d(128, 1, 1, bias=False), bn(1))
         (logger or logging.getLogger("RPN")).info("Finish RPN Initialization")
         self._low = _Lowered()
+        self.fused_bn_train = True   # train mode: BatchNorm2d + ReLU on sessd_bn2d_relu_train_* (False: the torch modules)
 
     def init_weights(self):
         for m in self.modules():
@@ -101,13 +102,23 @@ class SSFA(nn.Module):
 
     def _forward_train(self, x):
         """Train mode (batch-statistics BatchNorm, autograd), composed as rpn_v1.py:220-235. The twelve conv layers that
-        carry the FLOPs run forward AND backward on the HIP kernels (ops.Conv2dFunction); BatchNorm, ReLU, the two
-        128->1 weight branches and the softmax fusion are torch ops."""
+        carry the FLOPs run forward AND backward on the HIP kernels (ops.Conv2dFunction), and so do the BatchNorm2d + ReLU that
+        follow them (ops.bn2d_relu_train); the two 128->1 weight branches and the softmax fusion are torch ops."""
         def block(seq, inp):
-            for m in seq._modules.values():
-                if isinstance(m, nn.ZeroPad2d):
-                    continue  # ZeroPad2d(1) + unpadded 3x3 == the padding-1 conv the kernels implement
-                inp = ops.conv2d_module(inp, m) if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)) else m(inp)
+            mods = [m for m in seq._modules.values() if not isinstance(m, nn.ZeroPad2d)]  # ZeroPad2d(1) + unpadded 3x3 == the
+            i = 0                                                                          # padding-1 conv the kernels implement
+            while i < len(mods):
+                m = mods[i]
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                    inp = ops.conv2d_module(inp, m)
+                    i += 1
+                elif isinstance(m, nn.BatchNorm2d) and type(m) is nn.BatchNorm2d and m.training and self.fused_bn_train:
+                    relu = i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)
+                    inp = ops.bn2d_relu_train(inp, m, relu)     # batch statistics + normalise + ReLU: three launches
+                    i += 2 if relu else 1
+                else:
+                    inp = m(inp)
+                    i += 1
             return inp
 
         x_0 = block(self.bottom_up_block_0, x)

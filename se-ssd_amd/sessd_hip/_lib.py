@@ -49,6 +49,8 @@ SIGNATURES = {
     "sessd_conv2d_mfma": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32,
                                 vp, vp, i32, vp, i32, vp]),
     "sessd_conv3x3_winograd": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
+    "sessd_conv2d_pack_taps": (i32, [vp, i64, i64, vp, i32, i32, i32, vp, vp]),
+    "sessd_conv3x3_winograd_pack": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, vp]),
     "sessd_conv3x3_winograd_sk_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "sessd_conv3x3_winograd_sk": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, sz, i32, i32, vp]),
     "sessd_deconv2d_s2_mfma": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
@@ -85,6 +87,9 @@ SIGNATURES = {
     "sessd_bn_relu_train_workspace_bytes": (sz, [i32]),
     "sessd_bn_relu_train_fwd": (i32, [vp, vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_bn_relu_train_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "sessd_bn2d_relu_train_workspace_bytes": (sz, [i32]),
+    "sessd_bn2d_relu_train_fwd": (i32, [vp, i32, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "sessd_bn2d_relu_train_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
     "sessd_sparse_rulebook_transpose": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
     "sessd_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
     "sessd_sparse_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, vp, sz, vp]),

@@ -460,9 +460,8 @@ def sparse_renumber_sites(indices, n_dev, feat, site_hash, batch):
 
 
 class BnReluTrainFunction(torch.autograd.Function):
-    """EXPERIMENTAL (not yet validated on hardware): train-mode BatchNorm1d + optional ReLU over the first *n_dev rows of a
-    sparse feature table, statistics and both passes on the HIP kernels of csrc/bn_train.hip; running statistics are updated
-    in place like torch.nn.BatchNorm1d does."""
+    """Train-mode BatchNorm1d + optional ReLU over the first *n_dev rows of a sparse feature table, statistics and both passes on
+    the HIP kernels of csrc/bn_train.hip; running statistics are updated in place like torch.nn.BatchNorm1d does."""
 
     @staticmethod
     def forward(ctx, x, n_dev, gamma, beta, running_mean, running_var, eps, momentum, relu):
@@ -504,6 +503,55 @@ def bn_relu_train(x, n_dev, bn, relu=True):
     if mom is None:  # BatchNorm(momentum=None): cumulative moving average, factor 1 / number of batches seen (torch semantics)
         mom = 1.0 / float(bn.num_batches_tracked.item()) if bn.num_batches_tracked is not None else 0.0
     return BnReluTrainFunction.apply(x, n_dev, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
+
+
+class Bn2dReluTrainFunction(torch.autograd.Function):
+    """Train-mode BatchNorm2d + optional ReLU on a dense (B, C, H, W) map (H * W % 4 == 0), both passes on csrc/bn_train.hip."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = x.float().contiguous()
+        _req(x, torch.float32, "x")
+        B, C, H, W = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        ws = workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), dev, "bn2d")
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        check(lib.sessd_bn2d_relu_train_fwd(x.data_ptr(), B, C, H * W, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
+                                            1 if relu else 0, _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(),
+                                            invstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_fwd")
+        ctx.save_for_backward(x, y, g, mean, invstd)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, g, mean, invstd = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        B, C, H, W = x.shape
+        dx = torch.empty_like(x)
+        dg, db = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
+        ws = workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), x.device, "bn2d")
+        check(lib.sessd_bn2d_relu_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), B, C, H * W, g.data_ptr(), mean.data_ptr(),
+                                            invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                            ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_bwd")
+        return dx, dg, db, None, None, None, None, None
+
+
+def bn2d_relu_train(x, bn, relu=True):
+    """x (B, C, H, W) float32 on the device; bn: a torch.nn.BatchNorm2d in train mode with affine parameters (running statistics
+    updated in place, num_batches_tracked incremented). Falls back to the torch module where the kernel's layout assumption
+    (H * W divisible by 4) does not hold."""
+    if (x.shape[2] * x.shape[3]) % 4 or bn.weight is None:
+        y = bn(x)
+        return torch.relu(y) if relu else y
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    mom = bn.momentum
+    if mom is None:
+        mom = 1.0 / float(bn.num_batches_tracked.item()) if bn.num_batches_tracked is not None else 0.0
+    return Bn2dReluTrainFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
 
 
 def points_in_bodies(points, planes):
@@ -672,7 +720,7 @@ class PackedConv:
     def __init__(self, launches, cin, cout, kind, stride):
         self.launches = launches  # list of dict(wpk, dy, dx, in_mul, out_mul, py, px, ntaps)
         self.cin, self.cout, self.kind, self.stride = cin, cout, kind, stride
-        self._w3 = None      # the 3x3 stride-1 weight the Winograd packings are made from, on demand
+        self._w3 = None      # (weight, adjoint): the 3x3 stride-1 weight the Winograd packings are made from, on demand
         self._upk = None
         self._upk_sk = [None, None]
 
@@ -680,45 +728,77 @@ class PackedConv:
     def upk(self):
         """U = G g G^T packed for sessd_conv3x3_winograd (tile_cfg 20 / 21); None if the layer is not eligible."""
         if self._upk is None and self._w3 is not None and self.cin % 8 == 0:
-            self._upk = pack_winograd(self._w3)
+            self._upk = pack_winograd(self._w3[0], adjoint=self._w3[1])
         return self._upk
 
     def upk_sk(self, shape):
         """U packed for sessd_conv3x3_winograd_sk (tile_cfg 22 / 23 = shape 0 / 1); None if not eligible."""
         if self._upk_sk[shape] is None and self._w3 is not None and self.cin % (16, 8)[shape] == 0:
-            self._upk_sk[shape] = pack_winograd_sk(self._w3, shape)
+            self._upk_sk[shape] = pack_winograd_sk(self._w3[0], shape, adjoint=self._w3[1])
         return self._upk_sk[shape]
 
 
-def _pack_taps(w_co_ci_t, cout):
-    """w (cout, cin, ntaps) -> [cin/2][ntaps][2][cout_pad] contiguous on the same device."""
-    co, ci, nt = w_co_ci_t.shape
-    cp = (co + 31) // 32 * 32
-    w = torch.zeros((ci // 2, nt, 2, cp), dtype=torch.float32, device=w_co_ci_t.device)
-    w[:, :, :, :co] = w_co_ci_t.permute(1, 2, 0).reshape(ci // 2, 2, nt, co).permute(0, 2, 1, 3)
-    return w.contiguous()
+def _pack_taps_view(w, out_stride, in_stride, tap_offsets, cout, cin):
+    """One launch (sessd_conv2d_pack_taps): [cin/2][ntaps][2][cout_pad32] with out[kp][t][h][o] = w.flat[o * out_stride +
+    (2 kp + h) * in_stride + tap_offsets[t]] -- a transposed / flipped / tap-selected view of the stored weight, no intermediate."""
+    import ctypes
+    _req(w, torch.float32, "weight")
+    nt = len(tap_offsets)
+    cp = (cout + 31) // 32 * 32
+    out = torch.empty((cin // 2, nt, 2, cp), dtype=torch.float32, device=w.device)
+    check(lib.sessd_conv2d_pack_taps(w.data_ptr(), int(out_stride), int(in_stride), (ctypes.c_int * nt)(*[int(t) for t in tap_offsets]),
+                                     nt, cout, cin, out.data_ptr(), _stream()), "conv2d_pack_taps")
+    return out
 
 
-def pack_conv2d(weight, stride=1, padding=None):
-    """nn.Conv2d weight (Cout,Cin,k,k), k in {1,3}; padding k//2 (the only form SSFA / Head use)."""
-    w = weight.detach().to(torch.float32)
+def _conv_view(w, adjoint):
+    """(cout, cin, out_stride, in_stride, flip) of a Conv2d weight (Cout, Cin, k, k) used as it is, or as the stride-1 ADJOINT layer
+    (correlation with the flipped kernel, channels swapped: the data-gradient pass)."""
     co, ci, kh, kw = w.shape
-    assert kh == kw and kh in (1, 3) and ci % 2 == 0
+    kk = kh * kw
+    return (ci, co, kk, ci * kk, True) if adjoint else (co, ci, ci * kk, kk, False)
+
+
+def pack_conv2d(weight, stride=1, padding=None, adjoint=False):
+    """nn.Conv2d weight (Cout,Cin,k,k), k in {1,3}; padding k//2 (the only form SSFA / Head use). adjoint (stride 1 only): pack the
+    layer whose forward is this layer's data gradient -- flipped taps, channels swapped -- straight from the same weight tensor."""
+    w = weight.detach().to(torch.float32).contiguous()
+    kh, kw = w.shape[2], w.shape[3]
+    assert kh == kw and kh in (1, 3) and not (adjoint and stride != 1)
+    co, ci, so, sc, flip = _conv_view(w, adjoint)
+    assert ci % 2 == 0
     pad = kh // 2 if padding is None else padding
     assert pad == kh // 2
+    kk = kh * kw
     dy = [ky - pad for ky in range(kh) for kx in range(kw)]
     dx = [kx - pad for ky in range(kh) for kx in range(kw)]
-    wpk = _pack_taps(w.reshape(co, ci, kh * kw), co)
+    wpk = _pack_taps_view(w, so, sc, [(kk - 1 - t) if flip else t for t in range(kk)], co, ci)
     la = dict(wpk=wpk, dy=torch.tensor(dy, dtype=torch.int32), dx=torch.tensor(dx, dtype=torch.int32), in_mul=stride,
               out_mul=1, py=0, px=0, ntaps=kh * kw)
     pc = PackedConv([la], ci, co, "conv", stride)
     if kh == 3 and stride == 1:
-        pc._w3 = w  # Winograd packings (tile_cfg 20-23) are made when first asked for
+        pc._w3 = (w, bool(adjoint))  # Winograd packings (tile_cfg 20-23) are made when first asked for
     return pc
 
 
+def _winograd_pack(weight, layout, adjoint):
+    w = weight.detach().to(torch.float32).contiguous()
+    _req(w, torch.float32, "weight")
+    assert w.shape[2] == 3 and w.shape[3] == 3
+    co, ci, so, sc, flip = _conv_view(w, adjoint)
+    if layout == 0:
+        out = torch.empty((ci // 2, 4, 2, (co + 31) // 32 * 32, 4), dtype=torch.float32, device=w.device)
+    else:
+        nw, c = ((8, 128), (4, 64))[layout - 1]
+        out = torch.empty(((co + c - 1) // c, ci // 2, nw, 2, 32, c // 32, 16 // nw), dtype=torch.float32, device=w.device)
+    check(lib.sessd_conv3x3_winograd_pack(w.data_ptr(), so, sc, 1 if flip else 0, co, ci, layout, out.data_ptr(), _stream()),
+          "conv3x3_winograd_pack")
+    return out
+
+
 def winograd_u(weight):
-    """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) -> (Cout, Cin, 16) float32, xi = 4 * row + col."""
+    """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) -> (Cout, Cin, 16) float32, xi = 4 * row + col (host-side reference of the
+    device packer, used by the tests)."""
     w = weight.detach().to(torch.float64)
     co, ci, kh, kw = w.shape
     assert kh == 3 and kw == 3
@@ -726,19 +806,11 @@ def winograd_u(weight):
     return torch.einsum("ia,ocab,jb->ocij", G, w, G).to(torch.float32).reshape(co, ci, 16)
 
 
-def pack_winograd_sk(weight, shape=0):
+def pack_winograd_sk(weight, shape=0, adjoint=False):
     """U for sessd_conv3x3_winograd_sk: [ceil(Cout/C)][Cin/2][wave NW][channel parity 2][cout%32][(cout/32)%(C/32)][xi%(16/NW)]
     with xi = (16/NW) * wave + xi%(16/NW) and (NW, C) = (8, 128) for shape 0, (4, 64) for shape 1 -- the 8 A operands of a lane
-    and k-step are 32 contiguous bytes."""
-    nw, c = ((8, 128), (4, 64))[shape]
-    xw, cbn = 16 // nw, c // 32
-    U = winograd_u(weight)
-    co, ci, _ = U.shape
-    ng = (co + c - 1) // c
-    Up = torch.zeros((ng * c, ci, 16), dtype=torch.float32, device=U.device)
-    Up[:co] = U
-    # (group, cb, j, ks, h, wave, xl) -> (group, ks, wave, h, j, cb, xl)
-    return Up.view(ng, cbn, 32, ci // 2, 2, nw, xw).permute(0, 3, 5, 4, 2, 1, 6).contiguous()
+    and k-step are 32 contiguous bytes. One launch (sessd_conv3x3_winograd_pack)."""
+    return _winograd_pack(weight, 1 + shape, adjoint)
 
 
 _SK_WS = {}
@@ -753,17 +825,10 @@ def winograd_sk_workspace(batch, h, w, cout, device, workgroups=0, shape=0):
     return torch.zeros(n, dtype=torch.uint8, device=device)
 
 
-def pack_winograd(weight):
+def pack_winograd(weight, adjoint=False):
     """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) for sessd_conv3x3_winograd, packed
-    [Cin/2][xi/4][channel parity][Cout_pad][xi%4]."""
-    w = weight.detach().to(torch.float64)
-    co, ci, kh, kw = w.shape
-    assert kh == 3 and kw == 3
-    G = torch.tensor([[1, 0, 0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0, 0, 1]], dtype=torch.float64, device=w.device)
-    U = torch.einsum("ia,ocab,jb->ocij", G, w, G).to(torch.float32)
-    p = _pack_taps(U.reshape(co, ci, 16).contiguous(), co)  # [Cin/2][16][2][Cout_pad]
-    cp = p.shape[3]
-    return p.view(ci // 2, 4, 4, 2, cp).permute(0, 1, 3, 4, 2).contiguous()
+    [Cin/2][xi/4][channel parity][Cout_pad][xi%4]. One launch (sessd_conv3x3_winograd_pack)."""
+    return _winograd_pack(weight, 0, adjoint)
 
 
 def pack_deconv2d_s2(weight):
@@ -775,11 +840,12 @@ def pack_deconv2d_s2(weight):
     assert kh == 3 and kw == 3 and ci % 2 == 0
     sel = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}
     launches = []
+    w = w.contiguous()
     for py in (0, 1):
         for px in (0, 1):
             taps = [(ky, ey, kx, ex) for (ky, ey) in sel[py] for (kx, ex) in sel[px]]
-            wt = torch.stack([w[:, :, ky, kx] for (ky, ey, kx, ex) in taps], -1)  # (ci, co, nt)
-            wpk = _pack_taps(wt.permute(1, 0, 2).contiguous(), co)
+            # (ci, co, 3, 3) weight: output channel o has element stride 9, input channel c stride co * 9, tap (ky, kx) offset 3 ky + kx
+            wpk = _pack_taps_view(w, 9, co * 9, [3 * ky + kx for (ky, ey, kx, ex) in taps], co, ci)
             launches.append(dict(wpk=wpk, dy=torch.tensor([t[1] for t in taps], dtype=torch.int32),
                                  dx=torch.tensor([t[3] for t in taps], dtype=torch.int32), in_mul=1, out_mul=2, py=py,
                                  px=px, ntaps=len(taps)))
@@ -960,8 +1026,7 @@ class Conv2dFunction(torch.autograd.Function):
             elif stride == 2:   # adjoint of the stride-2 conv = the transposed conv with the same weight tensor
                 gx = conv2d(g, pack_deconv2d_s2(w), None, None, False)
             else:               # stride 1: correlation with the flipped kernel, channels swapped
-                wd = (w.flip(2, 3) if k == 3 else w).transpose(0, 1).contiguous()
-                pcd = pack_conv2d(wd, 1)
+                pcd = pack_conv2d(w, 1, adjoint=True)
                 gx = conv2d(g, pcd, None, None, False, tile_cfg=_train_cfg(pcd, g))
         if ctx.needs_input_grad[1]:
             gw = conv2d_wgrad(g, x, 3, 2) if transposed else conv2d_wgrad(x, g, k, stride)

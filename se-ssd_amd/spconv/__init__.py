@@ -183,9 +183,9 @@ class SparseSequential(SparseModule):
     def add(self, module, name=None):
         self.add_module(str(len(self._modules)) if name is None else name, module)
 
-    # EXPERIMENTAL (not yet validated on hardware, off): in train mode run BatchNorm1d + the ReLU that follows it as the two
-    # fused HIP passes of csrc/bn_train.hip instead of the torch modules. Set `spconv.SparseSequential.FUSED_BN_TRAIN = True`.
-    FUSED_BN_TRAIN = False
+    # Train mode: BatchNorm1d + the ReLU that follows it run as the fused HIP passes of csrc/bn_train.hip (statistics, normalise +
+    # ReLU; backward likewise) instead of the torch modules (tests/test_bn_train_gpu.py). False restores the torch modules.
+    FUSED_BN_TRAIN = True
 
     def forward(self, input):
         mods = list(self._modules.values())

@@ -82,3 +82,73 @@ def test_sparse_sequential_with_the_fused_pair(dev):
         spconv.SparseSequential.FUSED_BN_TRAIN = False
     for a, b in zip(*results):
         assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(a.abs().max()))), (a - b).abs().max()
+
+
+@pytest.mark.parametrize("B,C,H,W", [(4, 128, 200, 176), (1, 256, 100, 88), (2, 1, 16, 12), (3, 24, 6, 10)])
+@pytest.mark.parametrize("relu", [True, False])
+def test_dense_layout_matches_torch_batchnorm2d(dev, B, C, H, W, relu):
+    """sessd_bn2d_relu_train_fwd / _bwd vs torch.nn.BatchNorm2d(eps=1e-3, momentum=0.01) (+ ReLU) in train mode: output, running
+    statistics, input / weight / bias gradients; bit-identical on a second run (fixed reduction order)."""
+    g = torch.Generator().manual_seed(B * 7 + C)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.3 + torch.randn(1, C, 1, 1, generator=g)).to(dev)
+    up = torch.randn(B, C, H, W, generator=g).to(dev)
+    ref = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    ref.weight.data.copy_(torch.rand(C, generator=g) + 0.5); ref.bias.data.copy_(torch.randn(C, generator=g) * 0.2)
+    ref.running_mean.data.copy_(torch.randn(C, generator=g) * 0.1); ref.running_var.data.copy_(torch.rand(C, generator=g) + 0.5)
+    mine = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    mine.load_state_dict(ref.state_dict())
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    yr = torch.relu(yr) if relu else yr
+    (yr * up).sum().backward()
+    xm = x.clone().requires_grad_(True)
+    ym = ops.bn2d_relu_train(xm, mine, relu)
+    (ym * up).sum().backward()
+    torch.cuda.synchronize()
+    assert torch.allclose(ym, yr, rtol=0, atol=2e-5 * max(1.0, float(yr.abs().max())))
+    assert torch.allclose(mine.running_mean, ref.running_mean, rtol=0, atol=1e-6)
+    assert torch.allclose(mine.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+    assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == 1
+    assert torch.allclose(xm.grad, xr.grad, rtol=0, atol=5e-5 * max(1.0, float(xr.grad.abs().max())))
+    assert torch.allclose(mine.weight.grad, ref.weight.grad, rtol=2e-4, atol=2e-2 if B * H * W > 10000 else 1e-3)
+    assert torch.allclose(mine.bias.grad, ref.bias.grad, rtol=2e-4, atol=2e-2 if B * H * W > 10000 else 1e-3)
+    mine2 = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    mine2.load_state_dict({k: v for k, v in ref.state_dict().items()})
+    mine2.weight.data.copy_(mine.weight.data); mine2.bias.data.copy_(mine.bias.data)
+    assert torch.equal(ops.bn2d_relu_train(x, mine2, relu), ym.detach())
+    # a plane that is not a multiple of four goes through the torch module
+    odd = torch.randn(2, C, 3, 5, generator=g).to(dev)
+    bn = torch.nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).to(dev).train()
+    want = torch.relu(torch.nn.functional.batch_norm(odd, None, None, bn.weight, bn.bias, True, 0.01, 1e-3))
+    assert torch.allclose(ops.bn2d_relu_train(odd, bn, True), want, atol=1e-5)
+
+
+def test_ssfa_train_mode_fused_vs_torch_modules(dev):
+    """SSFA in train mode with the fused BatchNorm2d + ReLU passes vs the torch modules: same output, same parameter gradients,
+    same running statistics (the convolutions are the HIP kernels in both)."""
+    import copy
+    from det3d.models.necks.rpn_v1 import SSFA
+    torch.manual_seed(3)
+    a = SSFA([5], [1], [128], [1], [128], 128).to(dev).train()
+    b = copy.deepcopy(a)
+    a.fused_bn_train, b.fused_bn_train = True, False
+    x = torch.randn(2, 128, 40, 48, device=dev)
+    outs = []
+    for m in (a, b):
+        y = m(x)
+        y = y[0] if isinstance(y, (tuple, list)) else y
+        (y * torch.linspace(0.5, 1.5, y.numel(), device=dev).view_as(y)).sum().backward()
+        outs.append(y.detach())
+    assert torch.allclose(outs[0], outs[1], rtol=0, atol=2e-4 * max(1.0, float(outs[1].abs().max())))
+    checked = 0
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert na == nb and pa.grad is not None and pb.grad is not None
+        # 13 BatchNorm layers deep, and a ReLU whose input differs in the last bit near zero switches a whole gradient path: single
+        # entries may move by a few percent, so the two gradients are compared in norm
+        err, ref = float((pa.grad - pb.grad).norm()), float(pb.grad.norm())
+        assert torch.isfinite(pa.grad).all() and err <= 1e-2 * max(1e-3, ref), (na, err, ref)
+        checked += 1
+    for (na, ba), (nb, bb) in zip(a.named_buffers(), b.named_buffers()):
+        if "running" in na:
+            assert torch.allclose(ba, bb, rtol=1e-4, atol=1e-5), na
+    assert checked > 30

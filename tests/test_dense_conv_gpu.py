@@ -178,3 +178,55 @@ def test_full_size_layer_bench(dev):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 20
         print("conv3x3 128->128 @200x176 cfg %d: %.3f ms  %.1f TFLOP/s" % (cfg, ms, 10.38e9 / ms / 1e9))
+
+
+def _taps_ref(w_co_ci_t):
+    """[cin/2][ntaps][2][cout_pad32] from (cout, cin, ntaps), as plain torch indexing"""
+    co, ci, nt = w_co_ci_t.shape
+    cp = (co + 31) // 32 * 32
+    out = torch.zeros((ci // 2, nt, 2, cp), dtype=torch.float32, device=w_co_ci_t.device)
+    out[:, :, :, :co] = w_co_ci_t.permute(1, 2, 0).reshape(ci // 2, 2, nt, co).permute(0, 2, 1, 3)
+    return out
+
+
+@pytest.mark.parametrize("co,ci", [(40, 16), (128, 128), (22, 32), (200, 64)])
+def test_device_weight_packers_equal_the_torch_restatement(dev, co, ci):
+    """sessd_conv2d_pack_taps / sessd_conv3x3_winograd_pack (one launch per packing) vs the torch permute / stack / einsum chains they
+    replace: direct layout, the adjoint (data-gradient) layer, the four tap classes of the transposed conv, the three Winograd layouts."""
+    g = torch.Generator().manual_seed(co + ci)
+    w = torch.randn(co, ci, 3, 3, generator=g).to(dev)
+    pc = ops.pack_conv2d(w, 1)
+    assert torch.equal(pc.launches[0]["wpk"], _taps_ref(w.reshape(co, ci, 9)))
+    if co % 2 == 0:
+        wd = w.flip(2, 3).transpose(0, 1).contiguous()          # (ci, co, 3, 3): the adjoint layer's weight
+        pa = ops.pack_conv2d(w, 1, adjoint=True)
+        assert (pa.cin, pa.cout) == (co, ci) and torch.equal(pa.launches[0]["wpk"], _taps_ref(wd.reshape(ci, co, 9)))
+    w1 = torch.randn(co, ci, 1, 1, generator=g).to(dev)
+    assert torch.equal(ops.pack_conv2d(w1).launches[0]["wpk"], _taps_ref(w1.reshape(co, ci, 1)))
+    # transposed conv: weight (Cin, Cout, 3, 3)
+    wt = torch.randn(ci, co, 3, 3, generator=g).to(dev)
+    pd = ops.pack_deconv2d_s2(wt)
+    sel = {0: [(1, 0)], 1: [(0, 1), (2, 0)]}
+    k = 0
+    for py in (0, 1):
+        for px in (0, 1):
+            taps = [(ky, kx) for (ky, _) in sel[py] for (kx, _) in sel[px]]
+            ref = _taps_ref(torch.stack([wt[:, :, ky, kx] for ky, kx in taps], -1).permute(1, 0, 2).contiguous())
+            assert torch.equal(pd.launches[k]["wpk"], ref), (py, px)
+            k += 1
+    # Winograd: U = G g G^T (float64, rounded once) in the three layouts
+    for adjoint in ((False, True) if co % 2 == 0 else (False,)):
+        wv = w.flip(2, 3).transpose(0, 1).contiguous() if adjoint else w
+        o, c = wv.shape[0], wv.shape[1]
+        U = ops.winograd_u(wv)                                  # (o, c, 16)
+        ref0 = _taps_ref(U.contiguous())
+        ref0 = ref0.view(c // 2, 4, 4, 2, ref0.shape[3]).permute(0, 1, 3, 4, 2).contiguous()
+        got0 = ops.pack_winograd(w, adjoint=adjoint)
+        assert got0.shape == ref0.shape and float((got0 - ref0).abs().max()) <= 1.2e-7 * float(U.abs().max())
+        for shape, (nw, cc) in enumerate(((8, 128), (4, 64))):
+            ng = (o + cc - 1) // cc
+            Up = torch.zeros((ng * cc, c, 16), dtype=torch.float32, device=dev)
+            Up[:o] = U
+            ref = Up.view(ng, cc // 32, 32, c // 2, 2, nw, 16 // nw).permute(0, 3, 5, 4, 2, 1, 6).contiguous()
+            got = ops.pack_winograd_sk(w, shape, adjoint=adjoint)
+            assert got.shape == ref.shape and float((got - ref).abs().max()) <= 1.2e-7 * float(U.abs().max())
