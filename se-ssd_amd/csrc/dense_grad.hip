@@ -66,37 +66,54 @@ __global__ __launch_bounds__(64) void conv_wgrad_partial_kernel(WgArgs A) {
       const int yin = y * S + ky - P;
       xrow[ky] = (ci_ok && yin >= 0 && yin < A.hi) ? (unsigned)((((size_t)b * A.ci + ci) * A.hi + yin) * A.wi * 4) : SESSD_OOB;
     }
-    for (int x0 = 0; x0 < A.wo; x0 += 8) {
-      const int xa = x0 + 4 * h;  // first of this lane's 4 output pixels
-      const f32x4 a = ld4(gr, grow == SESSD_OOB ? SESSD_OOB : grow + (unsigned)xa * 4u);
-      f32x4 bt[NT];
-#pragma unroll
-      for (int ky = 0; ky < KS; ++ky) {
-        const unsigned row = xrow[ky];
-        if (KS == 1) {
-          bt[0] = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xa * 4u);
-        } else if (S == 1) {
-          const f32x4 c = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xa * 4u);
-          const float l = ld1(xr, (row == SESSD_OOB || xa == 0) ? SESSD_OOB : row + (unsigned)(xa - 1) * 4u);
-          const float rr = ld1(xr, (row == SESSD_OOB || xa + 4 >= A.wi) ? SESSD_OOB : row + (unsigned)(xa + 4) * 4u);
-          bt[ky * 3 + 0] = (f32x4){l, c.x, c.y, c.z};
-          bt[ky * 3 + 1] = c;
-          bt[ky * 3 + 2] = (f32x4){c.y, c.z, c.w, rr};
-        } else {
-          const int xi = 2 * xa;  // input column of output pixel xa at kx = 1
-          const f32x4 v0 = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xi * 4u);
-          const f32x4 v1 = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)(xi + 4) * 4u);
-          const float l = ld1(xr, (row == SESSD_OOB || xi == 0) ? SESSD_OOB : row + (unsigned)(xi - 1) * 4u);
-          bt[ky * 3 + 0] = (f32x4){l, v0.y, v0.w, v1.y};
-          bt[ky * 3 + 1] = (f32x4){v0.x, v0.z, v1.x, v1.z};
-          bt[ky * 3 + 2] = (f32x4){v0.y, v0.w, v1.y, v1.w};
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c], bt[t][c], acc[t], 0, 0, 0);
+    // operands of the NEXT 8-pixel step are fetched before the 4 x NT MFMAs of the current one (two register sets, the loop is
+    // unrolled by two so that the set index is static; a step past the end of the row loads out-of-range offsets = zeros)
+#define SESSD_WG_LOAD(SET, X0)                                                                                      \
+  {                                                                                                                 \
+    const int xa = (X0) + 4 * h;                                                                                    \
+    const bool in = (X0) < A.wo;                                                                                    \
+    a[SET] = ld4(gr, (grow == SESSD_OOB || !in) ? SESSD_OOB : grow + (unsigned)xa * 4u);                            \
+    _Pragma("unroll") for (int ky = 0; ky < KS; ++ky) {                                                             \
+      const unsigned row = in ? xrow[ky] : SESSD_OOB;                                                               \
+      if (KS == 1) {                                                                                                \
+        bt[SET][0] = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xa * 4u);                               \
+      } else if (S == 1) {                                                                                          \
+        const f32x4 c = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xa * 4u);                            \
+        const float l = ld1(xr, (row == SESSD_OOB || xa == 0) ? SESSD_OOB : row + (unsigned)(xa - 1) * 4u);         \
+        const float rr = ld1(xr, (row == SESSD_OOB || xa + 4 >= A.wi) ? SESSD_OOB : row + (unsigned)(xa + 4) * 4u); \
+        bt[SET][ky * 3 + 0] = (f32x4){l, c.x, c.y, c.z};                                                            \
+        bt[SET][ky * 3 + 1] = c;                                                                                    \
+        bt[SET][ky * 3 + 2] = (f32x4){c.y, c.z, c.w, rr};                                                           \
+      } else {                                                                                                      \
+        const int xi = 2 * xa; /* input column of output pixel xa at kx = 1 */                                      \
+        const f32x4 v0 = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)xi * 4u);                           \
+        const f32x4 v1 = ld4(xr, row == SESSD_OOB ? SESSD_OOB : row + (unsigned)(xi + 4) * 4u);                     \
+        const float l = ld1(xr, (row == SESSD_OOB || xi == 0) ? SESSD_OOB : row + (unsigned)(xi - 1) * 4u);         \
+        bt[SET][ky * 3 + 0] = (f32x4){l, v0.y, v0.w, v1.y};                                                         \
+        bt[SET][ky * 3 + 1] = (f32x4){v0.x, v0.z, v1.x, v1.z};                                                      \
+        bt[SET][ky * 3 + 2] = (f32x4){v0.y, v0.w, v1.y, v1.w};                                                      \
+      }                                                                                                             \
+    }                                                                                                               \
+  }
+#define SESSD_WG_MMA(SET)                                                                                           \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                                     \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                  \
+      acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SET][c], bt[SET][t][c], acc[t], 0, 0, 0);
+    f32x4 a[2];
+    f32x4 bt[2][NT];
+    SESSD_WG_LOAD(0, 0)
+    for (int x0 = 0; x0 < A.wo; x0 += 16) {
+      SESSD_WG_LOAD(1, x0 + 8)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_WG_MMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_WG_LOAD(0, x0 + 16)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_WG_MMA(1)
+      __builtin_amdgcn_sched_barrier(0);
     }
+#undef SESSD_WG_LOAD
+#undef SESSD_WG_MMA
   }
   // D layout: column (ci) = lane & 31, row (co) = (e & 3) + 8 * (e >> 2) + 4 * h
   float* dst = A.partial + (size_t)blockIdx.y * A.co * A.ci * NT;
