@@ -6,6 +6,11 @@ module raises at import time, and every op raises on a non-zero return code.
 import ctypes as C
 import os
 
+# torch first, always: torch ships its own libamdhip64.so.7 and this library is linked against the system one of the same SONAME --
+# whichever is loaded first serves both. Loading ours first (a test module that imports sessd_hip before torch) put the process on
+# the system runtime under torch's other bundled ROCm libraries, and the first kernel launch failed with hipErrorNoDevice.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libsessd_hip.so")
 
