@@ -64,6 +64,7 @@ def parse():
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     ap.add_argument("--no-offset-split", action="store_true", help="autotune without the offset-split sparse conv variants")
     ap.add_argument("--no-streamk", action="store_true", help="autotune without the stream-K Winograd variants")
+    ap.add_argument("--wino-cfg", type=int, default=0, help="force this tile_cfg (20-23) on the seven 3x3 stride-1 SSFA layers after autotune")
     return ap.parse_args()
 
 
@@ -118,6 +119,9 @@ def main():
         eng.allow_streamk = not args.no_streamk
         rep = eng.autotune()
         log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
+    if args.wino_cfg:
+        for nm in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):
+            eng.tile_cfg[nm] = args.wino_cfg
     if args.sk_workgroups < 0:
         args.sk_workgroups = 224 if len(engines) > 1 else 0
     for e in engines:

@@ -814,6 +814,7 @@ def pack_winograd_sk(weight, shape=0, adjoint=False):
 
 
 _SK_WS = {}
+_SK_WS_RETIRED = []
 
 
 def winograd_sk_workspace(batch, h, w, cout, device, workgroups=0, shape=0):
@@ -886,6 +887,8 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
             need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(B, H, W, pc.cout, shape, workgroups))
             workspace = _SK_WS.get(key)
             if workspace is None or workspace.numel() < need:
+                if workspace is not None:
+                    _SK_WS_RETIRED.append(workspace)  # a captured graph may still point at it: never hand its memory back
                 workspace = _SK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=x.device)
         check(lib.sessd_conv3x3_winograd_sk(x.data_ptr(), B, ci, H, W, upk.data_ptr(), out.data_ptr(), pc.cout, _p(scale),
                                             _p(shift), 1 if relu else 0, _p(residual), workspace.data_ptr(), workspace.numel(),
