@@ -241,6 +241,11 @@ int sessd_points_global_transform(float* points, int num_points, int point_strid
 size_t sessd_points_compact_workspace_bytes(int num_points);
 int sessd_points_compact(const float* points, const uint8_t* keep, int num_points, int point_stride, float* out,
                          int out_capacity, int32_t* n_out, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+/* det3d/datasets/utils/sa_da_v2.py:76-205 pyramid_augment_v0, thinning step (`ifp_sample` of jackd/ifp-sample over all-pairs
+ * neighbourhoods = plain iterative farthest-point sampling): k indices of the n points, starting at point 0, the point farthest
+ * from the selection next (float64 Euclidean distance of the float32 coordinates, lowest index on ties); k <= n <= 4096. */
+int sessd_farthest_point_sample(const float* points, int num_points, int point_stride, int k, int32_t* out_indices,
+                                sessd_stream_t stream);
 
 /* ---- sparse conv backward (spconv's indice_conv backward as differentiated by the SE-SSD training
  * step, det3d/torchie/trainer/trainer_sessd.py:250-275 through det3d/models/backbones/scn.py:106-148) -------------

@@ -157,6 +157,57 @@ __global__ __launch_bounds__(NT) void compact_scatter_kernel(const float* __rest
 
 }  // namespace
 
+
+// Iterative farthest-point sampling of k of n points (sa_da_v2.py's thinning step: `ifp_sample` over all-pairs neighbourhoods,
+// restated in det3d/datasets/utils/sa_da_v2.py::ifp_sample): start at point 0; every pick lowers each point's distance-to-selection
+// (Euclidean, float64 from the float32 coordinates, as scipy's cKDTree returns it); the next pick is the point with the largest
+// remaining distance, lowest index on ties. One workgroup, distances in LDS.
+namespace {
+constexpr int FPS_MAX = 4096;
+__global__ __launch_bounds__(NT) void fps_kernel(const float* __restrict__ pts, int n, int stride, int k, int* __restrict__ out) {
+  __shared__ double rem[FPS_MAX];
+  __shared__ double s_v[NT / 64];
+  __shared__ int s_i[NT / 64];
+  __shared__ int s_pick;
+  for (int j = threadIdx.x; j < n; j += NT) rem[j] = INFINITY;
+  __syncthreads();
+  for (int s = 0; s < k; ++s) {
+    double bv = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < n; j += NT) {
+      const double v = rem[j];
+      if (v > bv || (v == bv && j < bi)) { bv = v; bi = j; }   // first maximum of this thread's strided slice
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(bv, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    if ((threadIdx.x & 63) == 0) { s_v[threadIdx.x >> 6] = bv; s_i[threadIdx.x >> 6] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double v = s_v[0];
+      int i = s_i[0];
+      for (int w = 1; w < NT / 64; ++w)
+        if (s_v[w] > v || (s_v[w] == v && s_i[w] < i)) { v = s_v[w]; i = s_i[w]; }
+      s_pick = i;
+      out[s] = i;
+    }
+    __syncthreads();
+    const int pick = s_pick;
+    const double px = pts[(size_t)pick * stride], py = pts[(size_t)pick * stride + 1], pz = pts[(size_t)pick * stride + 2];
+    for (int j = threadIdx.x; j < n; j += NT) {
+      const double dx = (double)pts[(size_t)j * stride] - px, dy = (double)pts[(size_t)j * stride + 1] - py,
+                   dz = (double)pts[(size_t)j * stride + 2] - pz;
+      const double d = sqrt(dx * dx + dy * dy + dz * dz);
+      rem[j] = j == pick ? -INFINITY : fmin(rem[j], d);
+    }
+    __syncthreads();
+  }
+}
+}  // namespace
+
 extern "C" {
 
 // points (num_points, point_stride) float32 (x, y, z first), planes (num_bodies, faces, 4) float32 [nx, ny, nz, d] with the
@@ -214,6 +265,16 @@ int sessd_points_compact(const float* points, const uint8_t* keep, int num_point
   SESSD_CHECK_LAUNCH();
   SESSD_LAUNCH(compact_scatter_kernel, dim3(nblk), dim3(NT), 0, stream, points, keep, num_points, point_stride, blk, nblk, out,
                out_capacity, n_out);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+
+// Farthest-point sampling: indices (k, int32, device) of k of the n points (n, point_stride floats, xyz first), starting at point
+// 0, ties to the lowest index; k <= n <= 4096.
+int sessd_farthest_point_sample(const float* points, int num_points, int point_stride, int k, int* out_indices, hipStream_t stream) {
+  if (num_points < 1 || num_points > FPS_MAX || point_stride < 3 || k < 1 || k > num_points) return SESSD_EINVAL;
+  SESSD_LAUNCH(fps_kernel, dim3(1), dim3(NT), 0, stream, points, num_points, point_stride, k, out_indices);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -77,8 +77,9 @@ class Preprocess(object):
         """The stage with the point cloud resident on the device (res["lidar"]["points"] is a CUDA tensor): box-level decisions and
         every random draw are the host stage's, in its order (a seed gives the same augmentation); the point-level work runs on
         sessd_points_in_bodies / _compact (GT-AUG removal), _rigid_moves (per-object noise), _global_transform (+ the points_raw
-        snapshot) and a device gather (shuffle). The shape-aware augmentation takes the cloud through the host once (its thinning
-        and pyramid swapping are not ported)."""
+        snapshot), the shape-aware augmentation (sa_da_v2.pyramid_augment_v0_device: membership, removal, farthest-point thinning
+        and the pyramid swap on the device) and a device gather (shuffle). What crosses to the host are per-pyramid point counts and
+        row counts of compactions."""
         import torch
         from det3d.core.bbox import box_np_ops
         from det3d.core.bbox.geometry import surface_equ_3d_jitv2
@@ -131,7 +132,7 @@ class Preprocess(object):
             res["lidar"]["annotations_raw"] = {k: v.copy() for k, v in gt_dict.items()}
             gt_dict["gt_boxes"], res["lidar"]["transformation"] = self._global_device(gt_dict["gt_boxes"], points, raw)
             res["lidar"]["points_raw"] = raw
-            points = torch.from_numpy(sa_da_v2.pyramid_augment_v0(gt_dict["gt_boxes"], points.cpu().numpy(), **self.sa_da)).to(dev)
+            points = sa_da_v2.pyramid_augment_v0_device(gt_dict["gt_boxes"], points, **self.sa_da)
         if self.shuffle_points:
             perm = np.random.choice(np.arange(points.shape[0]), points.shape[0], replace=False)
             points = points[torch.from_numpy(perm).to(dev)]

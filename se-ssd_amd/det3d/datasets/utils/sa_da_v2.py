@@ -141,3 +141,110 @@ def pyramid_augment_v0(gt_boxes, points, enable_sa_dropout=0.1, enable_sa_sparsi
                     moved += [np.concatenate([into_a, into_a_i], axis=1), np.concatenate([into_b, into_b_i], axis=1)]
                 points = np.concatenate([rest] + moved, axis=0)
     return points.astype(np.float32)
+
+
+def pyramid_augment_v0_device(gt_boxes, points, enable_sa_dropout=0.1, enable_sa_sparsity=[0.05, 50], enable_sa_swap=[0.05, 50]):
+    """pyramid_augment_v0 with the cloud on the device: `points` is a (P, C) float32 CUDA tensor and stays there. Every random
+    draw is the host function's, in its order and with its shapes (the per-pyramid point counts the decisions need come back as a
+    few hundred integers); membership tests run on sessd_points_in_bodies, removals on sessd_points_compact, the thinning on
+    sessd_farthest_point_sample, and the pyramid-to-pyramid re-expression of swapped points in float64 on the device like the
+    host's numpy arithmetic. Returns the augmented float32 device tensor (rest first, then the thinned / moved groups, as the
+    host function orders them)."""
+    import torch
+    from det3d.core.bbox.geometry import surface_equ_3d_jitv2
+    from sessd_hip import ops
+    dev = points.device
+    points = points.float().contiguous()
+
+    def planes_of(pyr):                               # (M, 15) pyramids -> (M, 5, 4) inward face planes on the device
+        v = pyr.reshape(-1, 5, 3)
+        surf = v[:, _PYRAMID_FACES].reshape(-1, 5, 3, 3)
+        nrm, d = surface_equ_3d_jitv2(surf[:, :, :3, :])
+        return torch.from_numpy(np.ascontiguousarray(np.concatenate([nrm, d[..., None]], axis=-1).astype(np.float32))).to(dev)
+
+    def masks_of(pts, pyr):                           # (P, M) bool on the device
+        if pyr.shape[0] == 0 or pts.shape[0] == 0:
+            return torch.zeros((pts.shape[0], pyr.shape[0]), dtype=torch.bool, device=dev)
+        return ops.points_in_bodies(pts, planes_of(pyr))
+
+    def keep_rows(pts, keep):                         # order-preserving compaction
+        if pts.shape[0] == 0:
+            return pts
+        out, n = ops.points_compact(pts, keep)
+        return out[: int(n.item())]
+
+    pyramids = get_pyramids(gt_boxes)
+    if enable_sa_dropout is not None and gt_boxes.shape[0] > 0:
+        which = one_hot(np.random.randint(0, 6, (pyramids.shape[0])), num_class=6)
+        box_sel = np.random.uniform(0, 1, (pyramids.shape[0])) <= enable_sa_dropout
+        sel = (box_sel[:, None] * which) > 0
+        if sel.any():
+            points = keep_rows(points, ~masks_of(points, pyramids[sel]).any(-1))
+        pyramids = pyramids[~box_sel]
+
+    if enable_sa_sparsity is not None and pyramids.shape[0] > 0:
+        prob, keep_num = enable_sa_sparsity
+        which = one_hot(np.random.randint(0, 6, (pyramids.shape[0])), num_class=6)
+        box_sel = np.random.uniform(0, 1, (pyramids.shape[0])) <= prob
+        sel = (box_sel[:, None] * which) > 0
+        all_m = masks_of(points, pyramids.reshape(-1, 15))
+        counts = all_m.sum(0).cpu().numpy()
+        sel = sel & (counts > keep_num).reshape(-1, 6)
+        chosen = pyramids[sel]
+        if chosen.shape[0] > 0:
+            m = all_m[:, torch.from_numpy(np.nonzero(sel.reshape(-1))[0]).to(dev)]
+            rest, thinned = keep_rows(points, ~m.any(-1)), []
+            for k in range(m.shape[1]):
+                part = keep_rows(points, m[:, k])
+                thinned.append(part[ops.farthest_point_sample(part, keep_num)])
+            points = torch.cat([rest] + thinned, dim=0).contiguous()
+        pyramids = pyramids[~box_sel]
+
+    if enable_sa_swap is not None:
+        prob, min_num = enable_sa_swap
+        box_sel = np.random.uniform(0, 1, (pyramids.shape[0])) <= prob
+        if box_sel.sum() > 0:
+            counts = masks_of(points, pyramids.reshape(-1, 15)).sum(0).cpu().numpy().reshape(pyramids.shape[0], -1)
+            dense = counts > min_num
+            cand = dense * box_sel[:, None]
+            if cand.sum() > 0:
+                bi, pj = np.nonzero(cand)
+                pick = [np.random.choice(pj[bi == i]) if e and (bi == i).any() else 0 for i, e in enumerate(box_sel)]
+                give = cand * one_hot(pick, num_class=6) == 1
+                src = pyramids[give]
+                bi, pj = np.nonzero(give)
+                dense[give] = False
+                partner = np.array([np.random.choice(np.where(dense[:, j])[0]) if np.where(dense[:, j])[0].shape[0] > 0 else bi[i]
+                                    for i, j in enumerate(pj.tolist())])
+                dst = pyramids[partner.astype(np.int32), pj.astype(np.int32)]
+                m = masks_of(points, np.concatenate([src, dst], axis=0))
+                rest, moved, ns = keep_rows(points, ~m.any(-1)), [], dst.shape[0]
+                t64 = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float64)).to(dev)
+
+                def ratio(p, pyr):                    # get_points_ratio, float64 on the device
+                    base_c = (pyr[3:6] + pyr[6:9] + pyr[9:12] + pyr[12:]) / 4.0
+                    e0, e1, ax = pyr[6:9] - pyr[3:6], pyr[12:] - pyr[3:6], pyr[0:3] - base_c
+                    rel = p[:, 0:3].double() - t64(pyr[3:6])
+                    return ((rel * t64(e0)).sum(-1) / float(np.power(e0, 2).sum()), (rel * t64(e1)).sum(-1) / float(np.power(e1, 2).sum()),
+                            ((p[:, 0:3].double() - t64(base_c)) * t64(ax)).sum(-1) / float(np.power(ax, 2).sum()))
+
+                def recover(r, pyr):                  # recover_points_by_ratio
+                    a, b, g = r
+                    base_c = (pyr[3:6] + pyr[6:9] + pyr[9:12] + pyr[12:]) / 4.0
+                    e0, e1, ax = pyr[6:9] - pyr[3:6], pyr[12:] - pyr[3:6], pyr[0:3] - base_c
+                    return (a[:, None] * t64(e0) + b[:, None] * t64(e1)) + t64(pyr[3:6]) + g[:, None] * t64(ax)
+
+                def iratio(p):                        # _intensity_ratio: float32 like the host's numpy on the float32 column
+                    lo, hi = p[:, -1:].min(), p[:, -1:].max()
+                    return (p[:, -1:] - lo) / torch.clamp(hi - lo, 1e-6, 1)
+
+                for k in range(ns):
+                    a_pts, b_pts = keep_rows(points, m[:, k]), keep_rows(points, m[:, k + ns])
+                    a_int, b_int = iratio(a_pts), iratio(b_pts)
+                    into_a = recover(ratio(b_pts, dst[k]), src[k])
+                    into_b = recover(ratio(a_pts, src[k]), dst[k])
+                    into_a_i = b_int * (a_pts[:, -1:].max() - a_pts[:, -1:].min()) + a_pts[:, -1:].min()
+                    into_b_i = a_int * (b_pts[:, -1:].max() - b_pts[:, -1:].min()) + b_pts[:, -1:].min()
+                    moved += [torch.cat([into_a, into_a_i.double()], dim=1), torch.cat([into_b, into_b_i.double()], dim=1)]
+                points = torch.cat([rest.double()] + moved, dim=0)
+    return points.float().contiguous()

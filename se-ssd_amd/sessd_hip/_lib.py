@@ -89,6 +89,7 @@ SIGNATURES = {
     "sessd_points_global_transform": (i32, [vp, i32, i32, i32, f32, f32, f32, vp, vp]),
     "sessd_points_compact_workspace_bytes": (sz, [i32]),
     "sessd_points_compact": (i32, [vp, vp, i32, i32, vp, i32, vp, vp, sz, vp]),
+    "sessd_farthest_point_sample": (i32, [vp, i32, i32, i32, vp, vp]),
     "sessd_bn_relu_train_workspace_bytes": (sz, [i32]),
     "sessd_bn_relu_train_fwd": (i32, [vp, vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_bn_relu_train_bwd": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),

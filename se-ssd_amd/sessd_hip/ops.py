@@ -673,6 +673,16 @@ def points_global_transform_(points, flip, angle, scale, raw_copy=None):
     return points
 
 
+def farthest_point_sample(points, k):
+    """Indices (k,) int64 on the device of k of the rows of points (n, >=3) float32 device tensor, n <= 4096: sa_da_v2's thinning
+    (start at row 0, farthest from the selection next, lowest index on ties)."""
+    _req(points, torch.float32, "points")
+    n = points.shape[0]
+    out = torch.empty((k,), dtype=torch.int32, device=points.device)
+    check(lib.sessd_farthest_point_sample(points.data_ptr(), n, points.shape[1], int(k), out.data_ptr(), _stream()), "farthest_point_sample")
+    return out.long()
+
+
 def points_compact(points, keep, out=None):
     """Order-preserving compaction on the device: rows of points (P, C) whose keep flag (P,) bool / uint8 is set.
     Returns (out (cap, C), n_out device int32 (1,)); nothing synchronises."""

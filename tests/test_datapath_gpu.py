@@ -206,3 +206,42 @@ def test_preprocess_stage_with_the_cloud_on_the_device(dev, golden_dir):
     val = Preprocess(cfg=dict(mode="val", shuffle_points=False, remove_environment=False, remove_unknown_examples=False))
     res, _ = val(dict(labeled=False, lidar=dict(points=torch.from_numpy(p).to(dev))), None)
     assert res["mode"] == "val" and res["lidar"]["points"].is_cuda and np.array_equal(res["lidar"]["points"].cpu().numpy(), p)
+
+
+def test_farthest_point_sampling_equals_the_host_restatement(dev):
+    from scipy.spatial import cKDTree
+    from det3d.datasets.utils import sa_da_v2
+    from sessd_hip import ops
+    rng = np.random.RandomState(4)
+    for n, k in ((300, 50), (51, 50), (1, 1), (2000, 64), (97, 97)):
+        p = np.concatenate([rng.uniform(-2, 2, (n, 3)), rng.uniform(0, 1, (n, 1))], 1).astype(np.float32)
+        if n > 20:
+            p[7] = p[3]                     # duplicate points: distance ties
+        d, idx = cKDTree(p[:, :3]).query(p[:, :3], n)
+        want = sa_da_v2.ifp_sample(d.reshape(n, -1), idx.reshape(n, -1), k)
+        got = ops.farthest_point_sample(torch.from_numpy(p).to(dev), k).cpu().numpy()
+        assert got.tolist() == want.tolist(), (n, k)
+    with pytest.raises(Exception):
+        ops.farthest_point_sample(torch.zeros((5000, 4), device=dev), 10)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_shape_aware_augmentation_on_the_device(dev, seed):
+    """sa_da_v2.pyramid_augment_v0_device vs the host function with the same seed and high stage probabilities: the same rows in
+    the same order (rest, then the thinned / swapped groups), coordinates to float32 rounding."""
+    from make_golden_datapath import make_scene
+    from det3d.datasets.utils import sa_da_v2
+    pts, boxes, names = make_scene(20 + seed)
+    kw = dict(enable_sa_dropout=0.3, enable_sa_sparsity=[0.6, 20], enable_sa_swap=[0.8, 10])
+    np.random.seed(900 + seed)
+    want = sa_da_v2.pyramid_augment_v0(boxes.copy(), pts.copy(), **kw)
+    after_host = np.random.uniform()
+    np.random.seed(900 + seed)
+    got = sa_da_v2.pyramid_augment_v0_device(boxes.copy(), torch.from_numpy(pts.copy()).to(dev), **kw)
+    after_dev = np.random.uniform()
+    assert got.is_cuda and got.dtype == torch.float32
+    assert after_host == after_dev                                   # the same number of random draws
+    g = got.cpu().numpy()
+    assert g.shape == want.shape and want.shape[0] < pts.shape[0]     # something was dropped / thinned
+    assert np.allclose(g, want, rtol=0, atol=2e-4)
+    assert float(np.abs(want[-200:, :3] - pts[-200:, :3]).max()) > 0  # the tail holds moved / re-ordered groups
