@@ -548,9 +548,9 @@ __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
 // (the four output-parity classes of the stride-2 transposed conv): blockIdx.z = batch*4 + (3 - class). The classes
 // have 1, 2, 2, 4 taps, i.e. 1x, 2x, 2x, 4x the work per workgroup: the heaviest class is dispatched first so that
 // the tail of the launch is made of the light workgroups.
-template <int NTAPS, int CT, int PT, int WC, int WP>
+template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
 __global__ __launch_bounds__(256) void conv2d_mfma4_kernel(ConvArgs4 A4) {
-  conv_body<NTAPS, CT, PT, WC, WP>(A4.c[3 - (blockIdx.z & 3)], blockIdx.z >> 2);
+  conv_body<NTAPS, CT, PT, WC, WP, DEEP>(A4.c[3 - (blockIdx.z & 3)], blockIdx.z >> 2);
 }
 
 // SSFA tail (rpn_v1.py:227-233): w0 = BN(conv1x1(x0)), w1 = BN(conv1x1(x1)) (C -> 1 channel, no ReLU),
@@ -605,7 +605,7 @@ int launch_conv(const ConvArgs* A, int nconv, int batch, hipStream_t stream) {
   } else {
     ConvArgs4 A4;
     for (int i = 0; i < 4; ++i) A4.c[i] = A[i];
-    SESSD_LAUNCH((conv2d_mfma4_kernel<NTAPS, CT, PT, WC, WP>), grid, dim3(256), 0, stream, A4);
+    SESSD_LAUNCH((conv2d_mfma4_kernel<NTAPS, CT, PT, WC, WP, DEEP>), grid, dim3(256), 0, stream, A4);
   }
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -623,8 +623,8 @@ int dispatch_tile(const ConvArgs* A, int nconv, int batch, int tile_cfg, hipStre
     case 6: return launch_conv<NTAPS, 2, 1, 1, 4>(A, nconv, batch, stream);  // wave 64c x 32p, WG 64c x 128p (weights shared by the 4 waves)
     case 7: return launch_conv<NTAPS, 2, 2, 1, 4>(A, nconv, batch, stream);  // wave 64c x 64p, WG 64c x 256p
     case 8: return launch_conv<NTAPS, 4, 1, 1, 4>(A, nconv, batch, stream);  // wave 128c x 32p, WG 128c x 128p
-    case 11: if (nconv == 1) return launch_conv<NTAPS, 1, 1, 1, 4, true>(A, nconv, batch, stream); return SESSD_EINVAL;  // cfg 4, 2-step look-ahead
-    case 12: if (nconv == 1) return launch_conv<NTAPS, 1, 1, 4, 1, true>(A, nconv, batch, stream); return SESSD_EINVAL;  // cfg 3, 2-step look-ahead
+    case 11: return launch_conv<NTAPS, 1, 1, 1, 4, true>(A, nconv, batch, stream);  // cfg 4, 2-step look-ahead
+    case 12: return launch_conv<NTAPS, 1, 1, 4, 1, true>(A, nconv, batch, stream);  // cfg 3, 2-step look-ahead
     case 13: if (nconv == 1) return launch_conv<NTAPS, 1, 2, 4, 1, true>(A, nconv, batch, stream); return SESSD_EINVAL;  // cfg 2, 2-step look-ahead
     default: return SESSD_EINVAL;
   }

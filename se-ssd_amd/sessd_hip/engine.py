@@ -349,7 +349,7 @@ class InferenceEngine:
             for cfg in cands:
                 if pc.cout <= 32 and cfg != 4:
                     continue
-                if cfg in (11, 12, 13) and pc.kind != "conv":
+                if cfg == 13 and pc.kind != "conv":
                     continue
                 for _ in range(2):
                     ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg, workspace=self.sk_ws, workgroups=self.sk_workgroups)

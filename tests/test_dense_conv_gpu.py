@@ -106,7 +106,7 @@ def test_winograd_stream_k(dev, cin, cout, H, W, B, wgs, cfg):
     assert float((plain - F.conv2d(x.double(), w.double(), padding=1)).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("cfg", [1, 3])
+@pytest.mark.parametrize("cfg", [1, 3, 4, 11, 12])
 def test_deconv_s2_with_residual(dev, cfg):
     g = torch.Generator().manual_seed(9)
     x = torch.randn(2, 256, 10, 12, generator=g)
