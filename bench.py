@@ -52,15 +52,16 @@ def parse():
                     help="BASELINE configs[4]: 200k points/frame, max 64000 voxels, batch 8 (a parity/roofline case, not the metric line)")
     ap.add_argument("--pool", type=int, default=16, help="distinct synthetic frames cycled through")
     ap.add_argument("--eager", action="store_true", help="no hipGraph: launch every kernel from Python")
-    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads of the baseline (capped by affinity)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU baseline sample")
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight: independent batch-1 engines on separate HIP streams (1 = strictly one frame at a time)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--sk-workgroups", type=int, default=-1,
-                    help="persistent workgroups of the stream-K Winograd launches (multiple of 8; 0 = the kernel's default, all CUs; "
-                         "-1 = 0 with one frame in flight, 224 with several: the free CUs take the other stream's small kernels)")
+    ap.add_argument("--sk-workgroups", type=int, default=0,
+                    help="persistent workgroups of the stream-K Winograd launches (multiple of 8; 0 = the kernel's default, all CUs). "
+                         "224 with two frames in flight leaves 32 CUs to the other stream's small kernels: +2 % frames/s, but the "
+                         "kernel then runs 14 % longer per launch -- the default keeps the timed kernel the one the roofline describes")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     ap.add_argument("--no-offset-split", action="store_true", help="autotune without the offset-split sparse conv variants")
     ap.add_argument("--no-streamk", action="store_true", help="autotune without the stream-K Winograd variants")
@@ -122,8 +123,6 @@ def main():
     if args.wino_cfg:
         for nm in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):
             eng.tile_cfg[nm] = args.wino_cfg
-    if args.sk_workgroups < 0:
-        args.sk_workgroups = 224 if len(engines) > 1 else 0
     for e in engines:
         e.sk_workgroups = args.sk_workgroups
     for e in engines[1:]:
@@ -221,9 +220,7 @@ def main():
             streamk = sum(1 for c in cfgs if c in (22, 23))
             log("dense tile_cfg:", {k: v for k, v in eng.tile_cfg.items()})
             eng.set_points(batch_of(0))
-            skw, eng.sk_workgroups = eng.sk_workgroups, 0   # the kernel on all CUs, one frame in flight (what the single-stream run times)
             lt = eng.dense_layer_times(reps=20)
-            eng.sk_workgroups = skw
             kms = sum(lt[nm] for nm in names) / len(names)
             flops = CONV_FLOPS * args.batch
             ach = flops / (kms * 1e-3) / 1e12
@@ -239,10 +236,8 @@ def main():
                                                   "convolution count for the Winograd kernel) / launch time / dense f32 MFMA peak",
                                "avg_launch_ms": kms,
                                "avg_launch_source": "HIP events before / after each of the kernel's 7 launches inside 20 whole frames "
-                                                    "(eager enqueue; same stream as the kernels; one frame in flight, stream-K "
-                                                    "launches on all CUs -- with two frames in flight the timed region launches them "
-                                                    "with config.streamk_workgroups workgroups and leaves the other CUs to the other "
-                                                    "stream)",
+                                                    "(eager enqueue; same stream as the kernels; one frame in flight, the same "
+                                                    "launch configuration as the timed region unless --sk-workgroups says otherwise)",
                                "dense_launch_ms": {k: round(v, 5) for k, v in lt.items()},
                                "dense_tile_cfg": {k: eng.tile_cfg.get(k) for k in lt},
                                "flops_per_launch_executed": flops * (16.0 / 36.0 if wino else 1.0),
