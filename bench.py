@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--streams", type=int, default=2,
                     help="frames in flight: independent batch-1 engines on separate HIP streams (1 = strictly one frame at a time)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-host-io", action="store_true", help="skip the informational host-buffer leg (kernel traces of the timed region)")
     ap.add_argument("--sk-workgroups", type=int, default=0,
                     help="persistent workgroups of the stream-K Winograd launches (multiple of 8; 0 = the kernel's default, all CUs). "
                          "224 with two frames in flight leaves 32 CUs to the other stream's small kernels: +2 % frames/s, but the "
@@ -271,7 +272,7 @@ def main():
         # ---- informational: the same frames handed over as HOST numpy buffers and detections read back to the host, one
         # frame at a time (H2D of P*16 B from pinned memory + graph replay + D2H of <= 100 boxes, synchronous per frame).
         # Never part of `value` (inputs are resident in HBM inside the timed region).
-        if not args.eager and args.batch == 1:
+        if not args.eager and args.batch == 1 and not args.no_host_io:
             pinned = [torch.from_numpy(f).pin_memory() for f in frames_np[:8]]
             stage = torch.empty((args.points, 4), dtype=torch.float32, device=dev)
             nio = 100

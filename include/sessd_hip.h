@@ -349,6 +349,24 @@ size_t sessd_conv3x3_winograd_sk_workspace_bytes(int batch, int h, int w, int co
 int sessd_conv3x3_winograd_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
                               const float* scale, const float* shift, int relu, const float* residual, void* workspace,
                               size_t workspace_bytes, int shape, int workgroups, sessd_stream_t stream);
+/* The convolutions that are NOT 3x3 stride 1 (stride-2 3x3, 1x1, the four output-parity classes of the stride-2 transposed conv;
+ * rpn_v1.py:150-210) as an LDS-tiled implicit GEMM, stream-K over `workgroups` persistent workgroups (a multiple of 8, 0 = one
+ * per CU): csrc/dense_conv_sk.hip, tile_cfg 30 of ops.conv2d. nclass (1..4) convolutions that share input, shapes and epilogue
+ * but not weights / taps / output phase run as ONE launch. Class c: wpk[c] = device pointer from sessd_conv2d_sk_pack
+ * ([ceil(cout/128)][cin/16][ntaps][2048]: the kernel's LDS image, element ((h*2+q)*128 + i)*4 + e of a chunk =
+ * w[(cg*128 + i) * out_stride + (cb*16 + 8h + 4q + e) * in_stride + tap_offsets[t]]), ntaps[c] <= 9 taps with input offsets
+ * taps_dy / taps_dx[9 c + t] (HOST ints); tile-space pixel (y, x) of tile_h x tile_w reads input (y*in_mul + dy, x*in_mul + dx)
+ * and writes output (y*out_mul + out_py[c], x*out_mul + out_px[c]). cin % 16 == 0. Exact float32 arithmetic; the summation
+ * order (hence the last bits) is fixed by (shapes, batch, workgroups), not by timing. workspace:
+ * sessd_conv2d_sk_workspace_bytes(...) bytes, zeroed ONCE by the caller, not shared between concurrently running launches. */
+size_t sessd_conv2d_sk_workspace_bytes(int batch, int tile_h, int tile_w, int cout, int nclass, int workgroups);
+int sessd_conv2d_sk_pack(const float* w, long long out_stride, long long in_stride, const int* tap_offsets, int ntaps, int cout,
+                         int cin, float* out, sessd_stream_t stream);
+int sessd_conv2d_sk(const float* in, int batch, int cin, int hin, int win, int nclass, const float* const* wpk,
+                    const int* ntaps, const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out,
+                    int cout, int hout, int wout, int out_mul, const int* out_py, const int* out_px, const float* scale,
+                    const float* shift, int relu, const float* residual, void* workspace, size_t workspace_bytes, int workgroups,
+                    sessd_stream_t stream);
 /* ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
  * classes (py,px) = (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps: wpk4[c] packed like above, taps_dy4/taps_dx4 are
  * 4 rows of 4 ints. input (B,cin,hin,win) -> output (B,cout,2*hin,2*win); cin % 8 == 0. */

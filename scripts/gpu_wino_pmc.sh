@@ -1,5 +1,6 @@
 #!/bin/bash
-# PMC passes of one Winograd variant alone: gpu_wino_pmc.sh "<wino_probe args>" <tag> <kernel name substring>
+# PMC passes of one dense conv kernel alone: gpu_wino_pmc.sh "<probe args>" <tag> <kernel name substring>
+# (PROBE=wino_probe.py by default; PASSES=4 by default, 2 = the SQ counter sets only)
 set -u
 R=$GRAFT_REPO_ROOT
 ARGS=${1:-21}
@@ -14,8 +15,9 @@ rm -f $OUT
 i=0
 for set in "$S1" "$S2" "FETCH_SIZE" "WRITE_SIZE"; do
   i=$((i+1))
+  [ $i -gt ${PASSES:-4} ] && break
   rm -rf $R/gpurun_out/${TAG}_pmc$i
-  timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/${TAG}_pmc$i -o p --output-format csv -- python $R/scripts/wino_probe.py $ARGS > $R/gpurun_out/${TAG}_pmc$i.log 2>&1
+  timeout -k 5 150 rocprofv3 --kernel-trace --pmc $set -d $R/gpurun_out/${TAG}_pmc$i -o p --output-format csv -- python $R/scripts/${PROBE:-wino_probe.py} $ARGS > $R/gpurun_out/${TAG}_pmc$i.log 2>&1
   echo "== pass $i rc=$? ($set)" >> $OUT
   f=$(find $R/gpurun_out/${TAG}_pmc$i -name "*counter_collection.csv" | head -1)
   [ -n "$f" ] && python $R/scripts/pmc_summary.py $f $KN >> $OUT

@@ -35,6 +35,28 @@ __global__ __launch_bounds__(256) void k16(float* out, int iters, float a0, floa
   for (int i = 0; i < NACC; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
   out[blockIdx.x * 256 + threadIdx.x] = s;
 }
+// Same with operands that differ per lane and per instruction (pseudo-random in [-1, 1)): with constant operands the matrix
+// pipe's inputs never toggle, the chip draws less power and holds a higher clock than any real GEMM sees.
+template <int NACC>
+__global__ __launch_bounds__(256) void k32r(float* out, int iters, float a0, float b0) {
+  f32x16 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float av[8], bv[8];
+  unsigned s = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+  for (int i = 0; i < 8; ++i) {
+    s = s * 1664525u + 1013904223u; av[i] = (float)(int)(s >> 8) * (1.f / 8388608.f) - 1.f + a0 * 1e-9f;
+    s = s * 1664525u + 1013904223u; bv[i] = (float)(int)(s >> 8) * (1.f / 8388608.f) - 1.f + b0 * 1e-9f;
+  }
+  for (int it = 0; it < iters; it += 2) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[(u + 3 * i) & 7], acc[i], 0, 0, 0);
+  }
+  float t = 0;
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) t += acc[i][r];
+  out[blockIdx.x * 256 + threadIdx.x] = t;
+}
 template <typename K>
 void run(const char* name, K kern, int nacc, int blocks, double flop_per_mfma) {
   float* out; hipMalloc(&out, blocks * 256 * 4);
@@ -55,6 +77,7 @@ int main() {
     run("32x32x2", k32<1>, 1, blocks, 4096.0);
     run("32x32x2", k32<2>, 2, blocks, 4096.0);
     run("32x32x2", k32<4>, 4, blocks, 4096.0);
+    run("32x32x2 random operands", k32r<4>, 4, blocks, 4096.0);
     run("16x16x4", k16<2>, 2, blocks, 2048.0);
     run("16x16x4", k16<4>, 4, blocks, 2048.0);
   }

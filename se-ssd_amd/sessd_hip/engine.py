@@ -232,8 +232,8 @@ class InferenceEngine:
         self.graph = None
         self._marks = None
         self.tile_cfg = {}
-        self.sk_ws = None  # workspace of the stream-K Winograd launches (autotune allocates it)
-        self.allow_streamk = True  # autotune may choose the stream-K Winograd kernel (tile_cfg 22 / 23)
+        self.sk_ws = None  # workspace of the stream-K launches, tile_cfg 22 / 23 / 30 (autotune allocates it)
+        self.allow_streamk = True  # autotune may choose the stream-K kernels (Winograd: tile_cfg 22 / 23; LDS-tiled direct: 30)
         self.allow_offset_split = True  # autotune may choose the offset-split sparse conv (see sessd_sparse_conv)
         self.sk_workgroups = 0  # persistent workgroups of those launches (0 = one or two per CU; fewer leaves CUs to a second stream)
         self.tune_report = {}
@@ -346,6 +346,15 @@ class InferenceEngine:
                             if self.sk_ws is None or self.sk_ws.numel() < need:
                                 self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=x.device)
                             cands.append(cfg)
+            # LDS-tiled stream-K implicit GEMM (csrc/dense_conv_sk.hip) for what is not 3x3 stride 1: the stride-2 conv, the 1x1
+            # convs, the transposed convs (four parity classes in one launch). Shares the engine's stream-K workspace.
+            if self.allow_streamk and pc.cout > 32 and not (pc.kind == "conv" and pc.stride == 1 and pc.launches[0]["ntaps"] == 9) \
+                    and pc.sk_args() is not None:
+                th, tw = (out.shape[2], out.shape[3]) if pc.kind == "conv" else (x.shape[2], x.shape[3])
+                need = int(lib.sessd_conv2d_sk_workspace_bytes(x.shape[0], th, tw, pc.cout, len(pc.launches), 0))
+                if self.sk_ws is None or self.sk_ws.numel() < need:
+                    self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=x.device)
+                cands.append(30)
             for cfg in cands:
                 if pc.cout <= 32 and cfg != 4:
                     continue

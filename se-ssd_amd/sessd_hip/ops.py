@@ -733,6 +733,7 @@ class PackedConv:
         self._w3 = None      # (weight, adjoint): the 3x3 stride-1 weight the Winograd packings are made from, on demand
         self._upk = None
         self._upk_sk = [None, None]
+        self._sk = None      # argument block of sessd_conv2d_sk (tile_cfg 30), made when first asked for
 
     @property
     def upk(self):
@@ -746,6 +747,32 @@ class PackedConv:
         if self._upk_sk[shape] is None and self._w3 is not None and self.cin % (16, 8)[shape] == 0:
             self._upk_sk[shape] = pack_winograd_sk(self._w3[0], shape, adjoint=self._w3[1])
         return self._upk_sk[shape]
+
+
+    def sk_args(self):
+        """Host-side argument block of sessd_conv2d_sk (tile_cfg 30): the launches' weights re-packed in the kernel's LDS image
+        (one launch each) + tap tables; None if the layer is not eligible (cin % 16, a launch without its weight view)."""
+        if self._sk is None:
+            import ctypes
+            n = len(self.launches)
+            if self.cin % 16 or n > 4 or any("view" not in la or la["ntaps"] > 9 for la in self.launches):
+                return None
+            ncg = (self.cout + 127) // 128
+            wpk, dy, dx = [], (ctypes.c_int * (9 * n))(), (ctypes.c_int * (9 * n))()
+            for c, la in enumerate(self.launches):
+                w, so, sc, taps = la["view"]
+                nt = len(taps)
+                out = torch.empty((ncg, self.cin // 16, nt, 2048), dtype=torch.float32, device=w.device)
+                check(lib.sessd_conv2d_sk_pack(w.data_ptr(), int(so), int(sc), (ctypes.c_int * nt)(*[int(t) for t in taps]), nt,
+                                               self.cout, self.cin, out.data_ptr(), _stream()), "conv2d_sk_pack")
+                wpk.append(out)
+                for t in range(nt):
+                    dy[9 * c + t], dx[9 * c + t] = int(la["dy"][t]), int(la["dx"][t])
+            self._sk = dict(wpk=wpk, wptr=(ctypes.c_void_p * n)(*[t.data_ptr() for t in wpk]),
+                            ntaps=(ctypes.c_int * n)(*[la["ntaps"] for la in self.launches]), dy=dy, dx=dx,
+                            py=(ctypes.c_int * n)(*[la["py"] for la in self.launches]),
+                            px=(ctypes.c_int * n)(*[la["px"] for la in self.launches]), n=n)
+        return self._sk
 
 
 def _pack_taps_view(w, out_stride, in_stride, tap_offsets, cout, cin):
@@ -782,9 +809,10 @@ def pack_conv2d(weight, stride=1, padding=None, adjoint=False):
     kk = kh * kw
     dy = [ky - pad for ky in range(kh) for kx in range(kw)]
     dx = [kx - pad for ky in range(kh) for kx in range(kw)]
-    wpk = _pack_taps_view(w, so, sc, [(kk - 1 - t) if flip else t for t in range(kk)], co, ci)
+    taps = [(kk - 1 - t) if flip else t for t in range(kk)]
+    wpk = _pack_taps_view(w, so, sc, taps, co, ci)
     la = dict(wpk=wpk, dy=torch.tensor(dy, dtype=torch.int32), dx=torch.tensor(dx, dtype=torch.int32), in_mul=stride,
-              out_mul=1, py=0, px=0, ntaps=kh * kw)
+              out_mul=1, py=0, px=0, ntaps=kh * kw, view=(w, so, sc, taps))
     pc = PackedConv([la], ci, co, "conv", stride)
     if kh == 3 and stride == 1:
         pc._w3 = (w, bool(adjoint))  # Winograd packings (tile_cfg 20-23) are made when first asked for
@@ -836,6 +864,15 @@ def winograd_sk_workspace(batch, h, w, cout, device, workgroups=0, shape=0):
     return torch.zeros(n, dtype=torch.uint8, device=device)
 
 
+def conv2d_sk_workspace(batch, tile_h, tile_w, cout, nclass, device, workgroups=0):
+    """Zeroed workspace of sessd_conv2d_sk (partial-unit scratch + counters)."""
+    with torch.cuda.device(device):
+        n = int(lib.sessd_conv2d_sk_workspace_bytes(batch, tile_h, tile_w, cout, nclass, workgroups))
+    if n == 0:
+        raise ValueError("conv2d_sk_workspace: bad arguments")
+    return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
 def pack_winograd(weight, adjoint=False):
     """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) for sessd_conv3x3_winograd, packed
     [Cin/2][xi/4][channel parity][Cout_pad][xi%4]. One launch (sessd_conv3x3_winograd_pack)."""
@@ -856,10 +893,11 @@ def pack_deconv2d_s2(weight):
         for px in (0, 1):
             taps = [(ky, ey, kx, ex) for (ky, ey) in sel[py] for (kx, ex) in sel[px]]
             # (ci, co, 3, 3) weight: output channel o has element stride 9, input channel c stride co * 9, tap (ky, kx) offset 3 ky + kx
-            wpk = _pack_taps_view(w, 9, co * 9, [3 * ky + kx for (ky, ey, kx, ex) in taps], co, ci)
+            offs = [3 * ky + kx for (ky, ey, kx, ex) in taps]
+            wpk = _pack_taps_view(w, 9, co * 9, offs, co, ci)
             launches.append(dict(wpk=wpk, dy=torch.tensor([t[1] for t in taps], dtype=torch.int32),
                                  dx=torch.tensor([t[3] for t in taps], dtype=torch.int32), in_mul=1, out_mul=2, py=py,
-                                 px=px, ntaps=len(taps)))
+                                 px=px, ntaps=len(taps), view=(w, 9, co * 9, offs)))
     pc = PackedConv(launches, ci, co, "deconv", 2)
     # host-side argument blocks of the single merged launch (sessd_deconv2d_s2_mfma)
     import ctypes
@@ -903,6 +941,29 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         check(lib.sessd_conv3x3_winograd_sk(x.data_ptr(), B, ci, H, W, upk.data_ptr(), out.data_ptr(), pc.cout, _p(scale),
                                             _p(shift), 1 if relu else 0, _p(residual), workspace.data_ptr(), workspace.numel(),
                                             shape, workgroups, _stream()), "conv3x3_winograd_sk")
+        return out
+    if tile_cfg == 30:
+        sk = pc.sk_args()
+        if sk is None:
+            raise ValueError("tile_cfg 30 (LDS-tiled stream-K) needs cin % 16 == 0")
+        la = pc.launches[0]
+        need = int(lib.sessd_conv2d_sk_workspace_bytes(B, th, tw, pc.cout, sk["n"], workgroups))
+        if workspace is None:
+            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, "csk", workgroups)
+            workspace = _SK_WS.get(key)
+            if workspace is None or workspace.numel() < need:
+                if workspace is not None:
+                    _SK_WS_RETIRED.append(workspace)
+                workspace = _SK_WS[key] = torch.zeros(need, dtype=torch.uint8, device=x.device)
+        elif workspace.numel() < need:
+            raise ValueError("conv2d: stream-K workspace too small (%d < %d bytes)" % (workspace.numel(), need))
+        import ctypes
+        check(lib.sessd_conv2d_sk(x.data_ptr(), B, ci, H, W, sk["n"], ctypes.cast(sk["wptr"], ctypes.c_void_p).value,
+                                  ctypes.cast(sk["ntaps"], ctypes.c_void_p).value, ctypes.cast(sk["dy"], ctypes.c_void_p).value,
+                                  ctypes.cast(sk["dx"], ctypes.c_void_p).value, la["in_mul"], th, tw, out.data_ptr(), pc.cout,
+                                  Ho, Wo, la["out_mul"], ctypes.cast(sk["py"], ctypes.c_void_p).value,
+                                  ctypes.cast(sk["px"], ctypes.c_void_p).value, _p(scale), _p(shift), 1 if relu else 0,
+                                  _p(residual), workspace.data_ptr(), workspace.numel(), workgroups, _stream()), "conv2d_sk")
         return out
     if tile_cfg in (20, 21):
         if getattr(pc, "upk", None) is None or (H & 1) or (W & 1):

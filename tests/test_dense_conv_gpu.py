@@ -106,6 +106,64 @@ def test_winograd_stream_k(dev, cin, cout, H, W, B, wgs, cfg):
     assert float((plain - F.conv2d(x.double(), w.double(), padding=1)).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,H,W,B,wgs", [(128, 256, 3, 2, 24, 40, 2, 0), (128, 128, 1, 1, 24, 40, 1, 0), (256, 256, 1, 1, 13, 19, 2, 8),
+                                                         (16, 40, 3, 1, 10, 66, 3, 8), (32, 130, 3, 2, 9, 7, 1, 16), (128, 256, 3, 2, 200, 176, 1, 0),
+                                                         (64, 22, 1, 1, 30, 20, 1, 64), (128, 128, 3, 1, 24, 40, 1, 248)])
+def test_conv2d_lds_stream_k(dev, cin, cout, k, stride, H, W, B, wgs):
+    """tile_cfg 30 (csrc/dense_conv_sk.hip): LDS-tiled implicit GEMM, rounds dealt out in equal shares. Whole units, units cut in
+    two and (few rounds per share) in three or more parts, partial pixel tiles and cout groups; the workspace is reused by three
+    launches (counters back at zero) that must give the same bits."""
+    g = torch.Generator().manual_seed(cin + H + W + wgs)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) * 0.05
+    scale = torch.rand(cout, generator=g) + 0.5
+    shift = torch.randn(cout, generator=g) * 0.1
+    conv = F.conv2d(x.double(), w.double(), stride=stride, padding=k // 2)
+    res = torch.randn(conv.shape, generator=g)
+    ref = torch.relu(conv * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)) + res.double()
+    pc = ops.pack_conv2d(w.to(dev), stride)
+    Ho, Wo = conv.shape[2], conv.shape[3]
+    ws = ops.conv2d_sk_workspace(B, Ho, Wo, cout, 1, dev, wgs)
+    args = (x.to(dev), pc, scale.to(dev), shift.to(dev), True)
+    a = ops.conv2d(*args, residual=res.to(dev), tile_cfg=30, workspace=ws, workgroups=wgs)
+    b = ops.conv2d(*args, residual=res.to(dev), tile_cfg=30, workspace=ws, workgroups=wgs)
+    c = ops.conv2d(*args, residual=res.to(dev), tile_cfg=30, workspace=ws, workgroups=wgs)
+    torch.cuda.synchronize()
+    units = B * ((Ho * Wo + 127) // 128) * ((cout + 127) // 128)
+    assert int(ws[:units * 4].view(torch.int32).abs().sum().item()) == 0       # counters left at zero
+    assert torch.equal(a, b) and torch.equal(a, c)
+    direct = ops.conv2d(*args, residual=res.to(dev), tile_cfg=3).cpu().double()
+    e_s, e_d = float((a.cpu().double() - ref).abs().max()), float((direct - ref).abs().max())
+    print("LDS stream-K err %.2e  direct err %.2e  (max|ref| %.2f)" % (e_s, e_d, float(ref.abs().max())))
+    assert e_s < 4 * e_d + 1e-6          # exact float32 arithmetic in a different summation order
+    plain = ops.conv2d(x.to(dev), pc, None, None, False, tile_cfg=30, workspace=ws, workgroups=wgs).cpu().double()
+    assert float((plain - conv).abs().max()) < 4 * e_d + 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,wgs", [(2, 10, 12, 0), (1, 100, 88, 0), (1, 7, 9, 8), (3, 16, 8, 40)])
+def test_deconv_s2_lds_stream_k(dev, B, H, W, wgs):
+    """The four output-parity classes of ConvTranspose2d(256, 128, 3, 2, 1, 1) as one stream-K launch (tile_cfg 30)."""
+    g = torch.Generator().manual_seed(9 + H)
+    x = torch.randn(B, 256, H, W, generator=g)
+    w = torch.randn(256, 128, 3, 3, generator=g) * 0.05
+    scale = torch.rand(128, generator=g) + 0.5
+    shift = torch.randn(128, generator=g) * 0.1
+    res = torch.randn(B, 128, 2 * H, 2 * W, generator=g)
+    ref = torch.relu(F.conv_transpose2d(x.double(), w.double(), stride=2, padding=1, output_padding=1) * scale.double().view(1, -1, 1, 1)
+                     + shift.double().view(1, -1, 1, 1)) + res.double()
+    pc = ops.pack_deconv2d_s2(w.to(dev))
+    ws = ops.conv2d_sk_workspace(B, H, W, 128, 4, dev, wgs)
+    args = (x.to(dev), pc, scale.to(dev), shift.to(dev), True)
+    a = ops.conv2d(*args, residual=res.to(dev), tile_cfg=30, workspace=ws, workgroups=wgs)
+    b = ops.conv2d(*args, residual=res.to(dev), tile_cfg=30, workspace=ws, workgroups=wgs)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    direct = ops.conv2d(*args, residual=res.to(dev), tile_cfg=4).cpu().double()
+    e_s, e_d = float((a.cpu().double() - ref).abs().max()), float((direct - ref).abs().max())
+    print("LDS stream-K deconv err %.2e  direct err %.2e" % (e_s, e_d))
+    assert e_s < 4 * e_d + 1e-6
+
+
 @pytest.mark.parametrize("cfg", [1, 3, 4, 11, 12])
 def test_deconv_s2_with_residual(dev, cfg):
     g = torch.Generator().manual_seed(9)

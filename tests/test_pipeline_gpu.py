@@ -64,7 +64,7 @@ def test_engine_vs_oracle(dev, model, state, batch, seeds, max_voxels):
     print("detections per frame", [len(g["scores"]) for g in got], "candidates", [d["num_candidates"] for d in inter["debug"]])
 
 
-@pytest.mark.parametrize("cfg,wgs", [(22, 0), (23, 0), (22, 224)])
+@pytest.mark.parametrize("cfg,wgs", [(22, 0), (23, 0), (22, 224), (30, 0)])
 def test_engine_with_stream_k_dense_layers_vs_oracle(dev, model, state, cfg, wgs):
     """The configuration bench.py times: the seven 3x3 stride-1 SSFA layers on the stream-K Winograd kernel (what
     engine.autotune() selects on MI355X), eagerly and through a captured graph replayed twice -- same oracle comparison as the
@@ -74,10 +74,15 @@ def test_engine_with_stream_k_dense_layers_vs_oracle(dev, model, state, cfg, wgs
     want, inter = pipeline.run_frames(frames, state, VG["range"], VG["voxel_size"], 5, 16000, anchors, None, return_intermediate=True)
     eng = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, batch_size=2, max_points_per_frame=20480,
                           device=dev)
+    if cfg == 30:  # the other dense layers on the LDS-tiled stream-K kernel (the 3x3 stride-1 ones stay on Winograd stream-K)
+        for name in ("b1.0", "trans_0", "trans_1", "deconv_0", "deconv_1"):
+            eng.tile_cfg[name] = 30
+        cfg = 22
     for name in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):
         eng.tile_cfg[name] = cfg
     eng.sk_workgroups = wgs
-    eng.sk_ws = ops.winograd_sk_workspace(2, 200, 176, 256, dev, 0, cfg - 22)
+    eng.sk_ws = torch.zeros(max(ops.winograd_sk_workspace(2, 200, 176, 256, dev, 0, cfg - 22).numel(),
+                                ops.conv2d_sk_workspace(2, 200, 176, 256, 4, dev, 0).numel()), dtype=torch.uint8, device=dev)
     eng.set_points([torch.from_numpy(f).to(dev) for f in frames])
     eng.enqueue()
     got = eng.results()
