@@ -29,7 +29,7 @@ g = torch.Generator().manual_seed(0)
 layers = [("b1.0 3x3 s2 128->256 @200x176", "conv", 128, 256, 3, 2, 200, 176, (0, 1, 3, 11, 13)),
           ("trans_0 1x1 128->128 @200x176", "conv", 128, 128, 1, 1, 200, 176, (3, 4)),
           ("trans_1 1x1 256->256 @100x88", "conv", 256, 256, 1, 1, 100, 88, (3, 4)),
-          ("deconv 3x3 s2 256->128 @100x88", "deconv", 256, 128, 3, 2, 100, 88, (4, 11))]
+          ("deconv 3x3 s2 256->128 @100x88", "deconv", 256, 128, 3, 2, 100, 88, (4, 40, 41, 42))]
 if os.environ.get("CSK_LAYERS"):
     layers = [layers[int(i)] for i in os.environ["CSK_LAYERS"].split(",")]
 for name, kind, ci, co, k, st, H, W, cfgs in layers:

@@ -176,28 +176,44 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
 #undef SESSD_LOAD
 #undef SESSD_MMA
 
-  // epilogue. D layout (32x32): column = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*h (cout)
-  const size_t out_plane = (size_t)A.hout * A.wout;
-  float* outb = A.out + (size_t)b * A.cout * out_plane;
-  const float* resb = A.residual ? A.residual + (size_t)b * A.cout * out_plane : nullptr;
+  // epilogue. D layout (32x32): column = lane&31 (pixel), row = (r&3) + 8*(r>>2) + 4*h (cout).
+  // Branch-free: scale / shift / residual / output go through buffer resources and an element outside the image or beyond cout
+  // gets an out-of-range offset (loads return 0, stores are dropped), so that the 48 loads of a 32x32 tile are in flight together.
+  // (With `if (co < cout)` / `if (residual)` around each element hipcc emitted load, s_waitcnt vmcnt(0), load, s_waitcnt vmcnt(0),
+  // store per element: 32 serialised memory round trips per tile, each also waiting for the previous store.)
+  const unsigned oplane4 = (unsigned)(A.hout * A.wout) * 4u;
+  const size_t boff = (size_t)b * A.cout * (size_t)(A.hout * A.wout);
+  const unsigned obytes = (unsigned)A.cout * oplane4;
+  const rsrc_t orr = make_rsrc(A.out + boff, obytes);
+  const rsrc_t rr = make_rsrc(A.residual ? A.residual + boff : A.out, A.residual ? obytes : 0u);
+  const rsrc_t scr = make_rsrc(A.scale ? A.scale : A.out, A.scale ? (unsigned)A.cout * 4u : 0u);
+  const rsrc_t shr = make_rsrc(A.shift ? A.shift : A.out, A.shift ? (unsigned)A.cout * 4u : 0u);
 #pragma unroll
   for (int q = 0; q < PT; ++q) {
     const int p = p_base + q * 32 + j;
-    if (p >= npix) continue;
-    const int y = p / A.wt, x = p - y * A.wt;
-    const size_t opix = (size_t)(y * A.out_mul + A.out_py) * A.wout + (x * A.out_mul + A.out_px);
+    const bool live = p < npix;
+    const int y = live ? p / A.wt : 0, x = live ? p - (p / A.wt) * A.wt : 0;
+    const unsigned pix4 = (unsigned)((y * A.out_mul + A.out_py) * A.wout + (x * A.out_mul + A.out_px)) * 4u;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
+      const int co0 = m_base + c * 32 + 4 * h;
+      const unsigned vbase = (unsigned)co0 * oplane4 + pix4;
+      float scv[16], shv[16], rv[16];
+      unsigned vo[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int co = m_base + c * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co >= A.cout) continue;
-        float v = acc[c][q][r];
-        const float sc = A.scale ? A.scale[co] : 1.f, sh = A.shift ? A.shift[co] : 0.f;
-        v = fmaf(v, sc, sh);
+        const int k = (r & 3) + 8 * (r >> 2);
+        scv[r] = bufload(scr, (unsigned)(co0 + k) * 4u, 0);
+        shv[r] = bufload(shr, (unsigned)(co0 + k) * 4u, 0);
+        vo[r] = (live && co0 + k < A.cout) ? vbase + (unsigned)k * oplane4 : SESSD_OOB;
+        rv[r] = bufload(rr, vo[r], 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float v = fmaf(acc[c][q][r], A.scale ? scv[r] : 1.f, shv[r]);
         if (A.relu) v = fmaxf(v, 0.f);
-        if (resb) v += resb[(size_t)co * out_plane + opix];
-        outb[(size_t)co * out_plane + opix] = v;
+        if (A.residual) v += rv[r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, (int)vo[r], 0, 0);
       }
     }
   }
@@ -632,6 +648,9 @@ int dispatch_tile(const ConvArgs* A, int nconv, int batch, int tile_cfg, hipStre
 
 // Fill one ConvArgs; few-tap convolutions are regrouped into NTAPS_eff "virtual taps" (several cin pairs per
 // k-step) so that every k-step issues a full batch of loads ahead of its MFMAs. Returns the effective tap count.
+// the epilogue addresses a batch element's output through a 32-bit buffer offset
+inline bool out_fits(int cout, int hout, int wout) { return (long long)cout * hout * wout * 4 < 0x7fffffffLL; }
+
 int fill_args(ConvArgs& A, const float* in, int cin, int hin, int win, const float* wpk, int ntaps, const int* dy,
               const int* dx, int in_mul, int tile_h, int tile_w, float* out, int cout, int hout, int wout, int out_mul,
               int py, int px, const float* scale, const float* shift, int relu, const float* residual) {
@@ -665,7 +684,7 @@ int sessd_conv2d_mfma(const float* in, int batch, int cin, int hin, int win, con
                       const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out, int cout,
                       int hout, int wout, int out_mul, int out_py, int out_px, const float* scale, const float* shift,
                       int relu, const float* residual, int tile_cfg, hipStream_t stream) {
-  if (cin % 2 || ntaps < 1 || ntaps > 9 || batch < 1 || cout < 1) return SESSD_EINVAL;
+  if (cin % 2 || ntaps < 1 || ntaps > 9 || batch < 1 || cout < 1 || !out_fits(cout, hout, wout)) return SESSD_EINVAL;
   ConvArgs A;
   const int eff = fill_args(A, in, cin, hin, win, wpk, ntaps, taps_dy, taps_dx, in_mul, tile_h, tile_w, out, cout, hout,
                             wout, out_mul, out_py, out_px, scale, shift, relu, residual);
@@ -809,6 +828,13 @@ int sessd_conv3x3_winograd_pack(const float* w, long long out_stride, long long 
   return SESSD_OK;
 }
 
+// tile_cfg 40 .. 42: both px classes of a row parity in every wave, whole-line stores (dense_deconv_pair.hip)
+}  // extern "C"
+int sessd_deconv_pair_launch(const float* in, int batch, int cin, int hin, int win, const float* const* wpk4, float* out, int cout,
+                             const float* scale, const float* shift, int relu, const float* residual, int variant,
+                             hipStream_t stream);
+extern "C" {
+
 // ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
 // classes. wpk4[c], ntaps4[c], taps_dy4/taps_dx4 (4 x 4 ints, row c = class c) in class order (py,px) =
 // (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps; input (B,cin,hin,win) -> output (B,cout,2*hin,2*win).
@@ -816,7 +842,19 @@ int sessd_deconv2d_s2_mfma(const float* in, int batch, int cin, int hin, int win
                            const int* ntaps4, const int* taps_dy4, const int* taps_dx4, float* out, int cout,
                            const float* scale, const float* shift, int relu, const float* residual, int tile_cfg,
                            hipStream_t stream) {
-  if (cin % 8 || batch < 1 || cout < 1) return SESSD_EINVAL;
+  if (cin % 8 || batch < 1 || cout < 1 || !out_fits(cout, 2 * hin, 2 * win)) return SESSD_EINVAL;
+  if (tile_cfg >= 40 && tile_cfg <= 42) {
+    // the paired kernel hard-codes the class tap tables of ops.pack_deconv2d_s2: refuse anything else
+    static const int nt[4] = {1, 2, 2, 4};
+    static const int dy[16] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 0, 0, 0, 1, 1, 0, 0};
+    static const int dx[16] = {0, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 1, 0, 1, 0};
+    for (int c = 0; c < 4; ++c) {
+      if (ntaps4[c] != nt[c]) return SESSD_EINVAL;
+      for (int t = 0; t < nt[c]; ++t)
+        if (taps_dy4[4 * c + t] != dy[4 * c + t] || taps_dx4[4 * c + t] != dx[4 * c + t]) return SESSD_EINVAL;
+    }
+    return sessd_deconv_pair_launch(in, batch, cin, hin, win, wpk4, out, cout, scale, shift, relu, residual, tile_cfg - 40, stream);
+  }
   ConvArgs A[4];
   for (int c = 0; c < 4; ++c) {
     const int eff = fill_args(A[c], in, cin, hin, win, wpk4[c], ntaps4[c], taps_dy4 + 4 * c, taps_dx4 + 4 * c, 1, hin, win,

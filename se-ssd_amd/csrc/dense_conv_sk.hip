@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
           for (int e = 0; e < 16; ++e) {
             float v = fmaf(acc[a][q][e], e_scale ? scv[e] : 1.f, shv[e]);
             if (e_relu) v = fmaxf(v, 0.f);
-            v += rv[e];
+            if (e_res) v += rv[e];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), orr, (int)vo[e], 0, 0);
           }
         }

@@ -97,6 +97,21 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   f32x4 acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // what only the epilogue needs is fetched NOW: loaded at their use, the BatchNorm constants (and the output coordinates of the
+  // dense scatter) cost one more memory round trip at the end of a kernel that lasts 5 .. 20 us
+  float scv[NTILE], shv[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int co = (tbase + t) * 16 + i;
+    scv[t] = scale ? scale[co] : 1.f;
+    shv[t] = shift ? shift[co] : 0.f;
+  }
+  int4 ocoord[DENSE_OUT ? 4 : 1];
+  if constexpr (DENSE_OUT) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      ocoord[r] = *reinterpret_cast<const int4*>(out_indices + (size_t)min(tile * 16 + kq * 4 + r, n - 1) * 4);
+  }
 
   // stage the tile's neighbour table: lane (i, kq) fetches offsets kq, kq+4, ... of site i (64-byte segments).
   // lanes of the last tile whose site is >= n read the tile's first site instead (their results are discarded below):
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) {
     const int co = (tbase + t) * 16 + i;
-    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+    const float sc = scv[t], sh = shv[t];
 #pragma unroll
     for (int r = 0; r < (KSPLIT ? 1 : 4); ++r) {
       const int site = tile * 16 + kq * 4 + (KSPLIT ? wv : r);
@@ -226,7 +241,7 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
       if (relu) v = fmaxf(v, 0.f);
       if (DENSE_OUT) {
         // .dense() + view(N, C*D, H, W): channel = c*D + z  (scn.py:184-187)
-        const int4 c = *reinterpret_cast<const int4*>(out_indices + (size_t)site * 4);
+        const int4 c = ocoord[DENSE_OUT ? r : 0];
         dense_out[(((size_t)c.x * COUT + co) * dD + c.y) * dH * dW + (size_t)c.z * dW + c.w] = v;
       } else {
         out_feat[(size_t)site * COUT + co] = v;
@@ -281,6 +296,13 @@ __global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __
     if (q == wv) mine = m;
   }
   mine = __builtin_amdgcn_readfirstlane(mine);
+  float scv[NTILE], shv[NTILE];  // fetched now, used by the epilogue (see sparse_conv_kernel)
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int co = (tbase + t) * 16 + i;
+    scv[t] = scale ? scale[co] : 1.f;
+    shv[t] = shift ? shift[co] : 0.f;
+  }
   f32x4 acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -367,7 +389,7 @@ __global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) {
     const int co = (tbase + t) * 16 + i;
-    const float sc = scale ? scale[co] : 1.f, sh = shift ? shift[co] : 0.f;
+    const float sc = scv[t], sh = shv[t];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int site = tile * 16 + kq * 4 + r;

@@ -355,6 +355,8 @@ class InferenceEngine:
                 if self.sk_ws is None or self.sk_ws.numel() < need:
                     self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=x.device)
                 cands.append(30)
+            if pc.kind == "deconv":
+                cands += [40, 41, 42]  # both px classes of a row parity in every wave: whole-line stores, shared input loads (same bits)
             for cfg in cands:
                 if pc.cout <= 32 and cfg != 4:
                     continue

@@ -164,6 +164,27 @@ def test_deconv_s2_lds_stream_k(dev, B, H, W, wgs):
     assert e_s < 4 * e_d + 1e-6
 
 
+@pytest.mark.parametrize("B,H,W,cin,cout", [(2, 10, 12, 256, 128), (1, 100, 88, 256, 128), (1, 7, 9, 16, 40), (3, 16, 8, 64, 22)])
+@pytest.mark.parametrize("cfg", [40, 41, 42])
+def test_deconv_s2_paired_classes_bit_identical(dev, cfg, B, H, W, cin, cout):
+    """tile_cfg 40 .. 42 (csrc/dense_deconv_pair.hip; three workgroup shapes): both px classes of a row parity in every wave, 8-byte stores. Per class the
+    same fmaf chain as the class-per-workgroup launch: equal bits, with and without BatchNorm / ReLU / residual."""
+    g = torch.Generator().manual_seed(cfg + H)
+    x = torch.randn(B, cin, H, W, generator=g).to(dev)
+    w = (torch.randn(cin, cout, 3, 3, generator=g) * 0.05).to(dev)
+    scale, shift = (torch.rand(cout, generator=g) + 0.5).to(dev), (torch.randn(cout, generator=g) * 0.1).to(dev)
+    res = torch.randn(B, cout, 2 * H, 2 * W, generator=g).to(dev)
+    pc = ops.pack_deconv2d_s2(w)
+    a = ops.conv2d(x, pc, scale, shift, True, residual=res, tile_cfg=cfg)
+    b = ops.conv2d(x, pc, scale, shift, True, residual=res, tile_cfg=4)
+    assert torch.equal(a, b)
+    a = ops.conv2d(x, pc, None, None, False, tile_cfg=cfg)
+    b = ops.conv2d(x, pc, None, None, False, tile_cfg=4)
+    assert torch.equal(a, b)
+    ref = F.conv_transpose2d(x.cpu().double(), w.cpu().double(), stride=2, padding=1, output_padding=1)
+    assert float((a.cpu().double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
+
+
 @pytest.mark.parametrize("cfg", [1, 3, 4, 11, 12])
 def test_deconv_s2_with_residual(dev, cfg):
     g = torch.Generator().manual_seed(9)
