@@ -91,8 +91,7 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   if (tile * 16 >= n) return;             // scalar branch; without KSPLIT every wave is independent (no workgroup barrier
                                           // below), with it the four waves of a workgroup leave together
   const int i = lane & 15, kq = lane >> 4;
-  const uint32_t tmask_all = __builtin_amdgcn_readfirstlane(tile_mask[tile]);
-  const uint32_t tmask = KSPLIT ? (tmask_all & (0x11111111u << wv)) : tmask_all;
+  const uint32_t tmask_raw = tile_mask[tile];  // used (readfirstlane) after the neighbour rows below have been requested
 
   f32x4 acc[NTILE];
 #pragma unroll
@@ -122,11 +121,15 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int k = p * 4 + kq;
-      r[p] = (k < kv && ((tmask >> k) & 1u)) ? nb[(size_t)k * n_cap] : -1;
+      // every (offset, site < n) entry of the rulebook is written (-1 = no neighbour): the fetch does not wait for the tile mask
+      r[p] = (k < kv && (!KSPLIT || (k & 3) == wv)) ? nb[(size_t)k * n_cap] : -1;
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int p = 0; p < 8; ++p) s_nbr[wv][p * 4 + kq][i] = r[p];
   }
+  const uint32_t tmask_all = __builtin_amdgcn_readfirstlane(tmask_raw);
+  const uint32_t tmask = KSPLIT ? (tmask_all & (0x11111111u << wv)) : tmask_all;
   __builtin_amdgcn_wave_barrier();
 
   // Software pipeline over the ACTIVE offsets of this tile (bits of tmask). All operand loads are unconditional
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
       const int k = p * 4 + kq;
-      r[p] = (k < kv && ((mine >> k) & 1u)) ? nb[(size_t)k * n_cap] : -1;
+      r[p] = (k < kv && live) ? nb[(size_t)k * n_cap] : -1;  // does not wait for the tile masks (see sparse_conv_kernel)
     }
 #pragma unroll
     for (int p = 0; p < 8; ++p) s_nbr[wv][p * 4 + kq][i] = r[p];
