@@ -378,6 +378,13 @@ int sessd_deconv2d_s2_mfma(const float* in, int batch, int cin, int hin, int win
 int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
                     float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,
                     float* out, sessd_stream_t stream);
+/* The same tail fused with the four 1x1 heads (mg_head_sessd.py:217-230): head_w (nout, channels) row-major = the concatenated
+ * conv_box | conv_cls | conv_dir | conv_iou weights, head_b (nout) or NULL, head_out (B, nout, num_pixels) planar; the blended
+ * value of every channel goes into the head sums while it is in a register, `out` (the SSFA output) is written only when not
+ * NULL. nout == 22, channels == 128 (the SSFA neck) or 64. */
+int sessd_ssfa_fuse_head(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0, float bn_shift0,
+                         float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels, float* out,
+                         const float* head_w, const float* head_b, int nout, float* head_out, sessd_stream_t stream);
 
 /* ------------------------------------------------------------------ predict / post-processing (a11-a14)
  * replaces det3d/models/bbox_heads/mg_head_sessd.py:893-1057 (MultiGroupHead.predict / get_task_detections),

@@ -612,6 +612,90 @@ __global__ __launch_bounds__(256) void ssfa_fuse_kernel(const float* __restrict_
   }
 }
 
+// The same tail FUSED with the 1x1 heads of the detection head (mg_head_sessd.py:217-230: box | cls | dir | iou = NOUT channels,
+// bias, no activation): the blended value of a channel is multiplied into the NOUT head sums of its pixel while it is in a
+// register, so the SSFA output (18 MB per frame) is neither written nor read back and one launch disappears. Thread = (pixel,
+// channel quarter) as above; the head weights sit in LDS (all lanes of a wave read the same address: broadcast); the four
+// quarter sums of a (pixel, head channel) meet in LDS and are added in quarter order. `out` may be null (inference).
+template <int NOUT, int CPER>
+__global__ __launch_bounds__(256, 2) void ssfa_fuse_head_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                              const float* __restrict__ w0, const float* __restrict__ w1,
+                                                              float s0, float t0, float s1, float t1, int npix,
+                                                              float* __restrict__ out, const float* __restrict__ hw,
+                                                              const float* __restrict__ hb, float* __restrict__ hout) {
+  constexpr int C = 4 * CPER;
+  __shared__ float part[2][4][64];
+  __shared__ __attribute__((aligned(16))) float s_hw[NOUT * C];  // head weights
+  __shared__ float s_acc[4 * NOUT * 64];                          // quarter sums of the head channels
+  const int px = threadIdx.x & 63, cq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int p = blockIdx.x * 64 + px;
+  const int b = blockIdx.y;
+  const int c0 = cq * CPER;
+  const bool live = p < npix;
+  // buffer resources over this batch element's maps: lane offset = pixel, SGPR offset = channel plane (no 64-bit address per
+  // channel in VGPRs); a dead lane reads / writes out of range
+  const unsigned plane4 = (unsigned)npix * 4u, mbytes = (unsigned)C * plane4;
+  const size_t boff = (size_t)b * C * npix;
+  const rsrc_t r0 = make_rsrc(x0 + boff, mbytes), r1 = make_rsrc(x1 + boff, mbytes);
+  const rsrc_t ro = make_rsrc(out ? out + boff : x0, out ? mbytes : 0u);
+  const unsigned vp = live ? (unsigned)p * 4u : SESSD_OOB;
+  // this thread's CPER channels of both maps: fetched once (all loads in flight together), used by the two dots and by the blend
+  float v0[CPER], v1[CPER];
+#pragma unroll
+  for (int c = 0; c < CPER; ++c) {
+    v0[c] = bufload(r0, vp, (unsigned)(c0 + c) * plane4);
+    v1[c] = bufload(r1, vp, (unsigned)(c0 + c) * plane4);
+  }
+  for (int k = threadIdx.x; k < NOUT * C; k += 256) s_hw[k] = hw[k];
+  float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPER; ++c) {
+    a0 = fmaf(v0[c], w0[c0 + c], a0);
+    a1 = fmaf(v1[c], w1[c0 + c], a1);
+  }
+  part[0][cq][px] = a0;
+  part[1][cq][px] = a1;
+  __syncthreads();
+  a0 = ((part[0][0][px] + part[0][1][px]) + part[0][2][px]) + part[0][3][px];
+  a1 = ((part[1][0][px] + part[1][1][px]) + part[1][2][px]) + part[1][3][px];
+  a0 = fmaf(a0, s0, t0);
+  a1 = fmaf(a1, s1, t1);
+  const float m = fmaxf(a0, a1);
+  const float e0 = expf(a0 - m), e1 = expf(a1 - m);
+  const float inv = 1.f / (e0 + e1);
+  const float p0 = e0 * inv, p1 = e1 * inv;
+  float acc[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) acc[o] = 0.f;
+#pragma unroll
+  for (int c = 0; c < CPER; c += 4) {
+    float bl[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      bl[e] = v0[c + e] * p0 + v1[c + e] * p1;
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bl[e]), ro, (int)vp, (int)((unsigned)(c0 + c + e) * plane4), 0);
+    }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) {
+      const float4 w = *reinterpret_cast<const float4*>(s_hw + o * C + c0 + c);
+      acc[o] = fmaf(bl[0], w.x, acc[o]);
+      acc[o] = fmaf(bl[1], w.y, acc[o]);
+      acc[o] = fmaf(bl[2], w.z, acc[o]);
+      acc[o] = fmaf(bl[3], w.w, acc[o]);
+    }
+    __builtin_amdgcn_sched_barrier(0);  // fully unrolled, hipcc would hoist all 8 x NOUT weight reads: 700 registers
+  }
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) s_acc[(cq * NOUT + o) * 64 + px] = acc[o];
+  __syncthreads();
+  if (!live) return;
+  for (int o = cq; o < NOUT; o += 4) {
+    const float v = ((s_acc[(0 * NOUT + o) * 64 + px] + s_acc[(1 * NOUT + o) * 64 + px]) + s_acc[(2 * NOUT + o) * 64 + px]) +
+                    s_acc[(3 * NOUT + o) * 64 + px];
+    hout[((size_t)b * NOUT + o) * npix + p] = v + (hb ? hb[o] : 0.f);
+  }
+}
+
 template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
 int launch_conv(const ConvArgs* A, int nconv, int batch, hipStream_t stream) {
   const int npix = A[0].ht * A[0].wt;
@@ -873,6 +957,26 @@ int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const flo
   if (channels % 4) return SESSD_EINVAL;
   SESSD_LAUNCH(ssfa_fuse_kernel, dim3(sessd_divup(num_pixels, 64), batch), dim3(256), 0, stream, x0, x1, w0, w1,
                      bn_scale0, bn_shift0, bn_scale1, bn_shift1, channels, num_pixels, out);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+
+// rpn_v1.py:227-233 + mg_head_sessd.py:217-230 in one launch: the SSFA fusion tail with the four 1x1 heads applied to its result
+// while it is in registers. head_w (nout, channels) row-major = the concatenated conv weights, head_b (nout) or null,
+// head_out (B, nout, num_pixels) planar. out (B, C, num_pixels) receives the SSFA output when not null. nout == 22 (the
+// single-task car head: 14 box + 2 cls + 4 dir + 2 iou), channels 128 (the SSFA neck) or 64.
+int sessd_ssfa_fuse_head(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0, float bn_shift0,
+                         float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels, float* out,
+                         const float* head_w, const float* head_b, int nout, float* head_out, hipStream_t stream) {
+  if (batch < 1 || (channels != 128 && channels != 64) || num_pixels < 1 || nout != 22) return SESSD_EINVAL;
+  const dim3 grid(sessd_divup(num_pixels, 64), batch);
+  if (channels == 128)
+    SESSD_LAUNCH((ssfa_fuse_head_kernel<22, 32>), grid, dim3(256), 0, stream, x0, x1, w0, w1, bn_scale0, bn_shift0, bn_scale1,
+                 bn_shift1, num_pixels, out, head_w, head_b, head_out);
+  else
+    SESSD_LAUNCH((ssfa_fuse_head_kernel<22, 16>), grid, dim3(256), 0, stream, x0, x1, w0, w1, bn_scale0, bn_shift0, bn_scale1,
+                 bn_shift1, num_pixels, out, head_w, head_b, head_out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -64,6 +64,7 @@ SIGNATURES = {
                               i32, vp, vp, sz, i32, vp]),
     "sessd_deconv2d_s2_mfma": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
     "sessd_ssfa_fuse": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp]),
+    "sessd_ssfa_fuse_head": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "sessd_predict_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "sessd_predict": (i32, [vp, i32, i32, vp, i32, vp, f32, i32, i32, f32, vp, f32, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_di_nms_workspace_bytes": (sz, [i32]),

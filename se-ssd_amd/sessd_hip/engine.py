@@ -93,6 +93,8 @@ class DensePlan:
                         head_task.conv_iou.bias], 0).detach().to(device).float().contiguous()
         assert hw.shape[0] == 22, "engine supports the single-task car head (14+2+4+2 channels)"
         self.head = (ops.pack_conv2d(hw), None, hb)
+        self.head_w = hw.reshape(22, -1).float().contiguous()  # row-major (22, C): the fused SSFA-tail + heads launch
+        self.head_b = hb
 
 
 class InferenceEngine:
@@ -233,6 +235,8 @@ class InferenceEngine:
         self._marks = None
         self.tile_cfg = {}
         self.sk_ws = None  # workspace of the stream-K launches, tile_cfg 22 / 23 / 30 (autotune allocates it)
+        self.fuse_head = True   # SSFA fusion tail + the 1x1 heads in one launch (the SSFA output stays in registers)
+        self.keep_ssfa = False  # with fuse_head: also write the SSFA output to self.t["out"] (tests compare it with the oracle)
         self.allow_streamk = True  # autotune may choose the stream-K kernels (Winograd: tile_cfg 22 / 23; LDS-tiled direct: 30)
         self.allow_offset_split = True  # autotune may choose the offset-split sparse conv (see sessd_sparse_conv)
         self.sk_workgroups = 0  # persistent workgroups of those launches (0 = one or two per CU; fewer leaves CUs to a second stream)
@@ -449,9 +453,19 @@ class InferenceEngine:
         mid1 = self._conv(tr1, d.deconv_1, t["mid1"], name="deconv_1")
         o0 = self._conv(mid0, d.conv_0, t["o0"], name="conv_0")
         o1 = self._conv(mid1, d.conv_1, t["o1"], name="conv_1")
-        ops.ssfa_fuse(o0, o1, d.w0, d.w1, *d.wbn, out=t["out"])
-        # ---- heads (a10) + predict (a11-a14)
-        self._conv(t["out"], d.head, self.head.view(B, 22, self.H, self.W), relu=False, name="head")
+        # ---- SSFA tail + heads (a10): one launch; the two-launch form stays for channel counts the fused kernel does not take
+        if self.fuse_head and d.head_w.shape[1] in (64, 128) and self._tuning is None:
+            if self._kmarks is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.ssfa_fuse_head(o0, o1, d.w0, d.w1, *d.wbn, d.head_w, d.head_b, head_out=self.head,
+                               out=t["out"] if self.keep_ssfa else None)
+            if self._kmarks is not None:
+                e1.record()
+                self._kmarks.append(("ssfa_tail+head", e0, e1))
+        else:
+            ops.ssfa_fuse(o0, o1, d.w0, d.w1, *d.wbn, out=t["out"])
+            self._conv(t["out"], d.head, self.head.view(B, 22, self.H, self.W), relu=False, name="head")
         self._mark("ssfa_head")
         check(lib.sessd_predict(self.head.data_ptr(), B, self.H * self.W, self.anchors.data_ptr(), 0,
                                 0 if self.frustum is None else self.frustum.data_ptr(), self.score_thresh, self.pre_max,

@@ -1137,6 +1137,22 @@ def ssfa_fuse(x0, x1, w0, w1, s0, t0, s1, t1, out=None):
     return out
 
 
+def ssfa_fuse_head(x0, x1, w0, w1, s0, t0, s1, t1, head_w, head_b, head_out=None, out=None):
+    """ssfa_fuse + the 1x1 heads in one launch: head_w (22, C) row-major, head_b (22) or None -> head_out (B, 22, H*W) planar.
+    `out` (B, C, H, W): optional buffer that receives the SSFA output (not written when None)."""
+    _req(x0, torch.float32, "x0")
+    _req(x1, torch.float32, "x1")
+    _req(head_w, torch.float32, "head_w")
+    B, C, H, W = x0.shape
+    nout = head_w.shape[0]
+    if head_out is None:
+        head_out = torch.empty((B, nout, H * W), dtype=torch.float32, device=x0.device)
+    check(lib.sessd_ssfa_fuse_head(x0.data_ptr(), x1.data_ptr(), w0.data_ptr(), w1.data_ptr(), float(s0), float(t0), float(s1),
+                                   float(t1), B, C, H * W, _p(out), head_w.data_ptr(), _p(head_b), nout, head_out.data_ptr(),
+                                   _stream()), "ssfa_fuse_head")
+    return head_out
+
+
 # ------------------------------------------------------------------ predict / post-processing
 def predict(head, anchors, frustum=None, score_thresh=0.3, pre_max=1000, post_max=100, nms_thresh=0.01,
             post_center_range=(0, -40.0, -5.0, 70.4, 40.0, 5.0), direction_offset=0.0, out=None):

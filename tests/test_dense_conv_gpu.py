@@ -237,6 +237,33 @@ def test_ssfa_fuse(dev):
     _close(got, ref, 1e-5)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(1, 128, 200, 176), (2, 128, 9, 7), (3, 64, 5, 13)])
+def test_ssfa_fuse_with_heads(dev, B, C, H, W):
+    """sessd_ssfa_fuse_head: the SSFA fusion tail (rpn_v1.py:227-233) and the four 1x1 heads (mg_head_sessd.py:217-230) in one launch
+    against the two-launch form and a float64 restatement; with and without the optional SSFA output."""
+    g = torch.Generator().manual_seed(B + C)
+    x0, x1 = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    w0, w1 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    s0, t0, s1, t1 = 1.3, -0.2, 0.7, 0.1
+    hw, hb = torch.randn(22, C, generator=g) * 0.05, torch.randn(22, generator=g) * 0.1
+    a = (x0.double() * w0.double().view(1, -1, 1, 1)).sum(1) * s0 + t0
+    b = (x1.double() * w1.double().view(1, -1, 1, 1)).sum(1) * s1 + t1
+    p = torch.softmax(torch.stack([a, b], 1), 1)
+    ssfa = x0.double() * p[:, 0:1] + x1.double() * p[:, 1:2]
+    head = torch.einsum("oc,bchw->bohw", hw.double(), ssfa) + hb.double().view(1, -1, 1, 1)
+    d = lambda t: t.to(dev)
+    out = torch.full((B, C, H, W), float("nan"), device=dev)
+    got = ops.ssfa_fuse_head(d(x0), d(x1), d(w0), d(w1), s0, t0, s1, t1, d(hw), d(hb), out=out)
+    assert float((out.cpu().double() - ssfa).abs().max()) < 1e-5 * max(1.0, float(ssfa.abs().max()))
+    assert float((got.cpu().double().view(B, 22, H, W) - head).abs().max()) < 2e-5 * max(1.0, float(head.abs().max()))
+    again = ops.ssfa_fuse_head(d(x0), d(x1), d(w0), d(w1), s0, t0, s1, t1, d(hw), d(hb))  # no SSFA output: same head bits
+    assert torch.equal(got, again)
+    two = ops.ssfa_fuse(d(x0), d(x1), d(w0), d(w1), s0, t0, s1, t1)
+    assert float((two - out).abs().max()) < 1e-6 * max(1.0, float(ssfa.abs().max()))   # the same blend (fma contraction may differ)
+    nob = ops.ssfa_fuse_head(d(x0), d(x1), d(w0), d(w1), s0, t0, s1, t1, d(hw), None)
+    assert float((nob.cpu().double().view(B, 22, H, W) - (head - hb.double().view(1, -1, 1, 1))).abs().max()) < 2e-5 * max(1.0, float(head.abs().max()))
+
+
 def test_full_size_layer_bench(dev):
     """KITTI-size 3x3 128->128 @200x176: correctness on a strided sample + a timing printout per tile cfg."""
     g = torch.Generator().manual_seed(0)

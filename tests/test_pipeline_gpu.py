@@ -47,6 +47,7 @@ def test_engine_vs_oracle(dev, model, state, batch, seeds, max_voxels):
                                       [fr] * batch, return_intermediate=True)
     eng = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, max_voxels, configs.TEST_CFG, batch_size=batch,
                           max_points_per_frame=20480, device=dev, use_frustum=True)
+    eng.keep_ssfa = True  # the fused tail + heads launch writes the SSFA output only on request
     eng.set_points([torch.from_numpy(f).to(dev) for f in frames], torch.from_numpy(np.stack([fr] * batch)).to(dev))
     eng.enqueue()
     got = eng.results()
@@ -83,6 +84,7 @@ def test_engine_with_stream_k_dense_layers_vs_oracle(dev, model, state, cfg, wgs
     eng.sk_workgroups = wgs
     eng.sk_ws = torch.zeros(max(ops.winograd_sk_workspace(2, 200, 176, 256, dev, 0, cfg - 22).numel(),
                                 ops.conv2d_sk_workspace(2, 200, 176, 256, 4, dev, 0).numel()), dtype=torch.uint8, device=dev)
+    eng.keep_ssfa = True  # the fused tail + heads launch writes the SSFA output only on request
     eng.set_points([torch.from_numpy(f).to(dev) for f in frames])
     eng.enqueue()
     got = eng.results()
