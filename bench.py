@@ -222,21 +222,28 @@ def main():
             log("dense tile_cfg:", {k: v for k, v in eng.tile_cfg.items()})
             eng.set_points(batch_of(0))
             lt = eng.dense_layer_times(reps=20)
-            kms = sum(lt[nm] for nm in names) / len(names)
-            flops = CONV_FLOPS * args.batch
+            # conv_0 + conv_1 may run as ONE launch of twice the work (engine.merge_branch_convs): per-launch figures are averages
+            # over the launches that carry the seven layers
+            times = [lt[nm] for nm in names if nm in lt] + ([lt["conv_0+conv_1"]] if "conv_0+conv_1" in lt else [])
+            nlayers = sum(1 for nm in names if nm in lt) + (2 if "conv_0+conv_1" in lt else 0)
+            assert nlayers == len(names)
+            kms = sum(times) / len(times)
+            flops = CONV_FLOPS * args.batch * nlayers / len(times)
             ach = flops / (kms * 1e-3) / 1e12
             log("roofline kernel: %.3f ms per launch in sequence" % kms)
             kname = (("conv3x3s1_winograd_sk_kernel / conv3x3s1_winograd_kernel (fused Winograd F(2x2,3x3) on f32 MFMA; %d of the 7 "
                       "launches are the stream-K kernel, as the per-layer autotune chose)" % streamk) if wino
                      else "conv2d_mfma_kernel<9 taps> (direct implicit GEMM on f32 MFMA)")
             exe = ach * (16.0 / 36.0 if wino else 1.0)  # Winograd F(2x2,3x3) multiplies 16 of the 36 products of direct convolution
-            out["roofline"] = {"bound": "mfma", "kernel": kname + ": Conv2d 3x3 128->128 @200x176 (5 launches per frame) and "
-                               "256->256 @100x88 (2 launches, same FLOPs); the seven are 72.6 of the frame's 90.8 dense GFLOP",
+            out["roofline"] = {"bound": "mfma", "kernel": kname + ": Conv2d 3x3 128->128 @200x176 (5 layers per frame%s) and "
+                               "256->256 @100x88 (2 launches, same FLOPs per layer); the seven layers are 72.6 of the frame's 90.8 "
+                               "dense GFLOP" % ("; conv_0 and conv_1 as one launch of two weight sets: %d launches" % len(times)
+                                                if "conv_0+conv_1" in lt else ""),
                                "achieved": exe, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": exe / F32_MFMA_PEAK_TFLOPS,
                                "frac_definition": "EXECUTED matrix-core FLOPs (what SQ_INSTS_MFMA counts: 16/36 of the direct-"
                                                   "convolution count for the Winograd kernel) / launch time / dense f32 MFMA peak",
                                "avg_launch_ms": kms,
-                               "avg_launch_source": "HIP events before / after each of the kernel's 7 launches inside 20 whole frames "
+                               "avg_launch_source": "HIP events before / after each of the kernel's %d launches inside 20 whole frames " % len(times) +
                                                     "(eager enqueue; same stream as the kernels; one frame in flight, the same "
                                                     "launch configuration as the timed region unless --sk-workgroups says otherwise)",
                                "dense_launch_ms": {k: round(v, 5) for k, v in lt.items()},

@@ -349,6 +349,12 @@ size_t sessd_conv3x3_winograd_sk_workspace_bytes(int batch, int h, int w, int co
 int sessd_conv3x3_winograd_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
                               const float* scale, const float* shift, int relu, const float* residual, void* workspace,
                               size_t workspace_bytes, int shape, int workgroups, sessd_stream_t stream);
+/* Several layers of ONE shape in one launch (conv_0 / conv_1 of the SSFA neck, rpn_v1.py:201-210): the batch dimension is nsets
+ * consecutive groups of batch / nsets elements, group s convolved with weight set s (upk = nsets packings back to back, scale /
+ * shift = nsets x cout): one round list, one pipeline fill and one tail instead of nsets. nsets == 1 is the call above. */
+int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int cin, int h, int w, const float* upk, float* out,
+                                   int cout, const float* scale, const float* shift, int relu, const float* residual,
+                                   void* workspace, size_t workspace_bytes, int shape, int workgroups, sessd_stream_t stream);
 /* The convolutions that are NOT 3x3 stride 1 (stride-2 3x3, 1x1, the four output-parity classes of the stride-2 transposed conv;
  * rpn_v1.py:150-210) as an LDS-tiled implicit GEMM, stream-K over `workgroups` persistent workgroups (a multiple of 8, 0 = one
  * per CU): csrc/dense_conv_sk.hip, tile_cfg 30 of ops.conv2d. nclass (1..4) convolutions that share input, shapes and epilogue

@@ -55,6 +55,9 @@ struct WinoArgs {
   unsigned* counters;     // [units], zero between launches
   int cin, hin, win, cout, relu;
   int tw, ntiles, tblocks, ngroups, rpu, total_rounds;
+  int bper;               // batch elements per weight set (several layers of one shape in one launch: set = b / bper)
+  int ss_stride;          // floats between the sets' scale / shift vectors (0 with one set)
+  long long upk_stride;   // floats between the sets' packed U
 };
 
 template <int NW, int CBN>
@@ -118,8 +121,9 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     const __attribute__((address_space(4))) WinoArgs* Fp =                                         \
         (const __attribute__((address_space(4))) WinoArgs*)__builtin_amdgcn_kernarg_segment_ptr(); \
     asm volatile("" : "+s"(Fp));                                                                   \
-    const float* f_scale = Fp->scale;                                                              \
-    const float* f_shift = Fp->shift;                                                              \
+    const int f_set = pend_b / Fp->bper;                                                           \
+    const float* f_scale = Fp->scale ? Fp->scale + (size_t)f_set * Fp->ss_stride : nullptr;        \
+    const float* f_shift = Fp->shift ? Fp->shift + (size_t)f_set * Fp->ss_stride : nullptr;        \
     const int e_cout = Fp->cout, e_relu = Fp->relu, e_win = Fp->win, f_tw = Fp->tw;                \
     const rsrc_t fr = make_rsrc(Fp->scratch, (unsigned)(2 * G) * SLOT * 4u);                       \
     float* outb = Fp->out + (size_t)pend_b * e_cout * out_plane;                                   \
@@ -162,7 +166,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     const int tb = __builtin_amdgcn_readfirstlane(ub % A.tblocks), b = __builtin_amdgcn_readfirstlane(ub / A.tblocks);
     const int t_base = tb * 32, m_base = cg * (CBN * 32);
     const rsrc_t xr = make_rsrc(A.in + (size_t)b * A.cin * in_plane, (unsigned)A.cin * in_plane * 4u);
-    const rsrc_t wr = make_rsrc(A.upk + (size_t)cg * (A.cin >> 1) * (WSTEP / 4), (unsigned)(A.cin >> 1) * WSTEP);
+    const int wset = __builtin_amdgcn_readfirstlane(b / A.bper);
+    const rsrc_t wr = make_rsrc(A.upk + (size_t)wset * A.upk_stride + (size_t)cg * (A.cin >> 1) * (WSTEP / 4), (unsigned)(A.cin >> 1) * WSTEP);
 
     // ---- transform role: lane = (tile j, channel parity h)
     const int t = t_base + j;
@@ -306,8 +311,8 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     const __attribute__((address_space(4))) WinoArgs* Ep =
         (const __attribute__((address_space(4))) WinoArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(Ep));
-    const float* e_scale = Ep->scale;
-    const float* e_shift = Ep->shift;
+    const float* e_scale = Ep->scale ? Ep->scale + (size_t)wset * Ep->ss_stride : nullptr;
+    const float* e_shift = Ep->shift ? Ep->shift + (size_t)wset * Ep->ss_stride : nullptr;
     const int e_cout = Ep->cout, e_relu = Ep->relu, e_win = Ep->win, e_tw = Ep->tw, e_ntiles = Ep->ntiles;
     unsigned* e_counter = Ep->counters + u;
     const rsrc_t sr = make_rsrc(Ep->scratch, (unsigned)(2 * G) * SLOT * 4u);
@@ -428,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
 }
 
 template <int NW, int CBN>
-int launch_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout, const float* scale,
+int launch_sk(const float* in, int batch, int nsets, int cin, int h, int w, const float* upk, float* out, int cout, const float* scale,
               const float* shift, int relu, const float* residual, void* workspace, size_t workspace_bytes, int workgroups,
               hipStream_t stream) {
   constexpr int SLOT = CBN * 32 * 32 * 4;
@@ -438,6 +443,8 @@ int launch_sk(const float* in, int batch, int cin, int h, int w, const float* up
   A.cin = cin; A.hin = h; A.win = w; A.cout = cout; A.relu = relu;
   A.tw = w / 2; A.ntiles = (h / 2) * (w / 2); A.tblocks = sessd_divup(A.ntiles, 32); A.ngroups = sessd_divup(cout, CBN * 32);
   A.rpu = cin / (2 * NW);
+  A.bper = batch / nsets; A.ss_stride = nsets > 1 ? cout : 0;
+  A.upk_stride = nsets > 1 ? (long long)sessd_divup(cout, CBN * 32) * (cin >> 1) * (NW * 2 * 32 * 32 / 4) : 0;
   const long long units = (long long)batch * A.tblocks * A.ngroups;
   if (units * A.rpu > 0x7fffffffLL) return SESSD_EINVAL;
   A.total_rounds = (int)(units * A.rpu);
@@ -479,17 +486,29 @@ size_t sessd_conv3x3_winograd_sk_workspace_bytes(int batch, int h, int w, int co
 // `workgroups` persistent workgroups (a multiple of 8; 0 = the shape's default).
 // upk = U = G g G^T packed [ceil(cout / C)][cin/2][NW][2][32][C/32][16/NW] with (NW, C) = (8, 128) for shape 0, (4, 64) for
 // shape 1 (ops.pack_winograd_sk); even H, W; cin % (2 NW) == 0.
-int sessd_conv3x3_winograd_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
-                              const float* scale, const float* shift, int relu, const float* residual, void* workspace,
-                              size_t workspace_bytes, int shape, int workgroups, hipStream_t stream) {
-  if ((h & 1) || (w & 1) || batch < 1 || cout < 1 || workgroups < 0 || (workgroups & 7) || shape < 0 || shape > 1) return SESSD_EINVAL;
+// Several layers of ONE shape in one launch (conv_0 / conv_1 of the SSFA neck, rpn_v1.py:201-210): the batch dimension is
+// nsets consecutive groups of batch / nsets elements, group s convolved with weight set s -- upk = nsets packings back to back,
+// scale / shift = nsets x cout. One round list, one pipeline fill and one tail instead of nsets.
+int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int cin, int h, int w, const float* upk, float* out,
+                                   int cout, const float* scale, const float* shift, int relu, const float* residual,
+                                   void* workspace, size_t workspace_bytes, int shape, int workgroups, hipStream_t stream) {
+  if ((h & 1) || (w & 1) || batch < 1 || nsets < 1 || batch % nsets || cout < 1 || workgroups < 0 || (workgroups & 7) || shape < 0 ||
+      shape > 1)
+    return SESSD_EINVAL;
   if (workgroups == 0) {
     const int rc = default_workgroups(shape, &workgroups);
     if (rc != SESSD_OK) return rc;
   }
   if (shape == 1)
-    return launch_sk<4, 2>(in, batch, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream);
-  return launch_sk<8, 4>(in, batch, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream);
+    return launch_sk<4, 2>(in, batch, nsets, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream);
+  return launch_sk<8, 4>(in, batch, nsets, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream);
+}
+
+int sessd_conv3x3_winograd_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
+                              const float* scale, const float* shift, int relu, const float* residual, void* workspace,
+                              size_t workspace_bytes, int shape, int workgroups, hipStream_t stream) {
+  return sessd_conv3x3_winograd_sk_sets(in, batch, 1, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace,
+                                        workspace_bytes, shape, workgroups, stream);
 }
 
 }  // extern "C"

@@ -57,6 +57,7 @@ SIGNATURES = {
     "sessd_conv2d_pack_taps": (i32, [vp, i64, i64, vp, i32, i32, i32, vp, vp]),
     "sessd_conv3x3_winograd_pack": (i32, [vp, i64, i64, i32, i32, i32, i32, vp, vp]),
     "sessd_conv3x3_winograd_sk_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
+    "sessd_conv3x3_winograd_sk_sets": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, sz, i32, i32, vp]),
     "sessd_conv3x3_winograd_sk": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, sz, i32, i32, vp]),
     "sessd_conv2d_sk_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "sessd_conv2d_sk_pack": (i32, [vp, i64, i64, vp, i32, i32, i32, vp, vp]),

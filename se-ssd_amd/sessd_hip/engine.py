@@ -209,7 +209,12 @@ class InferenceEngine:
             else:
                 L["indices"], L["n"] = self.chain.indices[li - 1], self.chain.n_dev[li - 1]
         self.bev = torch.zeros((B, self.bev_c, H, W), dtype=f32, device=dev)
-        self.t = {k: E(B, 128, H, W) for k in ("a", "b", "x0", "tr0", "mid0", "mid1", "o0", "o1", "out")}
+        self.t = {k: E(B, 128, H, W) for k in ("a", "b", "x0", "tr0", "out")}
+        # the two branches after the transposed convs are one shape: adjacent buffers, so that conv_0 / conv_1 can be one launch
+        self.t["mid"], self.t["o"] = E(2 * B, 128, H, W), E(2 * B, 128, H, W)
+        for k, src in (("mid0", "mid"), ("mid1", "mid"), ("o0", "o"), ("o1", "o")):
+            self.t[k] = self.t[src][:B] if k.endswith("0") else self.t[src][B:]
+        self.merge_branch_convs = True  # conv_0 + conv_1 as one stream-K Winograd launch when both were tuned to the same shape
         self.h = {k: E(B, 256, H // 2, W // 2) for k in ("a", "b", "x1", "tr1")}
         self.head = E(B, 22, H * W)
         if anchors is None:
@@ -284,6 +289,21 @@ class InferenceEngine:
                                     self.sparse_split.get(idx, 0), s), "sparse_conv")
         if self._tuning_sparse is not None and not dense:
             self._tuning_sparse.append((idx, lay, in_feat, nbr, tm, out_li, out_feat))
+
+    def _branch_sets(self, shape):
+        """conv_0 / conv_1 as two weight sets of one launch: packed U back to back, BatchNorm constants stacked (made once)."""
+        key = "_sets%d" % shape
+        if not hasattr(self, key):
+            d = self.dn
+            (p0, s0, t0), (p1, s1, t1) = d.conv_0, d.conv_1
+            u0, u1 = p0.upk_sk(shape), p1.upk_sk(shape)
+            ok = u0 is not None and u1 is not None and p0.cout == p1.cout == 128 and p0.cin == p1.cin and s0 is not None and s1 is not None
+            need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(2 * self.B, self.H, self.W, 128, shape, 0)) if ok else 0
+            if ok and self.sk_ws is not None and self.sk_ws.numel() < need:
+                self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+            setattr(self, key, dict(upk=torch.cat([u0.reshape(-1), u1.reshape(-1)]), scale=torch.stack([s0, s1]).contiguous(),
+                                    shift=torch.stack([t0, t1]).contiguous()) if ok else None)
+        return getattr(self, key)
 
     def _conv(self, x, layer, out, relu=True, residual=None, name=None):
         pc, scale, shift = layer
@@ -451,8 +471,22 @@ class InferenceEngine:
         tr1 = self._conv(x1, d.trans_1, h["tr1"], name="trans_1")
         mid0 = self._conv(tr1, d.deconv_0, t["mid0"], residual=tr0, name="deconv_0")
         mid1 = self._conv(tr1, d.deconv_1, t["mid1"], name="deconv_1")
-        o0 = self._conv(mid0, d.conv_0, t["o0"], name="conv_0")
-        o1 = self._conv(mid1, d.conv_1, t["o1"], name="conv_1")
+        c01 = self.tile_cfg.get("conv_0")
+        if self.merge_branch_convs and c01 in (22, 23) and self.tile_cfg.get("conv_1") == c01 and self._tuning is None \
+                and self.sk_ws is not None and self._branch_sets(c01 - 22) is not None:
+            sets = self._branch_sets(c01 - 22)
+            if self._kmarks is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.conv2d_winograd_sk_sets(t["mid"], sets["upk"], 2, 128, sets["scale"], sets["shift"], True, t["o"], c01 - 22,
+                                        self.sk_ws, self.sk_workgroups)
+            if self._kmarks is not None:
+                e1.record()
+                self._kmarks.append(("conv_0+conv_1", e0, e1))
+            o0, o1 = t["o0"], t["o1"]
+        else:
+            o0 = self._conv(mid0, d.conv_0, t["o0"], name="conv_0")
+            o1 = self._conv(mid1, d.conv_1, t["o1"], name="conv_1")
         # ---- SSFA tail + heads (a10): one launch; the two-launch form stays for channel counts the fused kernel does not take
         if self.fuse_head and d.head_w.shape[1] in (64, 128) and self._tuning is None:
             if self._kmarks is not None:

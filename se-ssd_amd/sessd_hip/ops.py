@@ -873,6 +873,17 @@ def conv2d_sk_workspace(batch, tile_h, tile_w, cout, nclass, device, workgroups=
     return torch.zeros(n, dtype=torch.uint8, device=device)
 
 
+def conv2d_winograd_sk_sets(x, upk_sets, nsets, cout, scale, shift, relu, out, shape, workspace, workgroups=0, residual=None):
+    """sessd_conv3x3_winograd_sk_sets: x (nsets * B, Cin, H, W), group s of B batch elements convolved with weight set s.
+    upk_sets = the sets' pack_winograd_sk packings concatenated, scale / shift (nsets, cout) or None; out like x with cout channels."""
+    _req(x, torch.float32, "x")
+    NB, ci, H, W = x.shape
+    check(lib.sessd_conv3x3_winograd_sk_sets(x.data_ptr(), NB, int(nsets), ci, H, W, upk_sets.data_ptr(), out.data_ptr(), int(cout),
+                                             _p(scale), _p(shift), 1 if relu else 0, _p(residual), workspace.data_ptr(),
+                                             workspace.numel(), int(shape), int(workgroups), _stream()), "conv3x3_winograd_sk_sets")
+    return out
+
+
 def pack_winograd(weight, adjoint=False):
     """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) for sessd_conv3x3_winograd, packed
     [Cin/2][xi/4][channel parity][Cout_pad][xi%4]. One launch (sessd_conv3x3_winograd_pack)."""

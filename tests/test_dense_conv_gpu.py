@@ -106,6 +106,34 @@ def test_winograd_stream_k(dev, cin, cout, H, W, B, wgs, cfg):
     assert float((plain - F.conv2d(x.double(), w.double(), padding=1)).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("shape,B,H,W,wgs", [(0, 1, 200, 176, 0), (1, 2, 24, 40, 0), (0, 2, 10, 66, 8), (1, 1, 14, 18, 16)])
+def test_winograd_stream_k_weight_sets(dev, shape, B, H, W, wgs):
+    """sessd_conv3x3_winograd_sk_sets: two layers of one shape (conv_0 / conv_1 of the SSFA neck) as ONE stream-K launch over a
+    (2 B, C, H, W) input, each half with its own weights and BatchNorm constants, against the two single-layer launches."""
+    C = 128
+    g = torch.Generator().manual_seed(shape + H)
+    x = torch.randn(2 * B, C, H, W, generator=g).to(dev)
+    ws_ = [(torch.randn(C, C, 3, 3, generator=g) * 0.05).to(dev) for _ in range(2)]
+    sc = torch.stack([torch.rand(C, generator=g) + 0.5 for _ in range(2)]).to(dev)
+    sh = torch.stack([torch.randn(C, generator=g) * 0.1 for _ in range(2)]).to(dev)
+    pcs = [ops.pack_conv2d(w_, 1) for w_ in ws_]
+    upk = torch.cat([pc.upk_sk(shape).reshape(-1) for pc in pcs])
+    ws = ops.winograd_sk_workspace(2 * B, H, W, C, dev, wgs, shape)
+    out = torch.empty_like(x)
+    ops.conv2d_winograd_sk_sets(x, upk, 2, C, sc, sh, True, out, shape, ws, wgs)
+    again = torch.empty_like(x)
+    ops.conv2d_winograd_sk_sets(x, upk, 2, C, sc, sh, True, again, shape, ws, wgs)
+    assert torch.equal(out, again)
+    for s_ in range(2):
+        one = ops.conv2d(x[s_ * B:(s_ + 1) * B].contiguous(), pcs[s_], sc[s_].contiguous(), sh[s_].contiguous(), True, tile_cfg=22 + shape,
+                         workspace=ws, workgroups=wgs)
+        ref = torch.relu(F.conv2d(x[s_ * B:(s_ + 1) * B].cpu().double(), ws_[s_].cpu().double(), padding=1) * sc[s_].cpu().double().view(1, -1, 1, 1)
+                         + sh[s_].cpu().double().view(1, -1, 1, 1))
+        e_m = float((out[s_ * B:(s_ + 1) * B].cpu().double() - ref).abs().max())
+        e_1 = float((one.cpu().double() - ref).abs().max())
+        assert e_m < 2e-4 * max(1.0, float(ref.abs().max())) and e_m < 4 * e_1 + 1e-6
+
+
 @pytest.mark.parametrize("cin,cout,k,stride,H,W,B,wgs", [(128, 256, 3, 2, 24, 40, 2, 0), (128, 128, 1, 1, 24, 40, 1, 0), (256, 256, 1, 1, 13, 19, 2, 8),
                                                          (16, 40, 3, 1, 10, 66, 3, 8), (32, 130, 3, 2, 9, 7, 1, 16), (128, 256, 3, 2, 200, 176, 1, 0),
                                                          (64, 22, 1, 1, 30, 20, 1, 64), (128, 128, 3, 1, 24, 40, 1, 248)])
