@@ -232,7 +232,7 @@ def main():
             ach = flops / (kms * 1e-3) / 1e12
             log("roofline kernel: %.3f ms per launch in sequence" % kms)
             kname = (("conv3x3s1_winograd_sk_kernel / conv3x3s1_winograd_kernel (fused Winograd F(2x2,3x3) on f32 MFMA; %d of the 7 "
-                      "launches are the stream-K kernel, as the per-layer autotune chose)" % streamk) if wino
+                      "layers are on the stream-K kernel, as the per-layer autotune chose)" % streamk) if wino
                      else "conv2d_mfma_kernel<9 taps> (direct implicit GEMM on f32 MFMA)")
             exe = ach * (16.0 / 36.0 if wino else 1.0)  # Winograd F(2x2,3x3) multiplies 16 of the 36 products of direct convolution
             out["roofline"] = {"bound": "mfma", "kernel": kname + ": Conv2d 3x3 128->128 @200x176 (5 layers per frame%s) and "
