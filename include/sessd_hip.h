@@ -380,6 +380,14 @@ int sessd_deconv2d_s2_mfma(const float* in, int batch, int cin, int hin, int win
                            const int* ntaps4, const int* taps_dy4, const int* taps_dx4, float* out, int cout,
                            const float* scale, const float* shift, int relu, const float* residual, int tile_cfg,
                            sessd_stream_t stream);
+/* Two such layers applied to the SAME input (deconv_block_0 / deconv_block_1 of the SSFA neck, rpn_v1.py:224-226) as one launch
+ * over their 2 x 4 parity classes; per layer wpk4 / out / scale / shift / residual as above, shared tap tables. tile_cfg 3, 4, 11
+ * or 12. The same bits as two single-layer launches. */
+int sessd_deconv2d_s2_mfma_pair(const float* in, int batch, int cin, int hin, int win, const float* const* wpk4_a,
+                                const float* const* wpk4_b, const int* ntaps4, const int* taps_dy4, const int* taps_dx4,
+                                float* out_a, float* out_b, int cout, const float* scale_a, const float* shift_a,
+                                const float* scale_b, const float* shift_b, int relu, const float* residual_a,
+                                const float* residual_b, int tile_cfg, sessd_stream_t stream);
 /* rpn_v1.py:227-233: softmax over the two 1-channel weight maps and the weighted sum of x0, x1 */
 int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
                     float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,

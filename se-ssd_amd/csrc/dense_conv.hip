@@ -44,6 +44,9 @@ struct ConvArgs {
 struct ConvArgs4 {
   ConvArgs c[4];
 };
+struct ConvArgs8 {
+  ConvArgs c[8];
+};
 
 // wave tile: (CT*32 couts) x (PT*32 pixels); workgroup = 4 waves arranged WC x WP
 // Raw buffer resource (V#) over [base, base + bytes): loads whose (voffset + imm) >= bytes return 0 in hardware.
@@ -569,6 +572,13 @@ __global__ __launch_bounds__(256) void conv2d_mfma4_kernel(ConvArgs4 A4) {
   conv_body<NTAPS, CT, PT, WC, WP, DEEP>(A4.c[3 - (blockIdx.z & 3)], blockIdx.z >> 2);
 }
 
+// Two transposed convs that read the SAME input (deconv_block_0 / deconv_block_1 of the SSFA neck, rpn_v1.py:224-226) in one
+// launch: eight classes, c[2k] / c[2k+1] = class k of the first / second layer; blockIdx.z = batch*8 + (7 - index), heaviest first.
+template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
+__global__ __launch_bounds__(256) void conv2d_mfma8_kernel(ConvArgs8 A8) {
+  conv_body<NTAPS, CT, PT, WC, WP, DEEP>(A8.c[7 - (blockIdx.z & 7)], blockIdx.z >> 3);
+}
+
 // SSFA tail (rpn_v1.py:227-233): w0 = BN(conv1x1(x0)), w1 = BN(conv1x1(x1)) (C -> 1 channel, no ReLU),
 // (s0, s1) = softmax(w0, w1), out = x0*s0 + x1*s1. Workgroup = 64 pixels x 4 channel quarters: each thread
 // dots its quarter of the channels (coalesced across the 64 pixels of a wave), the four partial sums meet in
@@ -707,6 +717,17 @@ int launch_conv(const ConvArgs* A, int nconv, int batch, hipStream_t stream) {
     for (int i = 0; i < 4; ++i) A4.c[i] = A[i];
     SESSD_LAUNCH((conv2d_mfma4_kernel<NTAPS, CT, PT, WC, WP, DEEP>), grid, dim3(256), 0, stream, A4);
   }
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+template <int CT, int PT, int WC, int WP, bool DEEP>
+int launch_conv8(const ConvArgs* A, int batch, hipStream_t stream) {
+  const int npix = A[0].ht * A[0].wt;
+  dim3 grid(sessd_divup(npix, WP * PT * 32) * sessd_divup(A[0].cout_pad, WC * CT * 32), 1, batch * 8);
+  ConvArgs8 A8;
+  for (int i = 0; i < 8; ++i) A8.c[i] = A[i];
+  SESSD_LAUNCH((conv2d_mfma8_kernel<4, CT, PT, WC, WP, DEEP>), grid, dim3(256), 0, stream, A8);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -946,6 +967,32 @@ int sessd_deconv2d_s2_mfma(const float* in, int batch, int cin, int hin, int win
     if (eff != 4) return SESSD_EINVAL;
   }
   return dispatch_tile<4>(A, 4, batch, tile_cfg, stream);
+}
+
+// Two ConvTranspose2d(cin, cout, 3, 2, 1, 1) layers applied to the SAME input (deconv_block_0 / deconv_block_1 of the SSFA neck)
+// as one launch over their 2 x 4 parity classes: per layer wpk4 / out / scale / shift / residual as in sessd_deconv2d_s2_mfma,
+// shared tap tables. tile_cfg 3, 4, 11 or 12. Per class the code of the single-layer launch: the same bits.
+int sessd_deconv2d_s2_mfma_pair(const float* in, int batch, int cin, int hin, int win, const float* const* wpk4_a,
+                                const float* const* wpk4_b, const int* ntaps4, const int* taps_dy4, const int* taps_dx4,
+                                float* out_a, float* out_b, int cout, const float* scale_a, const float* shift_a,
+                                const float* scale_b, const float* shift_b, int relu, const float* residual_a,
+                                const float* residual_b, int tile_cfg, hipStream_t stream) {
+  if (cin % 8 || batch < 1 || cout < 1 || !out_fits(cout, 2 * hin, 2 * win)) return SESSD_EINVAL;
+  ConvArgs A[8];
+  for (int c = 0; c < 4; ++c)
+    for (int l = 0; l < 2; ++l) {
+      const int eff = fill_args(A[2 * c + l], in, cin, hin, win, (l ? wpk4_b : wpk4_a)[c], ntaps4[c], taps_dy4 + 4 * c, taps_dx4 + 4 * c,
+                                1, hin, win, l ? out_b : out_a, cout, 2 * hin, 2 * win, 2, c >> 1, c & 1, l ? scale_b : scale_a,
+                                l ? shift_b : shift_a, relu, l ? residual_b : residual_a);
+      if (eff != 4) return SESSD_EINVAL;
+    }
+  switch (tile_cfg) {
+    case 3: return launch_conv8<1, 1, 4, 1, false>(A, batch, stream);
+    case 4: return launch_conv8<1, 1, 1, 4, false>(A, batch, stream);
+    case 11: return launch_conv8<1, 1, 1, 4, true>(A, batch, stream);
+    case 12: return launch_conv8<1, 1, 4, 1, true>(A, batch, stream);
+    default: return SESSD_EINVAL;
+  }
 }
 
 // SSFA fusion tail: x0, x1, out are (B, C, H, W); w0, w1 the (C,) 1x1 conv weights; (s, t) the folded

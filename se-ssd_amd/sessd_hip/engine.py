@@ -469,8 +469,21 @@ class InferenceEngine:
         x1 = self._conv(y, d.b1[2], h["x1"], name="b1.2")
         tr0 = self._conv(x0, d.trans_0, t["tr0"], name="trans_0")
         tr1 = self._conv(x1, d.trans_1, h["tr1"], name="trans_1")
-        mid0 = self._conv(tr1, d.deconv_0, t["mid0"], residual=tr0, name="deconv_0")
-        mid1 = self._conv(tr1, d.deconv_1, t["mid1"], name="deconv_1")
+        cd = self.tile_cfg.get("deconv_0")
+        if self.merge_branch_convs and cd in (3, 4, 11, 12) and self.tile_cfg.get("deconv_1") in (3, 4, 11, 12) and self._tuning is None:
+            # both transposed convs read tr1: one launch over their 2 x 4 parity classes (same bits as two launches)
+            (pa, sa, ta), (pb, sb, tb) = d.deconv_0, d.deconv_1
+            if self._kmarks is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.deconv2d_s2_pair(tr1, pa, pb, sa, ta, sb, tb, True, t["mid0"], t["mid1"], residual_a=tr0, tile_cfg=cd)
+            if self._kmarks is not None:
+                e1.record()
+                self._kmarks.append(("deconv_0+deconv_1", e0, e1))
+            mid0, mid1 = t["mid0"], t["mid1"]
+        else:
+            mid0 = self._conv(tr1, d.deconv_0, t["mid0"], residual=tr0, name="deconv_0")
+            mid1 = self._conv(tr1, d.deconv_1, t["mid1"], name="deconv_1")
         c01 = self.tile_cfg.get("conv_0")
         if self.merge_branch_convs and c01 in (22, 23) and self.tile_cfg.get("conv_1") == c01 and self._tuning is None \
                 and self.sk_ws is not None and self._branch_sets(c01 - 22) is not None:

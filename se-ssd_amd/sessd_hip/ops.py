@@ -922,6 +922,21 @@ def pack_deconv2d_s2(weight):
     return pc
 
 
+def deconv2d_s2_pair(x, pc_a, pc_b, scale_a, shift_a, scale_b, shift_b, relu, out_a, out_b, residual_a=None, residual_b=None, tile_cfg=4):
+    """Two ConvTranspose2d(3, 2, 1, 1) layers of one shape on the SAME input in one launch (sessd_deconv2d_s2_mfma_pair); the same
+    bits as two conv2d() calls with that tile_cfg (3, 4, 11 or 12)."""
+    import ctypes
+    _req(x, torch.float32, "x")
+    B, ci, H, W = x.shape
+    assert pc_a.kind == pc_b.kind == "deconv" and pc_a.cin == pc_b.cin == ci and pc_a.cout == pc_b.cout
+    check(lib.sessd_deconv2d_s2_mfma_pair(x.data_ptr(), B, ci, H, W, ctypes.cast(pc_a.wpk4, ctypes.c_void_p).value,
+                                          ctypes.cast(pc_b.wpk4, ctypes.c_void_p).value, pc_a.ntaps4.data_ptr(), pc_a.dy4.data_ptr(),
+                                          pc_a.dx4.data_ptr(), out_a.data_ptr(), out_b.data_ptr(), pc_a.cout, _p(scale_a), _p(shift_a),
+                                          _p(scale_b), _p(shift_b), 1 if relu else 0, _p(residual_a), _p(residual_b), int(tile_cfg),
+                                          _stream()), "deconv2d_s2_mfma_pair")
+    return out_a, out_b
+
+
 def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, tile_cfg=None, workspace=None, workgroups=0):
     """x (B,Cin,H,W) NCHW float32 on the device. Returns (B,Cout,Ho,Wo). tile_cfg 22 = stream-K Winograd: `workspace` from
     winograd_sk_workspace (one per concurrently running stream); without one a per-(device, stream) cache is used."""

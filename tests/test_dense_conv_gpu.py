@@ -213,6 +213,24 @@ def test_deconv_s2_paired_classes_bit_identical(dev, cfg, B, H, W, cin, cout):
     assert float((a.cpu().double() - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("cfg", [3, 4, 11, 12])
+@pytest.mark.parametrize("B,H,W", [(2, 10, 12), (1, 100, 88)])
+def test_deconv_s2_two_layers_one_launch(dev, cfg, B, H, W):
+    """sessd_deconv2d_s2_mfma_pair: deconv_block_0 (+ residual) and deconv_block_1 of the SSFA neck read the same input; one launch
+    over their 2 x 4 parity classes gives the bits of the two single-layer launches."""
+    g = torch.Generator().manual_seed(cfg + H)
+    x = torch.randn(B, 256, H, W, generator=g).to(dev)
+    pcs = [ops.pack_deconv2d_s2((torch.randn(256, 128, 3, 3, generator=g) * 0.05).to(dev)) for _ in range(2)]
+    sc = [(torch.rand(128, generator=g) + 0.5).to(dev) for _ in range(2)]
+    sh = [(torch.randn(128, generator=g) * 0.1).to(dev) for _ in range(2)]
+    res = torch.randn(B, 128, 2 * H, 2 * W, generator=g).to(dev)
+    a = ops.conv2d(x, pcs[0], sc[0], sh[0], True, residual=res, tile_cfg=cfg)
+    b = ops.conv2d(x, pcs[1], sc[1], sh[1], True, tile_cfg=cfg)
+    oa, ob = torch.empty_like(a), torch.empty_like(b)
+    ops.deconv2d_s2_pair(x, pcs[0], pcs[1], sc[0], sh[0], sc[1], sh[1], True, oa, ob, residual_a=res, tile_cfg=cfg)
+    assert torch.equal(oa, a) and torch.equal(ob, b)
+
+
 @pytest.mark.parametrize("cfg", [1, 3, 4, 11, 12])
 def test_deconv_s2_with_residual(dev, cfg):
     g = torch.Generator().manual_seed(9)
