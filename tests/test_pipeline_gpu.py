@@ -79,7 +79,9 @@ def test_engine_with_stream_k_dense_layers_vs_oracle(dev, model, state, cfg, wgs
         for name in ("b1.0", "trans_0", "trans_1", "deconv_0", "deconv_1"):
             eng.tile_cfg[name] = 30
         cfg = 22
-    for name in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):
+    else:  # the two transposed convs as ONE launch (engine.merge_branch_convs; same bits as two launches)
+        eng.tile_cfg["deconv_0"] = eng.tile_cfg["deconv_1"] = 4
+    for name in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):  # conv_0 + conv_1: one launch of two weight sets
         eng.tile_cfg[name] = cfg
     eng.sk_workgroups = wgs
     eng.sk_ws = torch.zeros(max(ops.winograd_sk_workspace(2, 200, 176, 256, dev, 0, cfg - 22).numel(),
