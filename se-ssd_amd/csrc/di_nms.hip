@@ -69,7 +69,6 @@ __global__ __launch_bounds__(DN) void di_select_kernel(DiArgs A) {
   __shared__ float s_red[16][10];
   __shared__ unsigned long long s_key[16];
   __shared__ float s_bc[12];
-  __shared__ int s_idx;
   const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
   const int n = A.n;
   const bool live = j < n;
