@@ -1017,6 +1017,7 @@ int sessd_ssfa_fuse_head(const float* x0, const float* x1, const float* w0, cons
                          float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels, float* out,
                          const float* head_w, const float* head_b, int nout, float* head_out, hipStream_t stream) {
   if (batch < 1 || (channels != 128 && channels != 64) || num_pixels < 1 || nout != 22) return SESSD_EINVAL;
+  if ((long long)channels * num_pixels * 4 >= 0x7fffffffLL) return SESSD_EINVAL;  // 32-bit buffer offsets per batch element
   const dim3 grid(sessd_divup(num_pixels, 64), batch);
   if (channels == 128)
     SESSD_LAUNCH((ssfa_fuse_head_kernel<22, 32>), grid, dim3(256), 0, stream, x0, x1, w0, w1, bn_scale0, bn_shift0, bn_scale1,

@@ -489,6 +489,8 @@ int sessd_conv2d_sk(const float* in, int batch, int cin, int hin, int win, int n
                     const float* shift, int relu, const float* residual, void* workspace, size_t workspace_bytes, int workgroups,
                     hipStream_t stream) {
   if (batch < 1 || cin < 16 || cin % 16 || cout < 1 || nclass < 1 || nclass > 4 || workgroups < 0 || (workgroups & 7)) return SESSD_EINVAL;
+  // a batch element's input and output are addressed through 32-bit buffer offsets
+  if ((long long)cin * hin * win * 4 >= 0x7fffffffLL || (long long)cout * hout * wout * 4 >= 0x7fffffffLL) return SESSD_EINVAL;
   if (workgroups == 0) {
     const int rc = default_workgroups(&workgroups);
     if (rc != SESSD_OK) return rc;

@@ -39,3 +39,26 @@ def test_ops_refuse_cpu_tensors():
     from sessd_hip import ops
     with pytest.raises(ValueError):
         ops.boxes_pairwise(1, torch.zeros(2, 5), torch.zeros(2, 5))
+
+
+def test_dense_entry_points_reject_bad_shapes_before_touching_the_device():
+    """Argument checks of the dense-conv entry points added in round 2 come before any device call: they can be exercised here
+    (null pointers, no GPU). SESSD_EINVAL = -1; workspace-size queries return 0 for bad arguments."""
+    import sessd_hip
+    lib = sessd_hip.lib
+    # LDS-tiled stream-K conv: cin % 16, class count, workgroups % 8, 32-bit buffer offsets
+    sk = lambda cin, nclass, wgs, hw=16: lib.sessd_conv2d_sk(None, 1, cin, hw, hw, nclass, None, None, None, None, 1, hw, hw, None, 32, hw, hw, 1,
+                                                             None, None, None, None, 1, None, None, 0, wgs, None)
+    assert sk(24, 1, 8) == -1 and sk(32, 5, 8) == -1 and sk(32, 1, 12) == -1 and sk(4096, 1, 8, hw=1024) == -1
+    assert lib.sessd_conv2d_sk_workspace_bytes(0, 8, 8, 32, 1, 8) == 0 and lib.sessd_conv2d_sk_workspace_bytes(1, 8, 8, 32, 5, 8) == 0
+    # explicit workgroup count: pure arithmetic (counters of nclass * batch * pixel tiles * cout groups + two 64 KB slots per workgroup)
+    assert lib.sessd_conv2d_sk_workspace_bytes(2, 100, 88, 256, 1, 256) == 256 * ((2 * 69 * 2 * 4 + 255) // 256) + 2 * 256 * 65536
+    assert lib.sessd_conv2d_sk_pack(None, 1, 1, None, 1, 32, 24, None, None) == -1
+    # Winograd stream-K over weight sets: the batch must split evenly
+    assert lib.sessd_conv3x3_winograd_sk_sets(None, 3, 2, 128, 8, 8, None, None, 128, None, None, 1, None, None, 0, 0, 8, None) == -1
+    assert lib.sessd_conv3x3_winograd_sk_sets(None, 2, 2, 128, 7, 8, None, None, 128, None, None, 1, None, None, 0, 0, 8, None) == -1
+    # two transposed convs in one launch / fused SSFA tail + heads
+    assert lib.sessd_deconv2d_s2_mfma_pair(None, 1, 12, 8, 8, None, None, None, None, None, None, None, 32, None, None, None, None, 1, None, None,
+                                           4, None) == -1
+    assert lib.sessd_ssfa_fuse_head(None, None, None, None, 1.0, 0.0, 1.0, 0.0, 1, 100, 64, None, None, None, 22, None, None) == -1
+    assert lib.sessd_ssfa_fuse_head(None, None, None, None, 1.0, 0.0, 1.0, 0.0, 1, 128, 64, None, None, None, 21, None, None) == -1
