@@ -5,7 +5,10 @@
   oracle/_ref/libref_iou3d.so  <- /root/reference/det3d/core/iou3d/src/iou3d_cpu.cpp
                                    + oracle/ref_iou3d_stub.cpp  (reference sources are
                                    compiled where they lie; nothing is copied)
-Both are git-ignored and travel to the GPU box with the gpurun snapshot.
+  oracle/_ref/ref_nms_cpu*.so  <- /root/reference/det3d/ops/nms/nms_cpu.h (greedy rotated NMS, DI-NMS), through
+                                   oracle/ref_nms_stub.cpp with <boost/geometry.hpp> resolved to oracle/boost_shim
+                                   (boost is not installed: the shim supplies the two polygon-area calls, see its header)
+All are git-ignored and travel to the GPU box with the gpurun snapshot.
 """
 import os
 import subprocess
@@ -61,6 +64,35 @@ def build_ref(verbose=False):
     return REF_LIB
 
 
+REF_NMS_H = "/root/reference/det3d/ops/nms/nms_cpu.h"
+
+
+def ref_nms_path():
+    import sysconfig
+    return os.path.join(REF_DIR, "ref_nms_cpu" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_ref_nms(verbose=False):
+    """Compile the reference's own nms_cpu.h (where it lies) into a Python module; boost::geometry comes from oracle/boost_shim.
+    Only possible where /root/reference exists; returns the module path or None."""
+    out = ref_nms_path()
+    if not os.path.exists(REF_NMS_H):
+        return out if os.path.exists(out) else None
+    stub, shim = os.path.join(HERE, "ref_nms_stub.cpp"), os.path.join(HERE, "boost_shim", "boost", "geometry.hpp")
+    if not _newer([stub, shim, REF_NMS_H], out):
+        return out
+    os.makedirs(REF_DIR, exist_ok=True)
+    import sysconfig
+    import pybind11
+    cmd = ["g++", "-O2", "-std=c++14", "-shared", "-fPIC", "-w", "-ffp-contract=off", "-I", os.path.join(HERE, "boost_shim"), "-I",
+           pybind11.get_include(), "-I", sysconfig.get_paths()["include"], '-DREF_NMS_CPU_H="%s"' % REF_NMS_H, stub, "-o", out]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return out
+
+
 if __name__ == "__main__":
     print(build_oracle(True))
     print(build_ref(True))
+    print(build_ref_nms(True))

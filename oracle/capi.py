@@ -62,6 +62,25 @@ def ref_lib():
     return _ref
 
 
+_ref_nms = None
+
+
+def ref_nms_module():
+    """The reference's det3d/ops/nms/nms_cpu.h compiled from source with the boost::geometry shim (oracle/build.py
+    build_ref_nms): module with rotate_non_max_suppression_cpu / IOU_weighted_rotate_non_max_suppression_cpu, or None."""
+    global _ref_nms
+    if _ref_nms is None:
+        from . import build
+        p = build.build_ref_nms()
+        if p is None or not os.path.exists(p):
+            return None
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_nms_cpu", p)
+        _ref_nms = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(_ref_nms)
+    return _ref_nms
+
+
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 

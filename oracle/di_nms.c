@@ -17,9 +17,12 @@
  *
  * Arithmetic follows the float instantiation the Python wrapper reaches (float32 arrays): accumulators are float, the
  * pow / sqrt / exp calls take their double overloads and round back to float on assignment. The reference intersects
- * and unites the quads with boost::geometry (absent here: this piece cannot be compiled from the reference sources,
- * PARITY UNPINNED for the polygon areas); the oracle uses the double-precision clipper of rotate_nms.c and
- * |A u B| = |A| + |B| - |A n B|, rounded to float like the reference's assignments. */
+ * and unites the quads with boost::geometry, which is not installed here; the oracle uses the double-precision clipper of
+ * rotate_nms.c and |A u B| = |A| + |B| - |A n B|, rounded to float like the reference's assignments.
+ * Pinned by: the reference's own nms_cpu.h COMPILED FROM SOURCE with a boost::geometry stand-in (oracle/boost_shim, the same
+ * clipping arithmetic; oracle/build.py build_ref_nms) -> tests/golden/nms_cpu_ref.npz, tests/test_nms_cpu_ref_cpu.py: identical
+ * selection, order, labels and directions, boxes and scores to 2e-5 on 16 clustered cases. That pins the CONTROL FLOW of
+ * :173-384; boost's own polygon-area arithmetic remains PARITY UNPINNED. */
 #include <math.h>
 #include <stdint.h>
 #include <stdlib.h>

@@ -10,8 +10,11 @@
  * piece cannot be compiled from the reference sources); the oracle clips convex quads
  * with Sutherland-Hodgman in double precision and uses area(P u Q) = |P| + |Q| - |P n Q|.
  * Corner, stand-up box and prefilter arithmetic is float32 exactly as numpy does it.
- * Pinned by: tests/golden/nms_helpers.npz (reference numpy helpers run from source) and
- * cross-agreement of the polygon IoU with the compiled iou3d reference (oracle/_ref).
+ * Pinned by: tests/golden/nms_helpers.npz (reference numpy helpers run from source),
+ * cross-agreement of the polygon IoU with the compiled iou3d reference (oracle/_ref), and the
+ * greedy loop itself by the reference's own nms_cpu.h compiled from source with a boost::geometry
+ * stand-in (oracle/boost_shim; tests/golden/nms_cpu_ref.npz, tests/test_nms_cpu_ref_cpu.py): the
+ * control flow of :72-168 is pinned, boost's polygon-area arithmetic is not.
  */
 #include <math.h>
 #include <stdint.h>

@@ -7,7 +7,8 @@
 The pybind core IOU_weighted_rotate_non_max_suppression_cpu (nms_cpu.h:173-384) needs boost::geometry and cannot be built
 here: it is substituted by oracle/di_nms.c (oracle.capi.di_nms_core, same 14-argument call and 5-list return), fed with the
 corners / stand-up IoU the REFERENCE code computed. So this fixture pins the wrappers around the core and the core's
-restatement against itself; the polygon areas of the core are "parity unpinned" (see oracle/di_nms.c).
+restatement against itself; the core itself is pinned separately against the reference's nms_cpu.h compiled from source with a
+boost::geometry stand-in (make_golden_nms_cpu.py); boost's polygon-area arithmetic stays "parity unpinned" (see oracle/di_nms.c).
 
     python tests/golden/make_golden_di_nms.py
 """
