@@ -12,7 +12,9 @@
 What cannot run here is substituted, and only that:
   * the pybind function rotate_non_max_suppression_cpu (nms.cc / nms_cpu.h:72-168, needs boost::geometry) -> the greedy loop of
     oracle/rotate_nms.c fed with the corners / order / stand-up IoU the REFERENCE code computed (its polygon IoU is cross-checked
-    against the compiled iou3d reference in tests/test_oracle_golden.py)
+    against the compiled iou3d reference in tests/test_oracle_golden.py); every call is ALSO given to the reference's own
+    nms_cpu.h compiled from source with a boost::geometry stand-in (oracle/build.py build_ref_nms) and must return the same
+    keep list (6 calls of 1000 candidates, 3 of them with near-threshold pairs: identical)
   * `.cuda()`, registries, logging / checkpoint helpers, matplotlib, torchvision, numba, syncbn -> identity / inert stubs
   * MultiGroupHead.__init__ is bypassed (it builds the loss modules and calls .cuda()); the attributes predict() reads are set
     from the constructor arguments config.py passes
@@ -127,6 +129,7 @@ def main():
     lib.oracle_quad_intersection_area.restype = C.c_double
     lib.oracle_quad_intersection_area.argtypes = [np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")] * 2
     stats = dict(calls=0, near=0)
+    ref_core = capi.ref_nms_module()  # None where /root/reference is absent
 
     def rotate_non_max_suppression_cpu(box_corners, order, standup_iou, thresh):
         """nms_cpu.h:72-168 restated (oracle/rotate_nms.c greedy loop) on the REFERENCE-computed corners / order / stand-up IoU."""
@@ -151,6 +154,13 @@ def main():
                 if ov >= thresh:
                     sup[j] = True
         stats["calls"] += 1
+        if ref_core is not None:
+            # the reference's own nms_cpu.h compiled from source (boost::geometry stand-in, oracle/build.py build_ref_nms) on the
+            # same arguments: the substitution above must be invisible
+            got = ref_core.rotate_non_max_suppression_cpu(np.ascontiguousarray(box_corners, np.float64), np.ascontiguousarray(order, np.int32),
+                                                          np.ascontiguousarray(standup_iou, np.float64), float(thresh))
+            assert [int(k) for k in got] == keep, "compiled reference core disagrees with the restated greedy loop"
+            stats["ref_checked"] = stats.get("ref_checked", 0) + 1
         return keep
 
     nms_cpu.rotate_non_max_suppression_cpu = rotate_non_max_suppression_cpu
@@ -231,7 +241,7 @@ def main():
     out["predict_near_threshold_pairs"] = np.array(stats["near"])
     out["predict_anchor_check"] = np.concatenate([anchors.sum(0), anchors[::997].reshape(-1)[:70]])
     out["predict_frustum"] = frustum
-    print("rotate_nms calls", stats["calls"], "near-threshold pairs", stats["near"])
+    print("rotate_nms calls", stats["calls"], "near-threshold pairs", stats["near"], "checked against the compiled reference core:", stats.get("ref_checked", 0))
 
     # ------------------------------------------------------------------ Reformat + collate_kitti from source
     mod("refpkg.datasets"); mod("refpkg.datasets.pipelines")
