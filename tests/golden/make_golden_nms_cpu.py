@@ -1,7 +1,7 @@
 """Generates tests/golden/nms_cpu_ref.npz by running the REFERENCE'S OWN det3d/ops/nms/nms_cpu.h, compiled from source
 (oracle/build.py build_ref_nms: the header is compiled where it lies; <boost/geometry.hpp>, not installed here, is resolved to
 oracle/boost_shim -- convex clipping + shoelace in double, see that header). What the vectors pin is the reference's control
-flow: the greedy rotated NMS (nms_cpu.h:72-168) and DI-NMS (IOU_weighted_rotate_non_max_suppression_cpu, :173-384: score
+flow: the axis-aligned NMS (nms_cpu.h:24-70; no polygon arithmetic: pinned completely), the greedy rotated NMS (:72-168) and DI-NMS (IOU_weighted_rotate_non_max_suppression_cpu, :173-384: score
 normalisation, centerness, pick / count / weighted average / suppress / recover). boost's own area arithmetic stays unpinned.
 Run in the build container (needs /root/reference): python tests/golden/make_golden_nms_cpu.py"""
 import os
@@ -39,6 +39,9 @@ for s in SEEDS:
     out["c%d_di_labels" % s] = np.asarray(r[2], np.int32)
     out["c%d_di_dirs" % s] = np.asarray(r[3], np.int32)
     out["c%d_di_keep" % s] = np.asarray(r[4], np.int32)
+for n, t, e in nc.AXIS_CASES:  # axis-aligned NMS with the +eps convention (float32 instantiation, as the wrappers reach it)
+    dets, order = nc.make_axis_case(n)
+    out["axis_%d_%g_%g" % (n, t, e)] = np.asarray(ref.non_max_suppression_cpu(dets[:, :4].copy(), order, np.float32(t), np.float32(e)), np.int32)
 out["seeds"] = np.asarray(SEEDS, np.int32)
 np.savez_compressed(os.path.join(HERE, "nms_cpu_ref.npz"), **out)
 print("wrote nms_cpu_ref.npz:", sum(len(out["c%d_di_keep" % s]) for s in SEEDS), "DI-NMS boxes,",

@@ -31,3 +31,14 @@ def standup_iou(corners):
     inter = np.clip(iw, 0, None) * np.clip(ih, 0, None)
     area = (mx[:, 0] - mn[:, 0]) * (mx[:, 1] - mn[:, 1])
     return (inter / (area[:, None] + area[None, :] - inter)).astype(np.float32)
+
+
+AXIS_CASES = ((300, 0.5, 1.0), (300, 0.1, 0.0), (120, 0.3, 0.0), (1, 0.5, 0.0))  # (boxes, threshold, eps) of nms_cpu.h:24-70
+
+
+def make_axis_case(n):
+    rng = np.random.RandomState(n + 1)
+    xy = rng.uniform(0, 60, (n, 2)).astype(np.float32)
+    wh = rng.uniform(2, 12, (n, 2)).astype(np.float32)
+    dets = np.concatenate([xy, xy + wh, rng.permutation(n).astype(np.float32)[:, None] / max(n, 1)], 1).astype(np.float32)
+    return dets, dets[:, 4].argsort()[::-1].astype(np.int32)

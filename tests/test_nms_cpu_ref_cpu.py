@@ -52,11 +52,24 @@ def test_di_nms_equals_the_reference_core(seed):
         assert np.allclose(np.asarray(got[1], np.float64), G["c%d_di_scores" % seed], rtol=2e-5, atol=2e-5)
 
 
+@pytest.mark.parametrize("n,thresh,eps", nc.AXIS_CASES)
+def test_axis_aligned_nms_loop_equals_the_reference_core(n, thresh, eps):
+    """The plain-loop restatement of nms_cpu.h:24-70 that tests/test_nms_module_gpu.py holds the device kernel to == the
+    reference's non_max_suppression_cpu<float> compiled from source."""
+    from test_nms_module_gpu import _axis_nms_loop
+    dets, order = nc.make_axis_case(n)
+    assert _axis_nms_loop(dets, order, thresh, eps) == [int(k) for k in G["axis_%d_%g_%g" % (n, thresh, eps)]]
+
+
 def test_fixture_is_what_the_compiled_reference_returns_now():
     """Where /root/reference exists the header is compiled again and must reproduce the committed vectors bit for bit."""
     ref = capi.ref_nms_module()
     if ref is None:
         pytest.skip("reference sources not present: the committed fixture stands in")
+    for n, t, e in nc.AXIS_CASES:
+        dets, order = nc.make_axis_case(n)
+        keep = ref.non_max_suppression_cpu(dets[:, :4].copy(), order, np.float32(t), np.float32(e))
+        assert np.array_equal(np.asarray(keep, np.int32), G["axis_%d_%g_%g" % (n, t, e)])
     for s in SEEDS:
         c, corners, su = _case(s)
         order = np.lexsort((np.arange(len(c["scores"])), -c["scores"].astype(np.float64))).astype(np.int32)
