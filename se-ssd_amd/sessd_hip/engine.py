@@ -103,8 +103,9 @@ class InferenceEngine:
                  use_frustum=False, allow_winograd=True, sort_sites=False):
         """growth[i]: capacity of sparse level i+1 relative to level i (observed ratios on KITTI-like scans are
         ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results().
-        sort_sites (EXPERIMENTAL, not yet validated on hardware): renumber the voxels by grid row between the voxelizer and
-        the first sparse conv (sessd_sparse_renumber_sites); results do not depend on it."""
+        sort_sites: renumber the voxels by grid row between the voxelizer and the first sparse conv
+        (sessd_sparse_renumber_sites; validated on hardware in round 2, tests/test_site_renumber_gpu.py); the detections do
+        not depend on it."""
         self.dev = torch.device("cuda:0") if device is None else device
         dev = self.dev
         self.B = int(batch_size)
@@ -317,6 +318,15 @@ class InferenceEngine:
             self._kmarks.append((name, e0, e1))
             return r
         return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name), workspace=self.sk_ws, workgroups=self.sk_workgroups)
+
+    def adopt_tuning(self, other):
+        """Take another engine's tuned configuration (per-layer tilings, sparse variants, stream-K workgroup count) with a
+        stream-K workspace of this engine's own: engines that run concurrently must not share one."""
+        self.tile_cfg = dict(other.tile_cfg)
+        self.sparse_split = dict(other.sparse_split)
+        self.sk_workgroups = other.sk_workgroups
+        self.merge_branch_convs = other.merge_branch_convs
+        self.sk_ws = torch.zeros_like(other.sk_ws) if other.sk_ws is not None else None
 
     def autotune(self, candidates=(1, 2, 3, 4, 6, 11, 12), reps=5):
         """Pick the wave/workgroup tiling of every dense conv launch by timing it on this device (one-off, ~0.1 s).

@@ -1025,6 +1025,16 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
 
 
 _TILE_CFG_OVERRIDE = {}
+# tile_cfg families of the 3x3 stride-1 convs: 20/21 first-generation Winograd F(2x2,3x3), 22/23 its stream-K form
+WINOGRAD_CFGS = (20, 21, 22, 23)
+WINOGRAD_SK_CFGS = (22, 23)
+
+
+def winograd_mult_ratio(tile_cfg):
+    """Matrix-core multiplies a 3x3 kernel executes per multiply of direct convolution: F(2x2,3x3) 16/36, direct 1."""
+    return 16.0 / 36.0 if tile_cfg in WINOGRAD_CFGS else 1.0
+
+
 # 3x3 stride-1 convolutions on large maps default to the fused Winograd F(2x2,3x3) kernel (1.4x the direct kernel on
 # MI355X; float32 Winograd rounding ~1e-6 of the output scale). Set to False for the exact fmaf-chain direct kernel.
 USE_WINOGRAD = True

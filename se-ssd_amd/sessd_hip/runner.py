@@ -1,0 +1,160 @@
+"""Host-fed inference without a host synchronisation per frame.
+
+The reference's evaluation loop (tools/test.py:121-146, det3d/torchie/apis/train_sessd.py:88-106) takes a batch from the
+DataLoader, `example_to_device`s it, runs the model and moves the detections back -- three host round trips per frame. Here the
+same contract (host point clouds in, host detections out, submission order) is a three-stage pipeline:
+
+  copy stream   : pinned host points --H2D--> a device staging ring, one or more frames AHEAD of the frame being computed
+  engine streams: frames alternate between independent batch-1 engines (two frames in flight, like bench.py's timed region);
+                  an engine waits for its frame's H2D event only, stages the points into its static input buffer and replays
+                  its captured graph; the frame appends its detections to the engine's device record ring by itself
+  fetch         : every `fetch_every` frames of an engine the filled part of its record ring goes D2H into pinned memory
+                  (asynchronously, on that engine's stream); the host only ever waits for the fetch BEFORE the newest one,
+                  which is also what bounds how far it can run ahead of the device.
+"""
+import numpy as np
+import torch
+
+from ._lib import check, lib
+
+
+class HostFedPipeline:
+    def __init__(self, engines, streams=None, ring=4, fetch_every=16, eager=False):
+        """engines: batch-1 InferenceEngines of ONE configuration (captured unless eager=True). ring: staging buffers per
+        engine (frames the H2D copies may run ahead). fetch_every: frames of an engine between two D2H record fetches."""
+        assert all(e.B == 1 for e in engines), "the pipeline feeds batch-1 engines"
+        self.engines = list(engines)
+        self.dev = self.engines[0].dev
+        self.streams = list(streams) if streams is not None else [torch.cuda.Stream(self.dev) for _ in self.engines]
+        self.copy_stream = torch.cuda.Stream(self.dev)
+        self.ring, self.fetch_every, self.eager = int(ring), int(fetch_every), bool(eager)
+        self.post_max = self.engines[0].post_max
+        cap = 2 * self.fetch_every
+        self._st = []
+        for e in self.engines:
+            if e.records is None or e.records.shape[0] != cap:
+                if e.graph is not None:
+                    raise RuntimeError("attach_records(%d) must precede capture(): the ring's address is baked into the graph" % cap)
+                e.attach_records(cap)
+            P = e.P_cap
+            self._st.append(dict(
+                stage=[torch.empty((P, 4), dtype=torch.float32, device=self.dev) for _ in range(self.ring)],
+                pinned=[torch.empty((P, 4), dtype=torch.float32).pin_memory() for _ in range(self.ring)],
+                h2d=[None] * self.ring, consumed=[None] * self.ring, submitted=0, fetched=0,
+                host_rec=[torch.empty((self.fetch_every, self.post_max, 9), dtype=torch.float32).pin_memory() for _ in range(2)],
+                host_cnt=[torch.empty((self.fetch_every,), dtype=torch.int32).pin_memory() for _ in range(2)],
+                pending=[]))  # (event, buffer index, first frame of the engine, number of frames)
+        self._n = 0
+        self._out = {}
+        self._next_out = 0
+
+    def reset(self):
+        """Start a new job: zero the device cursors (the engines must be idle)."""
+        for e, st in zip(self.engines, self._st):
+            e.record_cursor.zero_()
+            st.update(submitted=0, fetched=0, pending=[], h2d=[None] * self.ring, consumed=[None] * self.ring)
+        self._n, self._out, self._next_out = 0, {}, 0
+        torch.cuda.synchronize(self.dev)
+
+    # ------------------------------------------------------------------
+    def submit(self, points):
+        """points: (P,4) float32 host array / CPU tensor (pinned memory is used in place, anything else goes through the
+        pipeline's own pinned ring). Returns the frame's index; never blocks on the frame itself."""
+        i = self._n
+        ei = i % len(self.engines)
+        e, st, stream = self.engines[ei], self._st[ei], self.streams[ei]
+        k = st["submitted"] % self.ring
+        src = points if isinstance(points, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(points, np.float32))
+        n = int(src.shape[0])
+        if n > e.P_cap:
+            raise ValueError("frame has %d points, engine capacity is %d" % (n, e.P_cap))
+        if st["consumed"][k] is not None:
+            # slot k was last used `ring` frames of this engine ago: its staging copy must have been read, and (when the source is
+            # our own pinned buffer) its H2D must have left the host buffer
+            if not src.is_pinned():
+                st["h2d"][k].synchronize()
+        if not src.is_pinned():
+            st["pinned"][k][:n].copy_(src)
+            src = st["pinned"][k][:n]
+        with torch.cuda.stream(self.copy_stream):
+            if st["consumed"][k] is not None:
+                self.copy_stream.wait_event(st["consumed"][k])
+            dst = st["stage"][k][:n]
+            dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+            st["h2d"][k] = ev
+        with torch.cuda.stream(stream):
+            stream.wait_event(ev)
+            e.set_points([dst])
+            done = torch.cuda.Event()
+            done.record(stream)
+            st["consumed"][k] = done
+            if self.eager:
+                e.enqueue()
+            else:
+                e.replay()
+            st["submitted"] += 1
+            if st["submitted"] - st["fetched"] == self.fetch_every:
+                self._fetch(ei)
+        self._n += 1
+        return i
+
+    def _fetch(self, ei):
+        """D2H of the frames of engine ei that are on its ring and not yet fetched (on its stream, asynchronous)."""
+        e, st, stream = self.engines[ei], self._st[ei], self.streams[ei]
+        lo, hi = st["fetched"], st["submitted"]
+        if hi == lo:
+            return
+        # at most one fetch stays un-collected: collecting the older one frees its pinned buffer and throttles the host
+        while len(st["pending"]) > 1:
+            self._collect(ei)
+        buf = (lo // self.fetch_every) & 1
+        cap = e.records.shape[0]
+        s0 = lo % cap
+        cnt = hi - lo
+        assert s0 + cnt <= cap and cnt <= self.fetch_every
+        with torch.cuda.stream(stream):
+            st["host_rec"][buf][:cnt].copy_(e.records[s0:s0 + cnt], non_blocking=True)
+            st["host_cnt"][buf][:cnt].copy_(e.record_counts[s0:s0 + cnt], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        st["pending"].append((ev, buf, lo, cnt))
+        st["fetched"] = hi
+
+    def _collect(self, ei):
+        st = self._st[ei]
+        ev, buf, lo, cnt = st["pending"].pop(0)
+        ev.synchronize()
+        rec, c = st["host_rec"][buf].numpy(), st["host_cnt"][buf].numpy()
+        E = len(self.engines)
+        for j in range(cnt):
+            n = int(c[j])
+            a = rec[j, :n].copy()
+            self._out[(lo + j) * E + ei] = dict(box3d_lidar=a[:, :7], scores=a[:, 7], label_preds=a[:, 8].astype(np.int64))
+
+    def poll(self):
+        """Detections that are complete on the host, in submission order (possibly empty). Does not block."""
+        for ei, st in enumerate(self._st):
+            while st["pending"] and st["pending"][0][0].query():
+                self._collect(ei)
+        return self._drain()
+
+    def _drain(self):
+        out = []
+        while self._next_out in self._out:
+            out.append(self._out.pop(self._next_out))
+            self._next_out += 1
+        return out
+
+    def finish(self):
+        """Flush: fetch what is still on the device rings, wait, return the remaining detections in submission order."""
+        for ei in range(len(self.engines)):
+            self._fetch(ei)
+        for ei, st in enumerate(self._st):
+            while st["pending"]:
+                self._collect(ei)
+        for e in self.engines:
+            if int(e.err.item()) != 0:
+                raise RuntimeError("sparse level capacity overflow: raise `growth` or max_voxels")
+        return self._drain()
