@@ -110,7 +110,8 @@ def points_in_frustum(points, surfaces):
 
 
 def sigmoid32(x):
-    x = np.asarray(x, np.float32)
+    # clamped at +-88 (exp overflows float32 beyond): sigmoid is 0 / 1 to the last bit there, and numpy stays silent
+    x = np.clip(np.asarray(x, np.float32), np.float32(-88.0), np.float32(88.0))
     return (np.float32(1) / (np.float32(1) + np.exp(-x))).astype(np.float32)
 
 

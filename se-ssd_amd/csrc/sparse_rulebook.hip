@@ -38,6 +38,10 @@ __global__ __launch_bounds__(NT) void hash_build_kernel(const int* __restrict__ 
   int n = n_dev ? min(n_dev[0], n_cap) : n_cap;
   if (i >= n) return;
   const int4 c = *reinterpret_cast<const int4*>(indices + (size_t)i * 4);
+  // a key at or beyond the empty marker 0x7F7F7F7F (batch * D * H * W too large for 31-bit keys) would alias "empty" or wrap:
+  // such a site is left out -- its lookups then miss, as for any absent site -- rather than corrupting the table
+  const long long k64 = (((long long)c.x * G.in_dims[0] + c.y) * G.in_dims[1] + c.z) * G.in_dims[2] + c.w;
+  if (k64 < 0 || k64 >= 0x7F7F7F7Fll) return;
   uint32_t slot = sessd_hash_insert(keys, mask, lin_key(c.x, c.y, c.z, c.w, G.in_dims));
   if (slot != SESSD_HASH_FULL) vals[slot] = i;  // capacity >= 2 * n_cap: cannot fill up
 }
@@ -335,7 +339,10 @@ extern "C" {
 // >= 2 * n_cap (sessd_hash_capacity). The caller clears the hash first (sessd_hash_clear).
 int sessd_sparse_hash_build(const int* indices, const int* n_dev, int n_cap, const int* dims3, uint32_t* keys, int* vals,
                             uint32_t capacity, hipStream_t stream) {
-  if (n_cap <= 0 || (capacity & (capacity - 1)) != 0) return SESSD_EINVAL;
+  if (n_cap <= 0 || (capacity & (capacity - 1)) != 0 || !dims3) return SESSD_EINVAL;
+  // keys are ((b D + z) H + y) W + x in 31 bits below the empty marker: one batch element must fit (the batch index is device
+  // data; sites of batch elements beyond the key range are skipped by the kernel, see there)
+  if (dims3[0] <= 0 || dims3[1] <= 0 || dims3[2] <= 0 || (long long)dims3[0] * dims3[1] * dims3[2] >= 0x7F7F7F7Fll) return SESSD_EINVAL;
   ConvGeom G;
   fill_geom(G, nullptr, nullptr, nullptr, dims3, nullptr);
   SESSD_LAUNCH(hash_build_kernel, dim3(sessd_divup(n_cap, NT)), dim3(NT), 0, stream, indices, n_dev, n_cap, G, keys,

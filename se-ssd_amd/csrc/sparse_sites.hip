@@ -619,6 +619,9 @@ int sessd_sparse_chain_rulebooks(const int32_t* indices0, const int32_t* n0_dev,
     if (S.in_level < 0 || S.in_level > n_levels || S.out_level < 0 || S.out_level > n_levels || !S.nbr || !S.tile_mask)
       return SESSD_EINVAL;
     if (S.ksize[0] * S.ksize[1] * S.ksize[2] > 32) return SESSD_EINVAL;
+    // chain_rulebook_kernel walks the (kz, ky) pairs in three passes of four lane groups and kx in registers: kernels beyond
+    // 12 (kz, ky) pairs or 3 taps in x would leave table rows unwritten
+    if (S.ksize[0] * S.ksize[1] > 12 || S.ksize[2] > 3 || S.ksize[0] <= 0 || S.ksize[1] <= 0 || S.ksize[2] <= 0) return SESSD_EINVAL;
     for (int d = 0; d < 3; ++d) {
       J.ks[d] = S.ksize[d]; J.st[d] = S.stride[d]; J.pd[d] = S.pad[d];
       J.in_dims[d] = S.in_level == 0 ? dims0[d] : C.L[S.in_level - 1].dims[d];

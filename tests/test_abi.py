@@ -62,3 +62,38 @@ def test_dense_entry_points_reject_bad_shapes_before_touching_the_device():
                                            4, None) == -1
     assert lib.sessd_ssfa_fuse_head(None, None, None, None, 1.0, 0.0, 1.0, 0.0, 1, 100, 64, None, None, None, 22, None, None) == -1
     assert lib.sessd_ssfa_fuse_head(None, None, None, None, 1.0, 0.0, 1.0, 0.0, 1, 128, 64, None, None, None, 21, None, None) == -1
+
+
+def test_sparse_entry_points_reject_what_their_kernels_cannot_cover():
+    """Round-2 advisor / review items, checked before any device call (null device pointers, no GPU):
+    * sessd_sparse_chain_rulebooks: chain_rulebook_kernel covers at most 12 (kz, ky) pairs and 3 taps in x -- a (5,5,1) or
+      (1,1,5) kernel passed the old volume <= 32 check and would have left neighbour-table rows unwritten;
+    * sessd_sparse_hash_build: one batch element's D*H*W must stay below the empty marker 0x7F7F7F7F of the 31-bit keys."""
+    import ctypes as C
+    import sessd_hip
+    from sessd_hip._lib import ChainLevel, RulebookJob
+    lib = sessd_hip.lib
+    lv = (ChainLevel * 1)()
+    lv[0].ksize[:] = [3, 3, 3]
+    lv[0].stride[:] = [2, 2, 2]
+    lv[0].pad[:] = [1, 1, 1]
+    lv[0].out_dims[:] = [21, 800, 704]
+    lv[0].cap = 1024
+    dims0 = (C.c_int * 3)(41, 1600, 1408)
+    ws = (C.c_char * 16)()
+
+    def rulebooks(ks):
+        job = (RulebookJob * 1)()
+        job[0].in_level, job[0].out_level = 1, 1
+        job[0].ksize[:] = ks
+        job[0].stride[:] = [1, 1, 1]
+        job[0].pad[:] = [k // 2 for k in ks]
+        job[0].nbr, job[0].tile_mask = 16, 16  # non-null, never dereferenced: the call must fail first
+        return lib.sessd_sparse_chain_rulebooks(None, None, 1024, None, None, 1024, C.cast(dims0, C.c_void_p), 1, 1, C.cast(lv, C.c_void_p),
+                                                C.cast(ws, C.c_void_p), 1, C.cast(job, C.c_void_p), None)
+
+    assert rulebooks([5, 5, 1]) == -1 and rulebooks([1, 1, 5]) == -1 and rulebooks([4, 4, 2]) == -1 and rulebooks([0, 3, 3]) == -1
+    big = (C.c_int * 3)(2048, 2048, 1024)
+    assert lib.sessd_sparse_hash_build(None, None, 16, C.cast(big, C.c_void_p), None, None, 64, None) == -1
+    assert lib.sessd_sparse_hash_build(None, None, 16, None, None, None, 64, None) == -1
+    assert lib.sessd_sparse_hash_build(None, None, 16, C.cast(dims0, C.c_void_p), None, None, 48, None) == -1  # capacity not a power of two
