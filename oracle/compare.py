@@ -5,9 +5,15 @@ suppress each other, so a float32 kernel and the float64 oracle may take a margi
 decision changes who suppresses whom further down the score order. The rule:
 
   * with no near-threshold pair (|IoU - thresh| < 1e-4 among the pairs the oracle evaluated, oracle/rotate_nms.c) the
-    detections must be IDENTICAL: same count, same order, boxes within `box_tol`, scores within `score_rtol`;
+    detections must be IDENTICAL: same count, same order, boxes within `box_tol`, scores within `score_rtol`.
+    Box tolerance: centre x, y, z and the yaw angle `box_tol` ABSOLUTE (metres / radians); the sizes w, l, h
+    `box_tol * max(1, size)`, i.e. absolute up to 1 m and RELATIVE beyond -- a size is exp(code) * anchor size
+    (box_torch_ops.py:112-146), so an error of the float32 network output `code` is a relative error of the size, and the
+    synthetic benchmark weights (random) decode some boxes to hundreds or thousands of metres (found by
+    bench.py's parity gate in round 3: 5950.8 m against the oracle's 5946.9 m for a box code of 8.2 that differs by 6.6e-4,
+    where float64 says the oracle's own float32 code is off by 7e-5 and the device's by 2.4e-4 .. 8e-4);
   * otherwise the oracle is re-run with every combination of those LISTED decisions taken one way or the other
-    (`rerun(forced)`, at most 2**max_pairs combinations) and the detections must be identical to ONE of these outcomes.
+    (`rerun(forced)`, at most 2**max_pairs combinations, max_pairs = 10) and the detections must be identical to ONE of these outcomes.
     Nothing else may differ; more than `max_pairs` marginal decisions in one frame is itself a failure.
 No path returns success without having compared every box.
 """
@@ -32,15 +38,17 @@ def same_detections(got, want, box_tol=2e-3, score_rtol=1e-3):
     if not np.allclose(gs, ws, rtol=score_rtol, atol=1e-6):
         k = int(np.argmax(np.abs(gs - ws) > score_rtol * np.abs(ws) + 1e-6))
         return "score of detection %d: %.6f vs %.6f" % (k, gs[k], ws[k])
-    d = np.maximum(np.abs(gb[:, :6] - wb[:, :6]).max(1), _ang(gb[:, 6], wb[:, 6]))
-    if d.max() > box_tol:
+    dpos = np.abs(gb[:, :3].astype(np.float64) - wb[:, :3]).max(1)
+    dsize = (np.abs(gb[:, 3:6].astype(np.float64) - wb[:, 3:6]) / np.maximum(1.0, np.abs(wb[:, 3:6].astype(np.float64)))).max(1)
+    d = np.maximum(np.maximum(dpos, dsize), _ang(gb[:, 6], wb[:, 6]))
+    if not np.all(np.isfinite(d)) or d.max() > box_tol:
         return "box of detection %d differs by %.2e" % (int(np.argmax(d)), d.max())
     if "label_preds" in got and "label_preds" in want and not np.array_equal(np.asarray(got["label_preds"]), np.asarray(want["label_preds"])):
         return "labels differ"
     return None
 
 
-def compare_detections(got, want, dbg, box_tol=2e-3, score_rtol=1e-3, max_pairs=6):
+def compare_detections(got, want, dbg, box_tol=2e-3, score_rtol=1e-3, max_pairs=10):
     """got / want: dict(box3d_lidar (n,7), scores (n,), label_preds). dbg: the oracle's debug dict of the frame
     (oracle.pipeline.run_frames(return_intermediate=True)['debug'][b]; needs dbg['rerun'] when near pairs exist).
     Raises AssertionError on a mismatch; returns dict(n, matched, near_pairs, flipped) where `flipped` lists the

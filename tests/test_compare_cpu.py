@@ -116,3 +116,21 @@ def test_pairs_and_forced_entry_points_equal_the_plain_one():
     same, _, _ = capi.rotate_nms_cc(d, 0.01, forced=np.array([[i, j, 1]], np.int32))
     flip, _, _ = capi.rotate_nms_cc(d, 0.01, forced=np.array([[i, j, 0]], np.int32))
     assert np.array_equal(same, k0) and not np.array_equal(flip, k0)
+
+
+def test_box_tolerance_is_absolute_for_the_pose_and_relative_for_large_sizes():
+    """Centres and yaw: 2e-3 absolute. Sizes: 2e-3 * max(1, size) -- a size is exp(code) * anchor size, so the float32 error of
+    the network output is a RELATIVE error of the size (the random benchmark weights decode boxes of kilometres)."""
+    want = dict(box3d_lidar=np.array([[10.0, -3.0, -1.0, 1.6, 3.9, 1.5, 0.3], [19.2, -14.8, -1.2, 5946.9, 0.236, 26.578, 3.97]], np.float32),
+                scores=np.array([0.9, 0.5], np.float32))
+    ok = copy.deepcopy(want)
+    ok["box3d_lidar"][1, 3] = 5950.8   # 6.6e-4 relative: the case bench.py's parity gate found
+    ok["box3d_lidar"][0, 4] += 1.5e-3  # within 2e-3 * max(1, 3.9)
+    assert same_detections(ok, want) is None
+    for row, col, delta in ((0, 0, 3e-3), (1, 1, 3e-3), (0, 3, 5e-3), (1, 3, 20.0), (1, 4, 3e-3), (0, 6, 3e-3)):
+        bad = copy.deepcopy(want)
+        bad["box3d_lidar"][row, col] += delta
+        assert same_detections(bad, want) is not None, (row, col)
+    nan = copy.deepcopy(want)
+    nan["box3d_lidar"][0, 3] = np.nan
+    assert same_detections(nan, want) is not None

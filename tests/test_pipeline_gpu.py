@@ -4,7 +4,7 @@
 Tolerances: BEV / SSFA feature maps 2e-4 * max|ref| (float32 sums in another order through 14 + 14 layers);
 detections: same count and order, boxes within 2e-3 m / rad, scores within 1e-3 relative. When the oracle reports NMS
 decisions within 1e-4 of the 0.01 IoU threshold, the detections must equal the oracle's under SOME assignment of those listed
-decisions (at most 6 per frame; oracle/compare.py); no path returns success without comparing every box."""
+decisions (at most 10 per frame; oracle/compare.py); no path returns success without comparing every box."""
 import numpy as np
 import pytest
 import torch
@@ -30,7 +30,7 @@ def state(model):
 
 def _compare_dets(got, want, dbg):
     """oracle/compare.py: identical detections, or identical to the oracle re-run with some of its LISTED near-threshold NMS
-    decisions (|IoU - 0.01| < 1e-4, at most 6) taken the other way. Never returns without having compared every box."""
+    decisions (|IoU - 0.01| < 1e-4, at most 10) taken the other way. Never returns without having compared every box."""
     r = compare_detections(got, want, dbg)
     if r["flipped"]:
         print("device == oracle with near-threshold decisions (kept row, candidate row, suppress):", r["flipped"])
