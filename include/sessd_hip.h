@@ -30,6 +30,9 @@ typedef void* sessd_stream_t; /* hipStream_t */
 const char* sessd_version(void);
 /* 32-bit pattern fill as a kernel launch (graph-safe clear; the library itself never uses hipMemsetAsync) */
 int sessd_fill_u32(void* ptr, uint32_t value, size_t n_words, sessd_stream_t stream);
+/* up to four such clears (16-byte aligned pointers) in ONE launch: host arrays ptrs[n] / values[n] / n_words[n] */
+int sessd_fill_u32_multi(int n_segments, void* const* ptrs, const uint32_t* values, const size_t* n_words,
+                         sessd_stream_t stream);
 /* on != 0: sessd_voxelize_frame / sessd_sparse_downsample_sites stop clearing their scratch (per-cell lists + cut word
  * at the start of the voxelizer workspace; output hash keys/vals and the first `out_hash_capacity` words of the
  * downsample workspace) -- the caller fills them with 0x7F7F7F7F itself, e.g. one fill over a contiguous arena.
@@ -399,6 +402,15 @@ int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const flo
 int sessd_ssfa_fuse_head(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0, float bn_shift0,
                          float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels, float* out,
                          const float* head_w, const float* head_b, int nout, float* head_out, sessd_stream_t stream);
+/* The same launch also running the score filter of MultiGroupHead.predict (mg_head_sessd.py:956-972: sigmoid(cls) >=
+ * score_thresh, score *= ((iou + 1) / 2)^4) on the logits it has just produced: candidate keys (~score bits << 32 | anchor id,
+ * anchor id = 2 * pixel + a) are appended to keys[b * key_cap ...], key_count[b] (device, zeroed by the caller) counts them.
+ * Input of sessd_predict_fused (ext_keys / ext_key_count). keys == NULL: plain sessd_ssfa_fuse_head. */
+int sessd_ssfa_fuse_head_keys(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
+                              float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,
+                              float* out, const float* head_w, const float* head_b, int nout, float* head_out,
+                              float score_thresh, unsigned long long* keys, int key_cap, int32_t* key_count,
+                              sessd_stream_t stream);
 
 /* ------------------------------------------------------------------ predict / post-processing (a11-a14)
  * replaces det3d/models/bbox_heads/mg_head_sessd.py:893-1057 (MultiGroupHead.predict / get_task_detections),
@@ -413,6 +425,16 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
                   const float* post_center_range6, float direction_offset, float* out_box, float* out_score,
                   int32_t* out_label, int32_t* out_count, void* workspace, size_t workspace_bytes,
                   sessd_stream_t stream);
+/* sessd_predict with two optional fusions (same results): ext_keys / ext_key_count (both or neither) = the score-filter keys
+ * (B, 2 * num_pixels) and per-frame counts already produced by sessd_ssfa_fuse_head_keys; records / record_counts / cursor
+ * (all or none) = the frame's detection record written by the call's last launch (layout and ring rule of
+ * sessd_pack_detections: slot = (*cursor + b) % capacity_frames, *cursor += batch). Three launches per call with both. */
+int sessd_predict_fused(const float* head, int batch, int num_pixels, const float* anchors, int anchors_per_frame,
+                        const double* frustum, float score_thresh, int pre_max_size, int post_max_size,
+                        float nms_iou_thresh, const float* post_center_range6, float direction_offset, float* out_box,
+                        float* out_score, int32_t* out_label, int32_t* out_count, const unsigned long long* ext_keys,
+                        const int32_t* ext_key_count, float* records, int32_t* record_counts, int capacity_frames,
+                        int32_t* cursor, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 /* spconv.utils.rbbox_iou / rbbox_intersection (third-party spconv v1, imported by det3d/core/bbox/box_np_ops.py:9 for riou_cc /
  * rinter_cc :20-50): pairwise IoU (mode 0) or intersection area (mode 1) of convex quads given as corners (n,4,2) x (k,4,2);
  * pairs whose caller-supplied stand-up IoU is <= standup_thresh stay 0. standup_iou and out are (n,k) row-major. */

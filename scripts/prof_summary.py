@@ -14,7 +14,8 @@ nrows = int(sys.argv[3]) if len(sys.argv) > 3 else 45
 rows = list(db.execute("select name, start, end from kernels order by start"))
 div = 1.0
 if frames > 0:
-    starts = [i for i, r in enumerate(rows) if "vox_insert_kernel" in r[0]]
+    marker = "fill_multi_kernel" if any("fill_multi_kernel" in r[0] for r in rows) else "vox_insert_kernel"  # a frame's first launch
+    starts = [i for i, r in enumerate(rows) if marker in r[0]]
     rows = rows[starts[-frames]:]
     div = float(frames)
 agg = defaultdict(lambda: [0, 0.0, 1e30, 0.0])

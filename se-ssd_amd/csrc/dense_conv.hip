@@ -632,7 +632,9 @@ __global__ __launch_bounds__(256, 2) void ssfa_fuse_head_kernel(const float* __r
                                                               const float* __restrict__ w0, const float* __restrict__ w1,
                                                               float s0, float t0, float s1, float t1, int npix,
                                                               float* __restrict__ out, const float* __restrict__ hw,
-                                                              const float* __restrict__ hb, float* __restrict__ hout) {
+                                                              const float* __restrict__ hb, float* __restrict__ hout,
+                                                              float score_thresh, unsigned long long* __restrict__ keys,
+                                                              int key_cap, int* __restrict__ key_count) {
   constexpr int C = 4 * CPER;
   __shared__ float part[2][4][64];
   __shared__ __attribute__((aligned(16))) float s_hw[NOUT * C];  // head weights
@@ -699,10 +701,29 @@ __global__ __launch_bounds__(256, 2) void ssfa_fuse_head_kernel(const float* __r
   for (int o = 0; o < NOUT; ++o) s_acc[(cq * NOUT + o) * 64 + px] = acc[o];
   __syncthreads();
   if (!live) return;
-  for (int o = cq; o < NOUT; o += 4) {
+  auto head_value = [&](int o) {  // quarter sums in quarter order + bias: the value stored for (pixel, head channel o)
     const float v = ((s_acc[(0 * NOUT + o) * 64 + px] + s_acc[(1 * NOUT + o) * 64 + px]) + s_acc[(2 * NOUT + o) * 64 + px]) +
                     s_acc[(3 * NOUT + o) * 64 + px];
-    hout[((size_t)b * NOUT + o) * npix + p] = v + (hb ? hb[o] : 0.f);
+    return v + (hb ? hb[o] : 0.f);
+  };
+  for (int o = cq; o < NOUT; o += 4) hout[((size_t)b * NOUT + o) * npix + p] = head_value(o);
+  // The score filter of MultiGroupHead.predict (mg_head_sessd.py:956-972; postprocess.hip: score_filter_kernel) while the
+  // logits are at hand: sigmoid(cls) >= thresh -> key (~rectified score | anchor id) appended to the frame's candidate list.
+  // Planar head layout [box 14 | cls 2 | dir 4 | iou 2], two anchors per location; the same float operations on the same
+  // values as the stand-alone kernel reads back from `hout`, so the keys are the same set.
+  if (keys && cq == 0) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const float sg = 1.0f / (1.0f + expf(-head_value(14 + a)));
+      if (sg >= score_thresh) {
+        const float r = (head_value(20 + a) + 1.0f) * 0.5f;
+        const float sc = sg * (r * r * r * r);
+        const unsigned aid = (unsigned)(p * 2 + a);
+        const unsigned long long key = ((unsigned long long)(~__float_as_uint(sc)) << 32) | aid;
+        const int slot = atomicAdd(&key_count[b], 1);
+        if (slot < key_cap) keys[(size_t)b * key_cap + slot] = key;
+      }
+    }
   }
 }
 
@@ -1013,20 +1034,32 @@ int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const flo
 // while it is in registers. head_w (nout, channels) row-major = the concatenated conv weights, head_b (nout) or null,
 // head_out (B, nout, num_pixels) planar. out (B, C, num_pixels) receives the SSFA output when not null. nout == 22 (the
 // single-task car head: 14 box + 2 cls + 4 dir + 2 iou), channels 128 (the SSFA neck) or 64.
-int sessd_ssfa_fuse_head(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0, float bn_shift0,
-                         float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels, float* out,
-                         const float* head_w, const float* head_b, int nout, float* head_out, hipStream_t stream) {
+// keys != NULL: the launch also runs the score filter of predict (score_thresh on sigmoid(cls), IoU-rectified score) and
+// appends the candidates' 64-bit keys (~score bits << 32 | anchor id, anchor id = 2 * pixel + a) to keys[b * key_cap ..] with
+// key_count[b] (zeroed by the caller) counting them -- what sessd_predict_fused takes as ext_keys / ext_key_count.
+int sessd_ssfa_fuse_head_keys(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0, float bn_shift0,
+                              float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels, float* out,
+                              const float* head_w, const float* head_b, int nout, float* head_out, float score_thresh,
+                              unsigned long long* keys, int key_cap, int* key_count, hipStream_t stream) {
   if (batch < 1 || (channels != 128 && channels != 64) || num_pixels < 1 || nout != 22) return SESSD_EINVAL;
   if ((long long)channels * num_pixels * 4 >= 0x7fffffffLL) return SESSD_EINVAL;  // 32-bit buffer offsets per batch element
+  if ((keys == nullptr) != (key_count == nullptr) || (keys && key_cap < 1)) return SESSD_EINVAL;
   const dim3 grid(sessd_divup(num_pixels, 64), batch);
   if (channels == 128)
     SESSD_LAUNCH((ssfa_fuse_head_kernel<22, 32>), grid, dim3(256), 0, stream, x0, x1, w0, w1, bn_scale0, bn_shift0, bn_scale1,
-                 bn_shift1, num_pixels, out, head_w, head_b, head_out);
+                 bn_shift1, num_pixels, out, head_w, head_b, head_out, score_thresh, keys, key_cap, key_count);
   else
     SESSD_LAUNCH((ssfa_fuse_head_kernel<22, 16>), grid, dim3(256), 0, stream, x0, x1, w0, w1, bn_scale0, bn_shift0, bn_scale1,
-                 bn_shift1, num_pixels, out, head_w, head_b, head_out);
+                 bn_shift1, num_pixels, out, head_w, head_b, head_out, score_thresh, keys, key_cap, key_count);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
+}
+
+int sessd_ssfa_fuse_head(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0, float bn_shift0,
+                         float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels, float* out,
+                         const float* head_w, const float* head_b, int nout, float* head_out, hipStream_t stream) {
+  return sessd_ssfa_fuse_head_keys(x0, x1, w0, w1, bn_scale0, bn_shift0, bn_scale1, bn_shift1, batch, channels, num_pixels, out,
+                                   head_w, head_b, nout, head_out, 0.f, nullptr, 0, nullptr, stream);
 }
 
 }  // extern "C"

@@ -9,10 +9,14 @@
 //                     with a wave-aggregated atomic (order does not matter: the key is a total order)
 //   K2 topk_decode    1 workgroup / frame: running top-`pre_max` by bitonic sort in LDS (2048 keys at a time),
 //                     then decode ONLY the survivors (box, rectified score, direction label, BEV corners, AABB)
-//   K3 rnms_mask      64x64 suppression bitmask tiles: AABB prefilter (float32, iou_jit eps=0) then convex
-//                     polygon clipping in float64; suppress when IoU >= thresh
-//   K4 nms_reduce     one wave / frame, greedy, stops at post_max (iou3d.hip: sessd_nms_reduce_kernel)
-//   K5 finalize       frustum (float64 planes), direction fix, centre-range mask, ordered compaction
+//   K3 rnms_mask      one wave per row of the suppression bitmask: AABB prefilter (float32, iou_jit eps=0) over the
+//                     later candidates, the survivors COMPACTED in LDS, then convex polygon clipping in float64 on dense
+//                     lanes only; suppress when IoU >= thresh
+//   K4 nms_reduce     greedy walk over the mask (staged in LDS), stops at post_max, fused with
+//   K5 finalize       frustum (float64 planes), direction fix, centre-range mask, ordered compaction, and the frame's
+//                     fixed-size detection record (sessd_predict_fused; the unfused kernels serve pre_max > ~1280)
+// K1 can also run inside the producer of the head tensor (sessd_ssfa_fuse_head_keys, dense_conv.hip): the keys then arrive
+// with the head and the frame has one launch and one 35 k-thread pass less.
 // Head tensor layout consumed here: planar (B, 22, H*W): ch 0..13 box codes (anchor-major, 7 each),
 // 14..15 cls, 16..19 dir (2 per anchor), 20..21 iou; anchor id = pixel*2 + a (mg_head_sessd.py:409-481).
 #include "geom.hpp"
@@ -79,9 +83,17 @@ __global__ __launch_bounds__(SORT_NT) void topk_decode_kernel(const float* __res
                                                                int key_cap, const int* __restrict__ count,
                                                                float* __restrict__ cand_box, float* __restrict__ cand_score,
                                                                int* __restrict__ cand_dir, float* __restrict__ corners,
-                                                               float* __restrict__ standup, int* __restrict__ n_top) {
+                                                               float* __restrict__ standup, int* __restrict__ n_top,
+                                                               int* __restrict__ rec_cursor, int* __restrict__ rec_base, int batch) {
   __shared__ unsigned long long s[SORT_N];
   const int b = blockIdx.x;
+  // detection records (sessd_predict_fused): this batch takes the ring slots cursor .. cursor + batch - 1; the last kernel of
+  // the call reads the base from the workspace
+  if (rec_cursor && b == 0 && threadIdx.x == 0) {
+    const int c0 = *rec_cursor;
+    *rec_base = c0;
+    *rec_cursor = c0 + batch;
+  }
   const int n = min(count[b], key_cap);
   const unsigned long long* kb = keys + (size_t)b * key_cap;
   int T = 0, pos = 0;
@@ -140,16 +152,19 @@ __global__ __launch_bounds__(SORT_NT) void topk_decode_kernel(const float* __res
   }
 }
 
-__device__ __forceinline__ bool rnms_suppresses(const float* ci, const float* si, const float* cj, const float* sj,
-                                                float thresh) {
-  // iou_jit(eps=0) prefilter (box_np_ops.py:1007-1045), float32
+// iou_jit(eps=0) prefilter (box_np_ops.py:1007-1045), float32: stand-up IoU > 0
+__device__ __forceinline__ bool rnms_prefilter(const float* si, const float* sj) {
   const float iw = fminf(si[2], sj[2]) - fmaxf(si[0], sj[0]);
   if (!(iw > 0.f)) return false;
   const float ih = fminf(si[3], sj[3]) - fmaxf(si[1], sj[1]);
   if (!(ih > 0.f)) return false;
   const float ua = (si[2] - si[0]) * (si[3] - si[1]) + (sj[2] - sj[0]) * (sj[3] - sj[1]) - iw * ih;
   const float siou = iw * ih / ua;
-  if (siou <= 0.f) return false;
+  return !(siou <= 0.f);
+}
+
+// polygon IoU >= thresh (nms_cpu.h:130-160: area(P & Q) / area(P | Q)), float64 clipping
+__device__ __forceinline__ bool rnms_polygon(const float* ci, const float* cj, float thresh) {
   const double inter = sessd_quad_inter_area_green(ci, cj);
   if (inter <= 0) return false;
   double px[4], py[4], qx[4], qy[4];
@@ -160,40 +175,73 @@ __device__ __forceinline__ bool rnms_suppresses(const float* ci, const float* si
   return ov >= (double)thresh;
 }
 
-// One WAVE per (row i, 64-column word): lane j evaluates the pair (i, cblk*64 + j) and a ballot assembles the
-// suppression word -- 64-way parallel over the expensive polygon clipping instead of one thread per row.
-__global__ __launch_bounds__(256) void rnms_mask_kernel(const int* __restrict__ n_top, int pre_max, float thresh,
-                                                         const float* __restrict__ corners, const float* __restrict__ standup,
-                                                         unsigned long long* __restrict__ mask, int words) {
-  const int b = blockIdx.z, cblk = blockIdx.x;
+// One WAVE per row i of the suppression mask. Round 2 gave every (row, 64-column word) a wave and let the lanes that passed
+// the stand-up prefilter run the float64 polygon clipping (~1500 instructions) while the rest of the wave idled: with a
+// handful of overlapping neighbours per candidate nearly every one of the 8000 waves paid the full clipping time for 1-3
+// useful lanes (21.7 us per frame, max 38). Here the wave sweeps the later candidates j > i with the cheap prefilter (16-byte
+// coalesced loads), compacts the survivors into an LDS list (ballot + prefix popcount) and clips them on DENSE lanes -- one
+// clipping round per row for up to 64 overlapping neighbours. The row's words are assembled in LDS and written from word
+// i / 64 on (words left of the diagonal are never read).
+constexpr int RN_ROWS = 4;       // waves (rows) per workgroup
+constexpr int RN_MAXN = 4096;    // candidates (rotate_nms_common's limit)
+__global__ __launch_bounds__(RN_ROWS * 64) void rnms_mask_kernel(const int* __restrict__ n_top, int pre_max, float thresh,
+                                                                  const float* __restrict__ corners,
+                                                                  const float* __restrict__ standup,
+                                                                  unsigned long long* __restrict__ mask, int words) {
+  __shared__ unsigned short s_list[RN_ROWS][RN_MAXN];
+  __shared__ unsigned s_bits[RN_ROWS][RN_MAXN / 32];
+  const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-  const int n = n_top[b];
-  if (i >= n || cblk * 64 >= n || cblk < (i >> 6)) return;  // words left of the diagonal are never read
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i = blockIdx.x * RN_ROWS + wv;
+  const int n = min(n_top[b], pre_max);
+  if (i >= n) return;  // waves are independent: no workgroup barrier below
   const float* cb = corners + (size_t)b * pre_max * 8;
-  const float* sb = standup + (size_t)b * pre_max * 4;
-  const int col = cblk * 64 + lane;
-  bool sup = false;
-  if (col < n && col > i) {
-    float ci[8], si[4], cj[8], sj[4];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { ci[q] = cb[(size_t)i * 8 + q]; cj[q] = cb[(size_t)col * 8 + q]; }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) { si[q] = sb[(size_t)i * 4 + q]; sj[q] = sb[(size_t)col * 4 + q]; }
-    sup = rnms_suppresses(ci, si, cj, sj, thresh);
+  const float4* sb = reinterpret_cast<const float4*>(standup + (size_t)b * pre_max * 4);
+  const float4 s4 = sb[i];
+  const float si[4] = {s4.x, s4.y, s4.z, s4.w};
+  for (int w = lane; w < 2 * words; w += 64) s_bits[wv][w] = 0u;
+  int cnt = 0;
+  for (int j0 = (i + 1) & ~63; j0 < n; j0 += 64) {
+    const int j = j0 + lane;
+    bool pass = false;
+    if (j > i && j < n) {
+      const float4 t4 = sb[j];
+      const float sj[4] = {t4.x, t4.y, t4.z, t4.w};
+      pass = rnms_prefilter(si, sj);
+    }
+    const unsigned long long bal = __ballot(pass);
+    if (pass) s_list[wv][cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
+    cnt += __popcll(bal);
   }
-  const unsigned long long bits = __ballot(sup);
-  if (lane == 0) mask[((size_t)b * pre_max + i) * words + cblk] = bits;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the list and the cleared words are in LDS (one wave: LDS is in order)
+  if (cnt) {
+    float ci[8];
+    const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)i * 8);
+    const float4 a4 = c4[0], b4 = c4[1];
+    ci[0] = a4.x; ci[1] = a4.y; ci[2] = a4.z; ci[3] = a4.w; ci[4] = b4.x; ci[5] = b4.y; ci[6] = b4.z; ci[7] = b4.w;
+    for (int idx = lane; idx < cnt; idx += 64) {
+      const int j = s_list[wv][idx];
+      const float4* d4 = reinterpret_cast<const float4*>(cb + (size_t)j * 8);
+      const float4 e4 = d4[0], f4 = d4[1];
+      const float cj[8] = {e4.x, e4.y, e4.z, e4.w, f4.x, f4.y, f4.z, f4.w};
+      if (rnms_polygon(ci, cj, thresh)) atomicOr(&s_bits[wv][j >> 5], 1u << (j & 31));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  for (int w = (i >> 6) + lane; w < words; w += 64)
+    mask[((size_t)b * pre_max + i) * words + w] = (unsigned long long)s_bits[wv][2 * w] | ((unsigned long long)s_bits[wv][2 * w + 1] << 32);
 }
 
-// frustum: (B,1,6,4,3) float64 surfaces (or null). One wave per frame.
-__global__ __launch_bounds__(64) void finalize_kernel(PostCfg C, const int* __restrict__ keep, const int* __restrict__ n_keep,
-                                                       const float* __restrict__ cand_box, const float* __restrict__ cand_score,
-                                                       const int* __restrict__ cand_dir, const double* __restrict__ frustum,
-                                                       float* __restrict__ out_box, float* __restrict__ out_score,
-                                                       int* __restrict__ out_label, int* __restrict__ out_count) {
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const int nk = min(n_keep[b], C.post_max);
+// Post-NMS filters of one frame by ONE wave (mg_head_sessd.py:1024-1055): frustum (B,1,6,4,3) float64 surfaces (or null),
+// direction fix, centre-range mask, ordered compaction. keep = the frame's kept candidate rows (global or LDS), nk of them.
+// rec != nullptr: the finalized rows also go to rec[row * 9 + {box 7, score, label}] (LDS staging of the detection record).
+// Returns the number of detections written (wave-uniform).
+__device__ __forceinline__ int finalize_wave(const PostCfg& C, int b, int lane, const int* keep, int nk,
+                                             const float* __restrict__ cand_box, const float* __restrict__ cand_score,
+                                             const int* __restrict__ cand_dir, const double* __restrict__ frustum,
+                                             float* __restrict__ out_box, float* __restrict__ out_score,
+                                             int* __restrict__ out_label, float* rec) {
   double nx[6], ny[6], nz[6], nd[6];
   if (frustum) {
     const double* f = frustum + (size_t)b * 72;
@@ -215,7 +263,7 @@ __global__ __launch_bounds__(64) void finalize_kernel(PostCfg C, const int* __re
     float bx[7] = {0, 0, 0, 0, 0, 0, 0};
     float sc = 0.f;
     if (ok) {
-      const size_t o = (size_t)b * C.pre_max + keep[(size_t)b * C.post_max + k];
+      const size_t o = (size_t)b * C.pre_max + keep[k];
 #pragma unroll
       for (int q = 0; q < 7; ++q) bx[q] = cand_box[o * 7 + q];
       sc = cand_score[o];
@@ -239,64 +287,64 @@ __global__ __launch_bounds__(64) void finalize_kernel(PostCfg C, const int* __re
       for (int q = 0; q < 7; ++q) out_box[o * 7 + q] = bx[q];
       out_score[o] = sc;
       out_label[o] = 0;
+      if (rec) {
+#pragma unroll
+        for (int q = 0; q < 7; ++q) rec[dst * 9 + q] = bx[q];
+        rec[dst * 9 + 7] = sc;
+        rec[dst * 9 + 8] = 0.f;
+      }
     }
     written += __popcll(bal);
   }
+  return written;
+}
+
+__global__ __launch_bounds__(64) void finalize_kernel(PostCfg C, const int* __restrict__ keep, const int* __restrict__ n_keep,
+                                                       const float* __restrict__ cand_box, const float* __restrict__ cand_score,
+                                                       const int* __restrict__ cand_dir, const double* __restrict__ frustum,
+                                                       float* __restrict__ out_box, float* __restrict__ out_score,
+                                                       int* __restrict__ out_label, int* __restrict__ out_count) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const int nk = min(n_keep[b], C.post_max);
+  const int written = finalize_wave(C, b, lane, keep + (size_t)b * C.post_max, nk, cand_box, cand_score, cand_dir, frustum, out_box,
+                                    out_score, out_label, nullptr);
   if (lane == 0) out_count[b] = written;
 }
 
-// Greedy reduction with the WHOLE suppression mask staged in LDS (pre_max*ceil(pre_max/64)*8 B = 128 KB for
-// pre_max 1000; 160 KB LDS per CU): 1024 threads copy it in one coalesced sweep, then one wave walks it at LDS
-// latency instead of one dependent global load per kept row.
-__global__ __launch_bounds__(1024) void nms_reduce_lds_kernel(const int* __restrict__ n_top, int pre_max,
-                                                              const unsigned long long* __restrict__ mask, int words,
-                                                              int post_max, int* __restrict__ keep, int* __restrict__ n_keep) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
-  const int b = blockIdx.x;
-  const int n = min(n_top[b], pre_max);
-  const unsigned long long* mb = mask + (size_t)b * pre_max * words;
-  const int cb = sessd_divup(n, 64);
-  // blind 16-byte copy of the n x words matrix (words left of the diagonal were never written by the mask kernel
-  // and are never read below); 8 independent loads per thread in flight
-  {
-    const int total2 = (n * words + 1) >> 1;
-    const uint4* src = reinterpret_cast<const uint4*>(mb);
-    uint4* dst = reinterpret_cast<uint4*>(sm);
-#pragma unroll 8
-    for (int idx = threadIdx.x; idx < total2; idx += 1024) dst[idx] = src[idx];
-  }
-  __syncthreads();
-  if (threadIdx.x >= 64) return;
-  const int lane = threadIdx.x;
-  int* kb = keep + (size_t)b * post_max;
-  unsigned long long removed = 0;  // lane w owns word w
-  int nk = 0;
-  // the greedy walk is wave-uniform: rows' diagonal words are pulled out of the VGPR with v_readlane into scalars
-  // (no ds_bpermute round trip per candidate), the running "removed" word of the block lives in SGPRs
+// The greedy walk of the rotated NMS over a suppression mask in LDS by ONE wave (nms_cpu.h:86-168: candidates in score order,
+// a candidate is kept unless a kept one suppresses it; stops at post_max). lane w owns word w of the running "removed" set.
+// Round 2 tested every candidate of a block in turn (~20 scalar-ish instructions x 1000 candidates = 10 us of the 22 us this
+// kernel took); here the next kept candidate of a block is the lowest clear bit of (~removed & valid) -- s_ff1 -- so the loop
+// runs once per KEPT candidate (<= post_max in total). Kept rows go to `keep_out` (LDS or global); returns their number.
+__device__ __forceinline__ int nms_walk_lds(const unsigned long long* sm, int n, int words, int post_max, int lane, int* keep_out) {
   auto rdlane64 = [](unsigned long long v, int l) -> unsigned long long {
     const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)v, l);
     const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
     return ((unsigned long long)hi << 32) | lo;
   };
+  const int cb = sessd_divup(n, 64);
+  unsigned long long removed = 0;
+  int nk = 0;
   for (int blk = 0; blk < cb && nk < post_max; ++blk) {
     const int row = blk * 64 + lane;
     const unsigned long long diag = row < n ? sm[(size_t)row * words + blk] : 0ull;
     unsigned long long rem = rdlane64(removed, blk);
-    unsigned long long kept = 0;
     const int lim = min(64, n - blk * 64);
-    for (int bb = 0; bb < lim; ++bb) {
-      if (!((rem >> bb) & 1ull) && nk < post_max) {
-        kept |= 1ull << bb;
-        ++nk;
-        rem |= rdlane64(diag, bb);
-      }
+    const unsigned long long valid = lim >= 64 ? ~0ull : ((1ull << lim) - 1ull);
+    unsigned long long kept = 0;
+    unsigned long long avail = ~rem & valid;
+    while (avail && nk < post_max) {
+      const int bb = __builtin_amdgcn_readfirstlane(__builtin_ctzll(avail));
+      kept |= 1ull << bb;
+      ++nk;
+      rem |= rdlane64(diag, bb) | (1ull << bb);
+      avail = ~rem & valid;
     }
-    // kept rows of this block -> output list (lane t writes the t-th kept row of the block)
-    {
+    {  // kept rows of this block -> output list, ascending
       const int base = nk - __popcll(kept);
       unsigned long long k2 = kept;
       for (int t = 0; k2; ++t, k2 &= k2 - 1)
-        if (lane == 0) kb[base + t] = blk * 64 + __builtin_ctzll(k2);
+        if (lane == 0) keep_out[base + t] = blk * 64 + __builtin_ctzll(k2);
     }
     if (nk >= post_max) break;
     if (lane > blk && lane < cb) {
@@ -306,7 +354,86 @@ __global__ __launch_bounds__(1024) void nms_reduce_lds_kernel(const int* __restr
       removed |= acc;
     }
   }
-  if (lane == 0) n_keep[b] = nk;
+  return nk;
+}
+
+__device__ __forceinline__ void stage_mask_lds(unsigned long long* sm, const unsigned long long* mb, int n, int words) {
+  // blind 16-byte copy of the n x words matrix (words left of the diagonal were never written by the mask kernel and are
+  // never read by the walk); 8 independent loads per thread in flight
+  const int total2 = (n * words + 1) >> 1;
+  const uint4* src = reinterpret_cast<const uint4*>(mb);
+  uint4* dst = reinterpret_cast<uint4*>(sm);
+#pragma unroll 8
+  for (int idx = threadIdx.x; idx < total2; idx += 1024) dst[idx] = src[idx];
+}
+
+// The greedy reduction with the WHOLE suppression mask staged in LDS (pre_max*ceil(pre_max/64)*8 B = 128 KB for pre_max 1000;
+// 160 KB LDS per CU: 1024 threads copy it in one coalesced sweep, then one wave walks it at LDS latency instead of one
+// dependent global load per kept row),
+// FUSED with the post-NMS filters and the frame's detection record: after the walk the kept rows sit in LDS,
+// wave 0 runs finalize_wave on them (<= post_max boxes), the finalized rows are staged in LDS and all threads write the
+// fixed-size record (post_max x 9 floats + count; rows beyond the count zero) -- three launches of round 2 (nms_reduce 22 us,
+// finalize 4.9 us, pack_detections 4.2 us) as one. Dynamic LDS: mask | keep[post_max] | rec[post_max * 9].
+// records == nullptr: no record. rec_base = the slot counter value of this batch's first frame (written by topk_decode).
+__global__ __launch_bounds__(1024) void nms_reduce_finalize_kernel(PostCfg C, const int* __restrict__ n_top,
+                                                                   const unsigned long long* __restrict__ mask, int words,
+                                                                   const float* __restrict__ cand_box,
+                                                                   const float* __restrict__ cand_score,
+                                                                   const int* __restrict__ cand_dir,
+                                                                   const double* __restrict__ frustum, float* __restrict__ out_box,
+                                                                   float* __restrict__ out_score, int* __restrict__ out_label,
+                                                                   int* __restrict__ out_count, float* __restrict__ records,
+                                                                   int* __restrict__ rec_count, int capacity,
+                                                                   const int* __restrict__ rec_base) {
+  extern __shared__ __attribute__((aligned(16))) unsigned long long sm[];
+  __shared__ int s_written;
+  const int b = blockIdx.x;
+  const int n = min(n_top[b], C.pre_max);
+  const size_t mask_words = (size_t)C.pre_max * words;
+  int* s_keep = reinterpret_cast<int*>(sm + mask_words);
+  float* s_rec = reinterpret_cast<float*>(s_keep + C.post_max);
+  stage_mask_lds(sm, mask + (size_t)b * mask_words, n, words);
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int nk = nms_walk_lds(sm, n, words, C.post_max, threadIdx.x, s_keep);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // lane 0's list is read by the other lanes of this wave
+    const int written = finalize_wave(C, b, threadIdx.x, s_keep, nk, cand_box, cand_score, cand_dir, frustum, out_box, out_score,
+                                      out_label, records ? s_rec : nullptr);
+    if (threadIdx.x == 0) {
+      out_count[b] = written;
+      s_written = written;
+    }
+  }
+  if (!records) return;
+  __syncthreads();
+  const int written = s_written;
+  const int slot = (rec_base[0] + b) % capacity;
+  float* dst = records + (size_t)slot * C.post_max * 9;
+  for (int e = threadIdx.x; e < C.post_max * 9; e += 1024) dst[e] = e < written * 9 ? s_rec[e] : 0.f;
+  if (threadIdx.x == 0) rec_count[slot] = written;
+}
+
+// ---- detection records for the end-of-job gather (tools/dist_test.py:150-186 gathers pickled per-rank dicts; here every frame
+// leaves one fixed-size record on the device: (post_max, 9) float32 [box 7 | score | label] + a count), appended by the frame's
+// own launch sequence so that a captured graph needs no host-side bookkeeping: slot = (*cursor + b) % capacity, cursor += batch.
+__global__ __launch_bounds__(256) void pack_detections_kernel(const float* __restrict__ box, const float* __restrict__ score,
+                                                               const int* __restrict__ label, const int* __restrict__ count,
+                                                               int batch, int post_max, float* __restrict__ records,
+                                                               int* __restrict__ rec_count, int capacity, int* __restrict__ cursor,
+                                                               const int* __restrict__ base_in) {
+  // base_in: the batch's first slot was already taken (and the cursor advanced) by topk_decode_kernel
+  const int c0 = base_in ? *base_in : *cursor;
+  const int total = batch * post_max * 9;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    const int b = e / (post_max * 9), r = (e - b * post_max * 9) / 9, q = e % 9;
+    const int n = count[b];
+    float v = 0.f;
+    if (r < n) v = q < 7 ? box[((size_t)b * post_max + r) * 7 + q] : (q == 7 ? score[(size_t)b * post_max + r] : (float)label[(size_t)b * post_max + r]);
+    records[((size_t)((c0 + b) % capacity) * post_max + r) * 9 + q] = v;
+  }
+  if (threadIdx.x < batch) rec_count[(c0 + threadIdx.x) % capacity] = count[threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0 && !base_in) *cursor = c0 + batch;
 }
 
 struct PostWs {
@@ -321,6 +448,7 @@ struct PostWs {
   unsigned long long* mask;
   int* keep;
   int* n_keep;
+  int* rec_base;
 };
 
 size_t post_ws_layout(int batch, int num_anchors, int pre_max, int post_max, PostWs* w, char* base) {
@@ -342,6 +470,7 @@ size_t post_ws_layout(int batch, int num_anchors, int pre_max, int post_max, Pos
   size_t o_mask = take((size_t)batch * pre_max * words * 8);
   size_t o_keep = take((size_t)batch * post_max * 4);
   size_t o_nk = take((size_t)batch * 4);
+  size_t o_rb = take(4);
   if (w) {
     w->keys = (unsigned long long*)(base + o_keys);
     w->count = (int*)(base + o_count);
@@ -354,6 +483,7 @@ size_t post_ws_layout(int batch, int num_anchors, int pre_max, int post_max, Pos
     w->mask = (unsigned long long*)(base + o_mask);
     w->keep = (int*)(base + o_keep);
     w->n_keep = (int*)(base + o_nk);
+    w->rec_base = (int*)(base + o_rb);
   }
   return off;
 }
@@ -404,12 +534,23 @@ size_t sessd_predict_workspace_bytes(int batch, int num_anchors, int pre_max_siz
 // head (B,22,H*W) planar, anchors (A,7) shared by all frames (anchors_per_frame = 0) or (B,A,7),
 // frustum (B,1,6,4,3) float64 or NULL. Outputs: out_box (B,post,7), out_score (B,post), out_label (B,post) int32,
 // out_count (B,) -- rows [0,out_count[b]) are the detections of frame b in NMS order.
-int sessd_predict(const float* head, int batch, int num_pixels, const float* anchors, int anchors_per_frame,
-                  const double* frustum, float score_thresh, int pre_max_size, int post_max_size, float nms_iou_thresh,
-                  const float* post_center_range6, float direction_offset, float* out_box, float* out_score,
-                  int* out_label, int* out_count, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+// ext_keys / ext_key_count (both or neither): the score-filter keys (B, 2 * num_pixels) uint64 and their per-frame counts were
+// already produced with the head tensor (sessd_ssfa_fuse_head_keys; counts zeroed by the caller before that launch) -- the
+// count clear and the score_filter launch are skipped.
+// records != NULL: every frame also leaves its fixed-size detection record (sessd_pack_detections' layout and ring rule:
+// slot = (*cursor + b) % capacity_frames, *cursor += batch) from inside the last launch.
+// 3 launches per call with external keys and pre_max_size such that the suppression mask fits the LDS (<= ~1280): top-k +
+// decode, suppression mask, greedy walk + filters + record.
+int sessd_predict_fused(const float* head, int batch, int num_pixels, const float* anchors, int anchors_per_frame,
+                        const double* frustum, float score_thresh, int pre_max_size, int post_max_size, float nms_iou_thresh,
+                        const float* post_center_range6, float direction_offset, float* out_box, float* out_score,
+                        int* out_label, int* out_count, const unsigned long long* ext_keys, const int* ext_key_count,
+                        float* records, int* record_counts, int capacity_frames, int* cursor, void* workspace,
+                        size_t workspace_bytes, hipStream_t stream) {
   if (batch < 1 || num_pixels < 1 || pre_max_size < 1 || pre_max_size > 4096 || post_max_size < 1) return SESSD_EINVAL;
   if (pre_max_size > SORT_N - 64) return SESSD_EINVAL;  // running top-k keeps pre_max + a fresh chunk in 2048 slots
+  if ((ext_keys == nullptr) != (ext_key_count == nullptr)) return SESSD_EINVAL;
+  if (records && (!record_counts || !cursor || capacity_frames < batch || batch > 256)) return SESSD_EINVAL;
   const int A = num_pixels * APL;
   PostWs w;
   if (post_ws_layout(batch, A, pre_max_size, post_max_size, &w, (char*)workspace) > workspace_bytes)
@@ -422,38 +563,59 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
   C.nms_thresh = nms_iou_thresh;
   for (int i = 0; i < 6; ++i) C.range[i] = post_center_range6[i];
   C.dir_offset = direction_offset;
-  SESSD_FILL(w.count, 0, batch, stream);
-  SESSD_LAUNCH(score_filter_kernel, dim3(sessd_divup(num_pixels, 256), batch), dim3(256), 0, stream, head, C,
-                     w.keys, A, w.count);
-  SESSD_CHECK_LAUNCH();
+  const unsigned long long* keys = ext_keys;
+  const int* key_count = ext_key_count;
+  if (!ext_keys) {
+    SESSD_FILL(w.count, 0, batch, stream);
+    SESSD_LAUNCH(score_filter_kernel, dim3(sessd_divup(num_pixels, 256), batch), dim3(256), 0, stream, head, C,
+                       w.keys, A, w.count);
+    SESSD_CHECK_LAUNCH();
+    keys = w.keys;
+    key_count = w.count;
+  }
   SESSD_LAUNCH(topk_decode_kernel, dim3(batch), dim3(SORT_NT), 0, stream, head, anchors, anchors_per_frame, C,
-                     w.keys, A, w.count, w.cand_box, w.cand_score, w.cand_dir, w.corners, w.standup, w.n_top);
+                     keys, A, key_count, w.cand_box, w.cand_score, w.cand_dir, w.corners, w.standup, w.n_top,
+                     records ? cursor : (int*)nullptr, w.rec_base, batch);
   SESSD_CHECK_LAUNCH();
   const int words = sessd_divup(pre_max_size, 64);
-  SESSD_LAUNCH(rnms_mask_kernel, dim3(words, sessd_divup(pre_max_size, 4), batch), dim3(256), 0, stream, w.n_top,
+  SESSD_LAUNCH(rnms_mask_kernel, dim3(sessd_divup(pre_max_size, RN_ROWS), batch), dim3(RN_ROWS * 64), 0, stream, w.n_top,
                      pre_max_size, nms_iou_thresh, w.corners, w.standup, w.mask, words);
   SESSD_CHECK_LAUNCH();
-  {
-    const size_t lds = (size_t)pre_max_size * words * 8;
-    if (lds <= 160 * 1024 - 1024) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        SESSD_TRY(hipFuncSetAttribute((const void*)nms_reduce_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      160 * 1024 - 1024));
-        attr_set = true;
-      }
-      SESSD_LAUNCH(nms_reduce_lds_kernel, dim3(batch), dim3(1024), lds, stream, w.n_top, pre_max_size, w.mask, words,
-                         post_max_size, w.keep, w.n_keep);
-    } else {
-      SESSD_LAUNCH(nms_reduce_batch_kernel, dim3(batch), dim3(64), 0, stream, w.n_top, pre_max_size, w.mask, words,
-                         post_max_size, w.keep, w.n_keep);
+  const size_t lds = (size_t)pre_max_size * words * 8 + (size_t)post_max_size * 4 + (size_t)post_max_size * 9 * 4;
+  if (lds <= 160 * 1024 - 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      SESSD_TRY(hipFuncSetAttribute((const void*)nms_reduce_finalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    160 * 1024 - 1024));
+      attr_set = true;
     }
+    SESSD_LAUNCH(nms_reduce_finalize_kernel, dim3(batch), dim3(1024), lds, stream, C, w.n_top, w.mask, words, w.cand_box,
+                       w.cand_score, w.cand_dir, frustum, out_box, out_score, out_label, out_count, records, record_counts,
+                       capacity_frames, w.rec_base);
+    SESSD_CHECK_LAUNCH();
+    return SESSD_OK;
   }
+  SESSD_LAUNCH(nms_reduce_batch_kernel, dim3(batch), dim3(64), 0, stream, w.n_top, pre_max_size, w.mask, words,
+                     post_max_size, w.keep, w.n_keep);
   SESSD_CHECK_LAUNCH();
   SESSD_LAUNCH(finalize_kernel, dim3(batch), dim3(64), 0, stream, C, w.keep, w.n_keep, w.cand_box, w.cand_score,
                      w.cand_dir, frustum, out_box, out_score, out_label, out_count);
   SESSD_CHECK_LAUNCH();
+  if (records) {
+    SESSD_LAUNCH(pack_detections_kernel, dim3(1), dim3(256), 0, stream, out_box, out_score, out_label, out_count, batch,
+                 post_max_size, records, record_counts, capacity_frames, (int*)nullptr, w.rec_base);
+    SESSD_CHECK_LAUNCH();
+  }
   return SESSD_OK;
+}
+
+int sessd_predict(const float* head, int batch, int num_pixels, const float* anchors, int anchors_per_frame,
+                  const double* frustum, float score_thresh, int pre_max_size, int post_max_size, float nms_iou_thresh,
+                  const float* post_center_range6, float direction_offset, float* out_box, float* out_score,
+                  int* out_label, int* out_count, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return sessd_predict_fused(head, batch, num_pixels, anchors, anchors_per_frame, frustum, score_thresh, pre_max_size,
+                             post_max_size, nms_iou_thresh, post_center_range6, direction_offset, out_box, out_score, out_label,
+                             out_count, nullptr, nullptr, nullptr, nullptr, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
 // Stand-alone rotated NMS with the predict-path semantics (box_torch_ops.rotate_nms after its topk):
@@ -527,7 +689,7 @@ static int rotate_nms_common(const float* dets, const float* in_corners, int num
     SESSD_LAUNCH(rnms_prep_kernel, dim3(sessd_divup(num_boxes, 256)), dim3(256), 0, stream, dets, num_boxes, corners,
                        standup);
   SESSD_CHECK_LAUNCH();
-  SESSD_LAUNCH(rnms_mask_kernel, dim3(words, sessd_divup(num_boxes, 4), 1), dim3(256), 0, stream, n_top, num_boxes,
+  SESSD_LAUNCH(rnms_mask_kernel, dim3(sessd_divup(num_boxes, RN_ROWS), 1), dim3(RN_ROWS * 64), 0, stream, n_top, num_boxes,
                      iou_thresh, corners, standup, mask, words);
   SESSD_CHECK_LAUNCH();
   SESSD_LAUNCH(nms_reduce_batch_kernel, dim3(1), dim3(64), 0, stream, n_top, num_boxes, mask, words, post_max_size,
@@ -597,35 +759,12 @@ extern "C" int sessd_quads_pairwise(int mode, const float* corners_a, int n, con
   return SESSD_OK;
 }
 
-// ---- detection records for the end-of-job gather (tools/dist_test.py:150-186 gathers pickled per-rank dicts; here every frame
-// leaves one fixed-size record on the device: (post_max, 9) float32 [box 7 | score | label] + a count), appended by the frame's
-// own launch sequence so that a captured graph needs no host-side bookkeeping: slot = (*cursor + b) % capacity, cursor += batch.
-namespace {
-__global__ __launch_bounds__(256) void pack_detections_kernel(const float* __restrict__ box, const float* __restrict__ score,
-                                                               const int* __restrict__ label, const int* __restrict__ count,
-                                                               int batch, int post_max, float* __restrict__ records,
-                                                               int* __restrict__ rec_count, int capacity, int* __restrict__ cursor) {
-  const int c0 = *cursor;
-  const int total = batch * post_max * 9;
-  for (int e = threadIdx.x; e < total; e += 256) {
-    const int b = e / (post_max * 9), r = (e - b * post_max * 9) / 9, q = e % 9;
-    const int n = count[b];
-    float v = 0.f;
-    if (r < n) v = q < 7 ? box[((size_t)b * post_max + r) * 7 + q] : (q == 7 ? score[(size_t)b * post_max + r] : (float)label[(size_t)b * post_max + r]);
-    records[((size_t)((c0 + b) % capacity) * post_max + r) * 9 + q] = v;
-  }
-  if (threadIdx.x < batch) rec_count[(c0 + threadIdx.x) % capacity] = count[threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x == 0) *cursor = c0 + batch;
-}
-}  // namespace
-
 extern "C" int sessd_pack_detections(const float* out_box, const float* out_score, const int* out_label, const int* out_count,
                                      int batch, int post_max_size, float* records, int* record_counts, int capacity_frames,
                                      int* cursor, hipStream_t stream) {
   if (batch <= 0 || batch > 256 || post_max_size <= 0 || capacity_frames < batch) return SESSD_EINVAL;
   SESSD_LAUNCH(pack_detections_kernel, dim3(1), dim3(256), 0, stream, out_box, out_score, out_label, out_count, batch,
-               post_max_size, records, record_counts, capacity_frames, cursor);
+               post_max_size, records, record_counts, capacity_frames, cursor, (const int*)nullptr);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -34,6 +34,7 @@ class RulebookJob(C.Structure):
 SIGNATURES = {
     "sessd_version": (C.c_char_p, []),
     "sessd_fill_u32": (i32, [vp, u32, sz, vp]),
+    "sessd_fill_u32_multi": (i32, [i32, vp, vp, vp, vp]),
     "sessd_set_external_clear": (None, [i32]),
     "sessd_hash_capacity": (u32, [i32]),
     "sessd_hash_clear": (i32, [vp, vp, u32, vp]),
@@ -69,6 +70,8 @@ SIGNATURES = {
     "sessd_ssfa_fuse_head": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp, vp, i32, vp, vp]),
     "sessd_predict_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "sessd_predict": (i32, [vp, i32, i32, vp, i32, vp, f32, i32, i32, f32, vp, f32, vp, vp, vp, vp, vp, sz, vp]),
+    "sessd_predict_fused": (i32, [vp, i32, i32, vp, i32, vp, f32, i32, i32, f32, vp, f32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, sz, vp]),
+    "sessd_ssfa_fuse_head_keys": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp, vp, i32, vp, f32, vp, i32, vp, vp]),
     "sessd_di_nms_workspace_bytes": (sz, [i32]),
     "sessd_di_nms": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, i32, f32, vp, i32, vp, f32, i32, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_pack_detections": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp]),

@@ -174,12 +174,14 @@ class InferenceEngine:
                 jobs.append((li, li + 1, ks, st, pd))
                 li += 1
         chain_bytes = ops.SparseChain.workspace_bytes(self.sparse_shape, steps, [L["cap"] for L in self.levels[1:]], B)
-        # control words + the chain's occupancy maps, cleared to 0 by ONE fill per frame: prefix[B+1] | err | maps
-        n_ctrl = (B + 2 + 63) // 64 * 64
+        # control words + the chain's occupancy maps, cleared to 0 by the frame's one clear launch: prefix[B+1] | err |
+        # key_count[B] (candidates of the score filter that runs inside the head launch) | maps
+        n_ctrl = (2 * B + 2 + 63) // 64 * 64
         self.zero_arena = torch.zeros((n_ctrl + (chain_bytes + 3) // 4,), dtype=i32, device=dev)
         self.ctrl = self.zero_arena[:n_ctrl]
         self.prefix = self.ctrl[:B + 1]
         self.err = self.ctrl[B + 1:B + 2]
+        self.key_count = self.ctrl[B + 2:2 * B + 2]
         self.chain = ops.SparseChain(self.sparse_shape, steps, [L["cap"] for L in self.levels[1:]], B, jobs, dev,
                                      workspace_tensor=self.zero_arena[n_ctrl:].view(torch.uint8))
         self.chain.bind_tables(cap0)
@@ -227,6 +229,8 @@ class InferenceEngine:
                         count=torch.zeros((B,), dtype=i32, device=dev))
         self.pred_ws = torch.empty(int(lib.sessd_predict_workspace_bytes(B, 2 * H * W, self.pre_max, self.post_max)),
                                    dtype=torch.uint8, device=dev)
+        self.keys = torch.empty((B, 2 * H * W), dtype=torch.int64, device=dev)  # score-filter keys written by the head launch
+        self.fuse_predict = True  # score filter inside the head launch; NMS walk + filters + record in one launch
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -419,8 +423,9 @@ class InferenceEngine:
         s = torch.cuda.current_stream().cuda_stream
         B = self.B
         # ---- voxelize (a1-a3)
-        check(lib.sessd_fill_u32(self.zero_arena.data_ptr(), 0, self.zero_arena.numel(), s), "fill")
-        check(lib.sessd_fill_u32(self.arena.data_ptr(), 0x7F7F7F7F, self.arena.numel() // 4, s), "fill")
+        # every clear of the frame in ONE launch: control words + occupancy maps (0), hash tables and per-cell lists (empty marker),
+        # the dense BEV map the last sparse layer scatters into (0; round 2 cleared it between two sparse convs, on the critical path)
+        ops.fill_multi([(self.zero_arena, 0), (self.arena, 0x7F7F7F7F), (self.bev, 0)])
         lib.sessd_set_external_clear(1)  # the arena fill above replaces the per-call scratch clears
         try:
             return self._enqueue_body(s)
@@ -462,7 +467,6 @@ class InferenceEngine:
             else:
                 Lo = self.levels[li + 1]
                 if last:
-                    check(lib.sessd_fill_u32(self.bev.data_ptr(), 0, self.bev.numel(), s), "fill")
                     self._sconv(lay, feat, nbr, tm, li + 1, None, s, dense=True, idx=idx)
                 else:
                     self._sconv(lay, feat, nbr, tm, li + 1, Lo["feat_a"], s, idx=idx)
@@ -511,12 +515,15 @@ class InferenceEngine:
             o0 = self._conv(mid0, d.conv_0, t["o0"], name="conv_0")
             o1 = self._conv(mid1, d.conv_1, t["o1"], name="conv_1")
         # ---- SSFA tail + heads (a10): one launch; the two-launch form stays for channel counts the fused kernel does not take
+        fused_keys = False
         if self.fuse_head and d.head_w.shape[1] in (64, 128) and self._tuning is None:
             if self._kmarks is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+            fused_keys = True
             ops.ssfa_fuse_head(o0, o1, d.w0, d.w1, *d.wbn, d.head_w, d.head_b, head_out=self.head,
-                               out=t["out"] if self.keep_ssfa else None)
+                               out=t["out"] if self.keep_ssfa else None, score_thresh=self.score_thresh,
+                               keys=self.keys if self.fuse_predict else None, key_count=self.key_count if self.fuse_predict else None)
             if self._kmarks is not None:
                 e1.record()
                 self._kmarks.append(("ssfa_tail+head", e0, e1))
@@ -524,16 +531,18 @@ class InferenceEngine:
             ops.ssfa_fuse(o0, o1, d.w0, d.w1, *d.wbn, out=t["out"])
             self._conv(t["out"], d.head, self.head.view(B, 22, self.H, self.W), relu=False, name="head")
         self._mark("ssfa_head")
-        check(lib.sessd_predict(self.head.data_ptr(), B, self.H * self.W, self.anchors.data_ptr(), 0,
-                                0 if self.frustum is None else self.frustum.data_ptr(), self.score_thresh, self.pre_max,
-                                self.post_max, self.nms_thresh, self.post_range.data_ptr(), self.dir_offset,
-                                self.out["box"].data_ptr(), self.out["score"].data_ptr(), self.out["label"].data_ptr(),
-                                self.out["count"].data_ptr(), self.pred_ws.data_ptr(), self.pred_ws.numel(), s), "predict")
-        if self.records is not None:  # one fixed-size record per frame for the end-of-job gather (dist.gather_records)
-            check(lib.sessd_pack_detections(self.out["box"].data_ptr(), self.out["score"].data_ptr(), self.out["label"].data_ptr(),
-                                            self.out["count"].data_ptr(), B, self.post_max, self.records.data_ptr(),
-                                            self.record_counts.data_ptr(), self.records.shape[0], self.record_cursor.data_ptr(), s),
-                  "pack_detections")
+        # ---- predict (a11-a14): top-k + decode, suppression mask, greedy walk + filters (+ the frame's record): 3 launches
+        use_keys = fused_keys and self.fuse_predict
+        rec = self.records is not None
+        check(lib.sessd_predict_fused(self.head.data_ptr(), B, self.H * self.W, self.anchors.data_ptr(), 0,
+                                      0 if self.frustum is None else self.frustum.data_ptr(), self.score_thresh, self.pre_max,
+                                      self.post_max, self.nms_thresh, self.post_range.data_ptr(), self.dir_offset,
+                                      self.out["box"].data_ptr(), self.out["score"].data_ptr(), self.out["label"].data_ptr(),
+                                      self.out["count"].data_ptr(), self.keys.data_ptr() if use_keys else 0,
+                                      self.key_count.data_ptr() if use_keys else 0,
+                                      self.records.data_ptr() if rec else 0, self.record_counts.data_ptr() if rec else 0,
+                                      self.records.shape[0] if rec else 0, self.record_cursor.data_ptr() if rec else 0,
+                                      self.pred_ws.data_ptr(), self.pred_ws.numel(), s), "predict_fused")
         self._mark("predict")
         return self.out
 

@@ -1173,9 +1173,12 @@ def ssfa_fuse(x0, x1, w0, w1, s0, t0, s1, t1, out=None):
     return out
 
 
-def ssfa_fuse_head(x0, x1, w0, w1, s0, t0, s1, t1, head_w, head_b, head_out=None, out=None):
+def ssfa_fuse_head(x0, x1, w0, w1, s0, t0, s1, t1, head_w, head_b, head_out=None, out=None, score_thresh=0.0, keys=None,
+                   key_count=None):
     """ssfa_fuse + the 1x1 heads in one launch: head_w (22, C) row-major, head_b (22) or None -> head_out (B, 22, H*W) planar.
-    `out` (B, C, H, W): optional buffer that receives the SSFA output (not written when None)."""
+    `out` (B, C, H, W): optional buffer that receives the SSFA output (not written when None).
+    keys (B, 2*H*W) int64 + key_count (B,) int32 (zeroed by the caller): the launch also appends predict's score-filter keys
+    (sessd_ssfa_fuse_head_keys) -- the inputs predict_fused() takes instead of running its own score filter."""
     _req(x0, torch.float32, "x0")
     _req(x1, torch.float32, "x1")
     _req(head_w, torch.float32, "head_w")
@@ -1183,17 +1186,36 @@ def ssfa_fuse_head(x0, x1, w0, w1, s0, t0, s1, t1, head_w, head_b, head_out=None
     nout = head_w.shape[0]
     if head_out is None:
         head_out = torch.empty((B, nout, H * W), dtype=torch.float32, device=x0.device)
-    check(lib.sessd_ssfa_fuse_head(x0.data_ptr(), x1.data_ptr(), w0.data_ptr(), w1.data_ptr(), float(s0), float(t0), float(s1),
-                                   float(t1), B, C, H * W, _p(out), head_w.data_ptr(), _p(head_b), nout, head_out.data_ptr(),
-                                   _stream()), "ssfa_fuse_head")
+    if keys is not None:
+        assert key_count is not None and keys.dtype == torch.int64 and key_count.dtype == torch.int32 and keys.is_contiguous()
+        assert keys.numel() >= B * 2 * H * W and key_count.numel() >= B
+    check(lib.sessd_ssfa_fuse_head_keys(x0.data_ptr(), x1.data_ptr(), w0.data_ptr(), w1.data_ptr(), float(s0), float(t0), float(s1),
+                                        float(t1), B, C, H * W, _p(out), head_w.data_ptr(), _p(head_b), nout, head_out.data_ptr(),
+                                        float(score_thresh), _p(keys), 2 * H * W if keys is not None else 0, _p(key_count),
+                                        _stream()), "ssfa_fuse_head_keys")
     return head_out
+
+
+def fill_multi(segments):
+    """[(tensor, 32-bit pattern), ...] (<= 4, 16-byte aligned, sizes multiples of 4 bytes) cleared in ONE launch."""
+    import ctypes
+    n = len(segments)
+    ptrs = (ctypes.c_void_p * n)(*[t.data_ptr() for t, _ in segments])
+    vals = (ctypes.c_uint32 * n)(*[int(v) & 0xFFFFFFFF for _, v in segments])
+    cnts = (ctypes.c_size_t * n)(*[t.numel() * t.element_size() // 4 for t, _ in segments])
+    check(lib.sessd_fill_u32_multi(n, ctypes.cast(ptrs, ctypes.c_void_p), ctypes.cast(vals, ctypes.c_void_p),
+                                   ctypes.cast(cnts, ctypes.c_void_p), _stream()), "fill_u32_multi")
 
 
 # ------------------------------------------------------------------ predict / post-processing
 def predict(head, anchors, frustum=None, score_thresh=0.3, pre_max=1000, post_max=100, nms_thresh=0.01,
-            post_center_range=(0, -40.0, -5.0, 70.4, 40.0, 5.0), direction_offset=0.0, out=None):
+            post_center_range=(0, -40.0, -5.0, 70.4, 40.0, 5.0), direction_offset=0.0, out=None, keys=None, key_count=None,
+            records=None):
     """head (B,22,P) planar float32; anchors (A,7) or (B,A,7); frustum (B,1,6,4,3) float64 or None.
-    Returns dict(box (B,post,7), score (B,post), label (B,post) int32, count (B,) int32), all on the device."""
+    Returns dict(box (B,post,7), score (B,post), label (B,post) int32, count (B,) int32), all on the device.
+    keys / key_count: the score-filter keys already produced by ssfa_fuse_head(keys=...) (sessd_predict_fused skips its own
+    filter); records = (records (F,post,9) float32, counts (F,) int32, cursor (1,) int32): the call's last launch also appends the
+    frames' detection records to that ring."""
     _req(head, torch.float32, "head")
     _req(anchors, torch.float32, "anchors")
     B, ch, P = head.shape
@@ -1215,10 +1237,13 @@ def predict(head, anchors, frustum=None, score_thresh=0.3, pre_max=1000, post_ma
     need = lib.sessd_predict_workspace_bytes(B, 2 * P, pre_max, post_max)
     ws = workspace(need, dev, "predict")
     rng = torch.tensor(post_center_range, dtype=torch.float32)
-    check(lib.sessd_predict(head.data_ptr(), B, P, anchors.data_ptr(), per_frame, _p(frustum), float(score_thresh),
-                            pre_max, post_max, float(nms_thresh), rng.data_ptr(), float(direction_offset),
-                            out["box"].data_ptr(), out["score"].data_ptr(), out["label"].data_ptr(),
-                            out["count"].data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "predict")
+    rec, rcnt, rcur = records if records is not None else (None, None, None)
+    check(lib.sessd_predict_fused(head.data_ptr(), B, P, anchors.data_ptr(), per_frame, _p(frustum), float(score_thresh),
+                                  pre_max, post_max, float(nms_thresh), rng.data_ptr(), float(direction_offset),
+                                  out["box"].data_ptr(), out["score"].data_ptr(), out["label"].data_ptr(),
+                                  out["count"].data_ptr(), _p(keys), _p(key_count), _p(rec), _p(rcnt),
+                                  int(rec.shape[0]) if rec is not None else 0, _p(rcur), ws.data_ptr(), ws.numel(), _stream()),
+          "predict_fused")
     return out
 
 

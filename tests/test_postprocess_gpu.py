@@ -98,3 +98,63 @@ def test_rotate_nms_sorted_vs_oracle(dev, n, thresh):
     got = keep[:k].cpu().numpy()
     if not np.array_equal(got, want[:100]):
         assert near > 0, "rotated NMS differs without any near-threshold pair"
+
+
+def test_fused_forms_equal_the_plain_call(dev):
+    """sessd_predict_fused's two optional fusions give what the separate launches give, bit for bit:
+    * the score-filter keys produced INSIDE the head launch (sessd_ssfa_fuse_head_keys) -- same detections as the call that
+      filters the stored head tensor itself, and the same KEY SET as score_filter_kernel would append;
+    * the frame's detection record written by the call's last launch == sessd_pack_detections of the outputs (ring rule:
+      slot = (cursor + b) % capacity, cursor += batch), also across a wrap of the ring."""
+    torch.manual_seed(0)
+    B, C = 2, 128
+    x0 = torch.randn(B, C, H, W, device=dev)
+    x1 = torch.randn(B, C, H, W, device=dev)
+    w0, w1 = torch.randn(C, device=dev) * 0.05, torch.randn(C, device=dev) * 0.05
+    hw = torch.randn(22, C, device=dev) * 0.08
+    hb = torch.randn(22, device=dev) * 0.1
+    hb[14:16] = -2.2  # a few hundred to a few thousand candidates above the score threshold
+    anchors = torch.from_numpy(pp.create_anchors_3d_range().reshape(-1, 7)).to(dev)
+    keys = torch.zeros((B, 2 * H * W), dtype=torch.int64, device=dev)
+    kcnt = torch.zeros((B,), dtype=torch.int32, device=dev)
+    head = ops.ssfa_fuse_head(x0, x1, w0, w1, 1.1, 0.05, 0.9, -0.03, hw, hb, score_thresh=0.3, keys=keys, key_count=kcnt)
+    head_plain = ops.ssfa_fuse_head(x0, x1, w0, w1, 1.1, 0.05, 0.9, -0.03, hw, hb)
+    assert torch.equal(head, head_plain)
+    # the key set of the stand-alone filter, recomputed on the host from the stored tensor in float32
+    hc = head.cpu().numpy()
+    for b in range(B):
+        s = pp.sigmoid32(hc[b, 14:16].T.reshape(-1))
+        n_want = int((s >= np.float32(0.3)).sum())
+        n_got = int(kcnt[b].item())
+        assert abs(n_got - n_want) <= int((np.abs(s - 0.3) < 1e-6).sum()) and n_got > 100
+        aid = (keys[b, :n_got].cpu().numpy() & 0xFFFFFFFF).astype(np.int64)
+        assert len(np.unique(aid)) == n_got and (s[aid] >= 0.3 - 1e-6).all()
+    plain = ops.predict(head, anchors, None)
+    cap = 3
+    rec = torch.full((cap, 100, 9), -7.0, device=dev)
+    rcnt = torch.full((cap,), -1, dtype=torch.int32, device=dev)
+    cur = torch.zeros((1,), dtype=torch.int32, device=dev)
+    for rep in range(2):  # second call wraps: slots 2, 0
+        fused = ops.predict(head, anchors, None, keys=keys, key_count=kcnt, records=(rec, rcnt, cur))
+        for k in ("box", "score", "label", "count"):
+            assert torch.equal(fused[k][:, :int(plain["count"].max())] if k != "count" else fused[k],
+                               plain[k][:, :int(plain["count"].max())] if k != "count" else plain[k]), k
+        assert int(cur.item()) == 2 * (rep + 1)
+        for b in range(B):
+            slot = (2 * rep + b) % cap
+            n = int(plain["count"][b].item())
+            assert int(rcnt[slot].item()) == n and n > 5
+            r = rec[slot].cpu()
+            assert torch.equal(r[:n, :7], plain["box"][b, :n].cpu()) and torch.equal(r[:n, 7], plain["score"][b, :n].cpu())
+            assert float(r[:n, 8].abs().max()) == 0 and float(r[n:].abs().max()) == 0
+
+
+def test_fill_multi(dev):
+    a = torch.full((1000003,), 5, dtype=torch.int32, device=dev)[:1000000]   # not a multiple of 4096 words
+    b = torch.full((4096 * 3,), 5, dtype=torch.int32, device=dev)
+    c = torch.full((7,), 5.0, dtype=torch.float32, device=dev)
+    guard = a.clone()
+    ops.fill_multi([(a[:999996], 0x7F7F7F7F), (b, 0), (c[:4], 0x3F800000)])
+    assert int((a[:999996] != 0x7F7F7F7F).sum()) == 0 and torch.equal(a[999996:], guard[999996:])
+    assert int(b.abs().sum()) == 0
+    assert torch.equal(c.cpu(), torch.tensor([1.0, 1, 1, 1, 5, 5, 5]))
