@@ -9,9 +9,9 @@
 //                     with a wave-aggregated atomic (order does not matter: the key is a total order)
 //   K2 topk_decode    1 workgroup / frame: running top-`pre_max` by bitonic sort in LDS (2048 keys at a time),
 //                     then decode ONLY the survivors (box, rectified score, direction label, BEV corners, AABB)
-//   K3 rnms_mask      one wave per row of the suppression bitmask: AABB prefilter (float32, iou_jit eps=0) over the
-//                     later candidates, the survivors COMPACTED in LDS, then convex polygon clipping in float64 on dense
-//                     lanes only; suppress when IoU >= thresh
+//   K3 rnms_pairs / rnms_clip   suppression bitmask: AABB prefilter (float32, iou_jit eps=0) of every row over the later
+//                     candidates, the surviving pairs COMPACTED into one list, then convex polygon clipping in float64 on
+//                     dense lanes only; suppress when IoU >= thresh
 //   K4 nms_reduce     greedy walk over the mask (staged in LDS), stops at post_max, fused with
 //   K5 finalize       frustum (float64 planes), direction fix, centre-range mask, ordered compaction, and the frame's
 //                     fixed-size detection record (sessd_predict_fused; the unfused kernels serve pre_max > ~1280)
@@ -84,9 +84,11 @@ __global__ __launch_bounds__(SORT_NT) void topk_decode_kernel(const float* __res
                                                                float* __restrict__ cand_box, float* __restrict__ cand_score,
                                                                int* __restrict__ cand_dir, float* __restrict__ corners,
                                                                float* __restrict__ standup, int* __restrict__ n_top,
-                                                               int* __restrict__ rec_cursor, int* __restrict__ rec_base, int batch) {
+                                                               int* __restrict__ rec_cursor, int* __restrict__ rec_base, int batch,
+                                                               int* __restrict__ pair_count) {
   __shared__ unsigned long long s[SORT_N];
   const int b = blockIdx.x;
+  if (threadIdx.x == 0) pair_count[b] = 0;  // the suppression-mask launches that follow append this frame's pairs
   // detection records (sessd_predict_fused): this batch takes the ring slots cursor .. cursor + batch - 1; the last kernel of
   // the call reads the base from the workspace
   if (rec_cursor && b == 0 && threadIdx.x == 0) {
@@ -175,33 +177,51 @@ __device__ __forceinline__ bool rnms_polygon(const float* ci, const float* cj, f
   return ov >= (double)thresh;
 }
 
-// One WAVE per row i of the suppression mask. Round 2 gave every (row, 64-column word) a wave and let the lanes that passed
-// the stand-up prefilter run the float64 polygon clipping (~1500 instructions) while the rest of the wave idled: with a
-// handful of overlapping neighbours per candidate nearly every one of the 8000 waves paid the full clipping time for 1-3
-// useful lanes (21.7 us per frame, max 38). Here the wave sweeps the later candidates j > i with the cheap prefilter (16-byte
-// coalesced loads), compacts the survivors into an LDS list (ballot + prefix popcount) and clips them on DENSE lanes -- one
-// clipping round per row for up to 64 overlapping neighbours. The row's words are assembled in LDS and written from word
-// i / 64 on (words left of the diagonal are never read).
-constexpr int RN_ROWS = 4;       // waves (rows) per workgroup
-constexpr int RN_MAXN = 4096;    // candidates (rotate_nms_common's limit)
-__global__ __launch_bounds__(RN_ROWS * 64) void rnms_mask_kernel(const int* __restrict__ n_top, int pre_max, float thresh,
-                                                                  const float* __restrict__ corners,
-                                                                  const float* __restrict__ standup,
-                                                                  unsigned long long* __restrict__ mask, int words) {
-  __shared__ unsigned short s_list[RN_ROWS][RN_MAXN];
-  __shared__ unsigned s_bits[RN_ROWS][RN_MAXN / 32];
+// The suppression mask in two balanced launches. Round 2 gave every (row, 64-column word) a wave and let the lanes that passed
+// the stand-up prefilter run the float64 polygon clipping (~1500 instructions, ~6 us per wave) while the rest of the wave
+// idled: nearly every one of the 8000 waves paid a full clipping round for 1-3 useful lanes (21.7 us per frame, max 38). A
+// first round-3 form (one wave per row: sweep, compact in LDS, clip the row's survivors on dense lanes) was 10.7 us on typical
+// frames but 68 us on frames where a few boxes overlap everything (the synthetic weights decode some boxes to kilometres):
+// such a row is 16 clipping rounds on ONE wave. So:
+//   rnms_pairs_kernel  one wave per row i: clears the row's mask words, sweeps the later candidates j > i with the prefilter
+//                      (16-byte coalesced loads) and appends the surviving (i, j) pairs to ONE list per frame (one atomic per
+//                      64 candidates); pairs beyond the list's capacity (64 per row on average) are clipped on the spot;
+//   rnms_clip_kernel   the list's pairs dealt out over all lanes of the launch: one clipping round on dense lanes whatever
+//                      the distribution over rows; bits set with atomicOr.
+constexpr int RN_ROWS = 4;       // waves (rows) per workgroup of the pair kernel
+constexpr int RN_MAXN = 4096;    // candidates (rotate_nms_common's limit; pairs are packed i << 16 | j)
+constexpr int RN_PAIRS_PER_ROW = 64;
+
+__device__ __forceinline__ void rnms_clip_pair(const float* __restrict__ cb, int i, int j, float thresh,
+                                               unsigned long long* __restrict__ mrow_base, int words) {
+  const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)i * 8);
+  const float4 a4 = c4[0], b4 = c4[1];
+  const float4* d4 = reinterpret_cast<const float4*>(cb + (size_t)j * 8);
+  const float4 e4 = d4[0], f4 = d4[1];
+  const float ci[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+  const float cj[8] = {e4.x, e4.y, e4.z, e4.w, f4.x, f4.y, f4.z, f4.w};
+  if (rnms_polygon(ci, cj, thresh)) atomicOr(mrow_base + (size_t)i * words + (j >> 6), 1ull << (j & 63));
+}
+
+__global__ __launch_bounds__(RN_ROWS * 64) void rnms_pairs_kernel(const int* __restrict__ n_top, int pre_max, float thresh,
+                                                                   const float* __restrict__ corners,
+                                                                   const float* __restrict__ standup,
+                                                                   unsigned long long* __restrict__ mask, int words,
+                                                                   unsigned* __restrict__ pairs, int pair_cap,
+                                                                   int* __restrict__ pair_count) {
   const int b = blockIdx.y;
   const int lane = threadIdx.x & 63;
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int i = blockIdx.x * RN_ROWS + wv;
+  const int i = blockIdx.x * RN_ROWS + (int)(threadIdx.x >> 6);
   const int n = min(n_top[b], pre_max);
-  if (i >= n) return;  // waves are independent: no workgroup barrier below
+  if (i >= n) return;
+  unsigned long long* mb = mask + (size_t)b * pre_max * words;
+  for (int w = (i >> 6) + lane; w < words; w += 64) mb[(size_t)i * words + w] = 0ull;  // words left of the diagonal are never read
+  __builtin_amdgcn_s_waitcnt(0);  // the clears precede any atomicOr of the overflow path below
   const float* cb = corners + (size_t)b * pre_max * 8;
   const float4* sb = reinterpret_cast<const float4*>(standup + (size_t)b * pre_max * 4);
   const float4 s4 = sb[i];
   const float si[4] = {s4.x, s4.y, s4.z, s4.w};
-  for (int w = lane; w < 2 * words; w += 64) s_bits[wv][w] = 0u;
-  int cnt = 0;
+  unsigned* pl = pairs + (size_t)b * pair_cap;
   for (int j0 = (i + 1) & ~63; j0 < n; j0 += 64) {
     const int j = j0 + lane;
     bool pass = false;
@@ -211,26 +231,46 @@ __global__ __launch_bounds__(RN_ROWS * 64) void rnms_mask_kernel(const int* __re
       pass = rnms_prefilter(si, sj);
     }
     const unsigned long long bal = __ballot(pass);
-    if (pass) s_list[wv][cnt + __popcll(bal & ((1ull << lane) - 1ull))] = (unsigned short)j;
-    cnt += __popcll(bal);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the list and the cleared words are in LDS (one wave: LDS is in order)
-  if (cnt) {
-    float ci[8];
-    const float4* c4 = reinterpret_cast<const float4*>(cb + (size_t)i * 8);
-    const float4 a4 = c4[0], b4 = c4[1];
-    ci[0] = a4.x; ci[1] = a4.y; ci[2] = a4.z; ci[3] = a4.w; ci[4] = b4.x; ci[5] = b4.y; ci[6] = b4.z; ci[7] = b4.w;
-    for (int idx = lane; idx < cnt; idx += 64) {
-      const int j = s_list[wv][idx];
-      const float4* d4 = reinterpret_cast<const float4*>(cb + (size_t)j * 8);
-      const float4 e4 = d4[0], f4 = d4[1];
-      const float cj[8] = {e4.x, e4.y, e4.z, e4.w, f4.x, f4.y, f4.z, f4.w};
-      if (rnms_polygon(ci, cj, thresh)) atomicOr(&s_bits[wv][j >> 5], 1u << (j & 31));
+    if (bal == 0) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&pair_count[b], __popcll(bal));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (pass) {
+      const int idx = base + __popcll(bal & ((1ull << lane) - 1ull));
+      if (idx < pair_cap) pl[idx] = ((unsigned)i << 16) | (unsigned)j;
+      else rnms_clip_pair(cb, i, j, thresh, mb, words);  // list full: this pair is clipped here
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   }
-  for (int w = (i >> 6) + lane; w < words; w += 64)
-    mask[((size_t)b * pre_max + i) * words + w] = (unsigned long long)s_bits[wv][2 * w] | ((unsigned long long)s_bits[wv][2 * w + 1] << 32);
+}
+
+__global__ __launch_bounds__(256) void rnms_clip_kernel(int pre_max, float thresh, const float* __restrict__ corners,
+                                                         unsigned long long* __restrict__ mask, int words,
+                                                         const unsigned* __restrict__ pairs, int pair_cap,
+                                                         const int* __restrict__ pair_count) {
+  const int b = blockIdx.y;
+  const int np = min(pair_count[b], pair_cap);
+  const float* cb = corners + (size_t)b * pre_max * 8;
+  unsigned long long* mb = mask + (size_t)b * pre_max * words;
+  const unsigned* pl = pairs + (size_t)b * pair_cap;
+  for (int p = blockIdx.x * 256 + threadIdx.x; p < np; p += gridDim.x * 256) {
+    const unsigned pr = pl[p];
+    rnms_clip_pair(cb, (int)(pr >> 16), (int)(pr & 0xFFFFu), thresh, mb, words);
+  }
+}
+
+// both launches; pair_count[b] must be zero (sessd_predict_fused: cleared by topk_decode_kernel; rotate_nms_common: by its set kernel)
+int launch_rnms_mask(const int* n_top, int batch, int pre_max, float thresh, const float* corners, const float* standup,
+                     unsigned long long* mask, int words, unsigned* pairs, int* pair_count, hipStream_t stream) {
+  if (pre_max > RN_MAXN) return SESSD_EINVAL;  // pairs are packed i << 16 | j
+  const int pair_cap = pre_max * RN_PAIRS_PER_ROW;
+  SESSD_LAUNCH(rnms_pairs_kernel, dim3(sessd_divup(pre_max, RN_ROWS), batch), dim3(RN_ROWS * 64), 0, stream, n_top, pre_max,
+               thresh, corners, standup, mask, words, pairs, pair_cap, pair_count);
+  SESSD_CHECK_LAUNCH();
+  const int g = sessd_divup(pair_cap, 256) < 256 ? sessd_divup(pair_cap, 256) : 256;
+  SESSD_LAUNCH(rnms_clip_kernel, dim3(g, batch), dim3(256), 0, stream, pre_max, thresh, corners, mask, words, pairs, pair_cap,
+               pair_count);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
 }
 
 // Post-NMS filters of one frame by ONE wave (mg_head_sessd.py:1024-1055): frustum (B,1,6,4,3) float64 surfaces (or null),
@@ -449,6 +489,8 @@ struct PostWs {
   int* keep;
   int* n_keep;
   int* rec_base;
+  unsigned* pairs;
+  int* pair_count;
 };
 
 size_t post_ws_layout(int batch, int num_anchors, int pre_max, int post_max, PostWs* w, char* base) {
@@ -471,6 +513,8 @@ size_t post_ws_layout(int batch, int num_anchors, int pre_max, int post_max, Pos
   size_t o_keep = take((size_t)batch * post_max * 4);
   size_t o_nk = take((size_t)batch * 4);
   size_t o_rb = take(4);
+  size_t o_pairs = take((size_t)batch * pre_max * RN_PAIRS_PER_ROW * 4);
+  size_t o_pc = take((size_t)batch * 4);
   if (w) {
     w->keys = (unsigned long long*)(base + o_keys);
     w->count = (int*)(base + o_count);
@@ -484,6 +528,8 @@ size_t post_ws_layout(int batch, int num_anchors, int pre_max, int post_max, Pos
     w->keep = (int*)(base + o_keep);
     w->n_keep = (int*)(base + o_nk);
     w->rec_base = (int*)(base + o_rb);
+    w->pairs = (unsigned*)(base + o_pairs);
+    w->pair_count = (int*)(base + o_pc);
   }
   return off;
 }
@@ -575,12 +621,14 @@ int sessd_predict_fused(const float* head, int batch, int num_pixels, const floa
   }
   SESSD_LAUNCH(topk_decode_kernel, dim3(batch), dim3(SORT_NT), 0, stream, head, anchors, anchors_per_frame, C,
                      keys, A, key_count, w.cand_box, w.cand_score, w.cand_dir, w.corners, w.standup, w.n_top,
-                     records ? cursor : (int*)nullptr, w.rec_base, batch);
+                     records ? cursor : (int*)nullptr, w.rec_base, batch, w.pair_count);
   SESSD_CHECK_LAUNCH();
   const int words = sessd_divup(pre_max_size, 64);
-  SESSD_LAUNCH(rnms_mask_kernel, dim3(sessd_divup(pre_max_size, RN_ROWS), batch), dim3(RN_ROWS * 64), 0, stream, w.n_top,
-                     pre_max_size, nms_iou_thresh, w.corners, w.standup, w.mask, words);
-  SESSD_CHECK_LAUNCH();
+  {
+    const int rc = launch_rnms_mask(w.n_top, batch, pre_max_size, nms_iou_thresh, w.corners, w.standup, w.mask, words, w.pairs,
+                                    w.pair_count, stream);
+    if (rc != SESSD_OK) return rc;
+  }
   const size_t lds = (size_t)pre_max_size * words * 8 + (size_t)post_max_size * 4 + (size_t)post_max_size * 9 * 4;
   if (lds <= 160 * 1024 - 1024) {
     static bool attr_set = false;
@@ -622,7 +670,8 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
 // dets (N,5) [x,y,w,l,r] sorted by descending score. keep (device int32[post_max]), num_keep (device int).
 size_t sessd_rotate_nms_workspace_bytes(int num_boxes) {
   const int words = sessd_divup(num_boxes > 0 ? num_boxes : 1, 64);
-  return sessd_align((size_t)num_boxes * 12 * 4, 256) + sessd_align((size_t)num_boxes * words * 8, 256) + 512;
+  return sessd_align((size_t)num_boxes * 12 * 4, 256) + sessd_align((size_t)num_boxes * words * 8, 256) + 512 +
+         sessd_align((size_t)(num_boxes > 0 ? num_boxes : 1) * RN_PAIRS_PER_ROW * 4, 256);
 }
 
 }  // extern "C"
@@ -644,7 +693,7 @@ __global__ __launch_bounds__(256) void rnms_prep_kernel(const float* __restrict_
   for (int q = 0; q < 8; ++q) corners[(size_t)i * 8 + q] = c8[q];
   standup[(size_t)i * 4 + 0] = x0; standup[(size_t)i * 4 + 1] = y0; standup[(size_t)i * 4 + 2] = x1; standup[(size_t)i * 4 + 3] = y1;
 }
-__global__ void set_int_kernel(int* p, int v) { *p = v; }
+__global__ void set_int_kernel(int* p, int v) { p[0] = v; p[1] = 0; }  // n_top, pair_count
 // corners given by the caller (det3d.ops.nms.nms.rotate_non_max_suppression_cpu, nms_cpu.h:72-168): copy + AABB
 __global__ __launch_bounds__(256) void rnms_prep_corners_kernel(const float* __restrict__ in_corners, int n,
                                                                  float* __restrict__ corners, float* __restrict__ standup) {
@@ -681,6 +730,7 @@ static int rotate_nms_common(const float* dets, const float* in_corners, int num
   unsigned long long* mask = (unsigned long long*)(base + off);
   off += sessd_align((size_t)num_boxes * words * 8, 256);
   int* n_top = (int*)(base + off);
+  unsigned* pairs = (unsigned*)(base + off + 512);
   SESSD_LAUNCH(set_int_kernel, dim3(1), dim3(1), 0, stream, n_top, num_boxes);
   if (in_corners)
     SESSD_LAUNCH(rnms_prep_corners_kernel, dim3(sessd_divup(num_boxes, 256)), dim3(256), 0, stream, in_corners,
@@ -689,9 +739,10 @@ static int rotate_nms_common(const float* dets, const float* in_corners, int num
     SESSD_LAUNCH(rnms_prep_kernel, dim3(sessd_divup(num_boxes, 256)), dim3(256), 0, stream, dets, num_boxes, corners,
                        standup);
   SESSD_CHECK_LAUNCH();
-  SESSD_LAUNCH(rnms_mask_kernel, dim3(sessd_divup(num_boxes, RN_ROWS), 1), dim3(RN_ROWS * 64), 0, stream, n_top, num_boxes,
-                     iou_thresh, corners, standup, mask, words);
-  SESSD_CHECK_LAUNCH();
+  {
+    const int rc = launch_rnms_mask(n_top, 1, num_boxes, iou_thresh, corners, standup, mask, words, pairs, n_top + 1, stream);
+    if (rc != SESSD_OK) return rc;
+  }
   SESSD_LAUNCH(nms_reduce_batch_kernel, dim3(1), dim3(64), 0, stream, n_top, num_boxes, mask, words, post_max_size,
                      keep, num_keep);
   SESSD_CHECK_LAUNCH();
