@@ -152,6 +152,12 @@ int sessd_sparse_to_dense(const float* features, const int32_t* indices, int n, 
                           float* dense, sessd_stream_t stream);
 int sessd_dense_to_sparse(const float* dense, const int32_t* indices, int n, int channels, const int32_t* dims3,
                           float* features, sessd_stream_t stream);
+/* the same two on a table of CAPACITY n_cap rows whose live row count is the device int *n_dev (the capacity-based module path
+ * that a captured training graph runs: no host-read counts): rows >= *n_dev are not scattered; their gradient rows are zero */
+int sessd_sparse_to_dense_dev(const float* features, const int32_t* indices, int n_cap, const int32_t* n_dev, int channels,
+                              const int32_t* dims3, float* dense, sessd_stream_t stream);
+int sessd_dense_to_sparse_dev(const float* dense, const int32_t* indices, int n_cap, const int32_t* n_dev, int channels,
+                              const int32_t* dims3, float* features, sessd_stream_t stream);
 
 /* ---- the whole strided chain at once (csrc/sparse_sites.hip) ---------------------------------------------------------
  * replaces the per-layer spconv.ops.get_indice_pairs calls behind det3d/models/backbones/scn.py:106-148 (four SparseConv3d,
@@ -277,6 +283,16 @@ int sessd_grad_clip_coef(const float* grad, size_t n, float max_norm, void* work
 int sessd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema_param, size_t n,
                         double lr, double weight_decay, double beta1, double beta2, double eps, int step,
                         const float* clip2, double ema_alpha, sessd_stream_t stream);
+/* The schedule and the update with DEVICE-resident constants, so that a whole training iteration can be one captured graph
+ * (a replay must use the current learning rate, not the captured one): sessd_one_cycle_args reads and advances the device
+ * iteration counter *global_step and writes the nine Adam / EMA constants of that iteration (OneCycle of
+ * det3d/solver/learning_schedules_fastai.py:70-95 with config.py:260's parameters; optimizer step t = *global_step + 1; EMA
+ * alpha of trainer_sessd.py:316) to args9 and (lr, momentum) to lr_mom2 (may be NULL); sessd_adam_ema_step_dev consumes args9. */
+int sessd_one_cycle_args(int32_t* global_step, int total_steps, double lr_max, double mom_hi, double mom_lo, double div_factor,
+                         double pct_start, double weight_decay, double beta2, double eps, float* args9, float* lr_mom2,
+                         sessd_stream_t stream);
+int sessd_adam_ema_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema_param, size_t n,
+                            const float* args9, const float* clip2, sessd_stream_t stream);
 
 /* ---- dense conv backward (training step): data gradients are launches of the forward entry points
  * above with re-packed weights (3x3 s1 <-> flipped 3x3 s1, 3x3 s2 <-> sessd_deconv2d_s2_mfma, 1x1 <-> 1x1); the weight

@@ -19,6 +19,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--cpu", action="store_true")
+ap.add_argument("--graph", action="store_true", help="also capture the iteration as ONE hipGraph (capacity-form inputs) and time replays")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 VG = configs.VOXEL_GENERATOR
@@ -57,6 +58,24 @@ n = step.flat_s.numel
 out = {"what": "SE-SSD training iteration (slice): teacher fwd + student fwd/bwd + fused update", "batch": args.batch,
        "voxels": m, "ms_per_iter": ms, "samples_per_s": args.batch / ms * 1e3, "params": n,
        "fused_update_ms": upd_ms, "fused_update_GBps": n * 40 / (upd_ms * 1e-3) / 1e9, "fused_update_frac_of_8TBps": n * 40 / (upd_ms * 1e-3) / 8e12}
+if args.graph:
+    # the same iteration as ONE captured graph: capacity-sized inputs, device-side counts and schedule (TrainStep.capture)
+    cap_ex = strain.capacity_example(ex, 16384 * args.batch)
+    eager_cap = []
+    for mode in ("eager capacity form", "graph"):
+        if mode == "graph":
+            step.capture(cap_ex, warmup=1)
+        for _ in range(3):
+            step.replay() if mode == "graph" else step(cap_ex, device_schedule=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step.replay() if mode == "graph" else step(cap_ex, device_schedule=True)
+        torch.cuda.synchronize()
+        eager_cap.append((time.perf_counter() - t0) / args.steps * 1e3)
+    out["capacity_form_eager_ms_per_iter"], out["graph_ms_per_iter"] = eager_cap
+    out["graph_samples_per_s"] = args.batch / eager_cap[1] * 1e3
+    out["graph_overflow_flag"] = int(step.student.backbone.last_err.item())
 if args.cpu:
     from oracle import capi, dense_head, optim as ooptim, sparse_conv as osc
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}

@@ -69,9 +69,12 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
   if (t) *t = *t * A.alpha + A.one_m_alpha * p;
 }
 
+// Adev != nullptr: the step's constants come from device memory (written by one_cycle_args_kernel earlier on the stream), so
+// that a captured graph replays with the CURRENT learning rate / momentum / bias corrections instead of the captured ones
 __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                        float* __restrict__ v, float* __restrict__ teacher, size_t n, AdamArgs A,
-                                                        const float* __restrict__ clip2) {
+                                                        float* __restrict__ v, float* __restrict__ teacher, size_t n, AdamArgs Ahost,
+                                                        const AdamArgs* __restrict__ Adev, const float* __restrict__ clip2) {
+  const AdamArgs A = Adev ? *Adev : Ahost;
   const float coef = clip2 ? clip2[1] : 1.f;
   const size_t n4 = n >> 2;
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -93,6 +96,49 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
     const size_t e = (n4 << 2) + threadIdx.x;
     adam_one(p[e], g[e], m[e], v[e], teacher ? teacher + e : nullptr, A, coef);
   }
+}
+
+__host__ __device__ inline AdamArgs make_adam_args(double lr, double weight_decay, double beta1, double beta2, double eps, int step,
+                                                   double ema_alpha) {
+  AdamArgs A;
+  A.decay = (float)(1.0 - weight_decay * lr);
+  A.one_m_b1 = (float)(1.0 - beta1);
+  A.beta2 = (float)beta2;
+  A.one_m_b2 = (float)(1.0 - beta2);
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  A.sqrt_bc2 = (float)sqrt(bc2);
+  A.eps = (float)eps;
+  A.neg_step = (float)(-(lr / bc1));
+  A.alpha = (float)ema_alpha;
+  A.one_m_alpha = (float)(1.0 - ema_alpha);
+  return A;
+}
+
+// OneCycle (det3d/solver/learning_schedules_fastai.py:70-95, config.py:260) + the EMA coefficient (trainer_sessd.py:316) of
+// iteration *global_step, on the device: lr cos-anneals low -> lr_max over the first pct_start of total_steps, then
+// lr_max -> low / 1e4; the momentum mirrors it (mom_hi -> mom_lo -> mom_hi). Writes the Adam constants of that iteration
+// (optimizer step t = *global_step + 1), lr_mom[0..1] = (lr, momentum), and advances *global_step.
+__global__ void one_cycle_args_kernel(int* __restrict__ global_step, int total_steps, double lr_max, double mom_hi, double mom_lo,
+                                      double div_factor, double pct_start, double weight_decay, double beta2, double eps,
+                                      AdamArgs* __restrict__ out, float* __restrict__ lr_mom) {
+  const int step = *global_step;
+  const double pi = 3.141592653589793;
+  const int a1 = (int)((double)total_steps * pct_start);
+  const double low = lr_max / div_factor;
+  double lr, mom;
+  if (step < a1) {
+    const double c = cos(pi * ((double)step / (double)a1)) + 1.0;
+    lr = lr_max + (low - lr_max) / 2.0 * c;
+    mom = mom_lo + (mom_hi - mom_lo) / 2.0 * c;
+  } else {
+    const double c = cos(pi * ((double)(step - a1) / (double)(total_steps - a1))) + 1.0;
+    lr = low / 1e4 + (lr_max - low / 1e4) / 2.0 * c;
+    mom = mom_hi + (mom_lo - mom_hi) / 2.0 * c;
+  }
+  const double alpha = fmin(1.0 - 1.0 / (double)(step + 1), 0.999);
+  *out = make_adam_args(lr, weight_decay, mom, beta2, eps, step + 1, alpha);
+  if (lr_mom) { lr_mom[0] = (float)lr; lr_mom[1] = (float)mom; }
+  *global_step = step + 1;
 }
 
 }  // namespace
@@ -120,20 +166,40 @@ int sessd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* 
                         const float* clip2, double ema_alpha, hipStream_t stream) {
   if (step < 1 || n == 0) return SESSD_EINVAL;
   if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)ema_param) & 15)) return SESSD_EINVAL;
-  AdamArgs A;
-  A.decay = (float)(1.0 - weight_decay * lr);
-  A.one_m_b1 = (float)(1.0 - beta1);
-  A.beta2 = (float)beta2;
-  A.one_m_b2 = (float)(1.0 - beta2);
-  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-  A.sqrt_bc2 = (float)sqrt(bc2);
-  A.eps = (float)eps;
-  A.neg_step = (float)(-(lr / bc1));
-  A.alpha = (float)ema_alpha;
-  A.one_m_alpha = (float)(1.0 - ema_alpha);
+  const AdamArgs A = make_adam_args(lr, weight_decay, beta1, beta2, eps, step, ema_alpha);
   const size_t n4 = n >> 2;
   const unsigned blocks = (unsigned)((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1);
-  SESSD_LAUNCH(adam_ema_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, ema_param, n, A, clip2);
+  SESSD_LAUNCH(adam_ema_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, ema_param, n, A,
+               (const AdamArgs*)nullptr, clip2);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// The schedule on the device (so that the iteration can be a captured graph): reads and advances the device iteration counter
+// *global_step, writes the nine Adam / EMA constants of that iteration to args9 (device float[9], consumed by
+// sessd_adam_ema_step_dev) and (lr, momentum) to lr_mom2 (device float[2], may be NULL).
+int sessd_one_cycle_args(int32_t* global_step, int total_steps, double lr_max, double mom_hi, double mom_lo, double div_factor,
+                         double pct_start, double weight_decay, double beta2, double eps, float* args9, float* lr_mom2,
+                         hipStream_t stream) {
+  if (!global_step || !args9 || total_steps < 2 || !(pct_start > 0.0 && pct_start < 1.0) || div_factor <= 0.0) return SESSD_EINVAL;
+  if ((int)((double)total_steps * pct_start) < 1) return SESSD_EINVAL;
+  static_assert(sizeof(AdamArgs) == 9 * sizeof(float), "args9");
+  SESSD_LAUNCH(one_cycle_args_kernel, dim3(1), dim3(1), 0, stream, global_step, total_steps, lr_max, mom_hi, mom_lo, div_factor,
+               pct_start, weight_decay, beta2, eps, (AdamArgs*)args9, lr_mom2);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// sessd_adam_ema_step with its constants in device memory (args9 from sessd_one_cycle_args)
+int sessd_adam_ema_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema_param, size_t n,
+                            const float* args9, const float* clip2, hipStream_t stream) {
+  if (n == 0 || !args9) return SESSD_EINVAL;
+  if ((((uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq | (uintptr_t)ema_param) & 15)) return SESSD_EINVAL;
+  const size_t n4 = n >> 2;
+  const unsigned blocks = (unsigned)((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1);
+  AdamArgs unused = {};
+  SESSD_LAUNCH(adam_ema_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, ema_param, n, unused,
+               (const AdamArgs*)args9, clip2);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -185,12 +185,16 @@ __device__ __forceinline__ bool rnms_polygon(const float* ci, const float* cj, f
 // such a row is 16 clipping rounds on ONE wave. So:
 //   rnms_pairs_kernel  one wave per row i: clears the row's mask words, sweeps the later candidates j > i with the prefilter
 //                      (16-byte coalesced loads) and appends the surviving (i, j) pairs to ONE list per frame (one atomic per
-//                      64 candidates); pairs beyond the list's capacity (64 per row on average) are clipped on the spot;
+//                      64 candidates); the list holds every pair up to 1024 candidates (measured: frames where kilometre-sized
+//                      boxes overlap everything reach hundreds of thousands of pairs); beyond, pairs that do not fit (more than
+//                      64 per row on average) are clipped on the spot;
 //   rnms_clip_kernel   the list's pairs dealt out over all lanes of the launch: one clipping round on dense lanes whatever
 //                      the distribution over rows; bits set with atomicOr.
 constexpr int RN_ROWS = 4;       // waves (rows) per workgroup of the pair kernel
 constexpr int RN_MAXN = 4096;    // candidates (rotate_nms_common's limit; pairs are packed i << 16 | j)
 constexpr int RN_PAIRS_PER_ROW = 64;
+// capacity of a frame's pair list: every pair up to 1024 candidates (2 MB), an average of 64 per row beyond
+__host__ __device__ inline int rn_pair_cap(int n) { return n <= 1024 ? (n > 1 ? n * (n - 1) / 2 : 1) : n * RN_PAIRS_PER_ROW; }
 
 __device__ __forceinline__ void rnms_clip_pair(const float* __restrict__ cb, int i, int j, float thresh,
                                                unsigned long long* __restrict__ mrow_base, int words) {
@@ -262,11 +266,11 @@ __global__ __launch_bounds__(256) void rnms_clip_kernel(int pre_max, float thres
 int launch_rnms_mask(const int* n_top, int batch, int pre_max, float thresh, const float* corners, const float* standup,
                      unsigned long long* mask, int words, unsigned* pairs, int* pair_count, hipStream_t stream) {
   if (pre_max > RN_MAXN) return SESSD_EINVAL;  // pairs are packed i << 16 | j
-  const int pair_cap = pre_max * RN_PAIRS_PER_ROW;
+  const int pair_cap = rn_pair_cap(pre_max);
   SESSD_LAUNCH(rnms_pairs_kernel, dim3(sessd_divup(pre_max, RN_ROWS), batch), dim3(RN_ROWS * 64), 0, stream, n_top, pre_max,
                thresh, corners, standup, mask, words, pairs, pair_cap, pair_count);
   SESSD_CHECK_LAUNCH();
-  const int g = sessd_divup(pair_cap, 256) < 256 ? sessd_divup(pair_cap, 256) : 256;
+  const int g = sessd_divup(pair_cap, 256) < 512 ? sessd_divup(pair_cap, 256) : 512;
   SESSD_LAUNCH(rnms_clip_kernel, dim3(g, batch), dim3(256), 0, stream, pre_max, thresh, corners, mask, words, pairs, pair_cap,
                pair_count);
   SESSD_CHECK_LAUNCH();
@@ -513,7 +517,7 @@ size_t post_ws_layout(int batch, int num_anchors, int pre_max, int post_max, Pos
   size_t o_keep = take((size_t)batch * post_max * 4);
   size_t o_nk = take((size_t)batch * 4);
   size_t o_rb = take(4);
-  size_t o_pairs = take((size_t)batch * pre_max * RN_PAIRS_PER_ROW * 4);
+  size_t o_pairs = take((size_t)batch * rn_pair_cap(pre_max) * 4);
   size_t o_pc = take((size_t)batch * 4);
   if (w) {
     w->keys = (unsigned long long*)(base + o_keys);
@@ -671,7 +675,7 @@ int sessd_predict(const float* head, int batch, int num_pixels, const float* anc
 size_t sessd_rotate_nms_workspace_bytes(int num_boxes) {
   const int words = sessd_divup(num_boxes > 0 ? num_boxes : 1, 64);
   return sessd_align((size_t)num_boxes * 12 * 4, 256) + sessd_align((size_t)num_boxes * words * 8, 256) + 512 +
-         sessd_align((size_t)(num_boxes > 0 ? num_boxes : 1) * RN_PAIRS_PER_ROW * 4, 256);
+         sessd_align((size_t)rn_pair_cap(num_boxes > 0 ? num_boxes : 1) * 4, 256);
 }
 
 }  // extern "C"

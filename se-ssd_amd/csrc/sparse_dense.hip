@@ -7,11 +7,18 @@
 
 namespace {
 
+// n_dev != nullptr: the table has capacity `n` rows of which the first *n_dev are sites (rows beyond: untouched by the scatter,
+// zero in the gathered gradient)
 template <bool GATHER>
 __global__ __launch_bounds__(256) void sparse_dense_kernel(float* __restrict__ feat, const int* __restrict__ indices, int n,
-                                                            int channels, int D, int H, int W, float* __restrict__ dense) {
+                                                            const int* __restrict__ n_dev, int channels, int D, int H, int W,
+                                                            float* __restrict__ dense) {
   const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (id >= (size_t)n * channels) return;
+  if (n_dev && id >= (size_t)min(n_dev[0], n) * channels) {
+    if (GATHER) feat[id] = 0.f;
+    return;
+  }
   const int i = (int)(id / channels), c = (int)(id - (size_t)i * channels);
   const int4 s = *reinterpret_cast<const int4*>(indices + (size_t)i * 4);
   const size_t o = ((((size_t)s.x * channels + c) * D + s.y) * H + s.z) * W + s.w;
@@ -26,27 +33,37 @@ __global__ __launch_bounds__(256) void sparse_dense_kernel(float* __restrict__ f
 extern "C" {
 
 // features (n, channels) -> dense (batch, channels, D, H, W), pre-zeroed by the caller; indices (n,4) [b,z,y,x] unique
-int sessd_sparse_to_dense(const float* features, const int* indices, int n, int channels, const int* dims3, float* dense,
-                          hipStream_t stream) {
-  if (n < 0 || channels <= 0 || !dims3) return SESSD_EINVAL;
-  if (n == 0) return SESSD_OK;
-  const size_t total = (size_t)n * channels;
+int sessd_sparse_to_dense_dev(const float* features, const int* indices, int n_cap, const int* n_dev, int channels,
+                              const int* dims3, float* dense, hipStream_t stream) {
+  if (n_cap < 0 || channels <= 0 || !dims3) return SESSD_EINVAL;
+  if (n_cap == 0) return SESSD_OK;
+  const size_t total = (size_t)n_cap * channels;
   SESSD_LAUNCH((sparse_dense_kernel<false>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream,
-               const_cast<float*>(features), indices, n, channels, dims3[0], dims3[1], dims3[2], dense);
+               const_cast<float*>(features), indices, n_cap, n_dev, channels, dims3[0], dims3[1], dims3[2], dense);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
 
-// the gradient of the above: grad_features (n, channels) <- grad_dense at the sites
-int sessd_dense_to_sparse(const float* dense, const int* indices, int n, int channels, const int* dims3, float* features,
+int sessd_sparse_to_dense(const float* features, const int* indices, int n, int channels, const int* dims3, float* dense,
                           hipStream_t stream) {
-  if (n < 0 || channels <= 0 || !dims3) return SESSD_EINVAL;
-  if (n == 0) return SESSD_OK;
-  const size_t total = (size_t)n * channels;
-  SESSD_LAUNCH((sparse_dense_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, features, indices, n,
-               channels, dims3[0], dims3[1], dims3[2], const_cast<float*>(dense));
+  return sessd_sparse_to_dense_dev(features, indices, n, nullptr, channels, dims3, dense, stream);
+}
+
+// the gradient of the above: grad_features (n, channels) <- grad_dense at the sites
+int sessd_dense_to_sparse_dev(const float* dense, const int* indices, int n_cap, const int* n_dev, int channels,
+                              const int* dims3, float* features, hipStream_t stream) {
+  if (n_cap < 0 || channels <= 0 || !dims3) return SESSD_EINVAL;
+  if (n_cap == 0) return SESSD_OK;
+  const size_t total = (size_t)n_cap * channels;
+  SESSD_LAUNCH((sparse_dense_kernel<true>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, features, indices, n_cap,
+               n_dev, channels, dims3[0], dims3[1], dims3[2], const_cast<float*>(dense));
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
+}
+
+int sessd_dense_to_sparse(const float* dense, const int* indices, int n, int channels, const int* dims3, float* features,
+                          hipStream_t stream) {
+  return sessd_dense_to_sparse_dev(dense, indices, n, nullptr, channels, dims3, features, stream);
 }
 
 }  // extern "C"

@@ -40,10 +40,14 @@ class SpMiddleFHD(nn.Module):
     def init_weights(self, pretrained=None):
         pass
 
-    def forward(self, voxel_features, coors, batch_size, input_shape):
+    def forward(self, voxel_features, coors, batch_size, input_shape, n_dev=None):
+        """n_dev (ours; device int32[1]): the first n_dev[0] rows of voxel_features / coors are voxels, the tables are
+        capacity-sized and no count is read back (spconv capacity mode: a capturable iteration). `self.last_err` then holds
+        the device overflow flag of the pass."""
         sparse_shape = np.array([int(v) for v in input_shape[::-1]]) + [1, 0, 0]
         coors = coors.int()
-        ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape, batch_size)
+        ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape, batch_size, n_dev=n_dev)
+        self.last_err = ret.err
         ret = self.middle_conv(ret)
         ret = ret.dense()
         N, C, D, H, W = ret.shape

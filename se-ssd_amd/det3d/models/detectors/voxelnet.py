@@ -28,15 +28,19 @@ class VoxelNet(nn.Module):
 
     def extract_feat(self, data):
         feats = self.reader(data["voxels"], data["num_points_per_voxel"])
-        bev = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
+        if data.get("n_dev") is not None:  # capacity-sized inputs, live voxel count on the device (capturable iteration)
+            bev = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"], n_dev=data["n_dev"])
+        else:
+            bev = self.backbone(feats, data["coors"], data["batch_size"], data["input_shape"])
         return self.neck(bev) if self.with_neck else bev
 
     def forward_preds(self, example, raw=False):
         """Head outputs of one pass: `raw` selects the un-augmented `*_raw` voxelization (teacher input)."""
         suffix = "_raw" if raw else ""
         voxels, coords, npts, nvox, shape = (example[k + suffix] for k in _INPUT_KEYS)
+        # ours: `num_voxels_dev` (+ `_raw`), a device int32[1] with the batch's total voxel count, marks capacity-sized inputs
         bev = self.extract_feat(dict(voxels=voxels, num_points_per_voxel=npts, coors=coords, batch_size=len(nvox),
-                                     input_shape=shape[0]))
+                                     input_shape=shape[0], n_dev=example.get("num_voxels_dev" + suffix)))
         return self.bbox_head(bev)
 
     def forward(self, example, is_ema=[False, None], return_loss=True, **kwargs):

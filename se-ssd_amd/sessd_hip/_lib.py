@@ -87,6 +87,8 @@ SIGNATURES = {
     "sessd_sparse_downsample_sites_unordered": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, u32, vp, i32, vp, vp, vp]),
     "sessd_sparse_to_dense": (i32, [vp, vp, i32, i32, vp, vp, vp]),
     "sessd_dense_to_sparse": (i32, [vp, vp, i32, i32, vp, vp, vp]),
+    "sessd_sparse_to_dense_dev": (i32, [vp, vp, i32, vp, i32, vp, vp, vp]),
+    "sessd_dense_to_sparse_dev": (i32, [vp, vp, i32, vp, i32, vp, vp, vp]),
     "sessd_sparse_chain_workspace_bytes": (sz, [i32, i32, vp]),
     "sessd_sparse_chain_sites": (i32, [vp, vp, i32, i32, i32, vp, vp, sz, i32, vp, vp]),
     "sessd_sparse_chain_rulebooks": (i32, [vp, vp, i32, vp, vp, u32, vp, i32, i32, vp, vp, i32, vp, vp]),
@@ -117,6 +119,8 @@ SIGNATURES = {
     "sessd_assign_targets": (i32, [vp, i32, vp, vp, i32, f32, f32, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_odiou3d": (i32, [vp, vp, i32, vp, vp, vp]),
     "sessd_adam_ema_step": (i32, [vp, vp, vp, vp, vp, sz, f64, f64, f64, f64, f64, i32, vp, f64, vp]),
+    "sessd_one_cycle_args": (i32, [vp, i32, f64, f64, f64, f64, f64, f64, f64, f64, vp, vp, vp]),
+    "sessd_adam_ema_step_dev": (i32, [vp, vp, vp, vp, vp, sz, vp, vp, vp]),
 }
 
 

@@ -295,36 +295,38 @@ def sparse_rulebook(out_indices, n_out_dev, ksize, stride, pad, in_hash):
 
 class _SparseToDense(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, indices, spatial_shape, batch_size):
+    def forward(ctx, features, indices, spatial_shape, batch_size, n_dev):
         feats = features.float().contiguous()
         n, c = feats.shape
         dims = _i3(spatial_shape)
         out = torch.zeros([int(batch_size), c] + [int(v) for v in spatial_shape], dtype=torch.float32, device=feats.device)
-        check(lib.sessd_sparse_to_dense(feats.data_ptr(), indices.data_ptr(), n, c, dims.data_ptr(), out.data_ptr(), _stream()),
-              "sparse_to_dense")
-        ctx.save_for_backward(indices)
+        check(lib.sessd_sparse_to_dense_dev(feats.data_ptr(), indices.data_ptr(), n, _p(n_dev), c, dims.data_ptr(), out.data_ptr(),
+                                            _stream()), "sparse_to_dense")
+        ctx.save_for_backward(indices, n_dev) if n_dev is not None else ctx.save_for_backward(indices)
         ctx.shape = [int(v) for v in spatial_shape]
         ctx.nc = (n, c)
         return out
 
     @staticmethod
     def backward(ctx, grad):
-        (indices,) = ctx.saved_tensors
+        indices = ctx.saved_tensors[0]
+        n_dev = ctx.saved_tensors[1] if len(ctx.saved_tensors) > 1 else None
         n, c = ctx.nc
         g = grad.float().contiguous()
         dims = _i3(ctx.shape)
         gf = torch.empty((n, c), dtype=torch.float32, device=g.device)
-        check(lib.sessd_dense_to_sparse(g.data_ptr(), indices.data_ptr(), n, c, dims.data_ptr(), gf.data_ptr(), _stream()),
-              "dense_to_sparse")
-        return gf, None, None, None
+        check(lib.sessd_dense_to_sparse_dev(g.data_ptr(), indices.data_ptr(), n, _p(n_dev), c, dims.data_ptr(), gf.data_ptr(),
+                                            _stream()), "dense_to_sparse")
+        return gf, None, None, None, None
 
 
-def sparse_to_dense(features, indices, spatial_shape, batch_size):
-    """SparseConvTensor.dense(): (n,C) features at (n,4) int32 sites -> (B,C,D,H,W); differentiable w.r.t. the features."""
+def sparse_to_dense(features, indices, spatial_shape, batch_size, n_dev=None):
+    """SparseConvTensor.dense(): (n,C) features at (n,4) int32 sites -> (B,C,D,H,W); differentiable w.r.t. the features.
+    n_dev (1,) int32 on the device: only the first n_dev[0] rows are sites (capacity-based tables)."""
     _req(indices, torch.int32, "indices")
     if not features.is_cuda:
         raise ValueError("features must be on the HIP device")
-    return _SparseToDense.apply(features, indices, spatial_shape, batch_size)
+    return _SparseToDense.apply(features, indices, spatial_shape, batch_size, n_dev)
 
 
 class SparseChain:

@@ -10,7 +10,11 @@ What is here
   * allreduce_flat    ONE all-reduce of the flat gradient buffer (15.2 MB) over RCCL, replacing DDP's buckets plus the
                       duplicate DistOptimizerHook all-reduce (dist_utils.py:45-57); pre-divides like the reference
   * TrainStep         teacher forward (no grad, `*_raw` inputs) -> student forward -> loss -> backward -> all-reduce ->
-                      fused update, in the order of trainer_sessd.py:250-275,340-357
+                      fused update, in the order of trainer_sessd.py:250-275,340-357; `capture()` / `replay()`: the whole
+                      iteration as ONE hipGraph (capacity-sized inputs with device-side counts, the OneCycle schedule and the
+                      Adam constants computed on the device: sessd_one_cycle_args) -- nothing in it reads the host
+  * capacity_example  pads a collated example to fixed row capacities and adds the device-side voxel counts that switch the
+                      sparse module path to its capacity mode (spconv.SparseConvTensor(n_dev=...))
 The sparse backbone (spconv.IndiceConvFunction) and the twelve dense convs of the neck (ops.Conv2dFunction) run forward
 AND backward on the HIP kernels; BatchNorm, activations, the four 1x1 heads and the loss are torch ops."""
 import copy
@@ -96,6 +100,10 @@ class FusedAdamEMA:
         self.norm_coef = torch.zeros(2, dtype=torch.float32, device=dev)  # [grad norm, clip coefficient], device side
         self._ws = torch.empty(int(lib.sessd_grad_clip_workspace_bytes()), dtype=torch.uint8, device=dev)
         self.steps = 0
+        # device-resident schedule state (step_dev()): iteration counter, the nine Adam / EMA constants, (lr, momentum)
+        self.global_step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.args_dev = torch.zeros(9, dtype=torch.float32, device=dev)
+        self.lr_mom_dev = torch.zeros(2, dtype=torch.float32, device=dev)
 
     def step(self, lr, beta1, global_step):
         self.steps += 1
@@ -107,6 +115,44 @@ class FusedAdamEMA:
                                       float(lr), float(self.wd), float(beta1), float(self.beta2), float(self.eps), self.steps,
                                       self.norm_coef.data_ptr(), float(ema_alpha(global_step)), s), "adam_ema_step")
         ops.bump_param_generation()  # student and teacher were written through raw pointers: packed-weight caches are stale
+
+    def step_dev(self, total_steps, lr_max=3e-3, moms=(0.95, 0.85), div_factor=10.0, pct_start=0.4):
+        """The same update with the schedule evaluated ON THE DEVICE from the device iteration counter (three launches, no host
+        scalar in any kernel argument): what a captured iteration replays. Advances `global_step_dev`."""
+        self.steps += 1
+        s = _stream()
+        check(lib.sessd_one_cycle_args(self.global_step_dev.data_ptr(), int(total_steps), float(lr_max), float(moms[0]), float(moms[1]),
+                                       float(div_factor), float(pct_start), float(self.wd), float(self.beta2), float(self.eps),
+                                       self.args_dev.data_ptr(), self.lr_mom_dev.data_ptr(), s), "one_cycle_args")
+        check(lib.sessd_grad_clip_coef(self.s.grad.data_ptr(), self.s.numel, float(self.max_norm or 0.0), self._ws.data_ptr(),
+                                       self._ws.numel(), self.norm_coef.data_ptr(), s), "grad_clip_coef")
+        check(lib.sessd_adam_ema_step_dev(self.s.data.data_ptr(), self.s.grad.data_ptr(), self.exp_avg.data_ptr(),
+                                          self.exp_avg_sq.data_ptr(), 0 if self.t is None else self.t.data.data_ptr(), self.s.numel,
+                                          self.args_dev.data_ptr(), self.norm_coef.data_ptr(), s), "adam_ema_step_dev")
+        ops.bump_param_generation()
+
+
+def capacity_example(example, voxel_capacity, device=None):
+    """A collated example (collate_kitti + example_to_device) with its voxel tables padded to `voxel_capacity` rows and the
+    device-side counts `num_voxels_dev` (and `_raw`) added: the form a captured iteration takes its inputs in (static shapes;
+    the counts, not the shapes, say how many rows are voxels). Padded rows: coordinates -1, one point per voxel (so that the
+    mean reader does not divide by zero), zero features. Tensors are new; copy a later batch INTO them to replay on it."""
+    out = dict(example)
+    for suffix in ("", "_raw"):
+        if "voxels" + suffix not in example:
+            continue
+        vox, coo, npt = example["voxels" + suffix], example["coordinates" + suffix], example["num_points" + suffix]
+        dev = vox.device if device is None else device
+        n = int(vox.shape[0])
+        if n > voxel_capacity:
+            raise ValueError("batch has %d voxels, capacity is %d" % (n, voxel_capacity))
+        v = torch.zeros((voxel_capacity,) + tuple(vox.shape[1:]), dtype=torch.float32, device=dev)
+        c = torch.full((voxel_capacity, coo.shape[1]), -1, dtype=torch.int32, device=dev)
+        p = torch.ones((voxel_capacity,), dtype=torch.int32, device=dev)
+        v[:n], c[:n], p[:n] = vox.to(dev), coo.to(dev).int(), npt.to(dev).int()
+        out["voxels" + suffix], out["coordinates" + suffix], out["num_points" + suffix] = v, c, p
+        out["num_voxels_dev" + suffix] = torch.tensor([n], dtype=torch.int32, device=dev)
+    return out
 
 
 def allreduce_flat(flat_grad, group=None):
@@ -150,9 +196,9 @@ class TrainStep:
         self.flat_s, self.flat_t = FlatParams(self.student), FlatParams(self.teacher, with_grad=False)
         self.opt = FusedAdamEMA(self.flat_s, self.flat_t, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         self.global_step = 0
+        self.graph = None
 
-    def __call__(self, example, consistency_weight=1.0):
-        lr, mom = one_cycle(self.global_step, self.total_steps, **self.sched)  # lr_scheduler.step(global_step) first
+    def _iteration(self, example, consistency_weight, device_schedule):
         self.student.train()
         self.teacher.train()  # trainer_sessd.py:321-322: both nets in train mode
         with torch.no_grad():
@@ -166,6 +212,54 @@ class TrainStep:
             loss = self.loss_fn(example, self.student.forward_preds(example), teacher_preds, consistency_weight)
         loss.backward()
         allreduce_flat(self.flat_s.grad)
+        if device_schedule:
+            self.opt.step_dev(self.total_steps, **self.sched)
+            return loss.detach(), None, None
+        lr, mom = one_cycle(self.global_step, self.total_steps, **self.sched)  # lr_scheduler.step(global_step) first
         self.opt.step(lr, mom, self.global_step)
-        self.global_step += 1
         return loss.detach(), lr, mom
+
+    def __call__(self, example, consistency_weight=1.0, device_schedule=False):
+        """One eager iteration. device_schedule=True evaluates the OneCycle schedule and the Adam constants on the device from
+        the device iteration counter (the arithmetic a captured iteration replays) instead of passing host scalars."""
+        if device_schedule and int(self.opt.global_step_dev.item()) != self.global_step:
+            self.opt.global_step_dev.fill_(self.global_step)
+        out = self._iteration(example, consistency_weight, device_schedule)
+        self.global_step += 1
+        if not device_schedule:
+            self.opt.global_step_dev.fill_(self.global_step)
+        return out
+
+    # ------------------------------------------------------------------ the iteration as ONE hipGraph
+    def capture(self, example, consistency_weight=1.0, warmup=2):
+        """Capture teacher forward + student forward / backward + all-reduce + fused update on `example` as one graph. `example`
+        must be in capacity form (capacity_example: fixed shapes, device-side voxel counts) and the loss free of host reads
+        (a `loss_fn` on the head outputs; the reference loss selects anchors by boolean masks, i.e. with host-read shapes, and
+        stays eager). Runs `warmup` real iterations first (they count: parameters and the step counter advance). Later batches
+        are copied INTO the example's tensors before replay()."""
+        if "num_voxels_dev" not in example:
+            raise ValueError("capture() needs a capacity-form example (sessd_hip.train.capacity_example)")
+        self.static_example = example
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self(example, consistency_weight, device_schedule=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.opt.global_step_dev.fill_(self.global_step)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss, _, _ = self._iteration(example, consistency_weight, True)
+        # the captured launches did not run: undo the host-side bookkeeping of the capture pass
+        self.opt.steps -= 1
+        self.graph, self.static_loss = g, loss
+        return g
+
+    def replay(self):
+        """One captured iteration on whatever the static example's tensors hold now. Returns the (device) loss tensor."""
+        self.graph.replay()
+        self.global_step += 1
+        self.opt.steps += 1
+        ops.bump_param_generation()  # parameters changed under the packed-weight caches of any eager code that runs next
+        return self.static_loss

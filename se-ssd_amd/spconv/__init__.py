@@ -3,7 +3,17 @@ gfx950 HIP kernels of libsessd_hip.so. Mirrors: spconv.SparseConvTensor, SubMCon
 SparseSequential, SparseModule (reference call sites scn.py:4,9,24-44,46,106-148,182-184).
 
 This generic path keeps the spconv API contract (`.features` has exactly N rows), which costs one
-device->host read of the site count after every strided conv. The fused engine (sessd_hip.engine) does not."""
+device->host read of the site count after every strided conv. The fused engine (sessd_hip.engine) does not.
+
+CAPACITY MODE (SparseConvTensor(..., n_dev=count)): the tables keep a fixed row CAPACITY and the live row count stays on the
+device (`n_dev`, int32[1]); a strided conv sizes its output by `capacity_growth` instead of reading the count back, every
+kernel takes the device count (rows beyond it are never read), and nothing synchronises or copies from the host -- which is
+what lets a whole training iteration (sessd_hip.train.TrainStep.capture) be ONE captured graph. Overflow of a capacity is
+reported in `err` (device int, checked by the caller after the step)."""
+
+# capacity of a strided conv's output level relative to its input level, in the order of the strided convs of SpMiddleFHD
+# (observed ratios on KITTI-like scans: ~1.05-1.25, 0.5, 0.4, 0.85; the engine uses the same table)
+CAPACITY_GROWTH = (1.5, 1.0, 0.75, 0.75)
 import math
 
 import numpy as np
@@ -18,13 +28,18 @@ def _t3(v):
 
 
 class SparseConvTensor(object):
-    def __init__(self, features, indices, spatial_shape, batch_size, grid=None):
+    def __init__(self, features, indices, spatial_shape, batch_size, grid=None, n_dev=None, err=None, growth=None):
         self.features = features
         self.indices = indices.int().contiguous()
         self.spatial_shape = [int(v) for v in spatial_shape]
         self.batch_size = int(batch_size)
         self.indice_dict = {}
         self.grid = grid
+        self.n_dev = n_dev          # capacity mode: live rows (device int32[1]); None: every row is a site
+        self.err = err              # capacity mode: device int32[1], non-zero after a capacity overflow
+        self.growth = list(CAPACITY_GROWTH if growth is None else growth)  # consumed front to back by the strided convs
+        if n_dev is not None and err is None:
+            self.err = torch.zeros((1,), dtype=torch.int32, device=self.indices.device)
 
     @property
     def spatial_size(self):
@@ -34,13 +49,14 @@ class SparseConvTensor(object):
         return None if key is None else self.indice_dict.get(key)
 
     def dense(self, channels_first=True):
-        out = ops.sparse_to_dense(self.features, self.indices, self.spatial_shape, self.batch_size)  # (B,C,D,H,W), HIP scatter
+        out = ops.sparse_to_dense(self.features, self.indices, self.spatial_shape, self.batch_size, self.n_dev)  # (B,C,D,H,W), HIP scatter
         return out if channels_first else out.permute(0, 2, 3, 4, 1).contiguous()
 
     def _hash(self):
         h = self.indice_dict.get("__hash__")
         if h is None:
-            n = torch.tensor([self.indices.shape[0]], dtype=torch.int32, device=self.indices.device)
+            n = self.n_dev if self.n_dev is not None else torch.tensor([self.indices.shape[0]], dtype=torch.int32,
+                                                                       device=self.indices.device)
             h = (ops.sparse_hash_build(self.indices, n, self.spatial_shape), n)
             self.indice_dict["__hash__"] = h
         return h
@@ -56,16 +72,19 @@ class IndiceConvFunction(torch.autograd.Function):
     GEMM kernel (sessd_sparse_conv_wgrad), db = column sums. Deterministic (no atomics on floats)."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, nbr, tm, n_out):
+    def forward(ctx, feats, weight, bias, nbr, tm, n_out, n_in=None):
         cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
         out = ops.sparse_conv(feats, nbr, tm, n_out, ops.sparse_pack_weight(weight), cin, cout, None, bias, relu=False)
-        ctx.save_for_backward(feats, weight, nbr, tm, n_out)
+        if n_in is None:
+            ctx.save_for_backward(feats, weight, nbr, tm, n_out)
+        else:  # capacity mode: the input table's live row count lives on the device
+            ctx.save_for_backward(feats, weight, nbr, tm, n_out, n_in)
         ctx.has_bias = bias is not None
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        feats, weight, nbr, tm, n_out = ctx.saved_tensors
+        feats, weight, nbr, tm, n_out = ctx.saved_tensors[:5]
         cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
         kv = nbr.shape[0]
         g = grad_out.float().contiguous()
@@ -74,13 +93,14 @@ class IndiceConvFunction(torch.autograd.Function):
             n_in = feats.shape[0]
             nbr_t, tm_t = ops.sparse_rulebook_transpose(nbr, n_out, n_in)
             w_t = weight.detach().reshape(kv, cin, cout).transpose(1, 2).contiguous()  # per offset W_k^T: (cout, cin)
-            n_in_dev = torch.tensor([n_in], dtype=torch.int32, device=feats.device)
+            n_in_dev = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else torch.tensor([n_in], dtype=torch.int32,
+                                                                                              device=feats.device)
             gx = ops.sparse_conv(g, nbr_t, tm_t, n_in_dev, ops.sparse_pack_weight(w_t), cout, cin, None, None, relu=False)
         if ctx.needs_input_grad[1]:
             gw = ops.sparse_conv_wgrad(feats, g, nbr, tm, n_out, cin, cout).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 class SparseConvolution(SparseModule):
@@ -120,9 +140,21 @@ class SparseConvolution(SparseModule):
                 if self.indice_key is not None:
                     x.indice_dict[self.indice_key] = cached
             nbr, tm = cached
-            out = SparseConvTensor(None, x.indices, x.spatial_shape, x.batch_size)
+            out = SparseConvTensor(None, x.indices, x.spatial_shape, x.batch_size, n_dev=x.n_dev, err=x.err, growth=x.growth)
             out.indice_dict = x.indice_dict
             n_out = n_in
+        elif x.n_dev is not None:
+            # capacity mode: the output level keeps `growth` x the input capacity (at most every cell), its row count stays on
+            # the device; nothing is read back
+            oshape = [(d + 2 * p - k) // s + 1 for d, k, s, p in zip(x.spatial_shape, self.kernel_size, self.stride, self.padding)]
+            cells = x.batch_size * int(np.prod(oshape))
+            g = x.growth[0] if x.growth else float(min(int(np.prod(self.kernel_size)), 8))
+            cap = max(64, (min(cells, int(math.ceil(g * x.indices.shape[0]))) + 63) // 64 * 64)
+            oidx, n_out, ohash, _ = ops.sparse_downsample_sites(x.indices, n_in, self.kernel_size, self.stride, self.padding, oshape,
+                                                                 cap, err_flag=x.err)
+            nbr, tm = ops.sparse_rulebook(oidx, n_out, self.kernel_size, self.stride, self.padding, in_hash)
+            out = SparseConvTensor(None, oidx, oshape, x.batch_size, n_dev=n_out, err=x.err, growth=x.growth[1:])
+            out.indice_dict["__hash__"] = (ops.SiteHash(ohash.capacity, oshape, oidx.device, ohash.keys, ohash.vals), n_out)
         else:
             oshape = [(d + 2 * p - k) // s + 1 for d, k, s, p in zip(x.spatial_shape, self.kernel_size, self.stride, self.padding)]
             cells = x.batch_size * int(np.prod(oshape))
@@ -140,7 +172,7 @@ class SparseConvolution(SparseModule):
             out.indice_dict["__hash__"] = (ops.SiteHash(ohash.capacity, oshape, oidx.device, ohash.keys, ohash.vals), n_out)
         feats = x.features.float().contiguous()
         if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
-            out.features = IndiceConvFunction.apply(feats, self.weight, self.bias, nbr, tm, n_out)
+            out.features = IndiceConvFunction.apply(feats, self.weight, self.bias, nbr, tm, n_out, n_in if x.n_dev is not None else None)
         else:
             out.features = ops.sparse_conv(feats, nbr, tm, n_out, self._wpk(), self.in_channels, self.out_channels, None,
                                            self.bias, relu=False)
@@ -201,7 +233,8 @@ class SparseSequential(SparseModule):
                     if (self.FUSED_BN_TRAIN and module.training and isinstance(module, torch.nn.BatchNorm1d)
                             and module.track_running_stats and module.affine and input.features.is_cuda):
                         relu = pos + 1 < len(mods) and isinstance(mods[pos + 1], torch.nn.ReLU)
-                        n_dev = torch.tensor([input.features.shape[0]], dtype=torch.int32, device=input.features.device)
+                        n_dev = input.n_dev if input.n_dev is not None else torch.tensor(
+                            [input.features.shape[0]], dtype=torch.int32, device=input.features.device)
                         input.features = ops.bn_relu_train(input.features, n_dev, module, relu=relu)
                         skip = relu
                     else:

@@ -267,3 +267,89 @@ def test_train_step_two_ranks_identical_parameters(dev):
     assert t0 == t1 and ta0 == ta1, "teacher parameters differ across ranks"
     assert g0 == g1  # the averaged flat gradient is the same buffer content on both ranks
     assert rm0 != rm1  # different data: rank-local BatchNorm statistics
+
+
+def test_device_schedule_equals_the_host_schedule(dev):
+    """sessd_one_cycle_args (OneCycle + EMA coefficient + Adam constants from the device iteration counter) against the host
+    schedule that was pinned to the reference's own OneCycle / OptimWrapper run (tests/golden/train_ref.npz): (lr, momentum) over
+    both phases of the cycle, and the update of the same gradients through step() and step_dev() -- same parameters to float32
+    rounding of the nine constants."""
+    n = 4099
+    rng = np.random.RandomState(1)
+    p0 = rng.randn(n).astype(np.float32)
+    mk = lambda: (types.SimpleNamespace(data=torch.from_numpy(p0.copy()).to(dev), grad=torch.zeros(n, device=dev), numel=n),
+                  types.SimpleNamespace(data=torch.from_numpy(p0.copy()).to(dev), numel=n))
+    (sa, ta), (sb, tb) = mk(), mk()
+    oa, ob = strain.FusedAdamEMA(sa, ta), strain.FusedAdamEMA(sb, tb)
+    total = 12
+    for step in range(total):
+        g = torch.from_numpy((rng.randn(n) * (30.0 if step % 3 == 0 else 0.01)).astype(np.float32)).to(dev)
+        sa.grad.copy_(g)
+        sb.grad.copy_(g)
+        lr, mom = strain.one_cycle(step, total)
+        oa.step(lr, mom, step)
+        ob.step_dev(total)
+        got = ob.lr_mom_dev.cpu().numpy()
+        assert abs(got[0] - lr) <= 1e-6 * lr and abs(got[1] - mom) <= 1e-6 * mom, (step, got, lr, mom)
+        assert int(ob.global_step_dev.item()) == step + 1
+        assert torch.allclose(sa.data, sb.data, rtol=2e-6, atol=1e-7) and torch.allclose(ta.data, tb.data, rtol=2e-6, atol=1e-7), step
+
+
+def test_capacity_mode_gives_the_exact_row_gradients(dev):
+    """spconv capacity mode (fixed-capacity tables, device-side counts, no host-read count anywhere in the pass) against the
+    exact-row module path on the same batch: identical head outputs and identical gradients of every parameter."""
+    model = configs.build_synthetic_detector(dev, seed=0)
+    model.train()
+    _, ex = _example(dev, (51, 52), 9000, 8000)
+    cap_ex = strain.capacity_example(ex, 16384)
+    assert cap_ex["voxels"].shape[0] == 16384 and int(cap_ex["num_voxels_dev"].item()) == ex["voxels"].shape[0]
+    outs = []
+    for e in (ex, cap_ex):
+        for m in model.modules():  # the same BatchNorm running statistics going in (they are updated by each pass)
+            if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+                m.reset_running_stats()
+        for p in model.parameters():
+            p.grad = None
+        preds = model.forward_preds(e)
+        _loss(preds).backward()
+        outs.append(([preds[0][k].detach().clone() for k in ("box_preds", "cls_preds", "dir_cls_preds", "iou_preds")],
+                     [p.grad.detach().clone() for p in model.parameters()]))
+    assert int(model.backbone.last_err.item()) == 0
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    for (name, _), a, b in zip(model.named_parameters(), outs[0][1], outs[1][1]):
+        assert torch.equal(a, b), name
+
+
+def test_captured_iteration_equals_eager(dev):
+    """TrainStep.capture(): teacher forward + student forward / backward + fused update as ONE hipGraph. Two trainers from the
+    same seed, one running eager iterations (device schedule), one replaying its graph, on the same three batches (copied INTO
+    the static example): identical losses and bit-identical student and teacher parameters after every iteration -- and the
+    learning rate of a replay is the schedule's CURRENT one, not the captured one."""
+    def make():
+        model = configs.build_synthetic_detector(dev, seed=0)
+        return strain.TrainStep(model, loss_fn=lambda ex, sp, tp, w: _loss(sp) + 0.1 * w * (sp[0]["cls_preds"] - tp[0]["cls_preds"]).pow(2).mean(),
+                                total_steps=20)
+    batches = [strain.capacity_example(_example(dev, seeds, 9000, 8000)[1], 16384) for seeds in ((61, 62), (63, 64), (65, 66), (67, 68))]
+
+    def load(dst, src):
+        for k in ("voxels", "coordinates", "num_points", "num_voxels_dev"):
+            dst[k].copy_(src[k])
+
+    eager, graph = make(), make()
+    static = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in batches[0].items()}
+    graph.capture(static, warmup=1)      # one real iteration on batch 0 ...
+    eager(batches[0], device_schedule=True)
+    lrs = []
+    for b in batches[1:]:                # ... then three replays / three eager iterations on batches 1..3
+        load(static, b)
+        lg = graph.replay()
+        le, _, _ = eager(b, device_schedule=True)
+        torch.cuda.synchronize()
+        assert torch.equal(lg, le), (float(lg), float(le))
+        assert torch.equal(graph.flat_s.data, eager.flat_s.data) and torch.equal(graph.flat_t.data, eager.flat_t.data)
+        lrs.append(float(graph.opt.lr_mom_dev[0].item()))
+    assert graph.global_step == eager.global_step == 4 and int(graph.opt.global_step_dev.item()) == 4
+    want = [strain.one_cycle(s, 20)[0] for s in (1, 2, 3)]
+    assert np.allclose(lrs, want, rtol=1e-6) and len(set(lrs)) == 3
+    assert int(graph.student.backbone.last_err.item()) == 0
