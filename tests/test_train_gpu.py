@@ -297,7 +297,9 @@ def test_device_schedule_equals_the_host_schedule(dev):
 
 def test_capacity_mode_gives_the_exact_row_gradients(dev):
     """spconv capacity mode (fixed-capacity tables, device-side counts, no host-read count anywhere in the pass) against the
-    exact-row module path on the same batch: identical head outputs and identical gradients of every parameter."""
+    exact-row module path on the same batch: identical head outputs; gradients equal to float32 summation order (the sparse
+    weight-gradient kernel cuts the site axis into chunks by table CAPACITY, so its partial sums group differently: 1e-5 of
+    the tensor's largest gradient)."""
     model = configs.build_synthetic_detector(dev, seed=0)
     model.train()
     _, ex = _example(dev, (51, 52), 9000, 8000)
@@ -318,7 +320,7 @@ def test_capacity_mode_gives_the_exact_row_gradients(dev):
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.equal(a, b)
     for (name, _), a, b in zip(model.named_parameters(), outs[0][1], outs[1][1]):
-        assert torch.equal(a, b), name
+        assert float((a - b).abs().max()) <= 1e-5 * float(a.abs().max()) + 1e-12, name
 
 
 def test_captured_iteration_equals_eager(dev):
