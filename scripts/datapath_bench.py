@@ -26,7 +26,7 @@ VCFG = dict(range=[0, -40.0, -3.0, 70.4, 40.0, 1.0], voxel_size=[0.05, 0.05, 0.1
 out = {"what": "training data path per sample: Preprocess (GT-AUG, object noise, global transform, shuffle) + Voxelization x 2",
        "samples": N}
 with tempfile.TemporaryDirectory() as tmp:
-    db = make_database(tmp, n_car=60)
+    db = make_database(tmp)
     scenes = [make_scene(100 + k, n_gt=15, n_bg=15000, per_box=330) for k in range(N + 3)]
     out["points_per_frame"] = int(np.mean([s[0].shape[0] for s in scenes]))
     for mode in ("host", "device"):

@@ -226,7 +226,11 @@ __global__ __launch_bounds__(RN_ROWS * 64) void rnms_pairs_kernel(const int* __r
   const float4 s4 = sb[i];
   const float si[4] = {s4.x, s4.y, s4.z, s4.w};
   unsigned* pl = pairs + (size_t)b * pair_cap;
-  for (int j0 = (i + 1) & ~63; j0 < n; j0 += 64) {
+  // sweep: lane c keeps the ballot of chunk c (<= 64 chunks of 64 candidates); ONE atomic per row reserves the row's run of the
+  // list (a first version reserved per chunk: sixteen dependent atomic round trips per wave, 22 us on busy frames)
+  const int c0 = (i + 1) >> 6;
+  unsigned long long mine = 0ull;
+  for (int j0 = c0 << 6; j0 < n; j0 += 64) {
     const int j = j0 + lane;
     bool pass = false;
     if (j > i && j < n) {
@@ -235,12 +239,30 @@ __global__ __launch_bounds__(RN_ROWS * 64) void rnms_pairs_kernel(const int* __r
       pass = rnms_prefilter(si, sj);
     }
     const unsigned long long bal = __ballot(pass);
+    if (lane == (j0 >> 6) - c0) mine = bal;
+  }
+  const int cnt = __popcll(mine);
+  int incl = cnt;  // inclusive prefix of the chunk counts over the lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  const int total = __shfl(incl, 63, 64);
+  if (total == 0) return;
+  int base = 0;
+  if (lane == 0) base = atomicAdd(&pair_count[b], total);
+  base = __builtin_amdgcn_readfirstlane(base);
+  const int excl = incl - cnt;
+  const int nchunk = ((n - 1) >> 6) - c0 + 1;
+  for (int c = 0; c < nchunk; ++c) {
+    const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)mine, c), hi = __builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), c);
+    const unsigned long long bal = ((unsigned long long)hi << 32) | lo;
     if (bal == 0) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&pair_count[b], __popcll(bal));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (pass) {
-      const int idx = base + __popcll(bal & ((1ull << lane) - 1ull));
+    const int cbase = base + __builtin_amdgcn_readlane(excl, c);
+    if ((bal >> lane) & 1ull) {
+      const int j = ((c0 + c) << 6) + lane;
+      const int idx = cbase + __popcll(bal & ((1ull << lane) - 1ull));
       if (idx < pair_cap) pl[idx] = ((unsigned)i << 16) | (unsigned)j;
       else rnms_clip_pair(cb, i, j, thresh, mb, words);  // list full: this pair is clipped here
     }
