@@ -72,6 +72,8 @@ def parse(argv=None):
                     help="persistent workgroups of the stream-K Winograd launches (multiple of 8; 0 = the kernel's default, all CUs). "
                          "224 with two frames in flight leaves 32 CUs to the other stream's small kernels: +2 % frames/s, but the "
                          "kernel then runs 14 % longer per launch -- the default keeps the timed kernel the one the roofline describes")
+    ap.add_argument("--spinup-seconds", type=float, default=0.5,
+                    help="untimed frames run for this long before the warm-up steps (the CPU oracle sample leaves the GPU idle at low clocks)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     ap.add_argument("--no-offset-split", action="store_true", help="autotune without the offset-split sparse conv variants")
     ap.add_argument("--no-streamk", action="store_true", help="autotune without the stream-K Winograd variants")
@@ -279,6 +281,16 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
             dist.barrier()
         sync()
 
+    # The oracle sample above leaves the GPU idle for tens of seconds: before the W warm-up steps the clocks are brought back up
+    # by running frames for a fixed wall time (untimed, like the warm-up; the driver's W may be as small as 5 frames = 4 ms)
+    if on_gpu:
+        spin_until = time.perf_counter() + args.spinup_seconds
+        i = 0
+        while time.perf_counter() < spin_until:
+            for _ in range(16):
+                step(i)
+                i += 1
+            sync()
     for i in range(args.warmup):
         step(i)
     barrier()

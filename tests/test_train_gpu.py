@@ -326,10 +326,11 @@ def test_capacity_mode_gives_the_exact_row_gradients(dev):
 def test_captured_iteration_equals_eager(dev):
     """TrainStep.capture(): teacher forward + student forward / backward + fused update as ONE hipGraph. Two trainers from the
     same seed, one running eager iterations (device schedule), one replaying its graph, on the same three batches (copied INTO
-    the static example): the same losses and the same student and teacher parameters after every iteration (to 1e-6 of the
-    largest parameter: the torch / MIOpen pieces of the step -- the 1x1 heads' weight gradients -- are not bit-reproducible from
-    run to run, which a second eager trainer shows as well) -- and the learning rate of a replay is the schedule's CURRENT one,
-    not the captured one."""
+    the static example): the same losses, and student / teacher parameters no further from the eager trainer's than a SECOND
+    eager trainer's are (x3, floor 1e-6 of the largest parameter): the torch / MIOpen pieces of the step (the 1x1 heads' weight
+    gradients) are not bit-reproducible from run to run, and Adam's m / sqrt(v) turns a last-bit gradient difference of a
+    near-zero gradient into a full-size step -- measured on MI355X: two eager trainers 2.5e-4 apart after three iterations,
+    graph and eager 1.5e-5. The learning rate of a replay is the schedule's CURRENT one, not the captured one."""
     def make():
         model = configs.build_synthetic_detector(dev, seed=0)
         return strain.TrainStep(model, loss_fn=lambda ex, sp, tp, w: _loss(sp) + 0.1 * w * (sp[0]["cls_preds"] - tp[0]["cls_preds"]).pow(2).mean(),
@@ -346,7 +347,7 @@ def test_captured_iteration_equals_eager(dev):
     eager(batches[0], device_schedule=True)
     eager2(batches[0], device_schedule=True)
     lrs = []
-    close = lambda a, b: float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    dist = lambda a, b: float((a - b).abs().max())
     for b in batches[1:]:                # ... then three replays / three eager iterations on batches 1..3
         load(static, b)
         lg = graph.replay()
@@ -357,7 +358,9 @@ def test_captured_iteration_equals_eager(dev):
         print("max |graph - eager| %.3e   max |eager2 - eager| %.3e   max |param| %.3e" % (
             float((graph.flat_s.data - eager.flat_s.data).abs().max()), float((eager2.flat_s.data - eager.flat_s.data).abs().max()),
             float(eager.flat_s.data.abs().max())))
-        assert close(graph.flat_s.data, eager.flat_s.data) and close(graph.flat_t.data, eager.flat_t.data)
+        floor = 1e-6 * float(eager.flat_s.data.abs().max())
+        assert dist(graph.flat_s.data, eager.flat_s.data) <= 3 * dist(eager2.flat_s.data, eager.flat_s.data) + floor
+        assert dist(graph.flat_t.data, eager.flat_t.data) <= 3 * dist(eager2.flat_t.data, eager.flat_t.data) + floor
         lrs.append(float(graph.opt.lr_mom_dev[0].item()))
     assert graph.global_step == eager.global_step == 4 and int(graph.opt.global_step_dev.item()) == 4
     want = [strain.one_cycle(s, 20)[0] for s in (1, 2, 3)]
