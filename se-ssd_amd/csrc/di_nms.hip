@@ -69,6 +69,8 @@ __global__ __launch_bounds__(DN) void di_select_kernel(DiArgs A) {
   __shared__ float s_red[16][10];
   __shared__ unsigned long long s_key[16];
   __shared__ float s_bc[12];
+  __shared__ float s_terms[1024];  // the pass's non-zero cnt terms in box order
+  __shared__ int s_nz[16];
   const int j = threadIdx.x, lane = j & 63, wv = j >> 6;
   const int n = A.n;
   const bool live = j < n;
@@ -161,7 +163,13 @@ __global__ __launch_bounds__(DN) void di_select_kernel(DiArgs A) {
         }
       }
     }
-    // ---- fixed-tree reduction of cnt, weight, 7 coordinates (sum) and the score (max)
+    // ---- cnt decides whether A is kept (cnt > cnt_thresh), and everything selected later follows from that: it is summed in the
+    // REFERENCE'S ORDER, box 0, 1, 2, ... in float32 (nms_cpu.h: `cnt += overlap * iou_pred[j]` inside the loop over j). Adding
+    // zero changes nothing, so only the non-zero terms (a handful: boxes that overlap A) are compacted in box order and one
+    // thread adds them up. (Round 2 reduced cnt in a tree: a cnt within an ulp of the threshold could flip a keep / recover.)
+    const float cnt_term = cnt;
+    const unsigned long long nzb = __ballot(cnt_term != 0.f);
+    // ---- fixed-tree reduction of the weight, the 7 coordinates (sum) and the score (max)
     cnt = wave_sum_f(cnt);
     wsum = wave_sum_f(wsum);
 #pragma unroll
@@ -173,12 +181,26 @@ __global__ __launch_bounds__(DN) void di_select_kernel(DiArgs A) {
       s_red[wv][0] = cnt; s_red[wv][1] = wsum; s_red[wv][9] = sbox;
 #pragma unroll
       for (int k = 0; k < 7; ++k) s_red[wv][2 + k] = avg[k];
+      s_nz[wv] = __popcll(nzb);
     }
     __syncthreads();
-    if (j < 10) {
+    if (cnt_term != 0.f) {
+      int off = 0;
+      for (int w = 0; w < wv; ++w) off += s_nz[w];
+      s_terms[off + __popcll(nzb & ((1ull << lane) - 1ull))] = cnt_term;
+    }
+    if (j >= 1 && j < 10) {
       float v = s_red[0][j];
       for (int w = 1; w < 16; ++w) v = (j == 9) ? fmaxf(v, s_red[w][j]) : v + s_red[w][j];
       s_bc[j] = v;
+    }
+    __syncthreads();
+    if (j == 0) {
+      int total = 0;
+      for (int w = 0; w < 16; ++w) total += s_nz[w];
+      float c = 0.f;
+      for (int t = 0; t < total; ++t) c += s_terms[t];
+      s_bc[0] = c;
     }
     __syncthreads();
     const bool kept = s_bc[0] > A.cnt_thresh;

@@ -86,7 +86,9 @@ def rotate_weighted_nms(box_preds, rbboxes, dir_labels, labels_preds, scores, io
     (K,7), rbboxes (K,5) [x,y,w,l,r], dir_labels / labels_preds (K,), scores / iou_preds (K,), anchors (K,7). Returns (boxes (k,7),
     dirs (k,), labels (k,), scores (k,), kept indices into the input) on the input's device. Like the reference, the input
     `scores` tensor is damped in place when enable_centerness is set without centerness_c, and an empty input returns None.
-    (Without pre_max_size the reference fails on an unbound `indices`; here the indices are then simply 0..K-1.)"""
+    (Without pre_max_size the reference fails on an unbound `indices`; here the indices are then simply 0..K-1.)
+    LIMIT of the device kernel: at most 1024 boxes after the top-k (config.py: nms_pre_max_size = 1000); pass pre_max_size <= 1024
+    -- more raises ValueError (the reference's host loop takes any K)."""
     indices = torch.arange(scores.shape[0], device=scores.device)
     if pre_max_size is not None:
         k = min(scores.shape[0], pre_max_size)

@@ -87,6 +87,7 @@ def fused_compute_statistics(overlaps, pr, gt_nums, dt_nums, dc_nums, gt_datas, 
         g, d, c = g + gt_nums[i], d + dt_nums[i], c + dc_nums[i]
 
 
+DEVICE_MAX_DETECTIONS_PER_FRAME = 256  # MAXDET of csrc/kitti_eval.hip
 ACCUMULATE_ON_DEVICE = True  # False: the host loops below (the reference's structure; what the CPU tests pin to the golden)
 
 
@@ -110,7 +111,10 @@ def eval_class_v3(gt_annos, dt_annos, current_classes, difficultys, metric, min_
             gt_datas, dt_datas, ign_gts, ign_dets, dontcares, n_dc, n_valid = prepare_data(gt_annos, dt_annos, cls, difficulty=diff,
                                                                                          clean_data=clean_data)
             stat = None
-            if on_device:
+            # the device kernels keep a frame's detections in fixed 256-entry bit masks (MAXDET, csrc/kitti_eval.hip): a
+            # (class, difficulty) with a busier frame -- low score thresholds, many classes -- takes the host loops below,
+            # which have no such limit (the reference's structure)
+            if on_device and max([d.shape[0] for d in dt_datas] + [0]) <= DEVICE_MAX_DETECTIONS_PER_FRAME:
                 import torch
                 from sessd_hip import ops
                 stat = ops.KittiStatistics(overlaps, gt_datas, dt_datas, ign_gts, ign_dets, dontcares,

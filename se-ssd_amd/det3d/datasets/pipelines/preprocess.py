@@ -119,8 +119,16 @@ class Preprocess(object):
                     points = torch.cat([torch.from_numpy(np.ascontiguousarray(pasted["points"], np.float32)).to(dev), points], dim=0).contiguous()
 
             def move(surfaces, centers, loc_t, rot_t, valid):
-                if points.shape[0] and surfaces.shape[0]:
+                if points.shape[0] and 0 < surfaces.shape[0] <= 128:
                     ops.points_rigid_moves_(points, planes_of(surfaces), centers, loc_t, rot_t, valid)
+                elif surfaces.shape[0] > 128:
+                    # more boxes than sessd_points_rigid_moves holds in LDS (128): membership must come from the UNMOVED cloud for
+                    # all boxes at once, so the call is not chunked -- this rare frame takes the host function and goes back
+                    ph = points.cpu().numpy()
+                    from det3d.core.bbox.geometry import points_in_convex_polygon_3d_jit
+                    masks = points_in_convex_polygon_3d_jit(ph[:, :3], surfaces)
+                    prep.points_transform_(ph, centers, masks, loc_t, rot_t, valid)
+                    points.copy_(torch.from_numpy(ph).to(dev))
 
             prep.noise_per_object_v4_(gt_dict["gt_boxes"], move, target, rotation_perturb=self.gt_rotation_noise,
                                       center_noise_std=self.gt_loc_noise_std, global_random_rot_range=self.global_random_rot_range,

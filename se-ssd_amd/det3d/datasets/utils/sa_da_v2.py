@@ -16,6 +16,9 @@ _BASE = np.array([[0, 1, 5, 4], [4, 5, 6, 7], [7, 6, 2, 3], [3, 2, 1, 0], [1, 2,
 _PYRAMID_FACES = [1, 2, 0, 2, 3, 0, 3, 4, 0, 4, 1, 0, 4, 3, 2]
 
 
+DEVICE_FPS_MAX_POINTS = 4096  # sessd_farthest_point_sample keeps a pyramid's points and distances in LDS
+
+
 def one_hot(x, num_class=None):
     if not num_class:
         num_class = np.max(x) + 1
@@ -196,7 +199,13 @@ def pyramid_augment_v0_device(gt_boxes, points, enable_sa_dropout=0.1, enable_sa
             rest, thinned = keep_rows(points, ~m.any(-1)), []
             for k in range(m.shape[1]):
                 part = keep_rows(points, m[:, k])
-                thinned.append(part[ops.farthest_point_sample(part, keep_num)])
+                if part.shape[0] <= DEVICE_FPS_MAX_POINTS:
+                    thinned.append(part[ops.farthest_point_sample(part, keep_num)])
+                else:  # beyond the kernel's LDS-resident limit (a close-range car face can exceed it): the host thinning
+                    from scipy.spatial import cKDTree
+                    ph = part.cpu().numpy()
+                    d, idx = cKDTree(ph[:, 0:3]).query(ph[:, 0:3], ph.shape[0])
+                    thinned.append(part[torch.from_numpy(ifp_sample(d, idx, keep_num)).to(dev)])
             points = torch.cat([rest] + thinned, dim=0).contiguous()
         pyramids = pyramids[~box_sel]
 

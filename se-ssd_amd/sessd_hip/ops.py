@@ -125,7 +125,8 @@ def di_nms(boxes, corners, standup_iou, scores, iou_preds, labels, dirs, anchors
     n = boxes.shape[0]
     dev = boxes.device
     if n > 1024:
-        raise ValueError("di_nms handles at most 1024 boxes (the post-processor's pre_max_size)")
+        raise ValueError("di_nms handles at most 1024 boxes (one 1024-thread workgroup walks the reference's sequential loop; the "
+                         "post-processor calls it after its top-k with nms_pre_max_size = 1000): pass pre_max_size <= 1024")
     labels = labels.to(torch.int32).contiguous()
     dirs = dirs.to(torch.int32).contiguous()
     if anchors is not None:
