@@ -24,6 +24,7 @@
 //               -- if that made it the last after all, it re-reads all parts in share order. No workgroup ever waits for
 //               another. Summation order is fixed (share order), so results do not depend on arrival order.
 // Numerics: Winograd rounding (1e-6 of the output scale); the bits depend on (shape, number of workgroups), not on timing.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -44,6 +45,13 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
 #define SESSD_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #define SESSD_SYSTEM_SCOPE 17  // sc0 | sc1: write-through to / read from memory, past the per-XCD L2
 
+// a float add the SLP vectoriser cannot pair into v_pk_add_f32 (variant bit 0 of the kernel below)
+__device__ __forceinline__ float sadd(float a, float b) {
+  float r;
+  asm volatile("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 struct WinoArgs {
   const float* in;        // (B, cin, H, W)
   const float* upk;       // [cout groups][cin/2][wave NW][h 2][j 32][cb CBN][xi_local XW]
@@ -60,7 +68,10 @@ struct WinoArgs {
   long long upk_stride;   // floats between the sets' packed U
 };
 
-template <int NW, int CBN>
+// VAR: measured code variants of the main loop (same arithmetic, same results; `SESSD_WINO_VAR` selects one at launch for
+// A/B runs, 0 ships): bit 0 = the patch transform with scalar adds instead of packed v_pk_add_f32 (MI355X_MICROARCH.md
+// measures packed adds beside MFMAs as an anti-lever), bit 1 = s_setprio around the MFMA groups.
+template <int NW, int CBN, int VAR = 0>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(WinoArgs A) {
   constexpr int XW = 16 / NW;                          // transform points per wave
   static_assert(XW * CBN == 8, "8 accumulators per wave");
@@ -218,10 +229,17 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
       }                                                                                            \
     }                                                                                              \
     f32x2v tl[4], tr[4];                                                                           \
+    if constexpr (VAR & 1) {                                                                       \
+      tl[0].x = sadd(pr[0].x, -pr[2].x); tl[0].y = sadd(pr[0].y, -pr[2].y); tr[0].x = sadd(pr[0].z, -pr[2].z); tr[0].y = sadd(pr[0].w, -pr[2].w); \
+      tl[1].x = sadd(pr[1].x, pr[2].x); tl[1].y = sadd(pr[1].y, pr[2].y); tr[1].x = sadd(pr[1].z, pr[2].z); tr[1].y = sadd(pr[1].w, pr[2].w); \
+      tl[2].x = sadd(pr[2].x, -pr[1].x); tl[2].y = sadd(pr[2].y, -pr[1].y); tr[2].x = sadd(pr[2].z, -pr[1].z); tr[2].y = sadd(pr[2].w, -pr[1].w); \
+      tl[3].x = sadd(pr[1].x, -pr[3].x); tl[3].y = sadd(pr[1].y, -pr[3].y); tr[3].x = sadd(pr[1].z, -pr[3].z); tr[3].y = sadd(pr[1].w, -pr[3].w); \
+    } else {                                                                                       \
     tl[0] = pr[0].xy - pr[2].xy; tr[0] = pr[0].zw - pr[2].zw;                                      \
     tl[1] = pr[1].xy + pr[2].xy; tr[1] = pr[1].zw + pr[2].zw;                                      \
     tl[2] = pr[2].xy - pr[1].xy; tr[2] = pr[2].zw - pr[1].zw;                                      \
     tl[3] = pr[1].xy - pr[3].xy; tr[3] = pr[1].zw - pr[3].zw;                                      \
+    }                                                                                              \
     float* dst = &lds[(VOFF) + wave * 1024 + h * 32 + j];                                          \
     _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                                \
       dst[(a * 4 + 0) * 64] = tl[a].x - tr[a].x;                                                   \
@@ -237,9 +255,11 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
   }
 #define SESSD_SK_MMA(SET, P)                                                                       \
   {                                                                                                \
+    if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(3);                                          \
     _Pragma("unroll") for (int c = 0; c < CBN; ++c)                                                \
       _Pragma("unroll") for (int x = 0; x < XW; ++x)                                               \
         acc[x][c] = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[SET][(c * XW + x) >> 2][(c * XW + x) & 3], bv[P][x], acc[x][c], 0, 0, 0); \
+    if constexpr (VAR & 2) __builtin_amdgcn_s_setprio(0);                                          \
   }
   // step KS of a round: k-step kg0 + KS from ring set KS; the set freed by the previous step receives k-step + RING - 1
 #define SESSD_SK_STEP(KS)                                                                          \
@@ -454,7 +474,13 @@ int launch_sk(const float* in, int batch, int nsets, int cin, int h, int w, cons
   if (workgroups > A.total_rounds) workgroups = A.total_rounds >= 8 ? (A.total_rounds & ~7) : A.total_rounds;
   A.counters = (unsigned*)workspace;
   A.scratch = (float*)((char*)workspace + sessd_align((size_t)units * 4, 256));
-  SESSD_LAUNCH((conv3x3s1_winograd_sk_kernel<NW, CBN>), dim3(workgroups), dim3(NW * 64), 0, stream, A);
+  static const int var = [] { const char* e = getenv("SESSD_WINO_VAR"); return e ? atoi(e) & 3 : 0; }();
+  switch (var) {
+    case 1: SESSD_LAUNCH((conv3x3s1_winograd_sk_kernel<NW, CBN, 1>), dim3(workgroups), dim3(NW * 64), 0, stream, A); break;
+    case 2: SESSD_LAUNCH((conv3x3s1_winograd_sk_kernel<NW, CBN, 2>), dim3(workgroups), dim3(NW * 64), 0, stream, A); break;
+    case 3: SESSD_LAUNCH((conv3x3s1_winograd_sk_kernel<NW, CBN, 3>), dim3(workgroups), dim3(NW * 64), 0, stream, A); break;
+    default: SESSD_LAUNCH((conv3x3s1_winograd_sk_kernel<NW, CBN, 0>), dim3(workgroups), dim3(NW * 64), 0, stream, A); break;
+  }
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
