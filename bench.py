@@ -74,6 +74,7 @@ def parse(argv=None):
                          "kernel then runs 14 % longer per launch -- the default keeps the timed kernel the one the roofline describes")
     ap.add_argument("--spinup-seconds", type=float, default=0.5,
                     help="untimed frames run for this long before the warm-up steps (the CPU oracle sample leaves the GPU idle at low clocks)")
+    ap.add_argument("--no-fork", action="store_true", help="engines without the parallel front branch (level-0 table + first two sparse convs beside the site chain)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     ap.add_argument("--no-offset-split", action="store_true", help="autotune without the offset-split sparse conv variants")
     ap.add_argument("--no-streamk", action="store_true", help="autotune without the stream-K Winograd variants")
@@ -110,6 +111,8 @@ def default_engine_factory(args, dev):
     engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], args.max_voxels,
                                configs.TEST_CFG, batch_size=args.batch, max_points_per_frame=args.points, device=dev)
                for _ in range(max(1, args.streams))]
+    for e in engines:
+        e.fork_front = not args.no_fork
     return model, engines
 
 

@@ -231,6 +231,11 @@ class InferenceEngine:
                                    dtype=torch.uint8, device=dev)
         self.keys = torch.empty((B, 2 * H * W), dtype=torch.int64, device=dev)  # score-filter keys written by the head launch
         self.fuse_predict = True  # score filter inside the head launch; NMS walk + filters + record in one launch
+        # The neighbour table of the voxels (level 0, hash lookups) and the two submanifold convs that use it depend on the
+        # voxelizer only, not on the site chain of the deeper levels: with fork_front they run on a second stream (a parallel
+        # branch of the captured graph) beside mark / gather / count / scan / emit and the remaining tables.
+        self.fork_front = True
+        self.side_stream = torch.cuda.Stream(device=dev)
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -452,26 +457,50 @@ class InferenceEngine:
         self._mark("voxelize")
         # ---- SpMiddleFHD (a4-a8): every level's sites and every rulebook first (4 launches), then the 14 convolutions
         L0 = self.levels[0]
-        self.chain.run(L0["indices"], self._n(0), L0["cap"], L0["hash"], self.err, clear=False, stream=s)
-        li = 0
         n_layers = len(self.sp.layers)
-        for idx, lay in enumerate(self.sp.layers):
-            last = idx == n_layers - 1
-            j = self._job_of[idx]
-            nbr, tm = self.chain.nbr[j], self.chain.tile_mask[j]
-            if lay["kind"] == "subm":
-                L = self.levels[li]
-                out = L["feat_a"] if feat is not L["feat_a"] else L["feat_b"]
-                self._sconv(lay, feat, nbr, tm, li, out, s, idx=idx)
-                feat = out
-            else:
-                Lo = self.levels[li + 1]
-                if last:
-                    self._sconv(lay, feat, nbr, tm, li + 1, None, s, dense=True, idx=idx)
+        # layers that only need level-0 tables (the leading submanifold convs) and the jobs they use
+        lead = 0
+        while lead < n_layers and self.sp.layers[lead]["kind"] == "subm":
+            lead += 1
+        lead_jobs = 1 + max([self._job_of[i] for i in range(lead)] + [-1])
+        fork = self.fork_front and lead > 0 and self._tuning_sparse is None and self._marks is None
+
+        def run_layers(lo, hi, feat, li, st):
+            for idx in range(lo, hi):
+                lay = self.sp.layers[idx]
+                last = idx == n_layers - 1
+                j = self._job_of[idx]
+                nbr, tm = self.chain.nbr[j], self.chain.tile_mask[j]
+                if lay["kind"] == "subm":
+                    L = self.levels[li]
+                    out = L["feat_a"] if feat is not L["feat_a"] else L["feat_b"]
+                    self._sconv(lay, feat, nbr, tm, li, out, st, idx=idx)
+                    feat = out
                 else:
-                    self._sconv(lay, feat, nbr, tm, li + 1, Lo["feat_a"], s, idx=idx)
-                    feat = Lo["feat_a"]
-                li += 1
+                    Lo = self.levels[li + 1]
+                    if last:
+                        self._sconv(lay, feat, nbr, tm, li + 1, None, st, dense=True, idx=idx)
+                    else:
+                        self._sconv(lay, feat, nbr, tm, li + 1, Lo["feat_a"], st, idx=idx)
+                        feat = Lo["feat_a"]
+                    li += 1
+            return feat, li
+
+        if fork:
+            main = torch.cuda.current_stream()
+            side = self.side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                s2 = side.cuda_stream
+                self.chain.run_rulebooks(L0["indices"], self._n(0), L0["cap"], L0["hash"], 0, lead_jobs, stream=s2)
+                feat, li = run_layers(0, lead, feat, 0, s2)
+            self.chain.run_sites(L0["indices"], self._n(0), L0["cap"], self.err, clear=False, stream=s)
+            self.chain.run_rulebooks(L0["indices"], self._n(0), L0["cap"], L0["hash"], lead_jobs, len(self.chain.jobs), stream=s)
+            main.wait_stream(side)
+            feat, li = run_layers(lead, n_layers, feat, li, s)
+        else:
+            self.chain.run(L0["indices"], self._n(0), L0["cap"], L0["hash"], self.err, clear=False, stream=s)
+            feat, li = run_layers(0, n_layers, feat, 0, s)
         self._mark("spmiddle")
         # ---- SSFA (a9) rpn_v1.py:220-235
         t, h, d = self.t, self.h, self.dn

@@ -396,16 +396,33 @@ class SparseChain:
             self.jobs[j].nbr, self.jobs[j].tile_mask = self.nbr[j].data_ptr(), self.tile_mask[j].data_ptr()
 
     def run(self, indices0, n0_dev_ptr, n0_cap, hash0, err_flag, clear=True, stream=None):
+        self.run_sites(indices0, n0_dev_ptr, n0_cap, err_flag, clear, stream)
+        self.run_rulebooks(indices0, n0_dev_ptr, n0_cap, hash0, 0, len(self.jobs), stream)
+
+    def run_sites(self, indices0, n0_dev_ptr, n0_cap, err_flag, clear=True, stream=None):
+        """the site tables of every deeper level (mark / gather / count / scan / emit)"""
         s = _stream() if stream is None else stream
         if self.nbr and self.nbr[0] is None:
             self.bind_tables(n0_cap)
         check(lib.sessd_sparse_chain_sites(indices0.data_ptr(), n0_dev_ptr, int(n0_cap), self.batch, len(self.levels),
                                            self.levels, self.ws.data_ptr(), self.ws.numel(), 1 if clear else 0,
                                            err_flag.data_ptr(), s), "sparse_chain_sites")
+
+    def run_rulebooks(self, indices0, n0_dev_ptr, n0_cap, hash0, job_lo, job_hi, stream=None):
+        """the neighbour tables of jobs [job_lo, job_hi) in one launch. Jobs whose levels are both 0 (the submanifold table of the
+        voxels) need the voxelizer's hash only, not run_sites()."""
+        import ctypes
+        from ._lib import RulebookJob
+        s = _stream() if stream is None else stream
+        if self.nbr and self.nbr[0] is None:
+            self.bind_tables(n0_cap)
+        n = int(job_hi) - int(job_lo)
+        if n <= 0:
+            return
+        sub = (RulebookJob * n).from_address(ctypes.addressof(self.jobs) + int(job_lo) * ctypes.sizeof(RulebookJob))
         check(lib.sessd_sparse_chain_rulebooks(indices0.data_ptr(), n0_dev_ptr, int(n0_cap), hash0.keys.data_ptr(),
                                                hash0.vals.data_ptr(), hash0.capacity, hash0._dims_t.data_ptr(), self.batch,
-                                               len(self.levels), self.levels, self.ws.data_ptr(), len(self.jobs), self.jobs,
-                                               s), "sparse_chain_rulebooks")
+                                               len(self.levels), self.levels, self.ws.data_ptr(), n, sub, s), "sparse_chain_rulebooks")
 
 
 def _t3(v):

@@ -237,6 +237,11 @@ class SparseSequential(SparseModule):
                             [input.features.shape[0]], dtype=torch.int32, device=input.features.device)
                         input.features = ops.bn_relu_train(input.features, n_dev, module, relu=relu)
                         skip = relu
+                    elif (input.n_dev is not None and getattr(module, "training", False)
+                          and isinstance(module, torch.nn.modules.batchnorm._BatchNorm)):
+                        # a torch BatchNorm in train mode would take its batch statistics over the padding rows as well
+                        raise RuntimeError("capacity mode needs the fused train-mode BatchNorm (SparseSequential.FUSED_BN_TRAIN, "
+                                           "affine BatchNorm1d with running statistics on the device)")
                     else:
                         input.features = module(input.features)
             else:

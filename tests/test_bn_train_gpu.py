@@ -66,6 +66,7 @@ def test_sparse_sequential_with_the_fused_pair(dev):
     feat = torch.randn(n, 16, generator=g)
     w1, w2 = torch.randn(3, 3, 3, 16, 32, generator=g) * 0.1, torch.randn(3, 3, 3, 32, 64, generator=g) * 0.1
     results = []
+    before = spconv.SparseSequential.FUSED_BN_TRAIN
     try:
         for fused in (False, True):
             spconv.SparseSequential.FUSED_BN_TRAIN = fused
@@ -79,7 +80,7 @@ def test_sparse_sequential_with_the_fused_pair(dev):
             results.append((out.features.detach().cpu()[order], net[0].weight.grad.cpu(), net[3].weight.grad.cpu(), net[1].weight.grad.cpu(),
                             net[1].bias.grad.cpu(), net[1].running_mean.cpu(), net[1].running_var.cpu()))
     finally:
-        spconv.SparseSequential.FUSED_BN_TRAIN = False
+        spconv.SparseSequential.FUSED_BN_TRAIN = before  # (round 2 left it False: the rest of a full run then used the torch modules)
     for a, b in zip(*results):
         assert a.shape == b.shape and torch.allclose(a, b, rtol=1e-4, atol=1e-4 * max(1.0, float(a.abs().max()))), (a - b).abs().max()
 
