@@ -60,7 +60,7 @@ out = {"what": "SE-SSD training iteration (slice): teacher fwd + student fwd/bwd
        "fused_update_ms": upd_ms, "fused_update_GBps": n * 40 / (upd_ms * 1e-3) / 1e9, "fused_update_frac_of_8TBps": n * 40 / (upd_ms * 1e-3) / 8e12}
 if args.graph:
     # the same iteration as ONE captured graph: capacity-sized inputs, device-side counts and schedule (TrainStep.capture)
-    cap_ex = strain.capacity_example(ex, 16384 * args.batch)
+    cap_ex = strain.capacity_example(ex, (int(m * 1.08) + 4095) // 4096 * 4096)  # 8 % headroom over this batch's voxels
     eager_cap = []
     for mode in ("eager capacity form", "graph"):
         if mode == "graph":
