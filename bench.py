@@ -74,7 +74,7 @@ def parse(argv=None):
                          "kernel then runs 14 % longer per launch -- the default keeps the timed kernel the one the roofline describes")
     ap.add_argument("--spinup-seconds", type=float, default=0.5,
                     help="untimed frames run for this long before the warm-up steps (the CPU oracle sample leaves the GPU idle at low clocks)")
-    ap.add_argument("--no-fork", action="store_true", help="engines without the parallel front branch (level-0 table + first two sparse convs beside the site chain)")
+    ap.add_argument("--fork", action="store_true", help="engines with the parallel front branch (level-0 table + first two sparse convs beside the site chain; measured slower)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     ap.add_argument("--no-offset-split", action="store_true", help="autotune without the offset-split sparse conv variants")
     ap.add_argument("--no-streamk", action="store_true", help="autotune without the stream-K Winograd variants")
@@ -112,7 +112,7 @@ def default_engine_factory(args, dev):
                                configs.TEST_CFG, batch_size=args.batch, max_points_per_frame=args.points, device=dev)
                for _ in range(max(1, args.streams))]
     for e in engines:
-        e.fork_front = not args.no_fork
+        e.fork_front = bool(args.fork)
     return model, engines
 
 

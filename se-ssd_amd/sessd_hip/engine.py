@@ -233,8 +233,11 @@ class InferenceEngine:
         self.fuse_predict = True  # score filter inside the head launch; NMS walk + filters + record in one launch
         # The neighbour table of the voxels (level 0, hash lookups) and the two submanifold convs that use it depend on the
         # voxelizer only, not on the site chain of the deeper levels: with fork_front they run on a second stream (a parallel
-        # branch of the captured graph) beside mark / gather / count / scan / emit and the remaining tables.
-        self.fork_front = True
+        # branch of the captured graph) beside mark / gather / count / scan / emit and the remaining tables. MEASURED SLOWER on
+        # MI355X / ROCm 7.2 and therefore off: 1042 against 1067 frames/s one frame at a time, 1032 against 1310 with two frames in
+        # flight -- the cross-stream edges of a two-branch hipGraph cost more than the ~19 us of launches they take off the
+        # critical path, and with two engines the four streams serialise against each other.
+        self.fork_front = False
         self.side_stream = torch.cuda.Stream(device=dev)
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:

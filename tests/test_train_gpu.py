@@ -326,11 +326,12 @@ def test_capacity_mode_gives_the_exact_row_gradients(dev):
 def test_captured_iteration_equals_eager(dev):
     """TrainStep.capture(): teacher forward + student forward / backward + fused update as ONE hipGraph. Two trainers from the
     same seed, one running eager iterations (device schedule), one replaying its graph, on the same three batches (copied INTO
-    the static example): the same losses, and student / teacher parameters no further from the eager trainer's than a SECOND
-    eager trainer's are (x3, floor 1e-6 of the largest parameter): the torch / MIOpen pieces of the step (the 1x1 heads' weight
-    gradients) are not bit-reproducible from run to run, and Adam's m / sqrt(v) turns a last-bit gradient difference of a
-    near-zero gradient into a full-size step -- measured on MI355X: two eager trainers 2.5e-4 apart after three iterations,
-    graph and eager 1.5e-5. The learning rate of a replay is the schedule's CURRENT one, not the captured one."""
+    the static example): the same losses to 1e-6 (the loss of iteration k sees the parameters after k - 1 updates), and student /
+    teacher parameters that differ by less than ONE Adam step can move a parameter (sum of the learning rates so far): the torch /
+    MIOpen pieces of the step (the 1x1 heads' weight gradients) are not bit-reproducible from run to run, and Adam's m / sqrt(v)
+    turns a last-bit difference of a near-zero gradient into a full-size step -- measured on MI355X after three iterations: two
+    EAGER trainers 6.6e-6 ... 2.5e-4 apart, graph and eager 1.5e-5 ... 8.7e-5 (sum of learning rates 1.2e-3); the second eager
+    trainer is run to show that spread. The learning rate of a replay is the schedule's CURRENT one, not the captured one."""
     def make():
         model = configs.build_synthetic_detector(dev, seed=0)
         return strain.TrainStep(model, loss_fn=lambda ex, sp, tp, w: _loss(sp) + 0.1 * w * (sp[0]["cls_preds"] - tp[0]["cls_preds"]).pow(2).mean(),
@@ -358,9 +359,10 @@ def test_captured_iteration_equals_eager(dev):
         print("max |graph - eager| %.3e   max |eager2 - eager| %.3e   max |param| %.3e" % (
             float((graph.flat_s.data - eager.flat_s.data).abs().max()), float((eager2.flat_s.data - eager.flat_s.data).abs().max()),
             float(eager.flat_s.data.abs().max())))
-        floor = 1e-6 * float(eager.flat_s.data.abs().max())
-        assert dist(graph.flat_s.data, eager.flat_s.data) <= 3 * dist(eager2.flat_s.data, eager.flat_s.data) + floor
-        assert dist(graph.flat_t.data, eager.flat_t.data) <= 3 * dist(eager2.flat_t.data, eager.flat_t.data) + floor
+        moved = sum(strain.one_cycle(s, 20)[0] for s in range(eager.global_step))   # what the iterations so far can move a parameter
+        assert dist(graph.flat_s.data, eager.flat_s.data) <= moved and dist(graph.flat_t.data, eager.flat_t.data) <= moved
+        frac = float(((graph.flat_s.data - eager.flat_s.data).abs() > 1e-6).float().mean())
+        assert frac < 0.02, frac   # and only a small share of the 3.8 M parameters sits on such a noise-decided step
         lrs.append(float(graph.opt.lr_mom_dev[0].item()))
     assert graph.global_step == eager.global_step == 4 and int(graph.opt.global_step_dev.item()) == 4
     want = [strain.one_cycle(s, 20)[0] for s in (1, 2, 3)]
