@@ -129,7 +129,14 @@ class SSFA(nn.Module):
         x_middle_1 = block(self.deconv_block_1, x_trans_1)
         x_output_0 = block(self.conv_0, x_middle_0)
         x_output_1 = block(self.conv_1, x_middle_1)
-        w = torch.softmax(torch.cat([self.w_0(x_output_0), self.w_1(x_output_1)], dim=1), dim=1)
+        def wbranch(seq, inp):  # Conv2d(C, 1, 1) (torch) + BatchNorm2d(1) without ReLU (the fused train-mode passes)
+            y = seq[0](inp)
+            bn = seq[1]
+            if type(bn) is nn.BatchNorm2d and bn.training and self.fused_bn_train:
+                return ops.bn2d_relu_train(y, bn, False)
+            return bn(y)
+
+        w = torch.softmax(torch.cat([wbranch(self.w_0, x_output_0), wbranch(self.w_1, x_output_1)], dim=1), dim=1)
         return x_output_0 * w[:, 0:1] + x_output_1 * w[:, 1:]
 
     def forward(self, x):
