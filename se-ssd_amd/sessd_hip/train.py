@@ -278,12 +278,17 @@ class TrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.opt.global_step_dev.fill_(self.global_step)
+        # the iteration's output lives OUTSIDE the graph's private memory pool (allocated before the capture, written by a captured
+        # copy): a tensor inside the pool read back only after other work had run on the device was once seen overwritten
+        # (tests/test_train_gpu.py, three trainers in one process; not reproduced with the output outside the pool)
+        self.static_loss = torch.zeros((), dtype=torch.float32, device=self.flat_s.data.device)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss, _, _ = self._iteration(example, consistency_weight, True)
+            self.static_loss.copy_(loss)
         # the captured launches did not run: undo the host-side bookkeeping of the capture pass
         self.opt.steps -= 1
-        self.graph, self.static_loss = g, loss
+        self.graph = g
         return g
 
     def replay(self):
