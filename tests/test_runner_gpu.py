@@ -1,0 +1,67 @@
+"""sessd_hip.runner.HostFedPipeline: host point clouds in, host detections out, no host synchronisation per frame (the loop of
+the reference's tools/test.py:121-146 as a pipeline). Every frame's detections must equal what the same engines return one
+frame at a time, in submission order -- with pinned and pageable inputs, varying point counts, more frames than the staging ring
+and the record ring hold, through captured graphs and eagerly, and after reset()."""
+import numpy as np
+import pytest
+import torch
+
+from sessd_hip import configs, synth
+from sessd_hip.engine import InferenceEngine
+from sessd_hip.runner import HostFedPipeline
+
+pytestmark = pytest.mark.gpu
+VG = configs.VOXEL_GENERATOR
+
+
+@pytest.fixture(scope="module")
+def model(dev):
+    return configs.build_synthetic_detector(dev, seed=0)
+
+
+@pytest.mark.parametrize("eager", [False, True])
+def test_pipeline_returns_every_frame_in_order(dev, model, eager):
+    engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 1, 20480, dev) for _ in range(2)]
+    frames = [synth.make_frame(70 + i, 20000 - 700 * (i % 5)) for i in range(11)]
+    # reference: one frame at a time on engine 0 (both engines share the configuration, so their bits agree)
+    want = []
+    for f in frames:
+        engines[0].set_points([torch.from_numpy(f).to(dev)])
+        engines[0].enqueue()
+        want.append(engines[0].results()[0])
+    pipe = HostFedPipeline(engines, ring=3, fetch_every=4, eager=eager)   # rings of 8 records: 11 + 9 frames wrap them
+    if not eager:
+        for e in engines:
+            e.capture()
+    n_frames = 20
+    got = []
+    for rnd in range(2):
+        pipe.reset()
+        got = []
+        for i in range(n_frames):
+            f = frames[i % len(frames)]
+            src = torch.from_numpy(f).pin_memory() if i % 3 == 0 else f      # pinned tensors are used in place, numpy is staged
+            assert pipe.submit(src) == i
+            if i % 5 == 4:
+                got += pipe.poll()
+        got += pipe.finish()
+        assert len(got) == n_frames
+        for i, g in enumerate(got):
+            w = want[i % len(frames)]
+            for k in ("box3d_lidar", "scores", "label_preds"):
+                assert np.array_equal(g[k], w[k]), (rnd, i, k)
+    assert sum(len(g["scores"]) for g in got) > 100
+
+
+def test_pipeline_rejects_what_it_cannot_feed(dev, model):
+    eng = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 2, 20480, dev)
+    with pytest.raises(AssertionError):
+        HostFedPipeline([eng])           # batch-1 engines only
+    eng1 = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 1, 4096, dev)
+    pipe = HostFedPipeline([eng1], fetch_every=2, eager=True)
+    with pytest.raises(ValueError):
+        pipe.submit(np.zeros((5000, 4), np.float32))    # more points than the engine's capacity
+    eng1.attach_records(3)
+    eng1.capture()
+    with pytest.raises(RuntimeError):
+        HostFedPipeline([eng1], fetch_every=2)          # ring of the wrong size baked into a captured graph
