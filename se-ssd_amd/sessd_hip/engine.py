@@ -701,6 +701,7 @@ class InferenceEngine:
                 self.enqueue()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        ops.new_capture_epoch()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.enqueue()

@@ -27,11 +27,33 @@ def _req(t, dtype, name):
 
 
 _ws_cache = {}
+_CAPTURE_EPOCH = [0]
+
+
+def new_capture_epoch():
+    """Call before a stream capture begins (InferenceEngine.capture, TrainStep.capture). A scratch buffer that the module-level
+    caches below hand out DURING a capture is allocated from that graph's private memory pool, and its initialisation
+    (torch.zeros of a stream-K workspace) is a captured launch, not an executed one: a later capture must not find it in the cache
+    -- torch uses ONE process-wide capture stream, so the (device, stream) key alone cannot tell two captures apart. Entries made
+    while capturing therefore carry the epoch of their capture."""
+    _CAPTURE_EPOCH[0] += 1
+    # entries of earlier captures: the graphs that use them keep working without the cache's reference (their private pools
+    # stay reserved for them), and no later capture may pick them up
+    for cache in (_ws_cache, _SK_WS):
+        for key in [k for k in cache if k[1][1] != 0]:
+            del cache[key]
+    return _CAPTURE_EPOCH[0]
+
+
+def _cache_scope():
+    """(stream, capture epoch or 0): the part of a scratch-cache key that separates eager use from each capture"""
+    st = _stream()
+    return (st, _CAPTURE_EPOCH[0] if torch.cuda.is_current_stream_capturing() else 0)
 
 
 def workspace(nbytes, device, tag="default"):
-    """A cached per-(device, stream, tag) byte workspace, grown on demand (never shrinks)."""
-    key = (device.index, _stream(), tag)
+    """A cached per-(device, stream, capture, tag) byte workspace, grown on demand (never shrinks)."""
+    key = (device.index, _cache_scope(), tag)
     ws = _ws_cache.get(key)
     if ws is None or ws.numel() < nbytes:
         ws = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -977,7 +999,7 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         if upk is None or (H & 1) or (W & 1):
             raise ValueError("tile_cfg 22/23 (stream-K Winograd) needs a 3x3 stride-1 conv with cin % 16 (22) / 8 (23) == 0 and even H, W")
         if workspace is None:
-            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, shape, workgroups)
+            key = (x.device.index, _cache_scope(), shape, workgroups)
             need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(B, H, W, pc.cout, shape, workgroups))
             workspace = _SK_WS.get(key)
             if workspace is None or workspace.numel() < need:
@@ -995,7 +1017,7 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         la = pc.launches[0]
         need = int(lib.sessd_conv2d_sk_workspace_bytes(B, th, tw, pc.cout, sk["n"], workgroups))
         if workspace is None:
-            key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, "csk", workgroups)
+            key = (x.device.index, _cache_scope(), "csk", workgroups)
             workspace = _SK_WS.get(key)
             if workspace is None or workspace.numel() < need:
                 if workspace is not None:

@@ -282,6 +282,7 @@ class TrainStep:
         # copy): a tensor inside the pool read back only after other work had run on the device was once seen overwritten
         # (tests/test_train_gpu.py, three trainers in one process; not reproduced with the output outside the pool)
         self.static_loss = torch.zeros((), dtype=torch.float32, device=self.flat_s.data.device)
+        ops.new_capture_epoch()   # scratch caches: nothing allocated by an earlier capture is reused in this one
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss, _, _ = self._iteration(example, consistency_weight, True)
