@@ -46,7 +46,15 @@ class SpMiddleFHD(nn.Module):
         the device overflow flag of the pass."""
         sparse_shape = np.array([int(v) for v in input_shape[::-1]]) + [1, 0, 0]
         coors = coors.int()
-        ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape, batch_size, n_dev=n_dev)
+        err = None
+        if n_dev is not None:
+            # the overflow flag of the pass: ONE buffer per module, allocated at the first (eager) capacity-mode call, so that it is
+            # not a temporary inside a captured graph's private pool; cleared at the start of every pass
+            if getattr(self, "_err_buf", None) is None or self._err_buf.device != coors.device:
+                self._err_buf = torch.zeros((1,), dtype=torch.int32, device=coors.device)
+            err = self._err_buf
+            err.zero_()
+        ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape, batch_size, n_dev=n_dev, err=err)
         self.last_err = ret.err
         ret = self.middle_conv(ret)
         ret = ret.dense()
