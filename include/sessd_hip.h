@@ -293,6 +293,12 @@ int sessd_one_cycle_args(int32_t* global_step, int total_steps, double lr_max, d
                          sessd_stream_t stream);
 int sessd_adam_ema_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema_param, size_t n,
                             const float* args9, const float* clip2, sessd_stream_t stream);
+/* out[0] = scale * (sum of the n floats at x): deterministic two-stage reduction (double accumulation), workspace of
+ * sessd_grad_clip_workspace_bytes(). For losses inside a CAPTURED iteration: torch's multi-block reductions (sum / mean of a large
+ * tensor) clear a semaphore buffer with a memset, and a memset NODE of a replayed hipGraph is broken on ROCm 7.2 / gfx950 (correct
+ * on the first replay, garbage afterwards), so such a reduction returns stale or foreign values from the second replay on. */
+int sessd_sum_f32(const float* x, size_t n, float scale, void* workspace, size_t workspace_bytes, float* out,
+                  sessd_stream_t stream);
 
 /* ---- dense conv backward (training step): data gradients are launches of the forward entry points
  * above with re-packed weights (3x3 s1 <-> flipped 3x3 s1, 3x3 s2 <-> sessd_deconv2d_s2_mfma, 1x1 <-> 1x1); the weight

@@ -14,8 +14,9 @@ def _example(seeds, npts, max_voxels):
 comp = {}
 def loss_fn(ex, sp, tp, w):
     p = sp[0]
-    a, b, c, d = p["box_preds"].pow(2).mean(), torch.sigmoid(p["cls_preds"]).mean(), 0.2 * p["dir_cls_preds"].pow(2).mean(), p["iou_preds"].abs().mean()
-    e = 0.1 * w * (p["cls_preds"] - tp[0]["cls_preds"]).pow(2).mean()
+    M = ops.mean_all if not os.environ.get("DBG_TORCH_MEAN") else torch.mean
+    a, b, c, d = M(p["box_preds"].pow(2)), M(torch.sigmoid(p["cls_preds"])), 0.2 * M(p["dir_cls_preds"].pow(2)), M(p["iou_preds"].abs())
+    e = 0.1 * w * M((p["cls_preds"] - tp[0]["cls_preds"]).pow(2))
     comp["terms"] = torch.stack([a.detach(), b.detach(), c.detach(), d.detach(), e.detach()])
     return a + b + c + d + e
 def make():

@@ -27,8 +27,9 @@ VG = configs.VOXEL_GENERATOR
 
 def loss_fn(ex, s, t, w):
     p, q = s[0], t[0]
-    return (p["box_preds"].pow(2).mean() + torch.sigmoid(p["cls_preds"]).mean() + 0.2 * p["dir_cls_preds"].pow(2).mean()
-            + p["iou_preds"].abs().mean() + w * (p["cls_preds"] - q["cls_preds"]).pow(2).mean())
+    M = ops.mean_all   # not torch's .mean(): its semaphore memset breaks on graph replay on this stack
+    return (M(p["box_preds"].pow(2)) + M(torch.sigmoid(p["cls_preds"])) + 0.2 * M(p["dir_cls_preds"].pow(2)) + M(p["iou_preds"].abs())
+            + w * M((p["cls_preds"] - q["cls_preds"]).pow(2)))
 
 
 model = configs.build_synthetic_detector(dev, seed=0)

@@ -46,6 +46,29 @@ __global__ __launch_bounds__(64) void sumsq_final_kernel(const double* __restric
   }
 }
 
+// plain sum of n floats, the same deterministic two-stage shape (double accumulation, fixed grid and order). Exists because
+// torch's multi-block reductions clear a semaphore buffer with cudaMemsetAsync, and a hipMemsetAsync NODE of a replayed hipGraph
+// writes garbage from the second replay on (ROCm 7.2 / gfx950; scripts/dbg_memset_graph.py, scripts/dbg_torch_graph_ops.py: a
+// captured `x.mean()` of 1.4 M elements returns its first replay's value forever) -- a loss inside a captured training
+// iteration must not reduce through torch.
+__global__ __launch_bounds__(256) void sum_partial_kernel(const float* __restrict__ x, size_t n, double* __restrict__ partial) {
+  __shared__ double sm[4];
+  double s = 0.0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)NORM_BLOCKS * 256) s += (double)x[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ __launch_bounds__(64) void sum_final_kernel(const double* __restrict__ partial, float scale, float* __restrict__ out) {
+  double s = 0.0;
+  for (int i = threadIdx.x; i < NORM_BLOCKS; i += 64) s += partial[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (threadIdx.x == 0) out[0] = (float)(s * (double)scale);
+}
+
 struct AdamArgs {
   float decay;      // 1 - wd*lr
   float one_m_b1;   // 1 - beta1
@@ -171,6 +194,16 @@ int sessd_adam_ema_step(float* param, const float* grad, float* exp_avg, float* 
   const unsigned blocks = (unsigned)((n4 + 255) / 256 > 0 ? (n4 + 255) / 256 : 1);
   SESSD_LAUNCH(adam_ema_kernel, dim3(blocks), dim3(256), 0, stream, param, grad, exp_avg, exp_avg_sq, ema_param, n, A,
                (const AdamArgs*)nullptr, clip2);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// out[0] = scale * sum of the n floats at x (deterministic; workspace of sessd_grad_clip_workspace_bytes()); no memset, no atomics
+int sessd_sum_f32(const float* x, size_t n, float scale, void* workspace, size_t workspace_bytes, float* out, hipStream_t stream) {
+  if (workspace_bytes < sessd_grad_clip_workspace_bytes() || !x || !out) return SESSD_EINVAL;
+  SESSD_LAUNCH(sum_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, x, n, (double*)workspace);
+  SESSD_CHECK_LAUNCH();
+  SESSD_LAUNCH(sum_final_kernel, dim3(1), dim3(64), 0, stream, (const double*)workspace, scale, out);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

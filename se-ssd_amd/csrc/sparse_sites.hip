@@ -1,4 +1,4 @@
-// Active sites and rulebooks of the WHOLE strided chain of SpMiddleFHD: 2 + levels small launches (gfx950).
+// Active sites and rulebooks of the WHOLE strided chain of SpMiddleFHD: 3 + levels small launches (gfx950).
 // Replaces what the reference gets from spconv's get_indice_pairs, once per SparseConv3d / per indice_key:
 //   det3d/models/backbones/scn.py:106-148 (four SparseConv3d, four groups of SubMConv3d), :179-183.
 // Semantics (restated in oracle/sparse_conv.py, pinned against F.conv3d): an output cell of SparseConv3d(k, s, p) is
@@ -17,10 +17,11 @@
 //             from level 1 in one launch makes threads walk 49 / 105 rows each (57 us).
 //   emit      exclusive prefix of the popcounts = row number of every active cell; rows are numbered in ascending (b,z,y,x)
 //             order: deterministic (no atomic decides a number), and 16 consecutive rows are spatial neighbours -- what the
-//             16-site MFMA tiles of sparse_conv.hip want (fewer distinct offsets per tile). The per-block cell counts come
-//             from the mark / gather launches themselves (atomicOr returns the old word: the bits a call turns on are counted
-//             where they are set) and every block sums its level's earlier blocks itself: round 2 ran a popcount pass over all
-//             maps and a scan launch in front of this kernel (three launches, now one)
+//             16-site MFMA tiles of sparse_conv.hip want (fewer distinct offsets per tile). A popcount pass gives the cells per
+//             block (count) and every emit block sums its level's earlier blocks itself (round 2: a separate scan launch).
+//             Measured and dropped: counting the bits where they are set (atomicOr returns the old word, the fresh bits go to
+//             the block's counter with an atomicAdd) -- exact, one launch less, but ~10^5 atomics on a few hundred counters:
+//             chain_mark 6.8 -> 45.7 us, the gathers 8 -> 14 us
 //   rulebooks ALL neighbour tables of the chain in one launch (submanifold table of each level + the strided table
 //             into the next), nbr[k][o] + per-16-site tile masks exactly as sessd_sparse_rulebook builds them. A lookup
 //             "cell -> row or -1" is ONE 8-byte load + popcount and the x-neighbours of a window share a word; all loads
@@ -67,17 +68,8 @@ __device__ __forceinline__ void reach(int lo_in, int hi_in, int k, int s, int p,
 }
 
 // level 1 (chain index 0) from the level-0 sites
-// Every kernel that sets map bits also COUNTS them: atomicOr returns the word as it was, so mask & ~old are exactly the bits
-// this call turned on, and their number goes to the word's scan block (integer atomics: the sums are exact and order-independent).
-// That replaces the separate popcount pass over all maps (chain_count_kernel: 3.4 MB read + a launch per frame).
-__device__ __forceinline__ void set_bits_counted(uint2* __restrict__ o, unsigned word, unsigned mask, int* __restrict__ blk_cnt_level) {
-  const unsigned old = atomicOr(&o[word].x, mask);
-  const unsigned fresh = mask & ~old;
-  if (fresh) atomicAdd(&blk_cnt_level[word / SPAN], __popc(fresh));
-}
-
 __global__ __launch_bounds__(NT) void chain_mark_kernel(const int* __restrict__ indices0, const int* __restrict__ n0_dev,
-                                                         int n0_cap, ChainDev C, uint2* __restrict__ occ, int* __restrict__ blk_cnt) {
+                                                         int n0_cap, ChainDev C, uint2* __restrict__ occ) {
   const int i = blockIdx.x * NT + threadIdx.x;
   const int n = min(n0_dev[0], n0_cap);
   if (i >= n) return;
@@ -89,7 +81,6 @@ __global__ __launch_bounds__(NT) void chain_mark_kernel(const int* __restrict__ 
   reach(c.w, c.w, L.ks[2], L.st[2], L.pd[2], L.dims[2], lo[2], hi[2]);
   if (lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]) return;
   uint2* o = occ + (size_t)L.blk_off * SPAN;
-  int* bc = blk_cnt + L.blk_off;
   const int nz = hi[0] - lo[0] + 1, ny = hi[1] - lo[1] + 1, nx = hi[2] - lo[2] + 1;
   if (nz <= 3 && ny <= 3 && nx <= 3) {
     unsigned word[9][2], mask[9][2], have[9][2];
@@ -111,8 +102,8 @@ __global__ __launch_bounds__(NT) void chain_mark_kernel(const int* __restrict__ 
     }
 #pragma unroll
     for (int r = 0; r < 9; ++r) {  // a stale read only costs a redundant atomic
-      if (mask[r][0] & ~have[r][0]) set_bits_counted(o, word[r][0], mask[r][0], bc);
-      if (mask[r][1] & ~have[r][1]) set_bits_counted(o, word[r][1], mask[r][1], bc);
+      if (mask[r][0] & ~have[r][0]) atomicOr(&o[word[r][0]].x, mask[r][0]);
+      if (mask[r][1] & ~have[r][1]) atomicOr(&o[word[r][1]].x, mask[r][1]);
     }
     return;
   }
@@ -122,14 +113,14 @@ __global__ __launch_bounds__(NT) void chain_mark_kernel(const int* __restrict__ 
       for (int x = lo[2]; x <= hi[2]; ++x) {
         const unsigned cell = base + (unsigned)x;
         const unsigned m = 1u << (cell & 31u);
-        if (!(o[cell >> 5].x & m)) set_bits_counted(o, cell >> 5, m, bc);
+        if (!(o[cell >> 5].x & m)) atomicOr(&o[cell >> 5].x, m);
       }
     }
 }
 
 // levels l_first..l_last (chain indices >= 1) from the map of their `src` level
 __global__ __launch_bounds__(NT) void chain_gather_kernel(ChainDev C, int l_first, int l_last, int thr_base,
-                                                           uint2* __restrict__ occ, int* __restrict__ blk_cnt) {
+                                                           uint2* __restrict__ occ) {
   const int t = thr_base + blockIdx.x * NT + threadIdx.x;
   int l = l_first;
 #pragma unroll
@@ -221,12 +212,30 @@ __global__ __launch_bounds__(NT) void chain_gather_kernel(ChainDev C, int l_firs
   uint2* o = occ + (size_t)blk_o * SPAN;
   const unsigned cell = (unsigned)(((b * dims_o[0] + z) * dims_o[1] + y) * dims_o[2] + x0);
   const unsigned sh = cell & 31u;
-  int* bc = blk_cnt + blk_o;
-  set_bits_counted(o, cell >> 5, out << sh, bc);  // a word is shared by at most the few segments of neighbouring rows
-  if (sh && (out >> (32 - sh))) set_bits_counted(o, (cell >> 5) + 1, out >> (32 - sh), bc);
+  atomicOr(&o[cell >> 5].x, out << sh);  // a word is shared by at most the few segments of neighbouring rows
+  if (sh && (out >> (32 - sh))) atomicOr(&o[(cell >> 5) + 1].x, out >> (32 - sh));
 }
 
-// ranks + site table of one SPAN-word block. blk_cnt = live cells per block (counted by the mark / gather launches); the block's
+__global__ __launch_bounds__(NT) void chain_count_kernel(const uint2* __restrict__ occ, int* __restrict__ blk_cnt) {
+  __shared__ int sm[NT / 64];
+  const uint4* o = reinterpret_cast<const uint4*>(occ + (size_t)blockIdx.x * SPAN + threadIdx.x * WPT);
+  int s = 0;
+#pragma unroll
+  for (int j = 0; j < WPT / 2; ++j) {
+    const uint4 v = o[j];
+    s += __popc(v.x) + __popc(v.z);
+  }
+  s = sessd_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < NT / 64; ++w) t += sm[w];
+    blk_cnt[blockIdx.x] = t;
+  }
+}
+
+// ranks + site table of one SPAN-word block. blk_cnt = live cells per block (chain_count_kernel); the block's
 // first rank = the sum over the level's earlier blocks, taken by the block itself (<= a few hundred integers: round 2 ran a
 // separate scan launch for it); the level's last block also publishes the level's row count and the overflow flag.
 __global__ __launch_bounds__(NT) void chain_emit_kernel(uint2* __restrict__ occ, const int* __restrict__ blk_cnt, ChainDev C,
@@ -555,24 +564,23 @@ int sessd_sparse_chain_sites(const int32_t* indices0, const int32_t* n0_dev, int
   if (Y.total > workspace_bytes) return SESSD_EWORKSPACE;
   uint2* occ = (uint2*)workspace;
   int* blk_cnt = (int*)((char*)workspace + Y.blk_cnt_off);
-  if (clear) {
-    SESSD_FILL(occ, 0u, Y.occ_words * 2, stream);
-    SESSD_FILL(blk_cnt, 0u, (size_t)Y.nblk, stream);
-  }
-  SESSD_LAUNCH(chain_mark_kernel, dim3(sessd_divup(n0_cap, NT)), dim3(NT), 0, stream, indices0, n0_dev, n0_cap, C, occ, blk_cnt);
+  if (clear) SESSD_FILL(occ, 0u, Y.occ_words * 2, stream);
+  SESSD_LAUNCH(chain_mark_kernel, dim3(sessd_divup(n0_cap, NT)), dim3(NT), 0, stream, indices0, n0_dev, n0_cap, C, occ);
   SESSD_CHECK_LAUNCH();
   if (n_levels > 1) {
     if (Y.composite) {
-      SESSD_LAUNCH(chain_gather_kernel, dim3(sessd_divup(Y.gather_threads, NT)), dim3(NT), 0, stream, C, 1, n_levels - 1, 0, occ, blk_cnt);
+      SESSD_LAUNCH(chain_gather_kernel, dim3(sessd_divup(Y.gather_threads, NT)), dim3(NT), 0, stream, C, 1, n_levels - 1, 0, occ);
       SESSD_CHECK_LAUNCH();
     } else {
       for (int l = 1; l < n_levels; ++l) {
         const int thr = batch * C.L[l].dims[0] * C.L[l].dims[1] * C.L[l].nseg;
-        SESSD_LAUNCH(chain_gather_kernel, dim3(sessd_divup(thr, NT)), dim3(NT), 0, stream, C, l, l, 0, occ, blk_cnt);
+        SESSD_LAUNCH(chain_gather_kernel, dim3(sessd_divup(thr, NT)), dim3(NT), 0, stream, C, l, l, 0, occ);
         SESSD_CHECK_LAUNCH();
       }
     }
   }
+  SESSD_LAUNCH(chain_count_kernel, dim3(Y.nblk), dim3(NT), 0, stream, occ, blk_cnt);
+  SESSD_CHECK_LAUNCH();
   SESSD_LAUNCH(chain_emit_kernel, dim3(Y.nblk), dim3(NT), 0, stream, occ, blk_cnt, C, err_flag);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

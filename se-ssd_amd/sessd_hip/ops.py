@@ -1129,6 +1129,32 @@ def odiou_3d_loss(gboxes, qboxes, weights, batch_size):
     return OdiouFunction.apply(gboxes, qboxes, weights, batch_size)
 
 
+class _SumAll(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        xc = x.float().contiguous()
+        out = torch.empty((), dtype=torch.float32, device=xc.device)
+        ws = torch.empty(int(lib.sessd_grad_clip_workspace_bytes()), dtype=torch.uint8, device=xc.device)
+        check(lib.sessd_sum_f32(xc.data_ptr(), xc.numel(), float(scale), ws.data_ptr(), ws.numel(), out.data_ptr(), _stream()), "sum_f32")
+        ctx.shape, ctx.scale = x.shape, float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g * ctx.scale).expand(ctx.shape), None
+
+
+def sum_all(x):
+    """Sum of all elements as a 0-dim tensor (differentiable): sessd_sum_f32, deterministic, safe inside a captured graph --
+    unlike torch's x.sum() / x.mean() of a large tensor, whose semaphore memset breaks on graph replay on this stack."""
+    return _SumAll.apply(x, 1.0)
+
+
+def mean_all(x):
+    """Mean of all elements as a 0-dim tensor (differentiable); see sum_all."""
+    return _SumAll.apply(x, 1.0 / max(1, x.numel()))
+
+
 def conv2d_wgrad(inp, grad_out, ksize, stride):
     """Weight gradient (Cout, Cin, k, k) of Conv2d(k, stride, padding k//2): inp (B,Cin,H,W), grad_out (B,Cout,Ho,Wo).
     For ConvTranspose2d(3, s2, p1, op1) pass (inp=its grad_out, grad_out=its input) and get its (Cin, Cout, 3, 3) gradient."""

@@ -54,8 +54,8 @@ def _example(dev, seeds, npts, max_voxels):
 
 def _loss(preds):
     p = preds[0] if isinstance(preds, (list, tuple)) else preds
-    return (p["box_preds"].pow(2).mean() + torch.sigmoid(p["cls_preds"]).mean() + 0.2 * p["dir_cls_preds"].pow(2).mean()
-            + p["iou_preds"].abs().mean())
+    M = ops.mean_all   # not torch's .mean(): its semaphore memset breaks on graph replay on this stack
+    return M(p["box_preds"].pow(2)) + M(torch.sigmoid(p["cls_preds"])) + 0.2 * M(p["dir_cls_preds"].pow(2)) + M(p["iou_preds"].abs())
 
 
 def test_whole_model_gradients_vs_oracle(dev):
@@ -334,7 +334,7 @@ def test_captured_iteration_equals_eager(dev):
     trainer is run to show that spread. The learning rate of a replay is the schedule's CURRENT one, not the captured one."""
     def make():
         model = configs.build_synthetic_detector(dev, seed=0)
-        return strain.TrainStep(model, loss_fn=lambda ex, sp, tp, w: _loss(sp) + 0.1 * w * (sp[0]["cls_preds"] - tp[0]["cls_preds"]).pow(2).mean(),
+        return strain.TrainStep(model, loss_fn=lambda ex, sp, tp, w: _loss(sp) + 0.1 * w * ops.mean_all((sp[0]["cls_preds"] - tp[0]["cls_preds"]).pow(2)),
                                 total_steps=20)
     batches = [strain.capacity_example(_example(dev, seeds, 9000, 8000)[1], 16384) for seeds in ((61, 62), (63, 64), (65, 66), (67, 68))]
 
@@ -369,3 +369,27 @@ def test_captured_iteration_equals_eager(dev):
     want = [strain.one_cycle(s, 20)[0] for s in (1, 2, 3)]
     assert np.allclose(lrs, want, rtol=1e-6) and len(set(lrs)) == 3
     assert int(graph.student.backbone.last_err.item()) == 0
+
+
+def test_graph_safe_reductions(dev):
+    """ops.sum_all / mean_all (sessd_sum_f32): value and gradient against torch in eager mode, and -- the reason they exist --
+    correct on EVERY replay of a captured graph on changing inputs (torch's own mean of a tensor this size returns its first
+    replay's value forever on this stack: its semaphore memset node breaks from the second replay on, scripts/dbg_torch_graph_ops.py)."""
+    x = torch.randn(2, 200, 176, 20, device=dev, requires_grad=True)
+    s, m = ops.sum_all(x), ops.mean_all(x.abs())
+    assert abs(float(s) - float(x.double().sum())) <= 1e-6 * float(x.double().abs().sum())
+    assert abs(float(m) - float(x.double().abs().mean())) <= 1e-6
+    (gs,) = torch.autograd.grad(s + 3.0 * m, x)
+    assert torch.allclose(gs, 1.0 + 3.0 * torch.sign(x.detach()) / x.numel(), rtol=1e-6, atol=1e-9)
+    inp = torch.zeros(2, 200, 176, 20, device=dev)
+    for _ in range(2):
+        ops.mean_all(inp)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.mean_all(inp) + ops.sum_all(inp[0, :2])
+    for it in range(8):
+        fresh = torch.randn_like(inp) + 0.1 * it
+        inp.copy_(fresh)
+        g.replay()
+        want = float(fresh.double().mean() + fresh[0, :2].double().sum())
+        assert abs(float(out) - want) <= 1e-5 * max(1.0, abs(want)), (it, float(out), want)
