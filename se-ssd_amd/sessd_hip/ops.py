@@ -1132,6 +1132,8 @@ def odiou_3d_loss(gboxes, qboxes, weights, batch_size):
 class _SumAll(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale):
+        if not x.is_cuda:
+            raise ValueError("sum_all / mean_all: the tensor must be on the HIP device")
         xc = x.float().contiguous()
         out = torch.empty((), dtype=torch.float32, device=xc.device)
         ws = torch.empty(int(lib.sessd_grad_clip_workspace_bytes()), dtype=torch.uint8, device=xc.device)

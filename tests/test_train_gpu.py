@@ -54,7 +54,8 @@ def _example(dev, seeds, npts, max_voxels):
 
 def _loss(preds):
     p = preds[0] if isinstance(preds, (list, tuple)) else preds
-    M = ops.mean_all   # not torch's .mean(): its semaphore memset breaks on graph replay on this stack
+    # on the device not torch's .mean(): its semaphore memset breaks on graph replay on this stack
+    M = ops.mean_all if p["box_preds"].is_cuda else torch.mean
     return M(p["box_preds"].pow(2)) + M(torch.sigmoid(p["cls_preds"])) + 0.2 * M(p["dir_cls_preds"].pow(2)) + M(p["iou_preds"].abs())
 
 
