@@ -299,6 +299,10 @@ int sessd_adam_ema_step_dev(float* param, const float* grad, float* exp_avg, flo
  * on the first replay, garbage afterwards), so such a reduction returns stale or foreign values from the second replay on. */
 int sessd_sum_f32(const float* x, size_t n, float scale, void* workspace, size_t workspace_bytes, float* out,
                   sessd_stream_t stream);
+/* out[c] = sum over images and pixels of x (B, C, plane): a conv's bias gradient, on the statistics pass of the train-mode
+ * BatchNorm2d kernels (plane % 4 == 0; workspace of sessd_bn2d_relu_train_workspace_bytes(channels)); same reason as above */
+int sessd_nchw_channel_sum(const float* x, int batch, int channels, int plane, float* out, void* workspace,
+                           size_t workspace_bytes, sessd_stream_t stream);
 
 /* ---- dense conv backward (training step): data gradients are launches of the forward entry points
  * above with re-packed weights (3x3 s1 <-> flipped 3x3 s1, 3x3 s2 <-> sessd_deconv2d_s2_mfma, 1x1 <-> 1x1); the weight

@@ -107,7 +107,7 @@ __global__ void bn_bwd_final_kernel(const double* __restrict__ partial, int C, f
     s1 += partial[((size_t)b * 2 + 1) * C + c];
   }
   dbeta[c] = (float)s0;
-  dgamma[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s1;
 }
 
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -309,6 +309,22 @@ __global__ __launch_bounds__(NT) void bn2d_apply_kernel(const float* __restrict_
 extern "C" {
 
 size_t sessd_bn2d_relu_train_workspace_bytes(int channels) { return (size_t)channels * BN2D_SPLIT * 2 * sizeof(double); }
+
+// out[c] = sum over images and pixels of x[b][c][.] (the bias gradient of a conv: det3d's heads): the statistics pass of the
+// train-mode BatchNorm above with only its first sum kept -- deterministic, no atomics, no memset (a torch reduction of this
+// size clears a semaphore buffer with a memset, which a replayed hipGraph does not execute correctly on this stack).
+int sessd_nchw_channel_sum(const float* x, int batch, int channels, int plane, float* out, void* workspace, size_t workspace_bytes,
+                           hipStream_t stream) {
+  if (batch < 1 || channels < 1 || plane < 4 || (plane & 3)) return SESSD_EINVAL;
+  if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
+  double* partial = (double*)workspace;
+  SESSD_LAUNCH((bn2d_partial_kernel<false>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, (const float*)nullptr,
+               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, batch, channels, plane, 0, partial);
+  SESSD_CHECK_LAUNCH();
+  SESSD_LAUNCH(bn2d_bwd_final_kernel, dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, partial, channels, (float*)nullptr, out);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
 
 // BatchNorm2d (train mode) + optional ReLU on x (batch, channels, plane = H * W; plane % 4 == 0), torch.nn.BatchNorm2d semantics
 // (biased batch variance to normalise, unbiased into running_var); save_mean / save_invstd (channels) for the backward.

@@ -28,6 +28,7 @@ class Head(nn.Module):
         if self.use_dir:
             self.conv_dir = nn.Conv2d(num_input, num_dir, 1)
         self._packed = None
+        self.fused_train = True  # train mode: the heads as one conv on the HIP kernels (False: four torch / MIOpen convs)
 
     def __deepcopy__(self, memo):
         import copy
@@ -50,7 +51,19 @@ class Head(nn.Module):
         return ops.conv2d(x.float().contiguous(), pc, None, b, False), split
 
     def forward(self, x):
-        if self.training:  # autograd path: the four 1x1 convs as torch modules (mg_head_sessd.py:217-230)
+        if self.training and self.fused_train and x.is_cuda and x.shape[1] % 2 == 0:
+            # autograd path on the HIP kernels: the four 1x1 convs (mg_head_sessd.py:217-230) as ONE 22-channel conv through
+            # ops.Conv2dFunction (forward sessd_conv2d_mfma, data gradient = the adjoint 1x1 conv, weight gradient
+            # sessd_conv2d_wgrad); torch.cat / split route the gradients back to the four modules' parameters. Round 2 ran them
+            # as four MIOpen convs forward and backward.
+            convs = [self.conv_box, self.conv_cls] + ([self.conv_dir] if self.use_dir else []) + [self.conv_iou]
+            w = torch.cat([c.weight for c in convs], 0)
+            b = torch.cat([c.bias for c in convs], 0)
+            y = ops.Conv2dFunction.apply(x, w, b, False, 1)
+            parts = torch.split(y, [c.out_channels for c in convs], dim=1)
+            names = ["box_preds", "cls_preds"] + (["dir_cls_preds"] if self.use_dir else []) + ["iou_preds"]
+            return {n: p.permute(0, 2, 3, 1).contiguous() for n, p in zip(names, parts)}
+        if self.training:  # the four 1x1 convs as torch modules
             ret = dict(box_preds=self.conv_box(x).permute(0, 2, 3, 1).contiguous(),
                        cls_preds=self.conv_cls(x).permute(0, 2, 3, 1).contiguous())
             if self.use_dir:

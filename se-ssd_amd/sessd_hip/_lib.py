@@ -122,6 +122,7 @@ SIGNATURES = {
     "sessd_one_cycle_args": (i32, [vp, i32, f64, f64, f64, f64, f64, f64, f64, f64, vp, vp, vp]),
     "sessd_adam_ema_step_dev": (i32, [vp, vp, vp, vp, vp, sz, vp, vp, vp]),
     "sessd_sum_f32": (i32, [vp, sz, f32, vp, sz, vp, vp]),
+    "sessd_nchw_channel_sum": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
 }
 
 

@@ -1146,6 +1146,19 @@ class _SumAll(torch.autograd.Function):
         return (g * ctx.scale).expand(ctx.shape), None
 
 
+def channel_sum(x):
+    """(B, C, H, W) float32 on the device -> (C,) sums over images and pixels (a conv's bias gradient) on sessd_nchw_channel_sum;
+    torch's own reduction where the kernel's layout assumption (H * W % 4 == 0) does not hold."""
+    B, C, H, W = x.shape
+    if (H * W) % 4 or not x.is_cuda:
+        return x.sum((0, 2, 3))
+    xc = x.float().contiguous()
+    out = torch.empty((C,), dtype=torch.float32, device=x.device)
+    ws = workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), x.device, "bn2d")
+    check(lib.sessd_nchw_channel_sum(xc.data_ptr(), B, C, H * W, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "nchw_channel_sum")
+    return out
+
+
 def sum_all(x):
     """Sum of all elements as a 0-dim tensor (differentiable): sessd_sum_f32, deterministic, safe inside a captured graph --
     unlike torch's x.sum() / x.mean() of a large tensor, whose semaphore memset breaks on graph replay on this stack."""
@@ -1211,7 +1224,7 @@ class Conv2dFunction(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = conv2d_wgrad(g, x, 3, 2) if transposed else conv2d_wgrad(x, g, k, stride)
         if has_bias and ctx.needs_input_grad[2]:
-            gb = g.sum((0, 2, 3))
+            gb = channel_sum(g)
         return gx, gw, gb, None, None
 
 
