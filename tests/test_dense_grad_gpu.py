@@ -69,3 +69,42 @@ def test_wgrad_is_deterministic(dev):
     assert torch.equal(a, b)
     want = torch.nn.grad.conv2d_weight(x.cpu(), (64, 64, 3, 3), gy.cpu(), stride=1, padding=1)
     _close(a, want, "wgrad")
+
+
+def test_train_mode_heads_fused_equal_the_four_torch_convs(dev):
+    """det3d Head in train mode: the four 1x1 convs as ONE 22-channel conv through ops.Conv2dFunction (forward, data gradient,
+    weight gradient on the HIP kernels, bias gradient on sessd_nchw_channel_sum) against the four torch modules (MIOpen):
+    the four NHWC outputs, the gradients of all eight parameter tensors and of the input."""
+    from det3d.models.bbox_heads.mg_head_sessd import Head
+    torch.manual_seed(3)
+    head = Head(128, 14, 2, use_dir=True, num_dir=4).to(dev).train()
+    x = torch.randn(2, 128, 200, 176, device=dev)
+    gos = None
+    res = []
+    for fused in (False, True):
+        head.fused_train = fused
+        for p in head.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        out = head(xi)
+        assert [tuple(out[k].shape) for k in ("box_preds", "cls_preds", "dir_cls_preds", "iou_preds")] == \
+            [(2, 200, 176, 14), (2, 200, 176, 2), (2, 200, 176, 4), (2, 200, 176, 2)]
+        if gos is None:
+            gos = {k: torch.randn_like(v) for k, v in out.items()}
+        sum((out[k] * gos[k]).sum() for k in out).backward()
+        res.append(({k: v.detach().clone() for k, v in out.items()}, {n: p.grad.clone() for n, p in head.named_parameters()}, xi.grad.clone()))
+    (o0, g0, x0), (o1, g1, x1) = res
+    for k in o0:
+        _close(o1[k], o0[k].cpu(), k)
+    for n in g0:
+        _close(g1[n], g0[n].cpu(), n)
+    _close(x1, x0.cpu(), "input grad")
+
+
+def test_channel_sum(dev):
+    x = torch.randn(3, 22, 200, 176, device=dev)
+    got = ops.channel_sum(x)
+    want = x.double().sum((0, 2, 3))
+    assert float((got.double() - want).abs().max()) <= 1e-6 * float(x.double().abs().sum((0, 2, 3)).max())
+    odd = torch.randn(2, 5, 7, 9, device=dev)   # H * W not a multiple of 4: torch's reduction
+    assert torch.allclose(ops.channel_sum(odd), odd.sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
