@@ -267,7 +267,7 @@ __global__ void bn2d_bwd_final_kernel(const double* __restrict__ partial, int C,
     s1 += partial[((size_t)c * BN2D_SPLIT + s) * 2 + 1];
   }
   dbeta[c] = (float)s0;
-  dgamma[c] = (float)s1;
+  if (dgamma) dgamma[c] = (float)s1;  // null: only the plain channel sums are wanted (sessd_nchw_channel_sum)
 }
 
 // one thread = four consecutive pixels of one (image, channel) plane
