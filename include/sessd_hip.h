@@ -207,7 +207,10 @@ int sessd_sparse_renumber_sites(const int32_t* indices, const int32_t* n_dev, in
  * EXPERIMENTAL -- compiled, not yet validated on hardware, not wired into the module path.
  * replaces torch.nn.BatchNorm1d(eps=1e-3, momentum=0.01) + nn.ReLU after every sparse conv of det3d/models/backbones/scn.py:103-148
  * in train mode (both networks of the SE-SSD step): batch statistics over the rows < *n_dev, running statistics updated in
- * place (unbiased variance), deterministic reductions. channels must divide 256. */
+ * place (unbiased variance), deterministic reductions (two launches per pass: the statistics block that finishes last adds the
+ * partial sums in block order). channels: a power of two <= 256. Rows >= *n_dev of y / dx are written as zeros.
+ * WORKSPACE CONTRACT (both layouts): its leading counter words (256 bytes here; 4 bytes per channel rounded up to 256 for the
+ * dense layout and sessd_nchw_channel_sum) must be ZERO on entry -- clear a new workspace once -- and are zero again on return. */
 size_t sessd_bn_relu_train_workspace_bytes(int channels);
 int sessd_bn_relu_train_fwd(const float* x, const int32_t* n_dev, int n_cap, int channels, const float* gamma, const float* beta,
                             float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,

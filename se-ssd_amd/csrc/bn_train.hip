@@ -1,178 +1,280 @@
 // Train-mode BatchNorm1d + ReLU over a sparse level's feature table (N rows x C channels), forward and backward
 // (DESIGN.md section 9 item 2). In the SE-SSD training step (det3d/torchie/trainer/trainer_sessd.py:250-275) both networks run
 // SpMiddleFHD in train mode (scn.py:103-148: BatchNorm1d(eps=1e-3, momentum=0.01) + ReLU after each of the 14 sparse convs), which
-// as torch modules costs ~5 launches forward and ~6 backward per layer on tables of 3 k - 60 k rows: launch-bound. Here:
-//   forward   stats (partial sums per row chunk, double)  ->  finalise (mean, 1/sqrt(var + eps), running statistics)
-//             ->  y = max(0, (x - mean) * invstd * gamma + beta)
-//   backward  dz = dy * [y > 0];  partial sums of dz and dz * xhat  ->  dgamma, dbeta  ->
+// as torch modules costs ~5 launches forward and ~6 backward per layer on tables of 3 k - 60 k rows: launch-bound. Here each
+// pass is TWO launches:
+//   forward   statistics: per-block partial sums (float64) over a row chunk; the block that finishes LAST adds the partials in
+//             block order and writes mean, 1/sqrt(var + eps) and the running statistics  ->  y = max(0, xhat * gamma + beta)
+//   backward  dz = dy * [y > 0];  the same two-level sum of dz and dz * xhat -> dgamma, dbeta  ->
 //             dx = gamma * invstd * (dz - dbeta / N - xhat * dgamma / N)
-// The row count N stays on the device. Reductions are deterministic: a fixed grid of row chunks, partials summed in order.
-// HBM-bound elementwise work (3 passes over x forward, 3 backward).
-//
+// "Last block" = the one whose increment of a counter word brings it to the grid size (partials stored, __threadfence, one
+// atomic per block; the finisher fences again before it reads): no workgroup waits for another, and the order of the sum is
+// fixed, so the result does not depend on which block arrives last. The counter lives in the first 256 bytes of the workspace:
+// ZERO on entry (the caller clears a new workspace once), left zero by every call. The row count N stays on the device; rows
+// >= N of y / dx are written as zeros (the capacity form of the tables, spconv/__init__.py). HBM-bound: 2 passes over x forward,
+// 2 over (x, dy, y) backward, 16-byte accesses.
 //
 // Second half of the file: the same for the dense BEV layout (B, C, H, W) of the SSFA neck in train mode
 // (det3d/models/necks/rpn_v1.py:131-210: BatchNorm2d(eps=1e-3, momentum=0.01) + ReLU after each of its 13 convolutions) --
-// one block per (channel, plane slice), 16-byte accesses along the plane, the same three passes.
+// one block per (channel, plane slice), 16-byte accesses along the plane; the last slice of a CHANNEL to finish finalises that
+// channel (one counter word per channel).
 // tests/test_bn_train_gpu.py compares both with torch.nn.BatchNorm1d / BatchNorm2d + ReLU (forward, running statistics, gradients).
 #include "common.hpp"
 
 namespace {
 
-constexpr int BN_BLOCKS = 128;
+constexpr int BN_BLOCKS = 256;        // one per CU
 constexpr int NT = 256;
+constexpr size_t BN_COUNTER_BYTES = 256;
 
-// two per-channel sums over the rows of this block's chunk; thread = (row lane, channel); C in {4, 8, 16, 32, 64, 128}
-template <bool BWD>
-__global__ __launch_bounds__(NT) void bn_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                         const float* __restrict__ y, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, const int* __restrict__ n_dev,
-                                                         int n_cap, int C, int relu, double* __restrict__ partial) {
-  __shared__ double sm[2][NT];
+struct BnFinal {                      // what the finishing block writes
+  float eps, momentum;
+  float* running_mean;                // forward (both or neither)
+  float* running_var;
+  float* save_mean;
+  float* save_invstd;
+  float* dgamma;                      // backward
+  float* dbeta;
+};
+
+// Two per-channel sums over the rows of this block's chunk; thread = (row lane, group of VEC channels); C a power of two <= 256,
+// VEC = 4 when C % 4 == 0 (one 16-byte load per row and thread), else 1.
+template <bool BWD, int VEC>
+__global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ y, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, const int* __restrict__ n_dev, int n_cap,
+                                                       int C, int relu, double* partial, unsigned* counter, BnFinal F) {
+  __shared__ double sm[2 * VEC][NT];
+  __shared__ int s_last;
+  const int tid = threadIdx.x;
   const int n = min(n_dev[0], n_cap);
-  const int lanes = NT / C;                 // row lanes per block
-  const int c = threadIdx.x % C, rl = threadIdx.x / C;
-  const int chunk = sessd_divup(n, BN_BLOCKS);
+  const int Q = C / VEC;                    // channel groups per row
+  const int lanes = NT / Q;                 // rows per block and step
+  const int q = tid % Q, rl = tid / Q;
+  const int chunk = sessd_divup(n, (int)gridDim.x);
   const int r0 = blockIdx.x * chunk, r1 = min(n, r0 + chunk);
-  double s0 = 0.0, s1 = 0.0;
-  float mu = 0.f, is = 0.f;
-  if (BWD) { mu = mean[c]; is = invstd[c]; }
+  double s0[VEC], s1[VEC];
+  float mu[VEC], is[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    s0[v] = 0.0; s1[v] = 0.0;
+    mu[v] = BWD ? mean[q * VEC + v] : 0.f;
+    is[v] = BWD ? invstd[q * VEC + v] : 0.f;
+  }
+#pragma unroll 4
   for (int r = r0 + rl; r < r1; r += lanes) {
-    const size_t o = (size_t)r * C + c;
-    if (!BWD) {
-      const double v = x[o];
-      s0 += v;
-      s1 += v * v;
+    const size_t o = (size_t)r * C + q * VEC;
+    float xv[VEC], dz[VEC], yv[VEC];
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + o);
+      if (BWD) {
+        *reinterpret_cast<float4*>(dz) = *reinterpret_cast<const float4*>(dy + o);
+        if (relu) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y + o);
+      }
     } else {
-      float dz = dy[o];
-      if (relu && !(y[o] > 0.f)) dz = 0.f;
-      s0 += (double)dz;
-      s1 += (double)dz * (double)((x[o] - mu) * is);
+      xv[0] = x[o];
+      if (BWD) { dz[0] = dy[o]; if (relu) yv[0] = y[o]; }
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      if (!BWD) {
+        const double d = xv[v];
+        s0[v] += d;
+        s1[v] += d * d;
+      } else {
+        float g = dz[v];
+        if (relu && !(yv[v] > 0.f)) g = 0.f;
+        s0[v] += (double)g;
+        s1[v] += (double)g * (double)((xv[v] - mu[v]) * is[v]);
+      }
     }
   }
-  sm[0][threadIdx.x] = s0;
-  sm[1][threadIdx.x] = s1;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) { sm[v][tid] = s0[v]; sm[VEC + v][tid] = s1[v]; }
   __syncthreads();
-  if (rl == 0) {
-    for (int l = 1; l < lanes; ++l) {
-      s0 += sm[0][l * C + c];
-      s1 += sm[1][l * C + c];
+  for (int s = NT / 2; s >= Q; s >>= 1) {   // tid + s has the same channel group (Q, s powers of two, s >= Q)
+    if (tid < s) {
+#pragma unroll
+      for (int k = 0; k < 2 * VEC; ++k) sm[k][tid] += sm[k][tid + s];
     }
-    partial[((size_t)blockIdx.x * 2 + 0) * C + c] = s0;
-    partial[((size_t)blockIdx.x * 2 + 1) * C + c] = s1;
+    __syncthreads();
+  }
+  if (tid < Q) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      partial[((size_t)blockIdx.x * 2 + 0) * C + tid * VEC + v] = sm[v][tid];
+      partial[((size_t)blockIdx.x * 2 + 1) * C + tid * VEC + v] = sm[VEC + v][tid];
+    }
+  }
+  // ---- the last block to arrive adds the partials of all blocks, in block order
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_last = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  const int G = NT / C, c = tid % C, g = tid / C;   // G groups of blocks per channel
+  double t0 = 0.0, t1 = 0.0;
+  const int nb = (int)gridDim.x;
+  for (int b = g; b < nb; b += 8 * G) {
+    double a0[8], a1[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int bb = b + k * G;
+      const bool ok = bb < nb;
+      a0[k] = ok ? partial[((size_t)bb * 2 + 0) * C + c] : 0.0;
+      a1[k] = ok ? partial[((size_t)bb * 2 + 1) * C + c] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { t0 += a0[k]; t1 += a1[k]; }
+  }
+  sm[0][tid] = t0;
+  sm[1][tid] = t1;
+  __syncthreads();
+  for (int s = NT / 2; s >= C; s >>= 1) {
+    if (tid < s) { sm[0][tid] += sm[0][tid + s]; sm[1][tid] += sm[1][tid + s]; }
+    __syncthreads();
+  }
+  if (tid == 0) *counter = 0u;
+  if (tid >= C) return;
+  t0 = sm[0][tid];
+  t1 = sm[1][tid];
+  if (!BWD) {
+    const double m = n > 0 ? t0 / n : 0.0;
+    double var = n > 0 ? t1 / n - m * m : 0.0;
+    if (var < 0.0) var = 0.0;
+    F.save_mean[c] = (float)m;
+    F.save_invstd[c] = (float)(1.0 / sqrt(var + (double)F.eps));
+    if (F.running_mean && n > 0) {   // torch: running = (1 - momentum) * running + momentum * batch, variance unbiased
+      const double unbiased = n > 1 ? var * n / (n - 1) : var;
+      F.running_mean[c] = (float)((1.0 - F.momentum) * F.running_mean[c] + F.momentum * m);
+      F.running_var[c] = (float)((1.0 - F.momentum) * F.running_var[c] + F.momentum * unbiased);
+    }
+  } else {
+    F.dbeta[c] = (float)t0;
+    F.dgamma[c] = (float)t1;
   }
 }
 
-__global__ void bn_fwd_final_kernel(const double* __restrict__ partial, const int* __restrict__ n_dev, int n_cap, int C, float eps,
-                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                    float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// thread = VEC consecutive channels of one row; rows >= *n_dev (up to n_cap) are written as zeros
+template <bool BWD, int VEC>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ y_in, const int* __restrict__ n_dev, int n_cap,
+                                                       int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                       const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu,
+                                                       float* __restrict__ out) {
+  const size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * VEC;
+  if (i >= (size_t)n_cap * C) return;
   const int n = min(n_dev[0], n_cap);
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < BN_BLOCKS; ++b) {
-    s0 += partial[((size_t)b * 2 + 0) * C + c];
-    s1 += partial[((size_t)b * 2 + 1) * C + c];
+  const int c0 = (int)(i & (size_t)(C - 1));   // C is a power of two
+  float r[VEC];
+  if (i >= (size_t)n * C) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) r[v] = 0.f;
+  } else {
+    float xv[VEC], dz[VEC], yv[VEC];
+    if (VEC == 4) {
+      *reinterpret_cast<float4*>(xv) = *reinterpret_cast<const float4*>(x + i);
+      if (BWD) {
+        *reinterpret_cast<float4*>(dz) = *reinterpret_cast<const float4*>(dy + i);
+        if (relu) *reinterpret_cast<float4*>(yv) = *reinterpret_cast<const float4*>(y_in + i);
+      }
+    } else {
+      xv[0] = x[i];
+      if (BWD) { dz[0] = dy[i]; if (relu) yv[0] = y_in[i]; }
+    }
+    const float inv_n = 1.f / (float)n;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const int c = c0 + v;
+      const float g = gamma ? gamma[c] : 1.f;
+      if (!BWD) {
+        float t = (xv[v] - mean[c]) * invstd[c] * g + (beta ? beta[c] : 0.f);
+        if (relu) t = fmaxf(t, 0.f);
+        r[v] = t;
+      } else {
+        float d = dz[v];
+        if (relu && !(yv[v] > 0.f)) d = 0.f;
+        const float xhat = (xv[v] - mean[c]) * invstd[c];
+        r[v] = g * invstd[c] * (d - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n);
+      }
+    }
   }
-  const double mean = n > 0 ? s0 / n : 0.0;
-  double var = n > 0 ? s1 / n - mean * mean : 0.0;
-  if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean && n > 0) {   // torch: running = (1 - momentum) * running + momentum * batch, variance unbiased
-    const double unbiased = n > 1 ? var * n / (n - 1) : var;
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-  }
+  if (VEC == 4)
+    *reinterpret_cast<float4*>(out + i) = *reinterpret_cast<const float4*>(r);
+  else
+    out[i] = r[0];
 }
 
-__global__ __launch_bounds__(NT) void bn_fwd_apply_kernel(const float* __restrict__ x, const int* __restrict__ n_dev, int n_cap,
-                                                           int C, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                           int relu, float* __restrict__ y) {
-  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-  const size_t total = (size_t)min(n_dev[0], n_cap) * C;
-  if (i >= total) return;
-  const int c = (int)(i % C);
-  float v = (x[i] - mean[c]) * invstd[c] * (gamma ? gamma[c] : 1.f) + (beta ? beta[c] : 0.f);
-  if (relu) v = fmaxf(v, 0.f);
-  y[i] = v;
-}
-
-__global__ void bn_bwd_final_kernel(const double* __restrict__ partial, int C, float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int b = 0; b < BN_BLOCKS; ++b) {
-    s0 += partial[((size_t)b * 2 + 0) * C + c];
-    s1 += partial[((size_t)b * 2 + 1) * C + c];
-  }
-  dbeta[c] = (float)s0;
-  if (dgamma) dgamma[c] = (float)s1;
-}
-
-__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           const float* __restrict__ y, const int* __restrict__ n_dev, int n_cap,
-                                                           int C, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, const float* __restrict__ dgamma,
-                                                           const float* __restrict__ dbeta, int relu, float* __restrict__ dx) {
-  const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
-  const int n = min(n_dev[0], n_cap);
-  if (i >= (size_t)n * C) return;
-  const int c = (int)(i % C);
-  float dz = dy[i];
-  if (relu && !(y[i] > 0.f)) dz = 0.f;
-  const float xhat = (x[i] - mean[c]) * invstd[c];
-  const float inv_n = 1.f / (float)n;
-  dx[i] = (gamma ? gamma[c] : 1.f) * invstd[c] * (dz - dbeta[c] * inv_n - xhat * dgamma[c] * inv_n);
-}
-
-bool channels_ok(int C) { return C >= 1 && C <= NT && NT % C == 0; }
+bool channels_ok(int C) { return C >= 1 && C <= NT && (C & (C - 1)) == 0; }
 
 }  // namespace
 
 extern "C" {
 
-size_t sessd_bn_relu_train_workspace_bytes(int channels) { return (size_t)BN_BLOCKS * 2 * channels * sizeof(double); }
+// first BN_COUNTER_BYTES: the arrival counter (zero on entry, zero on return), then the per-block partial sums
+size_t sessd_bn_relu_train_workspace_bytes(int channels) {
+  return BN_COUNTER_BYTES + (size_t)BN_BLOCKS * 2 * channels * sizeof(double);
+}
 
 // y = relu?( (x - mean) * invstd * gamma + beta ) with the batch statistics of rows < *n_dev of x (n_cap, channels);
 // save_mean / save_invstd (channels) for the backward; running_mean / running_var updated in place when not NULL
-// (momentum, unbiased variance: torch.nn.BatchNorm1d semantics). channels must divide 256.
+// (momentum, unbiased variance: torch.nn.BatchNorm1d semantics). channels: a power of two <= 256. The workspace's first 256
+// bytes must be zero on entry (they are zero again on return).
 int sessd_bn_relu_train_fwd(const float* x, const int* n_dev, int n_cap, int channels, const float* gamma, const float* beta,
                             float eps, float momentum, int relu, float* running_mean, float* running_var, float* y,
                             float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (n_cap <= 0 || !channels_ok(channels)) return SESSD_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
-  double* partial = (double*)workspace;
-  SESSD_LAUNCH((bn_partial_kernel<false>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, (const float*)nullptr, (const float*)nullptr,
-               (const float*)nullptr, (const float*)nullptr, n_dev, n_cap, channels, 0, partial);
-  SESSD_CHECK_LAUNCH();
-  SESSD_LAUNCH(bn_fwd_final_kernel, dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, partial, n_dev, n_cap, channels, eps,
-               momentum, running_mean, running_var, save_mean, save_invstd);
-  SESSD_CHECK_LAUNCH();
+  unsigned* counter = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + BN_COUNTER_BYTES);
+  BnFinal F{eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
   const size_t total = (size_t)n_cap * channels;
-  SESSD_LAUNCH(bn_fwd_apply_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, x, n_dev, n_cap, channels, gamma,
-               beta, save_mean, save_invstd, relu, y);
+  const float* nf = nullptr;
+  if (channels % 4 == 0) {
+    SESSD_LAUNCH((bn_stats_kernel<false, 4>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, nf, nf, nf, nf, n_dev, n_cap, channels, 0,
+                 partial, counter, F);
+    SESSD_CHECK_LAUNCH();
+    SESSD_LAUNCH((bn_apply_kernel<false, 4>), dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, stream, x, nf, nf, n_dev,
+                 n_cap, channels, gamma, beta, (const float*)save_mean, (const float*)save_invstd, nf, nf, relu, y);
+  } else {
+    SESSD_LAUNCH((bn_stats_kernel<false, 1>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, nf, nf, nf, nf, n_dev, n_cap, channels, 0,
+                 partial, counter, F);
+    SESSD_CHECK_LAUNCH();
+    SESSD_LAUNCH((bn_apply_kernel<false, 1>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, x, nf, nf, n_dev, n_cap,
+                 channels, gamma, beta, (const float*)save_mean, (const float*)save_invstd, nf, nf, relu, y);
+  }
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
 
-// gradients of the above: dx (n_cap, channels; rows < *n_dev written), dgamma, dbeta (channels). y is the forward output
-// (the ReLU mask), x the forward input.
+// gradients of the above: dx (n_cap, channels; rows >= *n_dev zero), dgamma, dbeta (channels). y is the forward output
+// (the ReLU mask), x the forward input. Same workspace contract.
 int sessd_bn_relu_train_bwd(const float* dy, const float* x, const float* y, const int* n_dev, int n_cap, int channels,
                             const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
                             float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (n_cap <= 0 || !channels_ok(channels)) return SESSD_EINVAL;
+  if (n_cap <= 0 || !channels_ok(channels) || !dgamma || !dbeta) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
-  double* partial = (double*)workspace;
-  SESSD_LAUNCH((bn_partial_kernel<true>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, n_dev, n_cap,
-               channels, relu, partial);
-  SESSD_CHECK_LAUNCH();
-  SESSD_LAUNCH(bn_bwd_final_kernel, dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, partial, channels, dgamma, dbeta);
-  SESSD_CHECK_LAUNCH();
+  unsigned* counter = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + BN_COUNTER_BYTES);
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
   const size_t total = (size_t)n_cap * channels;
-  SESSD_LAUNCH(bn_bwd_apply_kernel, dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, dy, x, y, n_dev, n_cap, channels,
-               gamma, save_mean, save_invstd, dgamma, dbeta, relu, dx);
+  const float* nf = nullptr;
+  if (channels % 4 == 0) {
+    SESSD_LAUNCH((bn_stats_kernel<true, 4>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, n_dev, n_cap,
+                 channels, relu, partial, counter, F);
+    SESSD_CHECK_LAUNCH();
+    SESSD_LAUNCH((bn_apply_kernel<true, 4>), dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, n_dev,
+                 n_cap, channels, gamma, nf, save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, relu, dx);
+  } else {
+    SESSD_LAUNCH((bn_stats_kernel<true, 1>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, n_dev, n_cap,
+                 channels, relu, partial, counter, F);
+    SESSD_CHECK_LAUNCH();
+    SESSD_LAUNCH((bn_apply_kernel<true, 1>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, n_dev, n_cap,
+                 channels, gamma, nf, save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, relu, dx);
+  }
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -184,12 +286,18 @@ namespace {
 
 constexpr int BN2D_SPLIT = 16;   // plane slices per channel: C x 16 blocks of partial sums
 
-// block (c, s): the two sums over the pixels [s * chunk, (s + 1) * chunk) of channel c in every image; plane % 4 == 0
-template <bool BWD>
-__global__ __launch_bounds__(NT) void bn2d_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                           const float* __restrict__ y, const float* __restrict__ mean,
-                                                           const float* __restrict__ invstd, int B, int C, int plane, int relu,
-                                                           double* __restrict__ partial) {
+__host__ __device__ inline size_t bn2d_counter_bytes(int channels) { return ((size_t)channels * 4 + 255) / 256 * 256; }
+
+// block (c, s): the two sums over the pixels [s * chunk, (s + 1) * chunk) of channel c in every image; plane % 4 == 0.
+// MODE 0: sums of x and x^2 -> mean / invstd / running statistics; 1: sums of dz and dz * xhat -> dbeta / dgamma;
+// 2: sum of x -> dbeta (a conv's bias gradient). The slice of a channel that finishes last adds the channel's 16 partials in
+// slice order and writes the result (counter word per channel, zero on entry and on return).
+template <int MODE>
+__global__ __launch_bounds__(NT) void bn2d_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                         const float* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, int B, int C, int plane, int relu,
+                                                         double* partial, unsigned* counters, BnFinal F) {
+  constexpr bool BWD = MODE == 1;
   __shared__ double sm[2][NT / 64];
   const int c = blockIdx.x, s = blockIdx.y;
   const int quads = plane >> 2;
@@ -204,7 +312,7 @@ __global__ __launch_bounds__(NT) void bn2d_partial_kernel(const float* __restric
       const float4 xv = *reinterpret_cast<const float4*>(x + base + 4 * (size_t)q);
       if (!BWD) {
         s0 += (double)xv.x + (double)xv.y + (double)xv.z + (double)xv.w;
-        s1 += (double)xv.x * xv.x + (double)xv.y * xv.y + (double)xv.z * xv.z + (double)xv.w * xv.w;
+        if (MODE == 0) s1 += (double)xv.x * xv.x + (double)xv.y * xv.y + (double)xv.z * xv.z + (double)xv.w * xv.w;
       } else {
         float4 dz = *reinterpret_cast<const float4*>(dy + base + 4 * (size_t)q);
         if (relu) {
@@ -227,47 +335,38 @@ __global__ __launch_bounds__(NT) void bn2d_partial_kernel(const float* __restric
   }
   if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = s0; sm[1][threadIdx.x >> 6] = s1; }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    double t0 = 0.0, t1 = 0.0;
-    for (int w = 0; w < NT / 64; ++w) { t0 += sm[0][w]; t1 += sm[1][w]; }
-    partial[((size_t)c * BN2D_SPLIT + s) * 2 + 0] = t0;
-    partial[((size_t)c * BN2D_SPLIT + s) * 2 + 1] = t1;
+  if (threadIdx.x != 0) return;
+  double t0 = 0.0, t1 = 0.0;
+  for (int w = 0; w < NT / 64; ++w) { t0 += sm[0][w]; t1 += sm[1][w]; }
+  double* pc = partial + (size_t)c * BN2D_SPLIT * 2;
+  pc[s * 2 + 0] = t0;
+  pc[s * 2 + 1] = t1;
+  __threadfence();
+  if (atomicAdd(counters + c, 1u) != BN2D_SPLIT - 1) return;
+  __threadfence();
+  double a0[BN2D_SPLIT], a1[BN2D_SPLIT];
+#pragma unroll
+  for (int k = 0; k < BN2D_SPLIT; ++k) { a0[k] = pc[k * 2 + 0]; a1[k] = pc[k * 2 + 1]; }
+  t0 = 0.0; t1 = 0.0;
+#pragma unroll
+  for (int k = 0; k < BN2D_SPLIT; ++k) { t0 += a0[k]; t1 += a1[k]; }
+  counters[c] = 0u;
+  if (MODE == 0) {
+    const double n = (double)B * (double)plane;
+    const double m = t0 / n;
+    double var = t1 / n - m * m;
+    if (var < 0.0) var = 0.0;
+    F.save_mean[c] = (float)m;
+    F.save_invstd[c] = (float)(1.0 / sqrt(var + (double)F.eps));
+    if (F.running_mean) {
+      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+      F.running_mean[c] = (float)((1.0 - F.momentum) * F.running_mean[c] + F.momentum * m);
+      F.running_var[c] = (float)((1.0 - F.momentum) * F.running_var[c] + F.momentum * unbiased);
+    }
+  } else {
+    F.dbeta[c] = (float)t0;
+    if (MODE == 1) F.dgamma[c] = (float)t1;
   }
-}
-
-__global__ void bn2d_fwd_final_kernel(const double* __restrict__ partial, long long n, int C, float eps, float momentum,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var,
-                                      float* __restrict__ save_mean, float* __restrict__ save_invstd) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int s = 0; s < BN2D_SPLIT; ++s) {
-    s0 += partial[((size_t)c * BN2D_SPLIT + s) * 2 + 0];
-    s1 += partial[((size_t)c * BN2D_SPLIT + s) * 2 + 1];
-  }
-  const double mean = s0 / (double)n;
-  double var = s1 / (double)n - mean * mean;
-  if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) {
-    const double unbiased = n > 1 ? var * (double)n / (double)(n - 1) : var;
-    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-  }
-}
-
-__global__ void bn2d_bwd_final_kernel(const double* __restrict__ partial, int C, float* __restrict__ dgamma,
-                                      float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int s = 0; s < BN2D_SPLIT; ++s) {
-    s0 += partial[((size_t)c * BN2D_SPLIT + s) * 2 + 0];
-    s1 += partial[((size_t)c * BN2D_SPLIT + s) * 2 + 1];
-  }
-  dbeta[c] = (float)s0;
-  if (dgamma) dgamma[c] = (float)s1;  // null: only the plain channel sums are wanted (sessd_nchw_channel_sum)
 }
 
 // one thread = four consecutive pixels of one (image, channel) plane
@@ -308,7 +407,10 @@ __global__ __launch_bounds__(NT) void bn2d_apply_kernel(const float* __restrict_
 
 extern "C" {
 
-size_t sessd_bn2d_relu_train_workspace_bytes(int channels) { return (size_t)channels * BN2D_SPLIT * 2 * sizeof(double); }
+// first: one arrival counter per channel (zero on entry, zero on return; rounded up to 256 bytes), then the slice partials
+size_t sessd_bn2d_relu_train_workspace_bytes(int channels) {
+  return bn2d_counter_bytes(channels) + (size_t)channels * BN2D_SPLIT * 2 * sizeof(double);
+}
 
 // out[c] = sum over images and pixels of x[b][c][.] (the bias gradient of a conv: det3d's heads): the statistics pass of the
 // train-mode BatchNorm above with only its first sum kept -- deterministic, no atomics, no memset (a torch reduction of this
@@ -317,11 +419,12 @@ int sessd_nchw_channel_sum(const float* x, int batch, int channels, int plane, f
                            hipStream_t stream) {
   if (batch < 1 || channels < 1 || plane < 4 || (plane & 3)) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
-  double* partial = (double*)workspace;
-  SESSD_LAUNCH((bn2d_partial_kernel<false>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, (const float*)nullptr,
-               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, batch, channels, plane, 0, partial);
-  SESSD_CHECK_LAUNCH();
-  SESSD_LAUNCH(bn2d_bwd_final_kernel, dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, partial, channels, (float*)nullptr, out);
+  unsigned* counters = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + bn2d_counter_bytes(channels));
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, out};
+  const float* nf = nullptr;
+  SESSD_LAUNCH((bn2d_stats_kernel<2>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, batch, channels, plane, 0,
+               partial, counters, F);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -334,12 +437,12 @@ int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane
   if (batch <= 0 || channels <= 0 || plane <= 0 || (plane & 3)) return SESSD_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
-  double* partial = (double*)workspace;
-  SESSD_LAUNCH((bn2d_partial_kernel<false>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, (const float*)nullptr,
-               (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, batch, channels, plane, 0, partial);
-  SESSD_CHECK_LAUNCH();
-  SESSD_LAUNCH(bn2d_fwd_final_kernel, dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, partial, (long long)batch * plane,
-               channels, eps, momentum, running_mean, running_var, save_mean, save_invstd);
+  unsigned* counters = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + bn2d_counter_bytes(channels));
+  BnFinal F{eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
+  const float* nf = nullptr;
+  SESSD_LAUNCH((bn2d_stats_kernel<0>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, batch, channels, plane, 0,
+               partial, counters, F);
   SESSD_CHECK_LAUNCH();
   const size_t quads = (size_t)batch * channels * (plane >> 2);
   SESSD_LAUNCH((bn2d_apply_kernel<false>), dim3((unsigned)((quads + NT - 1) / NT)), dim3(NT), 0, stream, x, (const float*)nullptr,
@@ -355,11 +458,12 @@ int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, i
                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (batch <= 0 || channels <= 0 || plane <= 0 || (plane & 3)) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
-  double* partial = (double*)workspace;
-  SESSD_LAUNCH((bn2d_partial_kernel<true>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, batch,
-               channels, plane, relu, partial);
-  SESSD_CHECK_LAUNCH();
-  SESSD_LAUNCH(bn2d_bwd_final_kernel, dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, partial, channels, dgamma, dbeta);
+  if (!dgamma || !dbeta) return SESSD_EINVAL;
+  unsigned* counters = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + bn2d_counter_bytes(channels));
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
+  SESSD_LAUNCH((bn2d_stats_kernel<1>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, batch,
+               channels, plane, relu, partial, counters, F);
   SESSD_CHECK_LAUNCH();
   const size_t quads = (size_t)batch * channels * (plane >> 2);
   SESSD_LAUNCH((bn2d_apply_kernel<true>), dim3((unsigned)((quads + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, channels, plane,

@@ -61,6 +61,21 @@ def workspace(nbytes, device, tag="default"):
     return ws
 
 
+def zeroed_workspace(nbytes, device, tag):
+    """workspace() for the entry points whose contract is "counter words zero on entry, left zero on return" (the train-mode
+    BatchNorm statistics kernels): cleared ONCE when (re)allocated, by our own fill kernel (inside a capture that launch is part
+    of the graph; a torch memset would be a memset node, see sum_all)."""
+    key = (device.index, _cache_scope(), tag)
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        n = (max(int(nbytes), 256) + 15) // 16 * 16
+        ws = torch.empty(n, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device):
+            check(lib.sessd_fill_u32(ws.data_ptr(), 0, n // 4, _stream()), "fill_u32")
+        _ws_cache[key] = ws
+    return ws
+
+
 # ------------------------------------------------------------------ voxelizer
 class VoxelHash:
     """Open-addressing cell -> row hash shared by a batch of frames (and by SpMiddleFHD level 0)."""
@@ -511,9 +526,9 @@ class BnReluTrainFunction(torch.autograd.Function):
         _req(x, torch.float32, "x")
         cap, C = x.shape
         dev = x.device
-        y = torch.zeros_like(x)
+        y = torch.empty_like(x)   # the kernel writes rows >= *n_dev as zeros
         mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
-        ws = torch.empty(int(lib.sessd_bn_relu_train_workspace_bytes(C)), dtype=torch.uint8, device=dev)
+        ws = zeroed_workspace(lib.sessd_bn_relu_train_workspace_bytes(C), dev, "bn")
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         check(lib.sessd_bn_relu_train_fwd(x.data_ptr(), n_dev.data_ptr(), cap, C, g.data_ptr(), b.data_ptr(), float(eps),
                                           float(momentum), 1 if relu else 0, _p(running_mean), _p(running_var), y.data_ptr(),
@@ -527,23 +542,58 @@ class BnReluTrainFunction(torch.autograd.Function):
         x, y, g, mean, invstd, n_dev = ctx.saved_tensors
         dy = dy.float().contiguous()
         cap, C = x.shape
-        dx = torch.zeros_like(x)
+        dx = torch.empty_like(x)
         dg, db = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
-        ws = torch.empty(int(lib.sessd_bn_relu_train_workspace_bytes(C)), dtype=torch.uint8, device=x.device)
+        ws = zeroed_workspace(lib.sessd_bn_relu_train_workspace_bytes(C), x.device, "bn")
         check(lib.sessd_bn_relu_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), n_dev.data_ptr(), cap, C, g.data_ptr(),
                                           mean.data_ptr(), invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), dg.data_ptr(),
                                           db.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn_relu_train_bwd")
         return dx, None, dg, db, None, None, None, None, None
 
 
+_NBT_DEFER = [False]
+_NBT_PENDING = []
+
+
+class deferred_batch_counts:
+    """Inside this context the `num_batches_tracked += 1` of every fused train-mode BatchNorm call is collected and applied as ONE
+    multi-tensor launch on exit (56 one-element launches per SE-SSD iteration otherwise). Layers with momentum=None need the
+    count at once and are not deferred."""
+
+    def __enter__(self):
+        self.prev = _NBT_DEFER[0]
+        _NBT_DEFER[0] = True
+        return self
+
+    def __exit__(self, *exc):
+        _NBT_DEFER[0] = self.prev
+        if not self.prev and _NBT_PENDING:
+            pending = list(_NBT_PENDING)
+            _NBT_PENDING.clear()
+            torch._foreach_add_(pending, 1)
+        return False
+
+
+def _bn_momentum(bn):
+    """Counts the batch (torch.nn.modules.batchnorm._BatchNorm.forward) and returns the layer's update factor."""
+    nbt = bn.num_batches_tracked
+    if bn.momentum is not None:
+        if nbt is not None:
+            if _NBT_DEFER[0]:
+                _NBT_PENDING.append(nbt)
+            else:
+                nbt.add_(1)
+        return bn.momentum
+    if nbt is None:
+        return 0.0
+    nbt.add_(1)   # momentum=None: cumulative moving average, factor 1 / number of batches seen
+    return 1.0 / float(nbt.item())
+
+
 def bn_relu_train(x, n_dev, bn, relu=True):
     """x (cap, C) float32 on the device, rows < n_dev[0] valid; bn: a torch.nn.BatchNorm1d in train mode (its running statistics are
     updated in place, num_batches_tracked incremented)."""
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    mom = bn.momentum
-    if mom is None:  # BatchNorm(momentum=None): cumulative moving average, factor 1 / number of batches seen (torch semantics)
-        mom = 1.0 / float(bn.num_batches_tracked.item()) if bn.num_batches_tracked is not None else 0.0
+    mom = _bn_momentum(bn)
     return BnReluTrainFunction.apply(x, n_dev, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
 
 
@@ -558,7 +608,7 @@ class Bn2dReluTrainFunction(torch.autograd.Function):
         dev = x.device
         y = torch.empty_like(x)
         mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
-        ws = workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), dev, "bn2d")
+        ws = zeroed_workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), dev, "bn2d")
         g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
         check(lib.sessd_bn2d_relu_train_fwd(x.data_ptr(), B, C, H * W, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
                                             1 if relu else 0, _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(),
@@ -574,7 +624,7 @@ class Bn2dReluTrainFunction(torch.autograd.Function):
         B, C, H, W = x.shape
         dx = torch.empty_like(x)
         dg, db = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
-        ws = workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), x.device, "bn2d")
+        ws = zeroed_workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), x.device, "bn2d")
         check(lib.sessd_bn2d_relu_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), B, C, H * W, g.data_ptr(), mean.data_ptr(),
                                             invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                             ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_bwd")
@@ -588,11 +638,7 @@ def bn2d_relu_train(x, bn, relu=True):
     if (x.shape[2] * x.shape[3]) % 4 or bn.weight is None:
         y = bn(x)
         return torch.relu(y) if relu else y
-    if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    mom = bn.momentum
-    if mom is None:
-        mom = 1.0 / float(bn.num_batches_tracked.item()) if bn.num_batches_tracked is not None else 0.0
+    mom = _bn_momentum(bn)
     return Bn2dReluTrainFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
 
 
@@ -1154,7 +1200,7 @@ def channel_sum(x):
         return x.sum((0, 2, 3))
     xc = x.float().contiguous()
     out = torch.empty((C,), dtype=torch.float32, device=x.device)
-    ws = workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), x.device, "bn2d")
+    ws = zeroed_workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), x.device, "bn2d")
     check(lib.sessd_nchw_channel_sum(xc.data_ptr(), B, C, H * W, out.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "nchw_channel_sum")
     return out
 

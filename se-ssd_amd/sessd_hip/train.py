@@ -226,18 +226,19 @@ class TrainStep:
     def _iteration(self, example, consistency_weight, device_schedule):
         self.student.train()
         self.teacher.train()  # trainer_sessd.py:321-322: both nets in train mode
-        with torch.no_grad():
-            teacher_preds = self.teacher.forward_preds(example, raw="voxels_raw" in example)
-        if self.direct_grads:
-            self.flat_s.release_grads()
-        else:
-            self.flat_s.zero_grad()
-        if self.loss_fn is None:
-            losses = self.student(example, is_ema=[False, teacher_preds], return_loss=True)
-            loss = losses["loss"][0] + losses["consistency_loss"][0][0] * consistency_weight
-            self.last_losses = losses
-        else:
-            loss = self.loss_fn(example, self.student.forward_preds(example), teacher_preds, consistency_weight)
+        with ops.deferred_batch_counts():   # the 56 BatchNorm batch counters of the two networks: one launch at the end
+            with torch.no_grad():
+                teacher_preds = self.teacher.forward_preds(example, raw="voxels_raw" in example)
+            if self.direct_grads:
+                self.flat_s.release_grads()
+            else:
+                self.flat_s.zero_grad()
+            if self.loss_fn is None:
+                losses = self.student(example, is_ema=[False, teacher_preds], return_loss=True)
+                loss = losses["loss"][0] + losses["consistency_loss"][0][0] * consistency_weight
+                self.last_losses = losses
+            else:
+                loss = self.loss_fn(example, self.student.forward_preds(example), teacher_preds, consistency_weight)
         loss.backward()
         if self.direct_grads:
             self.flat_s.gather_grads()

@@ -11,7 +11,7 @@ from sessd_hip import ops
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("C", [4, 16, 32, 64, 128])
+@pytest.mark.parametrize("C", [2, 4, 16, 32, 64, 128, 256])
 @pytest.mark.parametrize("n,cap", [(15000, 16000), (1, 64), (2, 2), (3001, 3001)])
 @pytest.mark.parametrize("relu", [True, False])
 def test_matches_torch_batchnorm(dev, C, n, cap, relu):
@@ -51,6 +51,27 @@ def test_matches_torch_batchnorm(dev, C, n, cap, relu):
     mine2.weight.data.copy_(w); mine2.bias.data.copy_(b)
     y2 = ops.bn_relu_train(x.to(dev), n_dev, mine2, relu=relu)
     assert torch.equal(y2, ym.detach())
+
+
+def test_deferred_batch_counts(dev):
+    """ops.deferred_batch_counts: the layers' num_batches_tracked are incremented once each, together, when the context closes
+    (TrainStep wraps an iteration's forward passes in it); outputs are those of the immediate form."""
+    bns = [torch.nn.BatchNorm1d(16, eps=1e-3, momentum=0.01).to(dev).train() for _ in range(3)]
+    bn2 = torch.nn.BatchNorm2d(8, eps=1e-3, momentum=0.01).to(dev).train()
+    x = torch.randn(500, 16, device=dev)
+    n_dev = torch.tensor([500], dtype=torch.int32, device=dev)
+    with ops.deferred_batch_counts():
+        ys = [ops.bn_relu_train(x, n_dev, bn) for bn in bns]
+        ys.append(ops.bn_relu_train(x, n_dev, bns[0]))
+        ops.bn2d_relu_train(torch.randn(2, 8, 4, 4, device=dev), bn2)
+        assert all(int(bn.num_batches_tracked) == 0 for bn in bns + [bn2])
+    assert [int(bn.num_batches_tracked) for bn in bns + [bn2]] == [2, 1, 1, 1]
+    ref = torch.nn.BatchNorm1d(16, eps=1e-3, momentum=0.01).to(dev).train()
+    assert torch.allclose(ys[1], torch.relu(ref(x)), atol=2e-5)
+    cma = torch.nn.BatchNorm1d(16, eps=1e-3, momentum=None).to(dev).train()   # cumulative average: counted at once
+    with ops.deferred_batch_counts():
+        ops.bn_relu_train(x, n_dev, cma)
+        assert int(cma.num_batches_tracked) == 1
 
 
 def test_sparse_sequential_with_the_fused_pair(dev):
