@@ -7,9 +7,10 @@
 //             block order and writes mean, 1/sqrt(var + eps) and the running statistics  ->  y = max(0, xhat * gamma + beta)
 //   backward  dz = dy * [y > 0];  the same two-level sum of dz and dz * xhat -> dgamma, dbeta  ->
 //             dx = gamma * invstd * (dz - dbeta / N - xhat * dgamma / N)
-// "Last block" = the one whose increment of a counter word brings it to the grid size (partials stored, __threadfence, one
-// atomic per block; the finisher fences again before it reads): no workgroup waits for another, and the order of the sum is
-// fixed, so the result does not depend on which block arrives last. The counter lives in the first 256 bytes of the workspace:
+// "Last block" = the one whose increment of a counter word brings it to the grid size (partials stored through to the coherent
+// level and acknowledged, then one atomic per block): no workgroup waits for another, and the order of the sum is
+// fixed, so the result does not depend on which block arrives last. (The first version used the textbook __threadfence()
+// pair; on this chip that is a write-back + invalidate of the block's whole L2, paid by every block.) The counter lives in the first 256 bytes of the workspace:
 // ZERO on entry (the caller clears a new workspace once), left zero by every call. The row count N stays on the device; rows
 // >= N of y / dx are written as zeros (the capacity form of the tables, spconv/__init__.py). HBM-bound: 2 passes over x forward,
 // 2 over (x, dy, y) backward, 16-byte accesses.
@@ -36,6 +37,16 @@ struct BnFinal {                      // what the finishing block writes
   float* dgamma;                      // backward
   float* dbeta;
 };
+
+// Partial sums travel between workgroups (possibly on different XCDs, each with its own L2) as agent-scope relaxed atomic
+// stores / loads of the individual words: they go through to / come from the coherent level without the whole-L2 write-back
+// and invalidate that a __threadfence() pair costs every block (measured: the fence form made the iteration 10 % slower).
+// Order: a block's stores are acknowledged (vmcnt 0) before its thread 0 counts the block in.
+__device__ __forceinline__ void put_partial(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double get_partial(const double* p) {
+  return __hip_atomic_load(const_cast<double*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+#define SESSD_STORES_DONE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 
 // Two per-channel sums over the rows of this block's chunk; thread = (row lane, group of VEC channels); C a power of two <= 256,
 // VEC = 4 when C % 4 == 0 (one 16-byte load per row and thread), else 1.
@@ -102,17 +113,16 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   if (tid < Q) {
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      partial[((size_t)blockIdx.x * 2 + 0) * C + tid * VEC + v] = sm[v][tid];
-      partial[((size_t)blockIdx.x * 2 + 1) * C + tid * VEC + v] = sm[VEC + v][tid];
+      put_partial(partial + ((size_t)blockIdx.x * 2 + 0) * C + tid * VEC + v, sm[v][tid]);
+      put_partial(partial + ((size_t)blockIdx.x * 2 + 1) * C + tid * VEC + v, sm[VEC + v][tid]);
     }
   }
   // ---- the last block to arrive adds the partials of all blocks, in block order
-  __threadfence();
+  SESSD_STORES_DONE();
   __syncthreads();
-  if (tid == 0) s_last = (atomicAdd(counter, 1u) == gridDim.x - 1) ? 1 : 0;
+  if (tid == 0) s_last = (__hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
-  __threadfence();
   const int G = NT / C, c = tid % C, g = tid / C;   // G groups of blocks per channel
   double t0 = 0.0, t1 = 0.0;
   const int nb = (int)gridDim.x;
@@ -122,8 +132,8 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
     for (int k = 0; k < 8; ++k) {
       const int bb = b + k * G;
       const bool ok = bb < nb;
-      a0[k] = ok ? partial[((size_t)bb * 2 + 0) * C + c] : 0.0;
-      a1[k] = ok ? partial[((size_t)bb * 2 + 1) * C + c] : 0.0;
+      a0[k] = ok ? get_partial(partial + ((size_t)bb * 2 + 0) * C + c) : 0.0;
+      a1[k] = ok ? get_partial(partial + ((size_t)bb * 2 + 1) * C + c) : 0.0;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) { t0 += a0[k]; t1 += a1[k]; }
@@ -135,7 +145,7 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
     if (tid < s) { sm[0][tid] += sm[0][tid + s]; sm[1][tid] += sm[1][tid + s]; }
     __syncthreads();
   }
-  if (tid == 0) *counter = 0u;
+  if (tid == 0) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (tid >= C) return;
   t0 = sm[0][tid];
   t1 = sm[1][tid];
@@ -286,7 +296,9 @@ namespace {
 
 constexpr int BN2D_SPLIT = 16;   // plane slices per channel: C x 16 blocks of partial sums
 
-__host__ __device__ inline size_t bn2d_counter_bytes(int channels) { return ((size_t)channels * 4 + 255) / 256 * 256; }
+constexpr int BN2D_MAX_CHANNELS = 1024;
+// one counter word per channel in a region of FIXED size: one workspace serves calls with different channel counts
+constexpr size_t BN2D_COUNTER_BYTES = (size_t)BN2D_MAX_CHANNELS * 4;
 
 // block (c, s): the two sums over the pixels [s * chunk, (s + 1) * chunk) of channel c in every image; plane % 4 == 0.
 // MODE 0: sums of x and x^2 -> mean / invstd / running statistics; 1: sums of dz and dz * xhat -> dbeta / dgamma;
@@ -339,18 +351,17 @@ __global__ __launch_bounds__(NT) void bn2d_stats_kernel(const float* __restrict_
   double t0 = 0.0, t1 = 0.0;
   for (int w = 0; w < NT / 64; ++w) { t0 += sm[0][w]; t1 += sm[1][w]; }
   double* pc = partial + (size_t)c * BN2D_SPLIT * 2;
-  pc[s * 2 + 0] = t0;
-  pc[s * 2 + 1] = t1;
-  __threadfence();
-  if (atomicAdd(counters + c, 1u) != BN2D_SPLIT - 1) return;
-  __threadfence();
+  put_partial(pc + s * 2 + 0, t0);
+  put_partial(pc + s * 2 + 1, t1);
+  SESSD_STORES_DONE();
+  if (__hip_atomic_fetch_add(counters + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != BN2D_SPLIT - 1) return;
   double a0[BN2D_SPLIT], a1[BN2D_SPLIT];
 #pragma unroll
-  for (int k = 0; k < BN2D_SPLIT; ++k) { a0[k] = pc[k * 2 + 0]; a1[k] = pc[k * 2 + 1]; }
+  for (int k = 0; k < BN2D_SPLIT; ++k) { a0[k] = get_partial(pc + k * 2 + 0); a1[k] = get_partial(pc + k * 2 + 1); }
   t0 = 0.0; t1 = 0.0;
 #pragma unroll
   for (int k = 0; k < BN2D_SPLIT; ++k) { t0 += a0[k]; t1 += a1[k]; }
-  counters[c] = 0u;
+  __hip_atomic_store(counters + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (MODE == 0) {
     const double n = (double)B * (double)plane;
     const double m = t0 / n;
@@ -407,9 +418,10 @@ __global__ __launch_bounds__(NT) void bn2d_apply_kernel(const float* __restrict_
 
 extern "C" {
 
-// first: one arrival counter per channel (zero on entry, zero on return; rounded up to 256 bytes), then the slice partials
+// first: one arrival counter per channel (4 KB whatever the channel count; zero on entry, zero on return), then the slice
+// partials. channels <= 1024.
 size_t sessd_bn2d_relu_train_workspace_bytes(int channels) {
-  return bn2d_counter_bytes(channels) + (size_t)channels * BN2D_SPLIT * 2 * sizeof(double);
+  return BN2D_COUNTER_BYTES + (size_t)channels * BN2D_SPLIT * 2 * sizeof(double);
 }
 
 // out[c] = sum over images and pixels of x[b][c][.] (the bias gradient of a conv: det3d's heads): the statistics pass of the
@@ -417,10 +429,10 @@ size_t sessd_bn2d_relu_train_workspace_bytes(int channels) {
 // size clears a semaphore buffer with a memset, which a replayed hipGraph does not execute correctly on this stack).
 int sessd_nchw_channel_sum(const float* x, int batch, int channels, int plane, float* out, void* workspace, size_t workspace_bytes,
                            hipStream_t stream) {
-  if (batch < 1 || channels < 1 || plane < 4 || (plane & 3)) return SESSD_EINVAL;
+  if (batch < 1 || channels < 1 || channels > BN2D_MAX_CHANNELS || plane < 4 || (plane & 3)) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
   unsigned* counters = (unsigned*)workspace;
-  double* partial = (double*)((char*)workspace + bn2d_counter_bytes(channels));
+  double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
   BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, out};
   const float* nf = nullptr;
   SESSD_LAUNCH((bn2d_stats_kernel<2>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, batch, channels, plane, 0,
@@ -434,11 +446,11 @@ int sessd_nchw_channel_sum(const float* x, int batch, int channels, int plane, f
 int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane, const float* gamma, const float* beta, float eps,
                               float momentum, int relu, float* running_mean, float* running_var, float* y, float* save_mean,
                               float* save_invstd, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (batch <= 0 || channels <= 0 || plane <= 0 || (plane & 3)) return SESSD_EINVAL;
+  if (batch <= 0 || channels <= 0 || channels > BN2D_MAX_CHANNELS || plane <= 0 || (plane & 3)) return SESSD_EINVAL;
   if ((running_mean == nullptr) != (running_var == nullptr)) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
   unsigned* counters = (unsigned*)workspace;
-  double* partial = (double*)((char*)workspace + bn2d_counter_bytes(channels));
+  double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
   BnFinal F{eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
   const float* nf = nullptr;
   SESSD_LAUNCH((bn2d_stats_kernel<0>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, batch, channels, plane, 0,
@@ -456,11 +468,11 @@ int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane
 int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
                               const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-  if (batch <= 0 || channels <= 0 || plane <= 0 || (plane & 3)) return SESSD_EINVAL;
+  if (batch <= 0 || channels <= 0 || channels > BN2D_MAX_CHANNELS || plane <= 0 || (plane & 3)) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
   if (!dgamma || !dbeta) return SESSD_EINVAL;
   unsigned* counters = (unsigned*)workspace;
-  double* partial = (double*)((char*)workspace + bn2d_counter_bytes(channels));
+  double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
   BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
   SESSD_LAUNCH((bn2d_stats_kernel<1>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, batch,
                channels, plane, relu, partial, counters, F);
