@@ -424,6 +424,26 @@ int sessd_deconv2d_s2_mfma_pair(const float* in, int batch, int cin, int hin, in
 int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
                     float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,
                     float* out, sessd_stream_t stream);
+/* The same tail in TRAIN mode (both networks of the SE-SSD step, trainer_sessd.py:250-275): the two Conv2d(channels, 1, 1,
+ * bias=False) weight branches, their BatchNorm2d(1) with BATCH statistics (running statistics updated in place, unbiased
+ * variance, like torch), softmax and blend -- two launches forward, two backward, instead of ~30 torch / MIOpen launches.
+ * x0, x1, out, grad_out, dx0, dx1: (batch, channels, plane = H * W) float32, channels % 4 == 0 (<= 1024), plane % 4 == 0.
+ * w0, w1, dw0, dw1: (channels). gamma / beta / running_*: one float each (gamma, beta NULL = 1, 0; running_*: all four or none).
+ * Saved by the forward for the backward: smap (2, batch * plane) = the conv outputs, stats (4) = [mean0, invstd0, mean1, invstd1].
+ * dzmap (batch * plane): scratch of the backward. dgamma, dbeta (2) = gradients of [gamma0, gamma1], [beta0, beta1].
+ * Workspace contract as for sessd_bn_relu_train_*: its leading 4352 bytes (arrival counters) zero on entry, zero on return.
+ * Deterministic (fixed summation orders). */
+size_t sessd_ssfa_fuse_train_workspace_bytes(int batch, int channels, int plane);
+int sessd_ssfa_fuse_train_fwd(const float* x0, const float* x1, int batch, int channels, int plane, const float* w0,
+                              const float* w1, const float* gamma0, const float* beta0, const float* gamma1, const float* beta1,
+                              float eps, float momentum, float* running_mean0, float* running_var0, float* running_mean1,
+                              float* running_var1, float* out, float* smap, float* stats, void* workspace,
+                              size_t workspace_bytes, sessd_stream_t stream);
+int sessd_ssfa_fuse_train_bwd(const float* grad_out, const float* x0, const float* x1, int batch, int channels, int plane,
+                              const float* w0, const float* w1, const float* gamma0, const float* beta0, const float* gamma1,
+                              const float* beta1, const float* smap, const float* stats, float* dzmap, float* dx0, float* dx1,
+                              float* dw0, float* dw1, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                              sessd_stream_t stream);
 /* The same tail fused with the four 1x1 heads (mg_head_sessd.py:217-230): head_w (nout, channels) row-major = the concatenated
  * conv_box | conv_cls | conv_dir | conv_iou weights, head_b (nout) or NULL, head_out (B, nout, num_pixels) planar; the blended
  * value of every channel goes into the head sums while it is in a register, `out` (the SSFA output) is written only when not

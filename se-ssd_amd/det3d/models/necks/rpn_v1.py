@@ -103,7 +103,8 @@ class SSFA(nn.Module):
     def _forward_train(self, x):
         """Train mode (batch-statistics BatchNorm, autograd), composed as rpn_v1.py:220-235. The twelve conv layers that
         carry the FLOPs run forward AND backward on the HIP kernels (ops.Conv2dFunction), and so do the BatchNorm2d + ReLU that
-        follow them (ops.bn2d_relu_train); the two 128->1 weight branches and the softmax fusion are torch ops."""
+        follow them (ops.bn2d_relu_train); the two 128->1 weight branches with their BatchNorm2d(1), the softmax and the blend are
+        one fused pair of launches each way (ops.ssfa_fuse_train; the torch composition when a layer is not what it covers)."""
         def block(seq, inp):
             mods = [m for m in seq._modules.values() if not isinstance(m, nn.ZeroPad2d)]  # ZeroPad2d(1) + unpadded 3x3 == the
             i = 0                                                                          # padding-1 conv the kernels implement
@@ -136,6 +137,9 @@ class SSFA(nn.Module):
                 return ops.bn2d_relu_train(y, bn, False)
             return bn(y)
 
+        if self.fused_bn_train and ops.ssfa_fuse_train_covers(x_output_0, self.w_0[0], self.w_0[1], self.w_1[0], self.w_1[1]):
+            # both weight branches, their BatchNorm2d(1), the softmax and the blend: two launches forward, two backward
+            return ops.ssfa_fuse_train(x_output_0, x_output_1, self.w_0[0], self.w_0[1], self.w_1[0], self.w_1[1])
         w = torch.softmax(torch.cat([wbranch(self.w_0, x_output_0), wbranch(self.w_1, x_output_1)], dim=1), dim=1)
         return x_output_0 * w[:, 0:1] + x_output_1 * w[:, 1:]
 

@@ -1302,6 +1302,76 @@ def ssfa_fuse(x0, x1, w0, w1, s0, t0, s1, t1, out=None):
     return out
 
 
+class SsfaFuseTrainFunction(torch.autograd.Function):
+    """The SSFA attention tail in train mode on csrc/ssfa_train.hip: (x0, x1) -> x0 * a0 + x1 * a1 with
+    a = softmax(BN_0(conv1x1_0(x0)), BN_1(conv1x1_1(x1))), batch-statistics BatchNorm2d(1); running statistics updated in place."""
+
+    @staticmethod
+    def forward(ctx, x0, x1, w0, w1, g0, b0, g1, b1, rm0, rv0, rm1, rv1, eps, momentum):
+        x0, x1 = x0.float().contiguous(), x1.float().contiguous()
+        _req(x0, torch.float32, "x0")
+        B, C, H, W = x0.shape
+        dev = x0.device
+        w0f, w1f = w0.detach().float().reshape(-1).contiguous(), w1.detach().float().reshape(-1).contiguous()
+        gb = [t.detach().float().contiguous() for t in (g0, b0, g1, b1)]
+        out = torch.empty_like(x0)
+        smap = torch.empty((2, B * H * W), dtype=torch.float32, device=dev)
+        stats = torch.empty(4, dtype=torch.float32, device=dev)
+        ws = zeroed_workspace(lib.sessd_ssfa_fuse_train_workspace_bytes(B, C, H * W), dev, "ssfa_train")
+        check(lib.sessd_ssfa_fuse_train_fwd(x0.data_ptr(), x1.data_ptr(), B, C, H * W, w0f.data_ptr(), w1f.data_ptr(), gb[0].data_ptr(),
+                                            gb[1].data_ptr(), gb[2].data_ptr(), gb[3].data_ptr(), float(eps), float(momentum), _p(rm0),
+                                            _p(rv0), _p(rm1), _p(rv1), out.data_ptr(), smap.data_ptr(), stats.data_ptr(), ws.data_ptr(),
+                                            ws.numel(), _stream()), "ssfa_fuse_train_fwd")
+        ctx.save_for_backward(x0, x1, w0f, w1f, *gb, smap, stats)
+        ctx.wshape = (tuple(w0.shape), tuple(w1.shape))
+        return out
+
+    @staticmethod
+    def backward(ctx, grad):
+        x0, x1, w0f, w1f, g0, b0, g1, b1, smap, stats = ctx.saved_tensors
+        g = grad.float().contiguous()
+        B, C, H, W = x0.shape
+        dev = x0.device
+        dx0, dx1 = torch.empty_like(x0), torch.empty_like(x1)
+        dw0, dw1 = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        dgam, dbet = torch.empty(2, device=dev), torch.empty(2, device=dev)
+        dz = torch.empty(B * H * W, device=dev)
+        ws = zeroed_workspace(lib.sessd_ssfa_fuse_train_workspace_bytes(B, C, H * W), dev, "ssfa_train")
+        check(lib.sessd_ssfa_fuse_train_bwd(g.data_ptr(), x0.data_ptr(), x1.data_ptr(), B, C, H * W, w0f.data_ptr(), w1f.data_ptr(),
+                                            g0.data_ptr(), b0.data_ptr(), g1.data_ptr(), b1.data_ptr(), smap.data_ptr(), stats.data_ptr(),
+                                            dz.data_ptr(), dx0.data_ptr(), dx1.data_ptr(), dw0.data_ptr(), dw1.data_ptr(), dgam.data_ptr(),
+                                            dbet.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "ssfa_fuse_train_bwd")
+        return (dx0, dx1, dw0.reshape(ctx.wshape[0]), dw1.reshape(ctx.wshape[1]), dgam[0:1], dbet[0:1], dgam[1:2], dbet[1:2],
+                None, None, None, None, None, None)
+
+
+def ssfa_fuse_train(x0, x1, conv0, bn0, conv1, bn1):
+    """rpn_v1.py:225-235 in train mode: conv0 / conv1 = the Conv2d(C, 1, 1, bias=False) of w_0 / w_1, bn0 / bn1 their
+    BatchNorm2d(1) (train mode, affine; running statistics and batch counters updated like the torch modules do)."""
+    if not ssfa_fuse_train_covers(x0, conv0, bn0, conv1, bn1):
+        raise ValueError("ssfa_fuse_train: layer configuration outside the kernel's (see ssfa_fuse_train_covers)")
+    mom = _bn_momentum(bn0)
+    _bn_momentum(bn1)
+    return SsfaFuseTrainFunction.apply(x0, x1, conv0.weight, conv1.weight, bn0.weight, bn0.bias, bn1.weight, bn1.bias,
+                                       bn0.running_mean, bn0.running_var, bn1.running_mean, bn1.running_var, bn0.eps, mom)
+
+
+def ssfa_fuse_train_covers(x, conv0, bn0, conv1, bn1):
+    """What csrc/ssfa_train.hip implements: bias-free 1x1 convs to ONE channel, plain affine BatchNorm2d(1) layers in train mode
+    with a shared eps / fixed momentum, channels % 4 == 0 (<= 1024), H * W % 4 == 0."""
+    nn = torch.nn
+    convs_ok = all(type(c) is nn.Conv2d and c.bias is None and c.kernel_size == (1, 1) and c.out_channels == 1 and c.groups == 1
+                   and c.stride == (1, 1) and c.padding == (0, 0) for c in (conv0, conv1))
+    bns_ok = all(type(b) is nn.BatchNorm2d and b.training and b.weight is not None and b.momentum is not None and b.num_features == 1
+                 for b in (bn0, bn1))
+    if not (convs_ok and bns_ok):
+        return False
+    same = bn0.eps == bn1.eps and bn0.momentum == bn1.momentum and (bn0.running_mean is None) == (bn1.running_mean is None)
+    C = x.shape[1]
+    return bool(same and x.is_cuda and C % 4 == 0 and C <= 1024 and conv0.in_channels == C and conv1.in_channels == C
+                and (x.shape[2] * x.shape[3]) % 4 == 0)
+
+
 def ssfa_fuse_head(x0, x1, w0, w1, s0, t0, s1, t1, head_w, head_b, head_out=None, out=None, score_thresh=0.0, keys=None,
                    key_count=None):
     """ssfa_fuse + the 1x1 heads in one launch: head_w (22, C) row-major, head_b (22) or None -> head_out (B, 22, H*W) planar.

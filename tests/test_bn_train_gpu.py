@@ -174,3 +174,53 @@ def test_ssfa_train_mode_fused_vs_torch_modules(dev):
         if "running" in na:
             assert torch.allclose(ba, bb, rtol=1e-4, atol=1e-5), na
     assert checked > 30
+
+
+@pytest.mark.parametrize("B,C,H,W", [(4, 128, 200, 176), (1, 128, 200, 176), (2, 8, 6, 10), (3, 64, 4, 5)])
+def test_ssfa_attention_tail_train_mode(dev, B, C, H, W):
+    """ops.ssfa_fuse_train (csrc/ssfa_train.hip) vs the torch composition of rpn_v1.py:225-235 in train mode: output, the running
+    statistics of both BatchNorm2d(1), gradients of both inputs, both conv weights and the four BatchNorm parameters; a second
+    run gives the same bits."""
+    nn = torch.nn
+    g = torch.Generator().manual_seed(B * 100 + C)
+    x0 = (torch.randn(B, C, H, W, generator=g) * 1.2 + 0.2).to(dev)
+    x1 = (torch.randn(B, C, H, W, generator=g) * 0.8 - 0.1).to(dev)
+    up = torch.randn(B, C, H, W, generator=g).to(dev)
+
+    def branches():
+        torch.manual_seed(5)
+        mods = []
+        for k in range(2):
+            conv, bn = nn.Conv2d(C, 1, 1, bias=False), nn.BatchNorm2d(1, eps=1e-3, momentum=0.01)
+            bn.weight.data.fill_(1.3 - 0.5 * k); bn.bias.data.fill_(0.2 * k - 0.1)
+            bn.running_mean.data.fill_(0.05 * (k + 1)); bn.running_var.data.fill_(0.7 + 0.2 * k)
+            mods += [conv.to(dev), bn.to(dev).train()]
+        return mods
+
+    ref, mine = branches(), branches()
+    a0, a1 = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True)
+    w = torch.softmax(torch.cat([ref[1](ref[0](a0)), ref[3](ref[2](a1))], dim=1), dim=1)
+    yr = a0 * w[:, 0:1] + a1 * w[:, 1:]
+    (yr * up).sum().backward()
+    m0, m1 = x0.clone().requires_grad_(True), x1.clone().requires_grad_(True)
+    assert ops.ssfa_fuse_train_covers(m0, *mine)
+    ym = ops.ssfa_fuse_train(m0, m1, *mine)
+    (ym * up).sum().backward()
+    torch.cuda.synchronize()
+    tol = lambda t, r: r * max(1.0, float(t.abs().max()))
+    assert torch.allclose(ym, yr, rtol=0, atol=tol(yr, 2e-5))
+    for k in (1, 3):
+        assert torch.allclose(mine[k].running_mean, ref[k].running_mean, rtol=0, atol=1e-6)
+        assert torch.allclose(mine[k].running_var, ref[k].running_var, rtol=1e-5, atol=1e-6)
+        assert int(mine[k].num_batches_tracked) == int(ref[k].num_batches_tracked) == 1
+    assert torch.allclose(m0.grad, a0.grad, rtol=0, atol=tol(a0.grad, 5e-5))
+    assert torch.allclose(m1.grad, a1.grad, rtol=0, atol=tol(a1.grad, 5e-5))
+    for pm, pr in zip([p for m in mine for p in m.parameters()], [p for m in ref for p in m.parameters()]):
+        assert pm.grad is not None and pm.grad.shape == pr.grad.shape
+        assert torch.allclose(pm.grad, pr.grad, rtol=2e-3, atol=tol(pr.grad, 2e-3)), (pm.grad.flatten()[:4], pr.grad.flatten()[:4])
+    again = branches()
+    y2 = ops.ssfa_fuse_train(x0, x1, *again)
+    assert torch.equal(y2, ym.detach())
+    # not covered: a biased conv, an eval-mode BatchNorm
+    assert not ops.ssfa_fuse_train_covers(x0, nn.Conv2d(C, 1, 1).to(dev), mine[1], mine[2], mine[3])
+    assert not ops.ssfa_fuse_train_covers(x0, mine[0], mine[1].eval(), mine[2], mine[3])
