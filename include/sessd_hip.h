@@ -318,6 +318,15 @@ int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win,
                        int wout, int ksize, int stride, float* grad_weight, void* workspace, size_t workspace_bytes,
                        sessd_stream_t stream);
 
+/* The same weight gradient for Conv2d(cin, cout, 3, stride 1, padding 1) computed in the Winograd F(2x2,3x3) domain
+ * (dU_xi = sum over 2x2 output tiles of (A dY A^T)_xi (B^T d B)_xi on the f32 matrix cores, then G^T dU G: 16 instead of 36
+ * products per tile): cin, cout multiples of 64, h, w even, w >= 4. _workspace_bytes returns 0 for a shape it does not cover
+ * (use sessd_conv2d_wgrad). Deterministic (split over tile chunks, summed in chunk order); equal to sessd_conv2d_wgrad up to
+ * Winograd rounding (~1e-6 of the result's scale). */
+size_t sessd_conv3x3_wgrad_winograd_workspace_bytes(int batch, int cin, int cout, int h, int w);
+int sessd_conv3x3_wgrad_winograd(const float* input, int batch, int cin, int h, int w, const float* grad_out, int cout,
+                                 float* grad_weight, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+
 /* ---- ODIoU loss as one differentiable device op: det3d/models/losses/odious.py:837-900 (odiou_3D and
  * the host-side numpy / scipy functions it composes, :15-643). gboxes (targets), qboxes (predictions) (n,7) float32
  * [x,y,z,w,l,h,r] -> term (n,) = 1 - IoU3D + centre-distance / enclosing-diagonal + 1.25(1 - |cos dr|) and grad_q (n,7) =

@@ -3,6 +3,8 @@
 torch is plumbing only (device memory + the current HIP stream). Inputs must be contiguous CUDA
 tensors of the stated dtype; nothing here copies to the host or synchronises.
 """
+import os
+
 import torch
 
 from ._lib import lib, check, SessdError
@@ -568,9 +570,11 @@ class deferred_batch_counts:
     def __exit__(self, *exc):
         _NBT_DEFER[0] = self.prev
         if not self.prev and _NBT_PENDING:
-            pending = list(_NBT_PENDING)
+            counts = {}   # a layer applied twice appears twice: one entry per tensor (duplicates in one multi-tensor launch race)
+            for t in _NBT_PENDING:
+                counts[id(t)] = (t, counts.get(id(t), (t, 0))[1] + 1)
             _NBT_PENDING.clear()
-            torch._foreach_add_(pending, 1)
+            torch._foreach_add_([t for t, _ in counts.values()], [n for _, n in counts.values()])
         return False
 
 
@@ -1216,15 +1220,31 @@ def mean_all(x):
     return _SumAll.apply(x, 1.0 / max(1, x.numel()))
 
 
-def conv2d_wgrad(inp, grad_out, ksize, stride):
+USE_WINOGRAD_WGRAD = os.environ.get("SESSD_WINOGRAD_WGRAD", "1") != "0"   # 3x3 stride-1 weight gradients in the Winograd domain
+
+
+def conv2d_wgrad(inp, grad_out, ksize, stride, winograd=None):
     """Weight gradient (Cout, Cin, k, k) of Conv2d(k, stride, padding k//2): inp (B,Cin,H,W), grad_out (B,Cout,Ho,Wo).
-    For ConvTranspose2d(3, s2, p1, op1) pass (inp=its grad_out, grad_out=its input) and get its (Cin, Cout, 3, 3) gradient."""
+    For ConvTranspose2d(3, s2, p1, op1) pass (inp=its grad_out, grad_out=its input) and get its (Cin, Cout, 3, 3) gradient.
+    winograd: None = the Winograd-domain kernel where it covers the layer and the map is large enough to fill the chip
+    (USE_WINOGRAD / USE_WINOGRAD_WGRAD), True = that kernel (ValueError outside its shapes), False = the direct kernel."""
     _req(inp, torch.float32, "inp")
     _req(grad_out, torch.float32, "grad_out")
     B, ci, hi, wi = inp.shape
     B2, co, ho, wo = grad_out.shape
     assert B == B2
     gw = torch.empty((co, ci, ksize, ksize), dtype=torch.float32, device=inp.device)
+    if winograd is None:
+        winograd = USE_WINOGRAD and USE_WINOGRAD_WGRAD and hi * wi >= 4096
+    if winograd and ksize == 3 and stride == 1:
+        need = int(lib.sessd_conv3x3_wgrad_winograd_workspace_bytes(B, ci, co, hi, wi))
+        if not need and winograd is True:
+            raise ValueError("conv2d_wgrad: the Winograd-domain kernel needs cin, cout % 64 == 0, even H, W, W >= 4")
+        if need:   # the shape is one the Winograd-domain kernel covers (16 of the 36 products per tile)
+            ws = workspace(need, inp.device, "wwgrad")
+            check(lib.sessd_conv3x3_wgrad_winograd(inp.data_ptr(), B, ci, hi, wi, grad_out.data_ptr(), co, gw.data_ptr(), ws.data_ptr(),
+                                                   ws.numel(), _stream()), "conv3x3_wgrad_winograd")
+            return gw
     ws = torch.empty(int(lib.sessd_conv2d_wgrad_workspace_bytes(co, ci, ksize)), dtype=torch.uint8, device=inp.device)
     check(lib.sessd_conv2d_wgrad(inp.data_ptr(), B, ci, hi, wi, grad_out.data_ptr(), co, ho, wo, ksize, stride, gw.data_ptr(),
                                  ws.data_ptr(), ws.numel(), _stream()), "conv2d_wgrad")

@@ -108,3 +108,44 @@ def test_channel_sum(dev):
     assert float((got.double() - want).abs().max()) <= 1e-6 * float(x.double().abs().sum((0, 2, 3)).max())
     odd = torch.randn(2, 5, 7, 9, device=dev)   # H * W not a multiple of 4: torch's reduction
     assert torch.allclose(ops.channel_sum(odd), odd.sum((0, 2, 3)), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W", [(4, 128, 128, 200, 176), (2, 256, 256, 100, 88), (1, 64, 128, 8, 12), (3, 128, 64, 10, 8),
+                                             (1, 64, 64, 2, 4), (2, 64, 64, 6, 20)])
+def test_winograd_domain_weight_gradient(dev, B, cin, cout, H, W):
+    """sessd_conv3x3_wgrad_winograd (dU = sum over tiles of (A dY A^T)(B^T d B), then G^T dU G) vs the direct pixel-reduction
+    kernel sessd_conv2d_wgrad and, on the small shapes, vs torch autograd on the CPU: 2e-4 of the largest entry; the image
+    borders (tiles whose patch leaves the image), stages that straddle rows / images and ragged last stages are in the shapes.
+    A second run gives the same bits."""
+    g = torch.Generator().manual_seed(B * 1000 + cin + H)
+    x = torch.randn(B, cin, H, W, generator=g)
+    gy = torch.randn(B, cout, H, W, generator=g)
+    x[:, :, 0, :] += 2.0; x[:, :, -1, :] -= 1.5; x[:, :, :, 0] += 1.0; x[:, :, :, -1] -= 2.5   # borders must count
+    xd, gd = x.to(dev), gy.to(dev)
+    direct = ops.conv2d_wgrad(xd, gd, 3, 1, winograd=False)
+    wino = ops.conv2d_wgrad(xd, gd, 3, 1, winograd=True)
+    torch.cuda.synchronize()
+    _close(wino, direct.cpu(), "winograd-domain vs direct")
+    if B * H * W <= 4096:
+        w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
+        (F.conv2d(x, w, padding=1) * gy).sum().backward()
+        _close(wino, w.grad, "winograd-domain vs torch")
+    assert torch.equal(ops.conv2d_wgrad(xd, gd, 3, 1, winograd=True), wino)
+    with pytest.raises(ValueError):
+        ops.conv2d_wgrad(xd[:, :48], gd, 3, 1, winograd=True)
+
+
+def test_winograd_forward_at_the_last_pixel(dev):
+    """The 16-byte patch loads of the Winograd forward kernels at the right border of the LAST row of the LAST channel end
+    exactly at the tensor's end: a value there must reach the output (first-generation and stream-K kernels vs the direct one)."""
+    B, C, H, W = 1, 128, 64, 64
+    x = torch.zeros(B, C, H, W)
+    x[0, C - 1, H - 1, W - 1] = 3.0
+    x[0, C - 1, H - 1, W - 2] = -2.0
+    x[0, 0, 0, 0] = 1.5
+    w = torch.randn(C, C, 3, 3, generator=torch.Generator().manual_seed(1)) * 0.1
+    want = F.conv2d(x, w, padding=1)
+    pc = ops.pack_conv2d(w.to(dev), 1)
+    for cfg in (None, 20, 22):
+        got = ops.conv2d(x.to(dev), pc, None, None, False, tile_cfg=cfg)
+        _close(got, want, "tile_cfg %s" % cfg)
