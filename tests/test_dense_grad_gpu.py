@@ -122,10 +122,9 @@ def test_winograd_domain_weight_gradient(dev, B, cin, cout, H, W):
     gy = torch.randn(B, cout, H, W, generator=g)
     x[:, :, 0, :] += 2.0; x[:, :, -1, :] -= 1.5; x[:, :, :, 0] += 1.0; x[:, :, :, -1] -= 2.5   # borders must count
     xd, gd = x.to(dev), gy.to(dev)
-    direct = ops.conv2d_wgrad(xd, gd, 3, 1, winograd=False)
     wino = ops.conv2d_wgrad(xd, gd, 3, 1, winograd=True)
-    torch.cuda.synchronize()
-    _close(wino, direct.cpu(), "winograd-domain vs direct")
+    if W % 8 == 0:   # the direct kernel's own constraint
+        _close(wino, ops.conv2d_wgrad(xd, gd, 3, 1, winograd=False).cpu(), "winograd-domain vs direct")
     if B * H * W <= 4096:
         w = torch.zeros(cout, cin, 3, 3, requires_grad=True)
         (F.conv2d(x, w, padding=1) * gy).sum().backward()
