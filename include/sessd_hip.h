@@ -320,7 +320,7 @@ int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win,
 
 /* The same weight gradient for Conv2d(cin, cout, 3, stride 1, padding 1) computed in the Winograd F(2x2,3x3) domain
  * (dU_xi = sum over 2x2 output tiles of (A dY A^T)_xi (B^T d B)_xi on the f32 matrix cores, then G^T dU G: 16 instead of 36
- * products per tile): cin, cout multiples of 64, h, w even, w >= 4. _workspace_bytes returns 0 for a shape it does not cover
+ * products per tile): cin, cout multiples of 64, h, w even, w >= 16. _workspace_bytes returns 0 for a shape it does not cover
  * (use sessd_conv2d_wgrad). Deterministic (split over tile chunks, summed in chunk order); equal to sessd_conv2d_wgrad up to
  * Winograd rounding (~1e-6 of the result's scale). */
 size_t sessd_conv3x3_wgrad_winograd_workspace_bytes(int batch, int cin, int cout, int h, int w);

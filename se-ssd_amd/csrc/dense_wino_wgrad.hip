@@ -68,37 +68,43 @@ __global__ __launch_bounds__(WW_NT, 1) void conv3x3s1_wino_wgrad_kernel(WwArgs A
   const rsrc_t xr = make_rsrc(A.inp, (unsigned)((size_t)A.B * A.ci * plane * 4));
   const rsrc_t gr = make_rsrc(A.gout, (unsigned)((size_t)A.B * A.co * plane * 4));
   int T = s0 * WW_TILES + t8;   // linear tile (b, ty, tx)
-  int b = T / (A.th * A.tw);
-  int ty = (T - b * A.th * A.tw) / A.tw;
-  int tx = T - (b * A.th + ty) * A.tw;
+  int tx, ty, ex, eg;           // ex / eg: element index of the patch's top-left corner (row 2ty-1, column 2tx-1) / of the gout tile
+  {
+    const int b = T / (A.th * A.tw);
+    ty = (T - b * A.th * A.tw) / A.tw;
+    tx = T - (b * A.th + ty) * A.tw;
+    ex = (b * A.ci + cib * 64 + c) * plane + (2 * ty - 1) * A.W + 2 * tx - 1;
+    eg = (b * A.co + cob * 64 + c) * plane + 2 * ty * A.W + 2 * tx;
+  }
+  const int img_x = (A.ci - 1) * plane, img_g = (A.co - 1) * plane;
 
   f32x4v pr[4];
   f32x2v gy[2];
   bool mask_l = false, mask_r = false;
+  // The 16-byte row segment of a patch: columns 2tx-1 .. 2tx+2; at the left border it starts one column later, at the right
+  // border one column earlier (a load never crosses the end of a row, hence never the end of the tensor) and the lane masks of
+  // the transform shift it back. Rows -1 and H get an out-of-range offset (the hardware returns zeros). Then the thread moves
+  // 8 tiles on: +16 columns; past the end of a tile row +W more; past the end of an image + (channels - 1) planes (tw >= 8).
 #define SESSD_WW_LOAD()                                                                             \
   {                                                                                                 \
     const bool live = T < A.total_tiles;                                                            \
-    const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;                                                     \
-    /* row segment: columns x0 .. x0 + 3; at the left border it starts at 0, at the right border one column earlier (a    */ \
-    /* 16-byte load never crosses the end of a row, hence never the end of the tensor); the lane masks shift it back      */ \
-    const unsigned xbase = (unsigned)((b * A.ci + cib * 64 + c) * plane + (tx == A.tw - 1 ? x0 - 1 : max(x0, 0)));          \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
-      const int y = y0 + q;                                                                         \
-      const unsigned off = (live && y >= 0 && y < A.H) ? (xbase + (unsigned)(y * A.W)) * 4u : SESSD_OOB; \
-      pr[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0)); \
-    }                                                                                               \
-    const unsigned gbase = (unsigned)((b * A.co + cob * 64 + c) * plane + 2 * ty * A.W + 2 * tx);   \
-    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                 \
-      const unsigned off = live ? (gbase + (unsigned)(a * A.W)) * 4u : SESSD_OOB;                   \
-      gy[a] = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(gr, (int)off, 0, 0)); \
-    }                                                                                               \
     mask_l = live && tx == 0;                                                                       \
     mask_r = live && tx == A.tw - 1;                                                                \
-    /* next stage: 8 tiles on */                                                                    \
-    T += WW_TILES;                                                                                  \
-    tx += WW_TILES;                                                                                 \
-    while (tx >= A.tw) { tx -= A.tw; ++ty; }                                                        \
-    while (ty >= A.th) { ty -= A.th; ++b; }                                                         \
+    const int xs = ex + (tx == 0 ? 1 : 0) - (tx == A.tw - 1 ? 1 : 0);                               \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                 \
+      const bool row_ok = live && (q != 0 || ty > 0) && (q != 3 || ty < A.th - 1);                  \
+      const unsigned off = row_ok ? (unsigned)(xs + q * A.W) * 4u : SESSD_OOB;                      \
+      pr[q] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(xr, (int)off, 0, 0)); \
+    }                                                                                               \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a) {                                                 \
+      const unsigned off = live ? (unsigned)(eg + a * A.W) * 4u : SESSD_OOB;                        \
+      gy[a] = __builtin_bit_cast(f32x2v, __builtin_amdgcn_raw_buffer_load_b64(gr, (int)off, 0, 0)); \
+    }                                                                                               \
+    T += WW_TILES; tx += WW_TILES; ex += 2 * WW_TILES; eg += 2 * WW_TILES;                          \
+    if (tx >= A.tw) {                                                                               \
+      tx -= A.tw; ++ty; ex += A.W; eg += A.W;                                                       \
+      if (ty >= A.th) { ty -= A.th; ex += img_x; eg += img_g; }                                     \
+    }                                                                                               \
   }
   // both transforms of the loaded tile into LDS buffer VOFF (floats): dM at +0, V at + WW_OPER
 #define SESSD_WW_TRANSFORM(VOFF)                                                                    \
@@ -152,18 +158,20 @@ __global__ __launch_bounds__(WW_NT, 1) void conv3x3s1_wino_wgrad_kernel(WwArgs A
     SESSD_WW_TRANSFORM(0)
     __syncthreads();
     int voff = 0;
-    // operand role: lane (i, h): channel i of a 32-block, tiles 4h .. 4h + 3
+    // operand role: lane (i, h): channel i of a 32-block, tiles 4h .. 4h + 3 -- one 16-byte LDS read (indices in float4 units)
     const int i = lane & 31, h = lane >> 5;
-    const int ooff = (wave * 2) * 512 + i * 8 + h * 4;
+    const f32x4v* lds4 = reinterpret_cast<const f32x4v*>(lds);
+    const int ooff4 = wave * 256 + i * 2 + h;
     for (int s = s0; s < s1; ++s) {
       if (s + 1 < s1) SESSD_WW_LOAD()
+      const int voff4 = voff >> 2;
       f32x4v av[2][2], bv[2][2];
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int m = 0; m < 2; ++m) {
-          av[x][m] = *reinterpret_cast<const f32x4v*>(&lds[voff + ooff + x * 512 + m * 256]);
-          bv[x][m] = *reinterpret_cast<const f32x4v*>(&lds[voff + WW_OPER + ooff + x * 512 + m * 256]);
+          av[x][m] = lds4[voff4 + ooff4 + x * 128 + m * 64];
+          bv[x][m] = lds4[voff4 + WW_OPER / 4 + ooff4 + x * 128 + m * 64];
         }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -239,7 +247,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
 }
 
 bool ww_shape_ok(int batch, int cin, int cout, int h, int w) {
-  return batch >= 1 && cin >= 64 && cout >= 64 && cin % 64 == 0 && cout % 64 == 0 && h >= 2 && w >= 4 && (h & 1) == 0 && (w & 1) == 0 &&
+  return batch >= 1 && cin >= 64 && cout >= 64 && cin % 64 == 0 && cout % 64 == 0 && h >= 2 && w >= 16 && (h & 1) == 0 && (w & 1) == 0 &&
          (size_t)batch * cin * h * w * 4 < 0x7FFFFFFFull && (size_t)batch * cout * h * w * 4 < 0x7FFFFFFFull;
 }
 
@@ -264,7 +272,7 @@ size_t sessd_conv3x3_wgrad_winograd_workspace_bytes(int batch, int cin, int cout
 }
 
 // grad_weight (cout, cin, 3, 3) of Conv2d(cin, cout, 3, stride 1, padding 1): input (B, cin, h, w), grad_out (B, cout, h, w);
-// cin, cout multiples of 64, h, w even. Same result as sessd_conv2d_wgrad(..., 3, 1) up to Winograd rounding.
+// cin, cout multiples of 64, h, w even, w >= 16. Same result as sessd_conv2d_wgrad(..., 3, 1) up to Winograd rounding.
 int sessd_conv3x3_wgrad_winograd(const float* input, int batch, int cin, int h, int w, const float* grad_out, int cout,
                                  float* grad_weight, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (!ww_shape_ok(batch, cin, cout, h, w) || !input || !grad_out || !grad_weight) return SESSD_EINVAL;

@@ -1239,7 +1239,7 @@ def conv2d_wgrad(inp, grad_out, ksize, stride, winograd=None):
     if winograd and ksize == 3 and stride == 1:
         need = int(lib.sessd_conv3x3_wgrad_winograd_workspace_bytes(B, ci, co, hi, wi))
         if not need and winograd is True:
-            raise ValueError("conv2d_wgrad: the Winograd-domain kernel needs cin, cout % 64 == 0, even H, W, W >= 4")
+            raise ValueError("conv2d_wgrad: the Winograd-domain kernel needs cin, cout % 64 == 0, even H, W, W >= 16")
         if need:   # the shape is one the Winograd-domain kernel covers (16 of the 36 products per tile)
             ws = workspace(need, inp.device, "wwgrad")
             check(lib.sessd_conv3x3_wgrad_winograd(inp.data_ptr(), B, ci, hi, wi, grad_out.data_ptr(), co, gw.data_ptr(), ws.data_ptr(),
