@@ -181,6 +181,11 @@ int sessd_sparse_chain_rulebooks(const int32_t* indices0, const int32_t* n0_dev,
 /* weight (kernel_volume, cin, cout) row-major == spconv's [kz,ky,kx,Cin,Cout] flattened -> MFMA fragment order */
 int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, int cout, float* packed,
                              sessd_stream_t stream);
+/* The packed weight of the (cout -> cin) conv that computes the layer's data gradient, from the same weight tensor:
+ * W'[k] = W[k']^T with k' = kernel_volume - 1 - k when reverse_offsets (submanifold layers, whose gradient runs on the forward
+ * neighbour table), else k' = k (strided layers, on sessd_sparse_rulebook_transpose's table). cin % 16 == 0, cout % 4 == 0. */
+int sessd_sparse_pack_weight_adjoint(const float* weight, int kernel_volume, int cin, int cout, int reverse_offsets,
+                                     float* packed, sessd_stream_t stream);
 /* out[o] = act((sum_k W[k]^T in[nbr[k][o]]) * scale + shift); scale/shift = folded eval BatchNorm1d (may be NULL).
  * dense_out != NULL: scatter into the pre-zeroed BEV tensor (B, cout*D, H, W), dense_dims3 = (D,H,W).
  * tuning = cout_split + 256 * depth. cout_split: 0 heuristic | 1,2,4 waves per 16-site tile (each computes cout/split

@@ -406,7 +406,12 @@ __global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __
 
 // W (kv, cin, cout) row-major [the flattened spconv layout (kz,ky,kx,Cin,Cout)] -> fragment order
 //   wpk[(((k*NTILE + t)*SG + g)*64 + lane)*G + e] = W[k][ (lane>>4)*STEPS + g*G + e ][ t*16 + (lane&15) ]
-__global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin, int cout, float* __restrict__ wpk) {
+// (kv, cin, cout) are those of the PACKED conv. adjoint = 0: w is that conv's own (kv, cin, cout) tensor. adjoint = 1: w is the
+// (kv, cout, cin) tensor of the layer whose DATA GRADIENT the packed conv computes (its input channels are that layer's output
+// channels): element (k, ci, co) = w[k'][co][ci], k' = kv - 1 - k with reverse_k (a submanifold layer's gradient runs on the
+// forward tables with the offsets reversed), else k' = k (strided layers: on the transposed rulebook).
+__global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin, int cout, int adjoint, int reverse_k,
+                                   float* __restrict__ wpk) {
   const int steps = cin / 4, ntile = cout / 16, G = steps < 4 ? steps : 4, SG = steps / G;
   const size_t total = (size_t)kv * cin * cout;
   size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -418,7 +423,8 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin,
   int t = r % ntile;
   int k = (int)(r / ntile);
   int ci = (lane >> 4) * steps + g * G + e, co = t * 16 + (lane & 15);
-  wpk[idx] = w[((size_t)k * cin + ci) * cout + co];
+  const int ks = reverse_k ? kv - 1 - k : k;
+  wpk[idx] = adjoint ? w[((size_t)ks * cout + co) * cin + ci] : w[((size_t)ks * cin + ci) * cout + co];
 }
 
 template <int CIN, int COUT, int NTW, int DEPTH, bool KS = false>
@@ -532,7 +538,23 @@ int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, in
   if (steps > 4 && steps % 4) return SESSD_EINVAL;
   size_t total = (size_t)kernel_volume * cin * cout;
   SESSD_LAUNCH(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, weight,
-                     kernel_volume, cin, cout, packed);
+                     kernel_volume, cin, cout, 0, 0, packed);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// The packed weight of the conv that computes a layer's DATA GRADIENT, straight from the layer's own weight (kernel_volume, cin,
+// cout): a (cout -> cin) conv with W'[k] = W[k']^T, k' = kernel_volume - 1 - k when reverse_offsets (submanifold layers: the
+// forward tables read with the offsets reversed), else k (strided layers: on the transposed rulebook). Replaces a flip, a
+// transpose copy and a pack per layer and iteration. cout % 4 == 0, cin % 16 == 0.
+int sessd_sparse_pack_weight_adjoint(const float* weight, int kernel_volume, int cin, int cout, int reverse_offsets, float* packed,
+                                     hipStream_t stream) {
+  if (cout % 4 || cin % 16 || kernel_volume <= 0) return SESSD_EINVAL;
+  const int steps = cout / 4;
+  if (steps > 4 && steps % 4) return SESSD_EINVAL;
+  size_t total = (size_t)kernel_volume * cin * cout;
+  SESSD_LAUNCH(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, weight, kernel_volume, cout, cin, 1,
+               reverse_offsets ? 1 : 0, packed);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

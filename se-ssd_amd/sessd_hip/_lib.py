@@ -93,6 +93,7 @@ SIGNATURES = {
     "sessd_sparse_chain_sites": (i32, [vp, vp, i32, i32, i32, vp, vp, sz, i32, vp, vp]),
     "sessd_sparse_chain_rulebooks": (i32, [vp, vp, i32, vp, vp, u32, vp, i32, i32, vp, vp, i32, vp, vp]),
     "sessd_sparse_pack_weight": (i32, [vp, i32, i32, i32, vp, vp]),
+    "sessd_sparse_pack_weight_adjoint": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sessd_sparse_conv": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
     "sessd_sparse_renumber_workspace_bytes": (sz, [i32, vp]),
     "sessd_sparse_renumber_sites": (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, u32, vp, vp, vp, sz, vp]),

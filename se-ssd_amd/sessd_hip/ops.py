@@ -480,6 +480,19 @@ def sparse_pack_weight(weight):
     return out
 
 
+def sparse_pack_weight_adjoint(weight, reverse_offsets):
+    """Packed weight of the (Cout -> Cin) conv that computes the data gradient of the layer with `weight` (kz,ky,kx,Cin,Cout):
+    per offset W_k^T, offsets reversed for a submanifold layer (whose gradient runs on the forward neighbour table). One launch
+    from the stored weight (no flip / transpose copies)."""
+    w = weight.detach().to(torch.float32).contiguous()
+    cin, cout = w.shape[-2], w.shape[-1]
+    kv = w.numel() // (cin * cout)
+    out = torch.empty_like(w).view(-1)
+    check(lib.sessd_sparse_pack_weight_adjoint(w.data_ptr(), kv, cin, cout, 1 if reverse_offsets else 0, out.data_ptr(), _stream()),
+          "sparse_pack_weight_adjoint")
+    return out
+
+
 def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, scale=None, shift=None, relu=True,
                 out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0, offset_split=0, share_w=0):
     """cout_split (0 heuristic | 1, 2, 4) and depth (0 default | 2..4 operand sets in flight) only tune the launch: results are
@@ -880,6 +893,18 @@ def _pack_taps_view(w, out_stride, in_stride, tap_offsets, cout, cin):
     return out
 
 
+class _Launch(dict):
+    """A PackedConv launch whose fragment-order weight ("wpk") is packed when first asked for: a 3x3 stride-1 layer that runs on a
+    Winograd kernel never needs it (21 wasted pack launches per training iteration before)."""
+
+    def __missing__(self, key):
+        if key != "wpk":
+            raise KeyError(key)
+        w, so, sc, taps = self["view"]
+        self["wpk"] = _pack_taps_view(w, so, sc, taps, self["_co"], self["_ci"])
+        return self["wpk"]
+
+
 def _conv_view(w, adjoint):
     """(cout, cin, out_stride, in_stride, flip) of a Conv2d weight (Cout, Cin, k, k) used as it is, or as the stride-1 ADJOINT layer
     (correlation with the flipped kernel, channels swapped: the data-gradient pass)."""
@@ -902,9 +927,8 @@ def pack_conv2d(weight, stride=1, padding=None, adjoint=False):
     dy = [ky - pad for ky in range(kh) for kx in range(kw)]
     dx = [kx - pad for ky in range(kh) for kx in range(kw)]
     taps = [(kk - 1 - t) if flip else t for t in range(kk)]
-    wpk = _pack_taps_view(w, so, sc, taps, co, ci)
-    la = dict(wpk=wpk, dy=torch.tensor(dy, dtype=torch.int32), dx=torch.tensor(dx, dtype=torch.int32), in_mul=stride,
-              out_mul=1, py=0, px=0, ntaps=kh * kw, view=(w, so, sc, taps))
+    la = _Launch(dy=torch.tensor(dy, dtype=torch.int32), dx=torch.tensor(dx, dtype=torch.int32), in_mul=stride,
+                 out_mul=1, py=0, px=0, ntaps=kh * kw, view=(w, so, sc, taps), _co=co, _ci=ci)
     pc = PackedConv([la], ci, co, "conv", stride)
     if kh == 3 and stride == 1:
         pc._w3 = (w, bool(adjoint))  # Winograd packings (tile_cfg 20-23) are made when first asked for

@@ -66,6 +66,19 @@ class SparseModule(nn.Module):
     pass
 
 
+def _adjoint_pack(weight, reverse_offsets):
+    """Packed weight of the conv that computes a sparse layer's data gradient (per offset W_k^T; offsets reversed for a
+    submanifold layer): one launch from the stored weight where the pack kernel covers the shape, else flip / transpose / pack."""
+    cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
+    steps = cout // 4
+    if weight.is_cuda and cin % 16 == 0 and cout % 4 == 0 and (steps <= 4 or steps % 4 == 0):
+        return ops.sparse_pack_weight_adjoint(weight, reverse_offsets)
+    w = weight.detach().reshape(-1, cin, cout)
+    if reverse_offsets:
+        w = w.flip(0)
+    return ops.sparse_pack_weight(w.transpose(1, 2).contiguous())
+
+
 class IndiceConvFunction(torch.autograd.Function):
     """Differentiable sparse convolution y[j] = sum_k W_k^T x[nbr[k][j]] (+ bias) on the HIP kernels.
     backward: dx through the transposed rulebook with the same output-stationary kernel, dW by the site-reduction
@@ -96,15 +109,13 @@ class IndiceConvFunction(torch.autograd.Function):
             # read with the offsets reversed. dx[i] = sum_k W_k dy[nbrT[k][i]] = sum_k' W_{K-1-k'} dy[nbr[k'][i]] -- the forward
             # kernel on the forward tables with the per-offset weights reversed and transposed; no transpose launch, no fills
             # (10 of the 14 layers of SpMiddleFHD: 0.4 ms of rulebook work per iteration).
-            w_rev = weight.detach().reshape(kv, cin, cout).flip(0).transpose(1, 2).contiguous()
-            gx = ops.sparse_conv(g, nbr, tm, n_out, ops.sparse_pack_weight(w_rev), cout, cin, None, None, relu=False)
+            gx = ops.sparse_conv(g, nbr, tm, n_out, _adjoint_pack(weight, True), cout, cin, None, None, relu=False)
         elif ctx.needs_input_grad[0]:
             n_in = feats.shape[0]
             nbr_t, tm_t = ops.sparse_rulebook_transpose(nbr, n_out, n_in)
-            w_t = weight.detach().reshape(kv, cin, cout).transpose(1, 2).contiguous()  # per offset W_k^T: (cout, cin)
             n_in_dev = ctx.saved_tensors[5] if len(ctx.saved_tensors) > 5 else torch.tensor([n_in], dtype=torch.int32,
                                                                                               device=feats.device)
-            gx = ops.sparse_conv(g, nbr_t, tm_t, n_in_dev, ops.sparse_pack_weight(w_t), cout, cin, None, None, relu=False)
+            gx = ops.sparse_conv(g, nbr_t, tm_t, n_in_dev, _adjoint_pack(weight, False), cout, cin, None, None, relu=False)
         if ctx.needs_input_grad[1]:
             gw = ops.sparse_conv_wgrad(feats, g, nbr, tm, n_out, cin, cout).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:

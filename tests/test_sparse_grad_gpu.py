@@ -121,3 +121,19 @@ def test_spmiddle_backward_runs_and_matches_oracle(dev):
     out.features.pow(2).sum().backward()
     _close(net[3].weight.grad.cpu(), w2r.grad, "w2 grad")
     _close(net[0].weight.grad.cpu(), w1r.grad, "w1 grad")
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (16, 32), (32, 64), (64, 64), (64, 128)])
+@pytest.mark.parametrize("reverse", [False, True])
+def test_adjoint_weight_pack_equals_flip_transpose_pack(dev, cin, cout, reverse):
+    """sessd_sparse_pack_weight_adjoint (the data-gradient conv's packed weight straight from the layer's weight) == packing the
+    flipped / transposed copy: identical bits."""
+    import torch
+    from sessd_hip import ops
+    w = torch.randn(3, 3, 3, cin, cout, generator=torch.Generator().manual_seed(cin + cout)).to(dev)
+    ref = w.reshape(27, cin, cout)
+    if reverse:
+        ref = ref.flip(0)
+    want = ops.sparse_pack_weight(ref.transpose(1, 2).contiguous())
+    got = ops.sparse_pack_weight_adjoint(w, reverse)
+    assert torch.equal(got, want)
