@@ -41,17 +41,45 @@ __global__ __launch_bounds__(256) void rulebook_transpose_kernel(const int* __re
 }
 
 // One wave per (site chunk, offset): partial dW_k over the chunk's sites, full CIN x COUT block in registers.
-//   v_mfma_f32_16x16x4_f32:  D[ci 16][co 16] += A[ci 16][site 4] * B[site 4][co 16]
-//   A lane (i, kq) = x[nbr[k][j0 + kq]][cb*16 + i]   (missing neighbour / channel >= CIN: out-of-range offset -> 0)
-//   B lane (n, kq) = dy[j0 + kq][ob*16 + n]
-// 16-site tiles whose mask has no bit k are skipped wave-uniformly.
+//   v_mfma_f32_16x16x4_f32:  D[row 16][col 16] += A[row 16][site 4] * B[site 4][col 16]
+//   A lane (i, kq) = x[nbr[k][j0 + kq]][VA i .. VA i + VA-1]   -- ONE 16 / 8 / 4-byte load for the VA = CIN / 16 row blocks: row i
+//                    of block cb is channel VA i + cb (the channel order inside dW is ours to choose; it is undone by the store)
+//   B lane (n, kq) = dy[j0 + kq][VB n .. VB n + VB-1]           likewise, VB = COUT / 16
+//   (missing neighbour / site beyond the live count / channel >= CIN: out-of-range buffer offset -> 0)
+// 16-site tiles whose mask has no bit k are skipped wave-uniformly. The loop is software-pipelined over LIVE tiles: the operands
+// of the next live tile (4 steps: 2 x 4 vector loads) are gathered before the MFMAs of the current one, and the neighbour
+// indices of the tile after that before those gathers -- the first version issued index load -> gather -> MFMA per 4-site step
+// with ~1.7 waves per SIMD to hide it behind: 96 us for a 64 -> 64 level at batch 4, almost all of it load latency. Every load
+// is unconditional (a tile past the chunk's end gets out-of-range offsets), so the vmcnt waits are exact.
+template <int N> struct VecLoad;
+template <> struct VecLoad<1> {
+  static __device__ __forceinline__ void ld(rsrc_t r, unsigned off, float* v) {
+    v[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)off, 0, 0));
+  }
+};
+template <> struct VecLoad<2> {
+  static __device__ __forceinline__ void ld(rsrc_t r, unsigned off, float* v) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    const f2 t = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+    v[0] = t.x; v[1] = t.y;
+  }
+};
+template <> struct VecLoad<4> {
+  static __device__ __forceinline__ void ld(rsrc_t r, unsigned off, float* v) {
+    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+};
+
 template <int CIN, int COUT>
-__global__ __launch_bounds__(64) void wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__global__ __launch_bounds__(64, 2) void wgrad_partial_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const int* __restrict__ nbr,
                                                             const uint32_t* __restrict__ tile_mask,
                                                             const int* __restrict__ n_dev, int n_cap,
                                                             float* __restrict__ partial) {
-  constexpr int CIB = (CIN + 15) / 16, COB = COUT / 16;
+  constexpr int VA = CIN >= 16 ? CIN / 16 : 1, VB = COUT / 16;
+  static_assert(VA == 1 || VA == 2 || VA == 4, "CIN in {4, 16, 32, 64}");
+  static_assert(VB == 1 || VB == 2 || VB == 4, "COUT in {16, 32, 64}");
   const int chunk = blockIdx.x, k = blockIdx.y, kv = gridDim.y;
   const int lane = threadIdx.x, i = lane & 15, kq = lane >> 4;
   const int n = min(n_dev[0], n_cap);
@@ -61,44 +89,88 @@ __global__ __launch_bounds__(64) void wgrad_partial_kernel(const float* __restri
   const int live_tiles = (n + 15) >> 4;
   const int chunk_tiles = (live_tiles + WG_CHUNKS - 1) / WG_CHUNKS;
   const int t0 = chunk * chunk_tiles, t1 = min(t0 + chunk_tiles, live_tiles);
-  f32x4 acc[CIB][COB];
+  f32x4 acc[VA][VB];
 #pragma unroll
-  for (int a = 0; a < CIB; ++a)
+  for (int a = 0; a < VA; ++a)
 #pragma unroll
-    for (int b = 0; b < COB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < VB; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const rsrc_t xr = make_rsrc(x, 0x7FFFFFFFu);
   const rsrc_t yr = make_rsrc(dy, (unsigned)min((long long)n * COUT * 4, 0x7FFFFFFFll));  // rows >= n read as 0
-  const int* nb = nbr + (size_t)k * n_cap;
-  for (int t = t0; t < t1; ++t) {
-    if (!((tile_mask[t] >> k) & 1u)) continue;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int j = t * 16 + s * 4 + kq;
-      const int r = j < n ? nb[j] : -1;
-      float a[CIB], b[COB];
-#pragma unroll
-      for (int cb = 0; cb < CIB; ++cb)
-        a[cb] = bufload1(xr, (r >= 0 && cb * 16 + i < CIN) ? (unsigned)((r * CIN + cb * 16 + i) * 4) : SESSD_OOB, 0);
-#pragma unroll
-      for (int ob = 0; ob < COB; ++ob) b[ob] = bufload1(yr, (unsigned)((j * COUT + ob * 16 + i) * 4), 0);
-#pragma unroll
-      for (int cb = 0; cb < CIB; ++cb)
-#pragma unroll
-        for (int ob = 0; ob < COB; ++ob)
-          acc[cb][ob] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cb], b[ob], acc[cb][ob], 0, 0, 0);
+  const rsrc_t nr = make_rsrc(nbr + (size_t)k * n_cap, (unsigned)n_cap * 4u);
+  const bool a_ok = CIN >= 16 || i < CIN;
+
+  // first live tile at or after t (t1 if none): wave-uniform scalar walk over the mask words
+#define SESSD_SW_NEXT(T)                                                  \
+  {                                                                       \
+    while ((T) < t1 && !((tile_mask[(T)] >> k) & 1u)) ++(T);              \
+  }
+  // the four neighbour indices of this lane in tile T (sites 4 s + kq); a tile past the end reads out of range (= 0, unused)
+#define SESSD_SW_INDEX(R, T)                                                                                           \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
+    (R)[s] = __builtin_amdgcn_raw_buffer_load_b32(nr, (T) < t1 ? (int)(((T) * 16 + s * 4 + kq) * 4) : (int)SESSD_OOB, 0, 0);
+  // operands of tile T from its indices
+#define SESSD_SW_GATHER(A, B, R, T)                                                                                    \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                       \
+    const int j = (T) * 16 + s * 4 + kq;                                                                                \
+    const int r = ((T) < t1 && j < n) ? (int)(R)[s] : -1;                                                               \
+    VecLoad<VA>::ld(xr, (r >= 0 && a_ok) ? (unsigned)((r * CIN + VA * i) * 4) : SESSD_OOB, (A)[s]);                     \
+    VecLoad<VB>::ld(yr, (T) < t1 ? (unsigned)((j * COUT + VB * i) * 4) : SESSD_OOB, (B)[s]);                            \
+  }
+#define SESSD_SW_MMA(A, B)                                                                                             \
+  _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                         \
+    _Pragma("unroll") for (int cb = 0; cb < VA; ++cb)                                                                   \
+      _Pragma("unroll") for (int ob = 0; ob < VB; ++ob)                                                                 \
+        acc[cb][ob] = __builtin_amdgcn_mfma_f32_16x16x4f32((A)[s][cb], (B)[s][ob], acc[cb][ob], 0, 0, 0);
+
+  int ta = t0;
+  SESSD_SW_NEXT(ta)
+  if (ta < t1) {
+    unsigned ra[4], rb[4];
+    float a0[4][VA], b0[4][VB], a1[4][VA], b1[4][VB];
+    SESSD_SW_INDEX(ra, ta)
+    int tb = ta + 1;
+    SESSD_SW_NEXT(tb)
+    SESSD_SW_INDEX(rb, tb)
+    __builtin_amdgcn_sched_barrier(0);
+    SESSD_SW_GATHER(a0, b0, ra, ta)
+    __builtin_amdgcn_sched_barrier(0);
+    while (ta < t1) {   // set 0 holds live tile ta, rb the indices of tb (past the end: everything about it reads as zero)
+      SESSD_SW_GATHER(a1, b1, rb, tb)
+      int tc = tb < t1 ? tb + 1 : t1;
+      SESSD_SW_NEXT(tc)
+      SESSD_SW_INDEX(ra, tc)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_SW_MMA(a0, b0)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_SW_GATHER(a0, b0, ra, tc)
+      int td = tc < t1 ? tc + 1 : t1;
+      SESSD_SW_NEXT(td)
+      SESSD_SW_INDEX(rb, td)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_SW_MMA(a1, b1)   // a tile past the end multiplies zeros
+      __builtin_amdgcn_sched_barrier(0);
+      ta = tc;
+      tb = td;
     }
   }
-  // D layout: column (co) = lane & 15, rows (ci) = (lane >> 4) * 4 + r
+#undef SESSD_SW_NEXT
+#undef SESSD_SW_INDEX
+#undef SESSD_SW_GATHER
+#undef SESSD_SW_MMA
+  // D layout: column = lane & 15, rows = (lane >> 4) * 4 + r; row rho of block cb is channel VA rho + cb, column n of block ob is
+  // channel VB n + ob: the VB blocks of a lane are VB consecutive output channels
   float* dst = partial + ((size_t)chunk * kv + k) * CIN * COUT;
 #pragma unroll
-  for (int cb = 0; cb < CIB; ++cb)
+  for (int cb = 0; cb < VA; ++cb)
 #pragma unroll
-    for (int ob = 0; ob < COB; ++ob)
+    for (int r = 0; r < 4; ++r) {
+      const int ci = VA * (kq * 4 + r) + cb;
+      if (ci < CIN) {
+        float* o = dst + ci * COUT + VB * i;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int ci = cb * 16 + kq * 4 + r;
-        if (ci < CIN) dst[ci * COUT + ob * 16 + i] = acc[cb][ob][r];
+        for (int ob = 0; ob < VB; ++ob) o[ob] = acc[cb][ob][r];
       }
+    }
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int total,
