@@ -233,6 +233,12 @@ int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane
 int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
                               const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+/* The same gradients without the forward output y: the ReLU mask is re-derived from x with the forward's gamma / beta (the
+ * forward computes its pre-ReLU value in one fixed instruction sequence, so the mask is the same bit for bit); both launches read
+ * one tensor less. */
+int sessd_bn2d_relu_train_bwd_x(const float* dy, const float* x, int batch, int channels, int plane, const float* gamma,
+                                const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                                float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 
 /* ---- training data path, point-level work -----------------------------------------------------------
  * replaces det3d/core/bbox/geometry.py:215-276 points_in_convex_polygon_3d_jit (numba) as used by

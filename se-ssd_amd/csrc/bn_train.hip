@@ -296,6 +296,12 @@ namespace {
 
 constexpr int BN2D_SPLIT = 16;   // plane slices per channel: C x 16 blocks of partial sums
 
+// The normalised, scaled and shifted value before the ReLU, in ONE fixed instruction sequence (sub, mul, fma): the forward
+// writes max(0, z) and a backward that is not given y re-derives the ReLU mask as z > 0 from x -- the same bits, so the same mask.
+__device__ __forceinline__ float bn2d_z(float x, float mu, float is, float g, float bt) {
+  return __fmaf_rn(__fmul_rn(__fsub_rn(x, mu), is), g, bt);
+}
+
 constexpr int BN2D_MAX_CHANNELS = 1024;
 // one counter word per channel in a region of FIXED size: one workspace serves calls with different channel counts
 constexpr size_t BN2D_COUNTER_BYTES = (size_t)BN2D_MAX_CHANNELS * 4;
@@ -307,8 +313,10 @@ constexpr size_t BN2D_COUNTER_BYTES = (size_t)BN2D_MAX_CHANNELS * 4;
 template <int MODE>
 __global__ __launch_bounds__(NT) void bn2d_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          const float* __restrict__ y, const float* __restrict__ mean,
-                                                         const float* __restrict__ invstd, int B, int C, int plane, int relu,
+                                                         const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, int B, int C, int plane, int relu,
                                                          double* partial, unsigned* counters, BnFinal F) {
+  // MODE 1 with y == NULL: the ReLU mask is re-derived from x (gamma / beta of the forward; one tensor less to read)
   constexpr bool BWD = MODE == 1;
   __shared__ double sm[2][NT / 64];
   const int c = blockIdx.x, s = blockIdx.y;
@@ -316,8 +324,12 @@ __global__ __launch_bounds__(NT) void bn2d_stats_kernel(const float* __restrict_
   const int chunk = sessd_divup(quads, BN2D_SPLIT);
   const int q0 = s * chunk, q1 = min(quads, q0 + chunk);
   double s0 = 0.0, s1 = 0.0;
-  float mu = 0.f, is = 0.f;
-  if (BWD) { mu = mean[c]; is = invstd[c]; }
+  float mu = 0.f, is = 0.f, gm = 1.f, bt = 0.f;
+  if (BWD) {
+    mu = mean[c]; is = invstd[c];
+    if (gamma) gm = gamma[c];
+    if (beta) bt = beta[c];
+  }
   for (int b = 0; b < B; ++b) {
     const size_t base = ((size_t)b * C + c) * plane;
     for (int q = q0 + (int)threadIdx.x; q < q1; q += NT) {
@@ -328,7 +340,13 @@ __global__ __launch_bounds__(NT) void bn2d_stats_kernel(const float* __restrict_
       } else {
         float4 dz = *reinterpret_cast<const float4*>(dy + base + 4 * (size_t)q);
         if (relu) {
-          const float4 yv = *reinterpret_cast<const float4*>(y + base + 4 * (size_t)q);
+          float4 yv;
+          if (y) {
+            yv = *reinterpret_cast<const float4*>(y + base + 4 * (size_t)q);
+          } else {
+            yv.x = bn2d_z(xv.x, mu, is, gm, bt); yv.y = bn2d_z(xv.y, mu, is, gm, bt);
+            yv.z = bn2d_z(xv.z, mu, is, gm, bt); yv.w = bn2d_z(xv.w, mu, is, gm, bt);
+          }
           if (!(yv.x > 0.f)) dz.x = 0.f;
           if (!(yv.y > 0.f)) dz.y = 0.f;
           if (!(yv.z > 0.f)) dz.z = 0.f;
@@ -396,12 +414,19 @@ __global__ __launch_bounds__(NT) void bn2d_apply_kernel(const float* __restrict_
   float4 r;
   if (!BWD) {
     const float bt = beta ? beta[c] : 0.f;
-    r.x = (xv.x - mu) * is * g + bt; r.y = (xv.y - mu) * is * g + bt; r.z = (xv.z - mu) * is * g + bt; r.w = (xv.w - mu) * is * g + bt;
+    r.x = bn2d_z(xv.x, mu, is, g, bt); r.y = bn2d_z(xv.y, mu, is, g, bt); r.z = bn2d_z(xv.z, mu, is, g, bt); r.w = bn2d_z(xv.w, mu, is, g, bt);
     if (relu) { r.x = fmaxf(r.x, 0.f); r.y = fmaxf(r.y, 0.f); r.z = fmaxf(r.z, 0.f); r.w = fmaxf(r.w, 0.f); }
   } else {
     float4 dz = *reinterpret_cast<const float4*>(dy + 4 * i);
     if (relu) {
-      const float4 yv = *reinterpret_cast<const float4*>(y_in + 4 * i);
+      float4 yv;
+      if (y_in) {
+        yv = *reinterpret_cast<const float4*>(y_in + 4 * i);
+      } else {   // the mask from x (see bn2d_z)
+        const float bt = beta ? beta[c] : 0.f;
+        yv.x = bn2d_z(xv.x, mu, is, g, bt); yv.y = bn2d_z(xv.y, mu, is, g, bt);
+        yv.z = bn2d_z(xv.z, mu, is, g, bt); yv.w = bn2d_z(xv.w, mu, is, g, bt);
+      }
       if (!(yv.x > 0.f)) dz.x = 0.f;
       if (!(yv.y > 0.f)) dz.y = 0.f;
       if (!(yv.z > 0.f)) dz.z = 0.f;
@@ -435,7 +460,7 @@ int sessd_nchw_channel_sum(const float* x, int batch, int channels, int plane, f
   double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
   BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, out};
   const float* nf = nullptr;
-  SESSD_LAUNCH((bn2d_stats_kernel<2>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, batch, channels, plane, 0,
+  SESSD_LAUNCH((bn2d_stats_kernel<2>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, nf, nf, batch, channels, plane, 0,
                partial, counters, F);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -453,7 +478,7 @@ int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane
   double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
   BnFinal F{eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
   const float* nf = nullptr;
-  SESSD_LAUNCH((bn2d_stats_kernel<0>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, batch, channels, plane, 0,
+  SESSD_LAUNCH((bn2d_stats_kernel<0>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, nf, nf, batch, channels, plane, 0,
                partial, counters, F);
   SESSD_CHECK_LAUNCH();
   const size_t quads = (size_t)batch * channels * (plane >> 2);
@@ -465,24 +490,41 @@ int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane
 }
 
 // gradients of the above: dx (same shape), dgamma, dbeta (channels); y = the forward output (ReLU mask), x = the forward input
-int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
-                              const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
-                              float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+static int bn2d_bwd_launch(const float* dy, const float* x, const float* y, int batch, int channels, int plane, const float* gamma,
+                           const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx, float* dgamma,
+                           float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   if (batch <= 0 || channels <= 0 || channels > BN2D_MAX_CHANNELS || plane <= 0 || (plane & 3)) return SESSD_EINVAL;
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
   if (!dgamma || !dbeta) return SESSD_EINVAL;
   unsigned* counters = (unsigned*)workspace;
   double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
   BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
-  SESSD_LAUNCH((bn2d_stats_kernel<1>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, batch,
-               channels, plane, relu, partial, counters, F);
+  SESSD_LAUNCH((bn2d_stats_kernel<1>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, gamma, beta,
+               batch, channels, plane, relu, partial, counters, F);
   SESSD_CHECK_LAUNCH();
   const size_t quads = (size_t)batch * channels * (plane >> 2);
   SESSD_LAUNCH((bn2d_apply_kernel<true>), dim3((unsigned)((quads + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, channels, plane,
-               gamma, (const float*)nullptr, save_mean, save_invstd, dgamma, dbeta, 1.f / (float)((long long)batch * plane), relu, dx,
-               quads);
+               gamma, beta, save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta,
+               1.f / (float)((long long)batch * plane), relu, dx, quads);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
+}
+
+int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
+                              const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                              float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (relu && !y) return SESSD_EINVAL;
+  return bn2d_bwd_launch(dy, x, y, batch, channels, plane, gamma, nullptr, save_mean, save_invstd, relu, dx, dgamma, dbeta, workspace,
+                         workspace_bytes, stream);
+}
+
+// The same without the forward output: the ReLU mask is re-derived from x with the forward's gamma / beta (the forward computes
+// z in one fixed instruction sequence, so z > 0 here is y > 0 there, bit for bit) -- one tensor less to read in both launches.
+int sessd_bn2d_relu_train_bwd_x(const float* dy, const float* x, int batch, int channels, int plane, const float* gamma,
+                                const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
+                                float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  return bn2d_bwd_launch(dy, x, nullptr, batch, channels, plane, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta,
+                         workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

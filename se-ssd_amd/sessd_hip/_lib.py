@@ -109,6 +109,7 @@ SIGNATURES = {
     "sessd_bn2d_relu_train_workspace_bytes": (sz, [i32]),
     "sessd_bn2d_relu_train_fwd": (i32, [vp, i32, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_bn2d_relu_train_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "sessd_bn2d_relu_train_bwd_x": (i32, [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
     "sessd_sparse_rulebook_transpose": (i32, [vp, i32, vp, i32, i32, vp, vp, vp]),
     "sessd_sparse_conv_wgrad_workspace_bytes": (sz, [i32, i32, i32]),
     "sessd_sparse_conv_wgrad": (i32, [vp, i32, vp, i32, vp, vp, i32, vp, i32, vp, vp, sz, vp]),

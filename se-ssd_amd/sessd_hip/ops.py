@@ -630,21 +630,22 @@ class Bn2dReluTrainFunction(torch.autograd.Function):
         check(lib.sessd_bn2d_relu_train_fwd(x.data_ptr(), B, C, H * W, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
                                             1 if relu else 0, _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(),
                                             invstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_fwd")
-        ctx.save_for_backward(x, y, g, mean, invstd)
+        # the backward re-derives the ReLU mask from x (sessd_bn2d_relu_train_bwd_x): y is not kept for it
+        ctx.save_for_backward(x, g, b, mean, invstd)
         ctx.relu = bool(relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, g, mean, invstd = ctx.saved_tensors
+        x, g, b, mean, invstd = ctx.saved_tensors
         dy = dy.float().contiguous()
         B, C, H, W = x.shape
         dx = torch.empty_like(x)
         dg, db = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
         ws = zeroed_workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), x.device, "bn2d")
-        check(lib.sessd_bn2d_relu_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), B, C, H * W, g.data_ptr(), mean.data_ptr(),
-                                            invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
-                                            ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_bwd")
+        check(lib.sessd_bn2d_relu_train_bwd_x(dy.data_ptr(), x.data_ptr(), B, C, H * W, g.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                                              invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                              ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_bwd_x")
         return dx, dg, db, None, None, None, None, None
 
 

@@ -224,3 +224,36 @@ def test_ssfa_attention_tail_train_mode(dev, B, C, H, W):
     # not covered: a biased conv, an eval-mode BatchNorm
     assert not ops.ssfa_fuse_train_covers(x0, nn.Conv2d(C, 1, 1).to(dev), mine[1], mine[2], mine[3])
     assert not ops.ssfa_fuse_train_covers(x0, mine[0], mine[1].eval(), mine[2], mine[3])
+
+
+def test_dense_backward_mask_from_x_equals_mask_from_y(dev):
+    """sessd_bn2d_relu_train_bwd_x (ReLU mask re-derived from x) == sessd_bn2d_relu_train_bwd (mask read from the forward output):
+    the same bits for dx, dgamma, dbeta -- inputs with many values at and around the ReLU threshold."""
+    from sessd_hip._lib import lib, check
+    B, C, H, W = 2, 16, 24, 40
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(B, C, H, W, generator=g) * 1e-3).to(dev)          # z close to beta: both signs, tiny magnitudes
+    x[:, ::2] += torch.randn(B, C // 2, H, W, generator=g).to(dev)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 1e-4).to(dev)
+    dy = torch.randn(B, C, H, W, generator=g).to(dev)
+    y, mean, invstd = torch.empty_like(x), torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ws = ops.zeroed_workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), dev, "bn2d")
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.sessd_bn2d_relu_train_fwd(x.data_ptr(), B, C, H * W, gamma.data_ptr(), beta.data_ptr(), 1e-3, 0.01, 1, None, None,
+                                        y.data_ptr(), mean.data_ptr(), invstd.data_ptr(), ws.data_ptr(), ws.numel(), st), "fwd")
+    outs = []
+    for from_x in (False, True):
+        dx, dg, db = torch.empty_like(x), torch.empty(C, device=dev), torch.empty(C, device=dev)
+        if from_x:
+            check(lib.sessd_bn2d_relu_train_bwd_x(dy.data_ptr(), x.data_ptr(), B, C, H * W, gamma.data_ptr(), beta.data_ptr(),
+                                                  mean.data_ptr(), invstd.data_ptr(), 1, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), st), "bwd_x")
+        else:
+            check(lib.sessd_bn2d_relu_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), B, C, H * W, gamma.data_ptr(), mean.data_ptr(),
+                                                invstd.data_ptr(), 1, dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                                ws.numel(), st), "bwd")
+        outs.append((dx, dg, db))
+    torch.cuda.synchronize()
+    assert 0.2 < float((y > 0).float().mean()) < 0.8
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
