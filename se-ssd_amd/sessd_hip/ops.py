@@ -614,6 +614,9 @@ def bn_relu_train(x, n_dev, bn, relu=True):
     return BnReluTrainFunction.apply(x, n_dev, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
 
 
+BN_MASK_FROM_X = os.environ.get("SESSD_BN_MASK_FROM_Y", "0") == "0"   # dense train-mode BatchNorm backward: ReLU mask from x, not y
+
+
 class Bn2dReluTrainFunction(torch.autograd.Function):
     """Train-mode BatchNorm2d + optional ReLU on a dense (B, C, H, W) map (H * W % 4 == 0), both passes on csrc/bn_train.hip."""
 
@@ -631,18 +634,25 @@ class Bn2dReluTrainFunction(torch.autograd.Function):
                                             1 if relu else 0, _p(running_mean), _p(running_var), y.data_ptr(), mean.data_ptr(),
                                             invstd.data_ptr(), ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_fwd")
         # the backward re-derives the ReLU mask from x (sessd_bn2d_relu_train_bwd_x): y is not kept for it
-        ctx.save_for_backward(x, g, b, mean, invstd)
+        ctx.mask_from_x = BN_MASK_FROM_X
+        ctx.save_for_backward(x, g, b, mean, invstd, *(() if ctx.mask_from_x else (y,)))
         ctx.relu = bool(relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, g, b, mean, invstd = ctx.saved_tensors
+        x, g, b, mean, invstd = ctx.saved_tensors[:5]
         dy = dy.float().contiguous()
         B, C, H, W = x.shape
         dx = torch.empty_like(x)
         dg, db = torch.empty(C, device=x.device), torch.empty(C, device=x.device)
         ws = zeroed_workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), x.device, "bn2d")
+        if not ctx.mask_from_x:
+            y = ctx.saved_tensors[5]
+            check(lib.sessd_bn2d_relu_train_bwd(dy.data_ptr(), x.data_ptr(), y.data_ptr(), B, C, H * W, g.data_ptr(), mean.data_ptr(),
+                                                invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_bwd")
+            return dx, dg, db, None, None, None, None, None
         check(lib.sessd_bn2d_relu_train_bwd_x(dy.data_ptr(), x.data_ptr(), B, C, H * W, g.data_ptr(), b.data_ptr(), mean.data_ptr(),
                                               invstd.data_ptr(), 1 if ctx.relu else 0, dx.data_ptr(), dg.data_ptr(), db.data_ptr(),
                                               ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_bwd_x")
