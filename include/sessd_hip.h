@@ -181,6 +181,9 @@ int sessd_sparse_chain_rulebooks(const int32_t* indices0, const int32_t* n0_dev,
 /* weight (kernel_volume, cin, cout) row-major == spconv's [kz,ky,kx,Cin,Cout] flattened -> MFMA fragment order */
 int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, int cout, float* packed,
                              sessd_stream_t stream);
+/* Every sparse weight packing of a training iteration (teacher forward, student forward, student data gradient: 41 layers) in ONE
+ * launch: jobs_dev = device array of sessd_sparse_pack_job_t with ascending block_start, total_blocks = the launch's grid. */
+int sessd_sparse_pack_batch(const sessd_sparse_pack_job_t* jobs_dev, int n_jobs, int total_blocks, sessd_stream_t stream);
 /* The packed weight of the (cout -> cin) conv that computes the layer's data gradient, from the same weight tensor:
  * W'[k] = W[k']^T with k' = kernel_volume - 1 - k when reverse_offsets (submanifold layers, whose gradient runs on the forward
  * neighbour table), else k' = k (strided layers, on sessd_sparse_rulebook_transpose's table). cin % 16 == 0, cout % 4 == 0. */
@@ -324,6 +327,8 @@ int sessd_nchw_channel_sum(const float* x, int batch, int channels, int plane, f
  * summed in order). k in {1,3}, stride in {1,2}, wout % 8 == 0. For ConvTranspose2d(3, s2, p1, op1) swap the roles
  * (input := its grad_out, grad_out := its input): the result is its (Cin, Cout, 3, 3) weight gradient.
  * Replaces the ATen/MIOpen backward of det3d/models/necks/rpn_v1.py:135-235 under trainer_sessd.py:250-275. */
+/* Every dense weight packing of a training iteration (sessd_conv2d_pack_taps / sessd_conv3x3_winograd_pack jobs) in ONE launch. */
+int sessd_dense_pack_batch(const sessd_dense_pack_job_t* jobs_dev, int n_jobs, int total_blocks, sessd_stream_t stream);
 size_t sessd_conv2d_wgrad_workspace_bytes(int cout, int cin, int ksize);
 int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win, const float* grad_out, int cout, int hout,
                        int wout, int ksize, int stride, float* grad_weight, void* workspace, size_t workspace_bytes,

@@ -19,6 +19,7 @@
 //     input pixel = (y*in_mul + dy[t], x*in_mul + dx[t]),  output pixel = (y*out_mul + py, x*out_mul + px)
 // Numerics: bit-for-bit an fmaf chain over (cin pair, tap, cin parity) -- exact float32.
 #include "common.hpp"
+#include "sessd_hip_types.h"
 
 namespace {
 
@@ -877,9 +878,8 @@ __global__ __launch_bounds__(256) void pack_taps_kernel(PackArgs A, float* __res
 // layout 0: sessd_conv3x3_winograd      [ci/2][xi/4][h][cp32][xi%4]
 // layout 1: sessd_conv3x3_winograd_sk shape 0  [ceil(co/128)][ci/2][8][2][32][4][2]
 // layout 2: sessd_conv3x3_winograd_sk shape 1  [ceil(co/64)][ci/2][4][2][32][2][4]
-__global__ __launch_bounds__(256) void winograd_pack_kernel(PackArgs A, int flip, int layout, float* __restrict__ out) {
+__device__ __forceinline__ void winograd_pack_body(const PackArgs& A, int flip, int layout, float* __restrict__ out, size_t idx) {
   const int cpad = layout == 0 ? A.cp : (layout == 1 ? (A.co + 127) / 128 * 128 : (A.co + 63) / 64 * 64);
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)cpad * A.ci) return;
   const int o = (int)(idx % cpad), c = (int)(idx / cpad);
   double g[3][3];
@@ -921,8 +921,48 @@ __global__ __launch_bounds__(256) void winograd_pack_kernel(PackArgs A, int flip
     }
   }
 }
+__global__ __launch_bounds__(256) void winograd_pack_kernel(PackArgs A, int flip, int layout, float* __restrict__ out) {
+  winograd_pack_body(A, flip, layout, out, (size_t)blockIdx.x * 256 + threadIdx.x);
+}
+// All weight packings of a model pass in ONE launch: block -> job by binary search over the jobs' first blocks, then the body
+// of pack_taps_kernel / winograd_pack_kernel on the job's arguments (read from the device table).
+__global__ __launch_bounds__(256) void dense_pack_batch_kernel(const sessd_dense_pack_job_t* __restrict__ jobs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const sessd_dense_pack_job_t* J = jobs + lo;
+  const size_t idx = (size_t)((int)blockIdx.x - J->block_start) * 256 + threadIdx.x;
+  const int co = J->cout, ci = J->cin, cp = sessd_divup(co, 32) * 32;
+  const float* __restrict__ w = J->w;
+  float* __restrict__ out = J->out;
+  const long long so = J->out_stride, sc = J->in_stride;
+  if (J->kind == 0) {
+    const int nt = J->ntaps;
+    const size_t total = (size_t)(ci >> 1) * nt * 2 * cp;
+    if (idx >= total) return;
+    const int o = (int)(idx % cp);
+    size_t r = idx / cp;
+    const int h = (int)(r & 1); r >>= 1;
+    const int t = (int)(r % nt);
+    const int kp = (int)(r / nt);
+    out[idx] = o < co ? w[(long long)o * so + (long long)(2 * kp + h) * sc + J->tap_off[t]] : 0.f;
+    return;
+  }
+  PackArgs A;
+  A.w = w; A.so = so; A.sc = sc; A.co = co; A.ci = ci; A.nt = 9; A.cp = cp;
+  winograd_pack_body(A, J->flip, J->layout, out, idx);
+}
 }  // namespace
 extern "C" {
+
+int sessd_dense_pack_batch(const sessd_dense_pack_job_t* jobs_dev, int n_jobs, int total_blocks, hipStream_t stream) {
+  if (!jobs_dev || n_jobs < 1 || total_blocks < 1) return SESSD_EINVAL;
+  SESSD_LAUNCH(dense_pack_batch_kernel, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, n_jobs);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
 
 // Pack a conv weight for sessd_conv2d_mfma / sessd_deconv2d_s2_mfma: out [cin/2][ntaps][2][cout_pad32] with
 // out[kp][t][h][o] = w[o * out_stride + (2 kp + h) * in_stride + tap_offsets[t]] (element strides / offsets into w, so that a

@@ -16,6 +16,7 @@
 // y = max(0, acc*scale + shift). HBM traffic ~ features in (once per neighbour hit, L2-absorbed)
 // + features out once + 4*27 B/site of rulebook.
 #include "common.hpp"
+#include "sessd_hip_types.h"
 
 namespace {
 
@@ -410,11 +411,10 @@ __global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __
 // (kv, cout, cin) tensor of the layer whose DATA GRADIENT the packed conv computes (its input channels are that layer's output
 // channels): element (k, ci, co) = w[k'][co][ci], k' = kv - 1 - k with reverse_k (a submanifold layer's gradient runs on the
 // forward tables with the offsets reversed), else k' = k (strided layers: on the transposed rulebook).
-__global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin, int cout, int adjoint, int reverse_k,
-                                   float* __restrict__ wpk) {
+__device__ __forceinline__ void pack_weight_body(const float* __restrict__ w, int kv, int cin, int cout, int adjoint, int reverse_k,
+                                                 float* __restrict__ wpk, size_t idx) {
   const int steps = cin / 4, ntile = cout / 16, G = steps < 4 ? steps : 4, SG = steps / G;
   const size_t total = (size_t)kv * cin * cout;
-  size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   int e = idx % G;
   size_t r = idx / G;
@@ -425,6 +425,25 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin,
   int ci = (lane >> 4) * steps + g * G + e, co = t * 16 + (lane & 15);
   const int ks = reverse_k ? kv - 1 - k : k;
   wpk[idx] = adjoint ? w[((size_t)ks * cout + co) * cin + ci] : w[((size_t)ks * cin + ci) * cout + co];
+}
+__global__ void pack_weight_kernel(const float* __restrict__ w, int kv, int cin, int cout, int adjoint, int reverse_k,
+                                   float* __restrict__ wpk) {
+  pack_weight_body(w, kv, cin, cout, adjoint, reverse_k, wpk, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+// every sparse weight packing of an iteration in one launch (jobs: sessd_hip_types.h)
+__global__ __launch_bounds__(256) void sparse_pack_batch_kernel(const sessd_sparse_pack_job_t* __restrict__ jobs, int n) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  const sessd_sparse_pack_job_t* J = jobs + lo;
+  const size_t idx = (size_t)((int)blockIdx.x - J->block_start) * 256 + threadIdx.x;
+  // the packed conv's (cin, cout): swapped for the data-gradient layer
+  if (J->adjoint)
+    pack_weight_body(J->w, J->kernel_volume, J->cout, J->cin, 1, J->reverse_k, J->out, idx);
+  else
+    pack_weight_body(J->w, J->kernel_volume, J->cin, J->cout, 0, 0, J->out, idx);
 }
 
 template <int CIN, int COUT, int NTW, int DEPTH, bool KS = false>
@@ -539,6 +558,13 @@ int sessd_sparse_pack_weight(const float* weight, int kernel_volume, int cin, in
   size_t total = (size_t)kernel_volume * cin * cout;
   SESSD_LAUNCH(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, weight,
                      kernel_volume, cin, cout, 0, 0, packed);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+int sessd_sparse_pack_batch(const sessd_sparse_pack_job_t* jobs_dev, int n_jobs, int total_blocks, hipStream_t stream) {
+  if (!jobs_dev || n_jobs < 1 || total_blocks < 1) return SESSD_EINVAL;
+  SESSD_LAUNCH(sparse_pack_batch_kernel, dim3(total_blocks), dim3(256), 0, stream, jobs_dev, n_jobs);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

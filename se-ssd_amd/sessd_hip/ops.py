@@ -468,6 +468,168 @@ def _t3(v):
     return [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
 
 
+# ------------------------------------------------------------------ batched re-packing of a training iteration's weights
+# The training step re-packs every conv weight after every update: 14 sparse layers x (teacher forward, student forward, student
+# data gradient) + the SSFA layers' tap / Winograd layouts in three roles = 95 launches of ~5 us per iteration. Inside
+# `with ops.batched_repack(registry)` (TrainStep wraps an iteration in it) the packed objects of PARAMETER weights are kept, every
+# packing they were made with is recorded as a job, and the first access after an update re-runs ALL jobs as two launches
+# (sessd_sparse_pack_batch, sessd_dense_pack_batch). Staleness = ops.param_generation() (the fused update writes through raw
+# pointers) or the accessed parameter's `_version` (any other in-place change).
+_REPACK = [None]
+
+
+class RepackRegistry:
+    def __init__(self):
+        self.objects = {}
+        self.jobs = {"dense": [], "sparse": []}
+        self._table = {"dense": None, "sparse": None}   # (device tensor, n_jobs, total_blocks), rebuilt when jobs were added
+        self.versions = {}                               # id(parameter) -> [parameter, _version at the last refresh]
+        self.gen = -1
+        self._creating = 0
+        self.refreshes = 0
+
+    # -- recording (called by the low-level pack wrappers)
+    def recording(self):
+        return self._creating > 0
+
+    def note(self, kind, job):
+        self.jobs[kind].append(job)
+        self._table[kind] = None
+
+    # -- access
+    def cached(self, key, weight, factory):
+        self.ensure_fresh(weight)
+        obj = self.objects.get(key)
+        if obj is None:
+            self._creating += 1
+            try:
+                obj = factory()
+            finally:
+                self._creating -= 1
+            self.objects[key] = obj
+            self.versions[id(weight)] = [weight, weight._version]
+            if isinstance(obj, PackedConv):
+                obj._registry = self
+                for la in obj.launches:
+                    if isinstance(la, _Launch):
+                        la["_registry"] = self
+        return obj
+
+    def create(self, factory):
+        """A lazily made member of a cached object (a Winograd layout first asked for by a launch): record its packing too."""
+        self._creating += 1
+        try:
+            return factory()
+        finally:
+            self._creating -= 1
+
+    def ensure_fresh(self, weight=None):
+        seen = self.versions.get(id(weight)) if weight is not None else None
+        if self.gen == _PARAM_GENERATION[0] and (seen is None or seen[1] == weight._version):
+            return
+        self.refresh()
+
+    def refresh(self):
+        import ctypes
+        for kind in ("sparse", "dense"):
+            jobs = self.jobs[kind]
+            if not jobs:
+                continue
+            if self._table[kind] is None:
+                self._table[kind] = _repack_table(kind, jobs)
+            table, n, blocks = self._table[kind]
+            fn = lib.sessd_sparse_pack_batch if kind == "sparse" else lib.sessd_dense_pack_batch
+            with torch.cuda.device(table.device):
+                check(fn(table.data_ptr(), n, blocks, _stream()), "%s_pack_batch" % kind)
+        self.gen = _PARAM_GENERATION[0]
+        for rec in self.versions.values():
+            rec[1] = rec[0]._version
+        self.refreshes += 1
+
+
+def _repack_table(kind, jobs):
+    import ctypes
+    i32, vp, i64 = ctypes.c_int32, ctypes.c_void_p, ctypes.c_longlong
+    if kind == "dense":
+        class Job(ctypes.Structure):
+            _fields_ = [("w", vp), ("out", vp), ("so", i64), ("sc", i64), ("tap_off", i32 * 16), ("cout", i32), ("cin", i32),
+                        ("ntaps", i32), ("kind", i32), ("flip", i32), ("layout", i32), ("block_start", i32), ("pad_", i32)]
+    else:
+        class Job(ctypes.Structure):
+            _fields_ = [("w", vp), ("out", vp), ("kv", i32), ("cin", i32), ("cout", i32), ("adjoint", i32), ("reverse_k", i32),
+                        ("block_start", i32)]
+    arr = (Job * len(jobs))()
+    start = 0
+    for a, j in zip(arr, jobs):
+        a.w, a.out, a.block_start = j["w"].data_ptr(), j["out"].data_ptr(), start
+        if kind == "dense":
+            a.so, a.sc, a.cout, a.cin, a.kind, a.flip, a.layout = j["so"], j["sc"], j["cout"], j["cin"], j["kind"], j["flip"], j["layout"]
+            a.ntaps = len(j["taps"])
+            for t, off in enumerate(j["taps"]):
+                a.tap_off[t] = int(off)
+            cp = (j["cout"] + 31) // 32 * 32
+            if j["kind"] == 0:
+                total = (j["cin"] // 2) * len(j["taps"]) * 2 * cp
+            else:
+                cpad = cp if j["layout"] == 0 else ((j["cout"] + 127) // 128 * 128 if j["layout"] == 1 else (j["cout"] + 63) // 64 * 64)
+                total = cpad * j["cin"]
+        else:
+            a.kv, a.cin, a.cout, a.adjoint, a.reverse_k = j["kv"], j["cin"], j["cout"], j["adjoint"], j["reverse_k"]
+            total = j["kv"] * j["cin"] * j["cout"]
+        start += (total + 255) // 256
+    dev = jobs[0]["out"].device
+    table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+    return table, len(jobs), start
+
+
+class batched_repack:
+    """Context: packed weights of parameters are cached in `registry` and re-packed together (see RepackRegistry)."""
+
+    def __init__(self, registry):
+        self.registry = registry
+
+    def __enter__(self):
+        self.prev = _REPACK[0]
+        _REPACK[0] = self.registry
+        return self.registry
+
+    def __exit__(self, *exc):
+        _REPACK[0] = self.prev
+        return False
+
+
+def _repack_note(kind, **job):
+    reg = _REPACK[0]
+    if reg is not None and reg.recording():
+        reg.note(kind, job)
+
+
+def _registry_for(weight):
+    """The active registry if `weight` is a parameter (a stable pointer worth caching), else None."""
+    reg = _REPACK[0]
+    return reg if reg is not None and isinstance(weight, torch.nn.Parameter) and weight.is_cuda else None
+
+
+def packed_sparse_weight(weight, mode="fwd"):
+    """Packed weight of a sparse conv layer (mode "fwd") or of its data-gradient conv ("adj": strided layers, "adj_rev": submanifold
+    layers): through the active re-pack registry for parameters, a fresh packing otherwise."""
+    make = {"fwd": lambda: sparse_pack_weight(weight), "adj": lambda: sparse_pack_weight_adjoint(weight, False),
+            "adj_rev": lambda: sparse_pack_weight_adjoint(weight, True)}[mode]
+    reg = _registry_for(weight)
+    if reg is None:
+        return make()
+    return reg.cached(("sparse", weight.data_ptr(), tuple(weight.shape), mode), weight, make)
+
+
+def packed_conv2d(weight, stride=1, adjoint=False, transposed=False):
+    """pack_conv2d / pack_deconv2d_s2 through the active re-pack registry (parameters), else a fresh packing."""
+    make = (lambda: pack_deconv2d_s2(weight)) if transposed else (lambda: pack_conv2d(weight, stride, adjoint=adjoint))
+    reg = _registry_for(weight)
+    if reg is None:
+        return make()
+    return reg.cached(("dense", weight.data_ptr(), tuple(weight.shape), int(stride), bool(adjoint), bool(transposed)), weight, make)
+
+
 def sparse_pack_weight(weight):
     """weight (kz,ky,kx,Cin,Cout) (spconv v1 layout) on the device -> packed MFMA-fragment order."""
     w = weight.detach().to(torch.float32).contiguous()
@@ -477,6 +639,7 @@ def sparse_pack_weight(weight):
     kv = w.numel() // (cin * cout)
     out = torch.empty_like(w).view(-1)
     check(lib.sessd_sparse_pack_weight(w.data_ptr(), kv, cin, cout, out.data_ptr(), _stream()), "sparse_pack_weight")
+    _repack_note("sparse", w=w, out=out, kv=kv, cin=cin, cout=cout, adjoint=0, reverse_k=0)
     return out
 
 
@@ -490,6 +653,7 @@ def sparse_pack_weight_adjoint(weight, reverse_offsets):
     out = torch.empty_like(w).view(-1)
     check(lib.sessd_sparse_pack_weight_adjoint(w.data_ptr(), kv, cin, cout, 1 if reverse_offsets else 0, out.data_ptr(), _stream()),
           "sparse_pack_weight_adjoint")
+    _repack_note("sparse", w=w, out=out, kv=kv, cin=cin, cout=cout, adjoint=1, reverse_k=1 if reverse_offsets else 0)
     return out
 
 
@@ -850,18 +1014,21 @@ class PackedConv:
         self._upk = None
         self._upk_sk = [None, None]
         self._sk = None      # argument block of sessd_conv2d_sk (tile_cfg 30), made when first asked for
+        self._registry = None  # RepackRegistry that keeps this object fresh (training step), else None
 
     @property
     def upk(self):
         """U = G g G^T packed for sessd_conv3x3_winograd (tile_cfg 20 / 21); None if the layer is not eligible."""
         if self._upk is None and self._w3 is not None and self.cin % 8 == 0:
-            self._upk = pack_winograd(self._w3[0], adjoint=self._w3[1])
+            make = lambda: pack_winograd(self._w3[0], adjoint=self._w3[1])
+            self._upk = self._registry.create(make) if self._registry is not None else make()
         return self._upk
 
     def upk_sk(self, shape):
         """U packed for sessd_conv3x3_winograd_sk (tile_cfg 22 / 23 = shape 0 / 1); None if not eligible."""
         if self._upk_sk[shape] is None and self._w3 is not None and self.cin % (16, 8)[shape] == 0:
-            self._upk_sk[shape] = pack_winograd_sk(self._w3[0], shape, adjoint=self._w3[1])
+            make = lambda: pack_winograd_sk(self._w3[0], shape, adjoint=self._w3[1])
+            self._upk_sk[shape] = self._registry.create(make) if self._registry is not None else make()
         return self._upk_sk[shape]
 
 
@@ -901,6 +1068,8 @@ def _pack_taps_view(w, out_stride, in_stride, tap_offsets, cout, cin):
     out = torch.empty((cin // 2, nt, 2, cp), dtype=torch.float32, device=w.device)
     check(lib.sessd_conv2d_pack_taps(w.data_ptr(), int(out_stride), int(in_stride), (ctypes.c_int * nt)(*[int(t) for t in tap_offsets]),
                                      nt, cout, cin, out.data_ptr(), _stream()), "conv2d_pack_taps")
+    _repack_note("dense", w=w, out=out, so=int(out_stride), sc=int(in_stride), taps=[int(t) for t in tap_offsets], cout=int(cout),
+                 cin=int(cin), kind=0, flip=0, layout=0)
     return out
 
 
@@ -912,7 +1081,9 @@ class _Launch(dict):
         if key != "wpk":
             raise KeyError(key)
         w, so, sc, taps = self["view"]
-        self["wpk"] = _pack_taps_view(w, so, sc, taps, self["_co"], self["_ci"])
+        make = lambda: _pack_taps_view(w, so, sc, taps, self["_co"], self["_ci"])
+        reg = dict.get(self, "_registry")
+        self["wpk"] = reg.create(make) if reg is not None else make()
         return self["wpk"]
 
 
@@ -958,6 +1129,8 @@ def _winograd_pack(weight, layout, adjoint):
         out = torch.empty(((co + c - 1) // c, ci // 2, nw, 2, 32, c // 32, 16 // nw), dtype=torch.float32, device=w.device)
     check(lib.sessd_conv3x3_winograd_pack(w.data_ptr(), so, sc, 1 if flip else 0, co, ci, layout, out.data_ptr(), _stream()),
           "conv3x3_winograd_pack")
+    _repack_note("dense", w=w, out=out, so=int(so), sc=int(sc), taps=[], cout=int(co), cin=int(ci), kind=1, flip=1 if flip else 0,
+                 layout=int(layout))
     return out
 
 
@@ -1301,7 +1474,7 @@ class Conv2dFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, transposed, stride):
         x = x.float().contiguous()
-        pc = pack_deconv2d_s2(weight) if transposed else pack_conv2d(weight, stride)
+        pc = packed_conv2d(weight, stride, transposed=bool(transposed))
         ctx.save_for_backward(x, weight)
         ctx.cfg = (bool(transposed), int(stride), bias is not None)
         return conv2d(x, pc, None, None if bias is None else bias.detach().float().contiguous(), False, tile_cfg=_train_cfg(pc, x))
@@ -1311,16 +1484,16 @@ class Conv2dFunction(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         transposed, stride, has_bias = ctx.cfg
         g = grad.float().contiguous()
-        w = weight.detach().float()
+        w = weight   # (the packers detach; a parameter keeps its identity for the re-pack registry)
         k = w.shape[-1]
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             if transposed:      # adjoint of a stride-2 transposed conv = the stride-2 conv with the same weight tensor
-                gx = conv2d(g, pack_conv2d(w, 2), None, None, False)
+                gx = conv2d(g, packed_conv2d(w, 2), None, None, False)
             elif stride == 2:   # adjoint of the stride-2 conv = the transposed conv with the same weight tensor
-                gx = conv2d(g, pack_deconv2d_s2(w), None, None, False)
+                gx = conv2d(g, packed_conv2d(w, 2, transposed=True), None, None, False)
             else:               # stride 1: correlation with the flipped kernel, channels swapped
-                pcd = pack_conv2d(w, 1, adjoint=True)
+                pcd = packed_conv2d(w, 1, adjoint=True)
                 gx = conv2d(g, pcd, None, None, False, tile_cfg=_train_cfg(pcd, g))
         if ctx.needs_input_grad[1]:
             gw = conv2d_wgrad(g, x, 3, 2) if transposed else conv2d_wgrad(x, g, k, stride)

@@ -221,12 +221,15 @@ class TrainStep:
         self.opt = FusedAdamEMA(self.flat_s, self.flat_t, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
         self.global_step = 0
         self.graph = None
+        self.repack = ops.RepackRegistry()   # packed weights of both networks, re-packed together after every update
         self.direct_grads = True  # gradients handed over by autograd and packed with one multi-tensor copy (FlatParams.gather_grads)
 
     def _iteration(self, example, consistency_weight, device_schedule):
         self.student.train()
         self.teacher.train()  # trainer_sessd.py:321-322: both nets in train mode
-        with ops.deferred_batch_counts():   # the 56 BatchNorm batch counters of the two networks: one launch at the end
+        # packed weights of both networks are kept and re-packed together at the first use after an update (two launches instead
+        # of ~95); the 56 BatchNorm batch counters of the two networks: one launch at the end
+        with ops.batched_repack(self.repack), ops.deferred_batch_counts():
             with torch.no_grad():
                 teacher_preds = self.teacher.forward_preds(example, raw="voxels_raw" in example)
             if self.direct_grads:
@@ -239,7 +242,8 @@ class TrainStep:
                 self.last_losses = losses
             else:
                 loss = self.loss_fn(example, self.student.forward_preds(example), teacher_preds, consistency_weight)
-        loss.backward()
+        with ops.batched_repack(self.repack):
+            loss.backward()
         if self.direct_grads:
             self.flat_s.gather_grads()
         allreduce_flat(self.flat_s.grad)
@@ -284,6 +288,8 @@ class TrainStep:
         # (tests/test_train_gpu.py, three trainers in one process; not reproduced with the output outside the pool)
         self.static_loss = torch.zeros((), dtype=torch.float32, device=self.flat_s.data.device)
         ops.new_capture_epoch()   # scratch caches: nothing allocated by an earlier capture is reused in this one
+        if self.repack is not None:
+            self.repack.gen = -1  # the batched re-pack of all weights is the captured iteration's first two launches
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss, _, _ = self._iteration(example, consistency_weight, True)

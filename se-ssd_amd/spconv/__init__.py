@@ -72,7 +72,7 @@ def _adjoint_pack(weight, reverse_offsets):
     cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
     steps = cout // 4
     if weight.is_cuda and cin % 16 == 0 and cout % 4 == 0 and (steps <= 4 or steps % 4 == 0):
-        return ops.sparse_pack_weight_adjoint(weight, reverse_offsets)
+        return ops.packed_sparse_weight(weight, "adj_rev" if reverse_offsets else "adj")
     w = weight.detach().reshape(-1, cin, cout)
     if reverse_offsets:
         w = w.flip(0)
@@ -87,7 +87,7 @@ class IndiceConvFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feats, weight, bias, nbr, tm, n_out, n_in=None, subm=False):
         cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
-        out = ops.sparse_conv(feats, nbr, tm, n_out, ops.sparse_pack_weight(weight), cin, cout, None, bias, relu=False)
+        out = ops.sparse_conv(feats, nbr, tm, n_out, ops.packed_sparse_weight(weight, "fwd"), cin, cout, None, bias, relu=False)
         if n_in is None:
             ctx.save_for_backward(feats, weight, nbr, tm, n_out)
         else:  # capacity mode: the input table's live row count lives on the device
@@ -144,6 +144,8 @@ class SparseConvolution(SparseModule):
             self.weight.uniform_(-bound, bound)
 
     def _wpk(self):
+        if ops._registry_for(self.weight) is not None:   # inside a training iteration: kept and re-packed with all other layers
+            return ops.packed_sparse_weight(self.weight, "fwd")
         key = (self.weight.data_ptr(), self.weight._version, str(self.weight.device), ops.param_generation())
         if self._packed is None or self._packed[0] != key:
             self._packed = (key, ops.sparse_pack_weight(self.weight))

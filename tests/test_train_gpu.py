@@ -401,3 +401,39 @@ def test_graph_safe_reductions(dev):
         g.replay()
         want = float(fresh.double().mean() + fresh[0, :2].double().sum())
         assert abs(float(out) - want) <= 1e-5 * max(1.0, abs(want)), (it, float(out), want)
+
+
+def test_batched_repack_gives_the_same_iterations(dev):
+    """ops.RepackRegistry (TrainStep.repack): the packed weights of both networks kept across iterations and re-packed together in
+    two launches after every update, vs a fresh packing at every use (repack = None). Packing is a permutation (+ the exact
+    float64-rounded-once Winograd transform): the same losses and the same parameters, bit for bit, after three iterations; one
+    refresh per iteration; no job is added after the first iteration."""
+    def make(batched):
+        model = configs.build_synthetic_detector(dev, seed=0)
+        st = strain.TrainStep(model, loss_fn=lambda ex, sp, tp, w: _loss(sp) + 0.1 * w * ops.mean_all((sp[0]["cls_preds"] - tp[0]["cls_preds"]).pow(2)),
+                              total_steps=20)
+        if not batched:
+            st.repack = None
+        return st
+    a, b = make(True), make(False)
+    exs = [_example(dev, seeds, 9000, 8000)[1] for seeds in ((71, 72), (73, 74), (75, 76))]
+    jobs = None
+    for i, ex in enumerate(exs):
+        la, _, _ = a(ex)
+        lb, _, _ = b(ex)
+        torch.cuda.synchronize()
+        assert float(la) == float(lb), (i, float(la), float(lb))
+        assert torch.equal(a.flat_s.data, b.flat_s.data) and torch.equal(a.flat_t.data, b.flat_t.data)
+        n = (len(a.repack.jobs["sparse"]), len(a.repack.jobs["dense"]))
+        if jobs is not None:
+            assert n == jobs
+        jobs = n
+        assert a.repack.refreshes == i + 1
+    assert jobs[0] >= 14 * 3 - 2 and jobs[1] >= 30   # 14 sparse layers x 3 roles (the first layer has no data gradient); SSFA layouts
+    # a parameter changed behind the registry's back (in-place, version bump) is re-packed at its next use
+    with torch.no_grad():
+        a.student.backbone.middle_conv[3].weight.mul_(1.5)
+        b.student.backbone.middle_conv[3].weight.mul_(1.5)
+    la, _, _ = a(exs[0])
+    lb, _, _ = b(exs[0])
+    assert float(la) == float(lb)
