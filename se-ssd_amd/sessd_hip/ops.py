@@ -598,10 +598,10 @@ class batched_repack:
         return False
 
 
-def _repack_note(kind, **job):
+def _repack_note(group, **job):
     reg = _REPACK[0]
     if reg is not None and reg.recording():
-        reg.note(kind, job)
+        reg.note(group, job)
 
 
 def _registry_for(weight):
