@@ -237,7 +237,7 @@ int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, i
                               const float* gamma, const float* save_mean, const float* save_invstd, int relu, float* dx,
                               float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
 /* The same gradients without the forward output y: the ReLU mask is re-derived from x with the forward's gamma / beta (the
- * forward computes its pre-ReLU value in one fixed instruction sequence, so the mask is the same bit for bit); both launches read
+ * forward computes its pre-ReLU value with the same roundings, so the mask is the same bit for bit); both launches read
  * one tensor less. */
 int sessd_bn2d_relu_train_bwd_x(const float* dy, const float* x, int batch, int channels, int plane, const float* gamma,
                                 const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,

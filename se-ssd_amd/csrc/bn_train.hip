@@ -296,11 +296,15 @@ namespace {
 
 constexpr int BN2D_SPLIT = 16;   // plane slices per channel: C x 16 blocks of partial sums
 
-// The normalised, scaled and shifted value before the ReLU, in ONE fixed instruction sequence (sub, mul, fma): the forward
-// writes max(0, z) and a backward that is not given y re-derives the ReLU mask as z > 0 from x -- the same bits, so the same mask.
-__device__ __forceinline__ float bn2d_z(float x, float mu, float is, float g, float bt) {
-  return __fmaf_rn(__fmul_rn(__fsub_rn(x, mu), is), g, bt);
-}
+// The normalised, scaled and shifted value before the ReLU. This file is compiled with -ffp-contract=off (build.py), so the
+// expression is the same four roundings (sub, mul, mul, add) wherever it is inlined: the forward writes max(0, z) and a backward
+// that is not given y re-derives the ReLU mask as z > 0 from x -- the same bits, so the same mask
+// (tests/test_bn_train_gpu.py::test_dense_backward_mask_from_x_equals_mask_from_y). The FORM matters beyond that: with an fma in
+// its place (one rounding fewer) the whole-detector gradients moved by 1.5e-3 in norm on the layers behind deconv_block_0 --
+// the BEV map is mostly empty, thousands of pixels of a channel carry the SAME value, and where that value sits at the ReLU
+// threshold a last-bit change switches all of them at once; the four-rounding form is the one torch's CPU BatchNorm (the
+// oracle) agrees with to 1e-5 (scripts/dbg_grad_dump.py, three hybrid builds).
+__device__ __forceinline__ float bn2d_z(float x, float mu, float is, float g, float bt) { return (x - mu) * is * g + bt; }
 
 constexpr int BN2D_MAX_CHANNELS = 1024;
 // one counter word per channel in a region of FIXED size: one workspace serves calls with different channel counts
@@ -519,7 +523,7 @@ int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, i
 }
 
 // The same without the forward output: the ReLU mask is re-derived from x with the forward's gamma / beta (the forward computes
-// z in one fixed instruction sequence, so z > 0 here is y > 0 there, bit for bit) -- one tensor less to read in both launches.
+// z with the same roundings, so z > 0 here is y > 0 there, bit for bit) -- one tensor less to read in both launches.
 int sessd_bn2d_relu_train_bwd_x(const float* dy, const float* x, int batch, int channels, int plane, const float* gamma,
                                 const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
                                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
