@@ -529,13 +529,21 @@ class RepackRegistry:
             return
         self.refresh()
 
+    def prepare(self):
+        """Upload the job tables now (a host-to-device copy: not allowed inside a stream capture)."""
+        for kind in ("sparse", "dense"):
+            if self.jobs[kind] and self._table[kind] is None:
+                self._table[kind] = _repack_table(kind, self.jobs[kind])
+
     def refresh(self):
-        import ctypes
         for kind in ("sparse", "dense"):
             jobs = self.jobs[kind]
             if not jobs:
                 continue
             if self._table[kind] is None:
+                if torch.cuda.is_current_stream_capturing():
+                    raise RuntimeError("RepackRegistry: a packing was recorded that no eager iteration has run yet; run one warm-up "
+                                       "iteration (or registry.prepare()) before capturing")
                 self._table[kind] = _repack_table(kind, jobs)
             table, n, blocks = self._table[kind]
             fn = lib.sessd_sparse_pack_batch if kind == "sparse" else lib.sessd_dense_pack_batch

@@ -289,7 +289,8 @@ class TrainStep:
         self.static_loss = torch.zeros((), dtype=torch.float32, device=self.flat_s.data.device)
         ops.new_capture_epoch()   # scratch caches: nothing allocated by an earlier capture is reused in this one
         if self.repack is not None:
-            self.repack.gen = -1  # the batched re-pack of all weights is the captured iteration's first two launches
+            self.repack.prepare()  # job tables of everything the warm-up iterations packed: uploaded before the capture
+            self.repack.gen = -1   # the batched re-pack of all weights is the captured iteration's first two launches
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss, _, _ = self._iteration(example, consistency_weight, True)
