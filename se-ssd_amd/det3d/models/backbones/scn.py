@@ -15,6 +15,7 @@ class SpMiddleFHD(nn.Module):
     def __init__(self, num_input_features=128, norm_cfg=None, name="SpMiddleFHD", **kwargs):
         super().__init__()
         self.name = name
+        self.chain_tables = True   # capacity mode: sites + neighbour tables of all layers from one ops.SparseChain run (spconv.ChainPlan)
         self.dcn = None
         self.zero_init_residual = False
         if norm_cfg is None:
@@ -56,6 +57,12 @@ class SpMiddleFHD(nn.Module):
             err.zero_()
         ret = spconv.SparseConvTensor(voxel_features, coors, sparse_shape, batch_size, n_dev=n_dev, err=err)
         self.last_err = ret.err
+        if n_dev is not None and self.chain_tables:
+            # every resolution's sites and every layer's neighbour table in one chain of ~8 launches (spconv.ChainPlan)
+            key = spconv.ChainPlan.key_of(ret)
+            if getattr(self, "_plan", None) is None or self._plan.key != key:
+                self._plan = spconv.ChainPlan([m for m in self.middle_conv._modules.values() if isinstance(m, spconv.SparseConvolution)], ret)
+            self._plan.run(ret)
         ret = self.middle_conv(ret)
         ret = ret.dense()
         N, C, D, H, W = ret.shape

@@ -66,6 +66,56 @@ class SparseModule(nn.Module):
     pass
 
 
+class ChainPlan:
+    """Capacity mode: the site tables of every deeper resolution and the neighbour tables of EVERY conv layer of a sequence, built
+    together by ops.SparseChain (csrc/sparse_sites.hip: ~8 launches for the 14 layers of SpMiddleFHD) instead of 3 - 5 launches
+    per resolution (hash build, site generation, one rulebook per indice_key; 50 launches and their table fills for the two
+    networks of a training iteration). Buffers are allocated once per plan and reused by every pass; deeper levels are numbered
+    in ascending (b, z, y, x) order. A conv layer finds its tables through the tensor's indice_dict["__chain__"]."""
+
+    def __init__(self, convs, x):
+        steps, caps, jobs, subm_job = [], [], [], {}
+        self.job_of, self.level_of = {}, {}
+        level, shape, growth, cap = 0, list(x.spatial_shape), list(x.growth), int(x.indices.shape[0])
+        for m in convs:
+            if m.subm:
+                key = (level, tuple(m.kernel_size))
+                if key not in subm_job:
+                    subm_job[key] = len(jobs)
+                    jobs.append((level, level, m.kernel_size, 1, [k // 2 for k in m.kernel_size]))
+                self.job_of[id(m)] = subm_job[key]
+            else:
+                shape = [(d + 2 * p - k) // s + 1 for d, k, s, p in zip(shape, m.kernel_size, m.stride, m.padding)]
+                g = growth.pop(0) if growth else float(min(int(np.prod(m.kernel_size)), 8))
+                cap = max(64, (min(x.batch_size * int(np.prod(shape)), int(math.ceil(g * cap))) + 63) // 64 * 64)
+                steps.append((m.kernel_size, m.stride, m.padding))
+                caps.append(cap)
+                self.job_of[id(m)] = len(jobs)
+                jobs.append((level, level + 1, m.kernel_size, m.stride, m.padding))
+                level += 1
+                self.level_of[id(m)] = level
+        self.key = ChainPlan.key_of(x)
+        self.chain = ops.SparseChain(x.spatial_shape, steps, caps, x.batch_size, jobs, x.indices.device)
+        self.chain.bind_tables(int(x.indices.shape[0]))
+
+    @staticmethod
+    def key_of(x):
+        return (int(x.indices.shape[0]), tuple(x.spatial_shape), x.batch_size, str(x.indices.device), tuple(x.growth))
+
+    def run(self, x):
+        h, n = x._hash()
+        self.chain.run(x.indices, n.data_ptr(), int(x.indices.shape[0]), h, x.err, clear=True)
+        x.indice_dict["__chain__"] = self
+
+    def tables(self, conv):
+        j = self.job_of[id(conv)]
+        return self.chain.nbr[j], self.chain.tile_mask[j]
+
+    def level(self, conv):
+        l = self.level_of[id(conv)]
+        return self.chain.indices[l - 1], self.chain.n_dev[l - 1], self.chain.shapes[l]
+
+
 def _adjoint_pack(weight, reverse_offsets):
     """Packed weight of the conv that computes a sparse layer's data gradient (per offset W_k^T; offsets reversed for a
     submanifold layer): one launch from the stored weight where the pack kernel covers the shape, else flip / transpose / pack."""
@@ -153,8 +203,23 @@ class SparseConvolution(SparseModule):
 
     def forward(self, x):
         assert isinstance(x, SparseConvTensor)
-        in_hash, n_in = x._hash()
-        if self.subm:
+        plan = x.indice_dict.get("__chain__") if x.n_dev is not None else None
+        if plan is not None and id(self) not in plan.job_of:
+            plan = None
+        if plan is None:
+            in_hash, n_in = x._hash()
+        if plan is not None:   # sites and tables of this layer were built with all the others (ChainPlan): no hash of this level
+            n_in = x.n_dev
+            nbr, tm = plan.tables(self)
+            if self.subm:
+                out = SparseConvTensor(None, x.indices, x.spatial_shape, x.batch_size, n_dev=x.n_dev, err=x.err, growth=x.growth)
+                out.indice_dict = x.indice_dict
+                n_out = n_in
+            else:
+                oidx, n_out, oshape = plan.level(self)
+                out = SparseConvTensor(None, oidx, oshape, x.batch_size, n_dev=n_out, err=x.err, growth=x.growth[1:])
+                out.indice_dict["__chain__"] = plan
+        elif self.subm:
             cached = x.find_indice_pair(self.indice_key)
             if cached is None:
                 nbr, tm = ops.sparse_rulebook(x.indices, n_in, self.kernel_size, 1, [k // 2 for k in self.kernel_size], in_hash)

@@ -437,3 +437,28 @@ def test_batched_repack_gives_the_same_iterations(dev):
     la, _, _ = a(exs[0])
     lb, _, _ = b(exs[0])
     assert float(la) == float(lb)
+
+
+def test_chain_tables_equal_per_layer_tables(dev):
+    """SpMiddleFHD in capacity mode with all site / neighbour tables from ONE ops.SparseChain run (spconv.ChainPlan, `chain_tables`)
+    vs the per-layer construction (hash build + site generation + one rulebook per indice_key): the same BEV map and the same
+    parameter gradients (rows of the deeper levels are numbered differently: sums in another order, 1e-5 of the scale); no overflow."""
+    import copy
+    model = configs.build_synthetic_detector(dev, seed=0)
+    a = model.backbone.train()
+    b = copy.deepcopy(a)
+    a.chain_tables, b.chain_tables = True, False
+    _, ex = _example(dev, (81, 82), 9000, 8000)
+    cap = strain.capacity_example(ex, 16384)
+    outs = []
+    for m in (a, b):
+        feats = model.reader(cap["voxels"], cap["num_points"])
+        y = m(feats, cap["coordinates"], 2, cap["shape"][0], n_dev=cap["num_voxels_dev"])
+        (y * torch.linspace(0.5, 1.5, y.numel(), device=dev).view_as(y)).sum().backward()
+        assert int(m.last_err.item()) == 0
+        outs.append(y.detach())
+    scale = float(outs[1].abs().max())
+    assert float((outs[0] - outs[1]).abs().max()) <= 1e-5 * scale
+    for (na, pa), (nb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert pa.grad is not None and float((pa.grad - pb.grad).abs().max()) <= 2e-4 * max(1e-6, float(pb.grad.abs().max())), na
+    assert a._plan is not None and getattr(b, "_plan", None) is None
