@@ -126,17 +126,17 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   const int G = NT / C, c = tid % C, g = tid / C;   // G groups of blocks per channel
   double t0 = 0.0, t1 = 0.0;
   const int nb = (int)gridDim.x;
-  for (int b = g; b < nb; b += 8 * G) {
-    double a0[8], a1[8];
+  for (int b = g; b < nb; b += 16 * G) {   // 32 loads in flight per thread: these loads go past the L2, a round trip each
+    double a0[16], a1[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < 16; ++k) {
       const int bb = b + k * G;
       const bool ok = bb < nb;
       a0[k] = ok ? get_partial(partial + ((size_t)bb * 2 + 0) * C + c) : 0.0;
       a1[k] = ok ? get_partial(partial + ((size_t)bb * 2 + 1) * C + c) : 0.0;
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { t0 += a0[k]; t1 += a1[k]; }
+    for (int k = 0; k < 16; ++k) { t0 += a0[k]; t1 += a1[k]; }
   }
   sm[0][tid] = t0;
   sm[1][tid] = t1;

@@ -128,6 +128,79 @@ __global__ __launch_bounds__(64) void conv_wgrad_partial_kernel(WgArgs A) {
   }
 }
 
+// 1x1 convs with >= 64 channels on both sides (trans_0 / trans_1 of the SSFA neck): a plain GEMM dW[co][ci] = sum over pixels of
+// g[co][p] x[ci][p]. The general kernel above has ONE accumulator per wave for a 1x1 (two 16-byte loads per four MFMAs:
+// load-bound, 47 TFLOP/s); here a wave owns a 64 co x 64 ci block (2 x 2 accumulators: four loads per sixteen MFMAs), the row
+// chunks are four times finer to keep the chip filled. Same lane layout and summation rule (row chunks summed in order).
+__global__ __launch_bounds__(64) void conv1x1_wgrad_partial_kernel(WgArgs A) {
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int cib_n = sessd_divup(A.ci, 64);
+  const int cob = blockIdx.x / cib_n, cib = blockIdx.x - cob * cib_n;
+  const int R = A.batch * A.ho;
+  const int r0 = blockIdx.y * A.rows_per_chunk, r1 = min(R, r0 + A.rows_per_chunk);
+  const rsrc_t gr = make_rsrc(A.gout, (unsigned)((size_t)A.batch * A.co * A.ho * A.wo * 4));
+  const rsrc_t xr = make_rsrc(A.inp, (unsigned)((size_t)A.batch * A.ci * A.hi * A.wi * 4));
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const int b = r / A.ho, y = r - b * A.ho;
+    unsigned grow[2], xrow[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      const int co = cob * 64 + m * 32 + i, ci = cib * 64 + m * 32 + i;
+      grow[m] = co < A.co ? (unsigned)((((size_t)b * A.co + co) * A.ho + y) * A.wo * 4) : SESSD_OOB;
+      xrow[m] = ci < A.ci ? (unsigned)((((size_t)b * A.ci + ci) * A.hi + y) * A.wi * 4) : SESSD_OOB;
+    }
+    f32x4 a[2][2], bt[2][2];   // [set][block]
+#define SESSD_W1_LOAD(SET, X0)                                                                     \
+  {                                                                                                \
+    const unsigned xo = (unsigned)((X0) + 4 * h) * 4u;                                             \
+    const bool in = (X0) < A.wo;                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                \
+      a[SET][m] = ld4(gr, (grow[m] == SESSD_OOB || !in) ? SESSD_OOB : grow[m] + xo);               \
+      bt[SET][m] = ld4(xr, (xrow[m] == SESSD_OOB || !in) ? SESSD_OOB : xrow[m] + xo);              \
+    }                                                                                              \
+  }
+#define SESSD_W1_MMA(SET)                                                                          \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c)                                                    \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[SET][m][c], bt[SET][n][c], acc[m][n], 0, 0, 0);
+    SESSD_W1_LOAD(0, 0)
+    for (int x0 = 0; x0 < A.wo; x0 += 16) {
+      SESSD_W1_LOAD(1, x0 + 8)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_W1_MMA(0)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_W1_LOAD(0, x0 + 16)
+      __builtin_amdgcn_sched_barrier(0);
+      SESSD_W1_MMA(1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SESSD_W1_LOAD
+#undef SESSD_W1_MMA
+  }
+  float* dst = A.partial + (size_t)blockIdx.y * A.co * A.ci;
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int ci = cib * 64 + n * 32 + i;
+      if (ci < A.ci) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int cor = cob * 64 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (cor < A.co) dst[(size_t)cor * A.ci + ci] = acc[m][n][e];
+        }
+      }
+    }
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int total,
                                                                  float* __restrict__ gw) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -145,13 +218,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
 }
 
 constexpr int WG_MAX_CHUNKS = 64;
+constexpr int W1_MAX_CHUNKS = 256;   // conv1x1_wgrad_partial_kernel: 64 x 64 wave tiles, finer row chunks
 
 }  // namespace
 
 extern "C" {
 
 size_t sessd_conv2d_wgrad_workspace_bytes(int cout, int cin, int ksize) {
-  return (size_t)WG_MAX_CHUNKS * cout * cin * ksize * ksize * sizeof(float);
+  return (size_t)(ksize == 1 ? W1_MAX_CHUNKS : WG_MAX_CHUNKS) * cout * cin * ksize * ksize * sizeof(float);
 }
 
 // grad_weight (cout, cin, k, k) of Conv2d(cin, cout, k, stride, padding = k/2, bias-free part): input (B, cin, hin, win),
@@ -172,6 +246,22 @@ int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win,
   WgArgs A;
   A.inp = input; A.gout = grad_out; A.partial = (float*)workspace;
   A.batch = batch; A.ci = cin; A.hi = hin; A.wi = win; A.co = cout; A.ho = hout; A.wo = wout;
+  if (ksize == 1 && cout >= 64 && cin >= 64) {
+    const int tiles = sessd_divup(cout, 64) * sessd_divup(cin, 64), rows = batch * hout;
+    int nchunks = 1024 / tiles;
+    nchunks = nchunks < 8 ? 8 : (nchunks > W1_MAX_CHUNKS ? W1_MAX_CHUNKS : nchunks);
+    if (nchunks > rows) nchunks = rows;
+    A.rows_per_chunk = sessd_divup(rows, nchunks);
+    nchunks = sessd_divup(rows, A.rows_per_chunk);
+    A.cib_n = sessd_divup(cin, 64);
+    SESSD_LAUNCH(conv1x1_wgrad_partial_kernel, dim3(tiles, nchunks), dim3(64), 0, stream, A);
+    SESSD_CHECK_LAUNCH();
+    const int total = cout * cin;
+    SESSD_LAUNCH(conv_wgrad_reduce_kernel, dim3(sessd_divup(total, 256)), dim3(256), 0, stream, (const float*)workspace, nchunks,
+                 total, grad_weight);
+    SESSD_CHECK_LAUNCH();
+    return SESSD_OK;
+  }
   const int cob_n = sessd_divup(cout, 32);
   A.cib_n = sessd_divup(cin, 32);
   const int tiles = cob_n * A.cib_n, rows = batch * hout;

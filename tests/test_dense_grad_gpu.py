@@ -24,6 +24,8 @@ CASES = [
     ("conv", 16, 48, 3, 2, 32, 48, False),
     ("conv", 32, 16, 1, 1, 24, 40, False),
     ("conv", 16, 22, 1, 1, 16, 24, True),
+    ("conv", 128, 128, 1, 1, 40, 48, False),   # 1x1 with >= 64 channels: the 64 x 64 wave-tile weight-gradient kernel
+    ("conv", 64, 160, 1, 1, 12, 24, True),    # ... with a ragged channel block
     ("deconv", 32, 16, 3, 2, 12, 24, False),
     ("deconv", 256, 128, 3, 2, 20, 16, False),
 ]
