@@ -24,7 +24,9 @@
 
 namespace {
 
-constexpr int BN_BLOCKS = 256;        // one per CU
+constexpr int BN_BLOCKS = 128;        // statistics blocks. The finishing block reads 2 x C doubles per block past the L2 (~65 GB/s for
+                                      // one block): 256 blocks made the finisher the longer half of the launch (14.4 us), 64 starve the
+                                      // row pass; measured on the captured iteration: 256 -> 15.09 ms, 128 -> 15.01, 64 -> 15.16
 constexpr int NT = 256;
 constexpr size_t BN_COUNTER_BYTES = 256;
 
