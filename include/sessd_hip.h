@@ -249,6 +249,15 @@ int sessd_bn2d_relu_train_bwd_x(const float* dy, const float* x, int batch, int 
  * points (num_points, point_stride) float32; planes (num_bodies, faces, 4) float32 [nx,ny,nz,d], inward normals, from the host
  * (geometry.py:352-377 arithmetic); out_mask (num_points, ceil(num_bodies/32)) uint32, bit set = strictly inside
  * (x*nx + y*ny + z*nz + d < 0 for every face, float32, left to right, no contraction: identical to the numba loop). */
+/* HOST functions (no device work): the box-level decisions of the same stage -- det3d/core/sampler/preprocess.py:944-1027
+ * box_collision_test and :579-611 noise_per_box (numba in the reference; sequential over tens of boxes, so they stay on the
+ * host even when the cloud is on the device). boxes / qboxes / corners: (n, 4, 2) BEV corners, float32 (is_f32) or float64;
+ * the arithmetic is that of the numpy mirror in that precision, decisions identical. out (n, k) uint8. noise_per_box: corners
+ * are updated in place with the accepted moves; loc_xy (n, tries, 2), sin_r / cos_r (n, tries) float64; chosen (n) int64 = first
+ * collision-free candidate or -1. */
+int sessd_box_collision_host(const void* boxes, int n, const void* qboxes, int k, int is_f32, int clockwise, uint8_t* out);
+int sessd_noise_per_box_host(void* corners, const void* centers, const uint8_t* valid, const double* loc_xy, const double* sin_r,
+                             const double* cos_r, int n, int tries, int is_f32, int64_t* chosen);
 int sessd_points_in_bodies(const float* points, int num_points, int point_stride, const float* planes, int num_bodies,
                            int faces, uint32_t* out_mask, sessd_stream_t stream);
 /* det3d/core/sampler/preprocess.py:544-560 points_transform_ (the point side of noise_per_object_v4_): in place, every point takes

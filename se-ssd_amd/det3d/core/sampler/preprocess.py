@@ -96,9 +96,42 @@ def mask_points_in_corners(points, box_corners):
     return points_in_convex_polygon_3d_jit(points[:, :3], box_np_ops.corner_to_surfaces_3d(box_corners))
 
 
+def _native():
+    """libsessd_hip.so's host functions for the box-level decisions (csrc/host_boxes.hip), or None if the library cannot be
+    loaded in this process (then the numpy forms below run: same decisions, ~10x the time)."""
+    global _NATIVE
+    if _NATIVE is None:
+        try:
+            from sessd_hip._lib import lib
+            _NATIVE = lib if hasattr(lib, "sessd_box_collision_host") else False
+        except Exception:  # noqa: BLE001 -- a data-loader worker without the library still works
+            _NATIVE = False
+    return _NATIVE or None
+
+
+_NATIVE = None
+USE_NATIVE_BOX_OPS = True
+
+
 def box_collision_test(boxes, qboxes, clockwise=True):
     """(N, 4, 2) x (K, 4, 2) BEV quadrilaterals -> (N, K) bool: their bounding rectangles overlap and either two edges cross
-    or one quadrilateral lies inside the other (preprocess.py:944-1027; the branch structure of the numba kernel -- compiled,
+    or one quadrilateral lies inside the other (preprocess.py:944-1027). Runs sessd_box_collision_host (plain C++, the same
+    arithmetic in the arrays' precision) when both arrays are float32 or both float64; box_collision_test_numpy otherwise."""
+    lib = _native() if USE_NATIVE_BOX_OPS else None
+    if lib is not None and boxes.dtype == qboxes.dtype and boxes.dtype in (np.float32, np.float64) and boxes.ndim == 3 \
+            and boxes.shape[1:] == (4, 2) and qboxes.shape[1:] == (4, 2):
+        a, b = np.ascontiguousarray(boxes), np.ascontiguousarray(qboxes)
+        out = np.empty((a.shape[0], b.shape[0]), dtype=np.uint8)
+        rc = lib.sessd_box_collision_host(a.ctypes.data, a.shape[0], b.ctypes.data, b.shape[0], 1 if a.dtype == np.float32 else 0,
+                                          1 if clockwise else 0, out.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("sessd_box_collision_host: %d" % rc)
+        return out.astype(np.bool_)
+    return box_collision_test_numpy(boxes, qboxes, clockwise)
+
+
+def box_collision_test_numpy(boxes, qboxes, clockwise=True):
+    """The vectorised numpy form of box_collision_test (the branch structure of the reference's numba kernel -- compiled,
     `flag is False` compares values -- collapses to this expression)."""
     sa, sb = box_np_ops.corner_to_standup_nd_jit(boxes), box_np_ops.corner_to_standup_nd_jit(qboxes)
     iw = np.minimum(sa[:, None, 2], sb[None, :, 2]) - np.maximum(sa[:, None, 0], sb[None, :, 0])
@@ -129,6 +162,23 @@ def noise_per_box(boxes, valid_mask, loc_noises, rot_noises):
     accepted move is what later boxes are tested against; boxes outside valid_mask stay but still block (preprocess.py:579-611)."""
     n = boxes.shape[0]
     corners = box_np_ops.box2d_to_corner_jit(boxes)
+    lib = _native() if USE_NATIVE_BOX_OPS else None
+    if lib is not None and n and boxes.dtype in (np.float32, np.float64) and rot_noises.shape[1]:
+        # the sequential loop in C++ (sessd_noise_per_box_host); sines / cosines of the candidates from numpy, so that the
+        # candidate footprints are the numpy form's bit for bit
+        corners = np.ascontiguousarray(corners)
+        centers = np.ascontiguousarray(boxes[:, :2])
+        valid = np.ascontiguousarray(np.asarray(valid_mask, dtype=np.uint8))
+        rot = np.ascontiguousarray(rot_noises, dtype=np.float64)
+        loc_xy = np.ascontiguousarray(np.asarray(loc_noises, dtype=np.float64)[:, :, :2])
+        sin_r, cos_r = np.sin(rot), np.cos(rot)
+        chosen = np.empty((n,), dtype=np.int64)
+        rc = lib.sessd_noise_per_box_host(corners.ctypes.data, centers.ctypes.data, valid.ctypes.data, loc_xy.ctypes.data,
+                                          sin_r.ctypes.data, cos_r.ctypes.data, n, rot.shape[1], 1 if boxes.dtype == np.float32 else 0,
+                                          chosen.ctypes.data)
+        if rc != 0:
+            raise RuntimeError("sessd_noise_per_box_host: %d" % rc)
+        return chosen
     chosen = -np.ones((n,), dtype=np.int64)
     for i in range(n):
         if not valid_mask[i]:
@@ -142,7 +192,7 @@ def noise_per_box(boxes, valid_mask, loc_noises, rot_noises):
             cand[..., 0] = local[None, :, 0] * c + local[None, :, 1] * s
             cand[..., 1] = local[None, :, 0] * -s + local[None, :, 1] * c
             cand += (boxes[i, :2] + loc_noises[i, t0:t1, :2])[:, None, :]
-            hit = box_collision_test(cand, corners)
+            hit = box_collision_test_numpy(cand, corners)
             hit[:, i] = False
             free = np.nonzero(~hit.any(axis=1))[0]
             if free.size:
