@@ -97,3 +97,45 @@ def test_sparse_entry_points_reject_what_their_kernels_cannot_cover():
     assert lib.sessd_sparse_hash_build(None, None, 16, C.cast(big, C.c_void_p), None, None, 64, None) == -1
     assert lib.sessd_sparse_hash_build(None, None, 16, None, None, None, 64, None) == -1
     assert lib.sessd_sparse_hash_build(None, None, 16, C.cast(dims0, C.c_void_p), None, None, 48, None) == -1  # capacity not a power of two
+
+
+def test_round3_training_entry_points_reject_bad_arguments_before_touching_the_device():
+    """Argument checks of the training-path entry points of round 3, before any device call (null pointers, no GPU):
+    the Winograd-domain weight gradient's shape rule and workspace arithmetic, the fused SSFA attention tail, the train-mode
+    BatchNorm layouts, the batched packers, the channel sum and the host box functions."""
+    import ctypes as C
+    import numpy as np
+    import sessd_hip
+    lib = sessd_hip.lib
+    wb = lib.sessd_conv3x3_wgrad_winograd_workspace_bytes
+    # covered: cin, cout % 64, even H, W >= 16;  64 chunks x 16 xi x cin x cout floats for the SSFA layers at batch 4
+    assert wb(4, 128, 128, 200, 176) == 64 * 16 * 128 * 128 * 4 and wb(4, 256, 256, 100, 88) == 16 * 16 * 256 * 256 * 4
+    assert wb(1, 48, 128, 64, 64) == 0 and wb(1, 128, 128, 63, 64) == 0 and wb(1, 128, 128, 64, 12) == 0 and wb(0, 128, 128, 64, 64) == 0
+    assert lib.sessd_conv3x3_wgrad_winograd(None, 1, 128, 64, 64, None, 128, None, None, 0, None) == -1        # null tensors
+    assert lib.sessd_conv3x3_wgrad_winograd(16, 1, 128, 64, 64, 16, 128, 16, None, 0, None) == -2               # workspace too small
+    # fused SSFA tail: channels % 4, plane % 4, all-or-none running statistics
+    sb = lib.sessd_ssfa_fuse_train_workspace_bytes
+    assert sb(4, 128, 35200) > 4352 and sb(4, 126, 35200) == 0 and sb(4, 128, 35202) == 0 and sb(0, 128, 64) == 0
+    assert lib.sessd_ssfa_fuse_train_fwd(None, None, 1, 128, 64, None, None, None, None, None, None, 1e-3, 0.01, None, None, None, None, None,
+                                         None, None, None, 0, None) == -1
+    assert lib.sessd_ssfa_fuse_train_fwd(16, 16, 1, 128, 64, 16, 16, None, None, None, None, 1e-3, 0.01, 16, None, None, None, 16, 16, 16, 16,
+                                         1 << 20, None) == -1   # one of the four running-statistics pointers
+    # train-mode BatchNorm: power-of-two channels <= 256 (sparse layout), plane % 4 and <= 1024 channels (dense layout)
+    assert lib.sessd_bn_relu_train_fwd(None, None, 64, 24, None, None, 1e-3, 0.01, 1, None, None, None, None, None, None, 0, None) == -1
+    assert lib.sessd_bn_relu_train_fwd(None, None, 64, 16, None, None, 1e-3, 0.01, 1, None, None, None, None, None, None, 0, None) == -2
+    assert lib.sessd_bn2d_relu_train_fwd(None, 1, 8, 30, None, None, 1e-3, 0.01, 1, None, None, None, None, None, None, 0, None) == -1
+    assert lib.sessd_bn2d_relu_train_bwd_x(None, None, 1, 2048, 64, None, None, None, None, 1, None, None, None, None, 0, None) == -1
+    assert lib.sessd_bn2d_relu_train_bwd(None, None, None, 1, 8, 64, None, None, None, 1, None, 16, 16, 16, 1 << 20, None) == -1   # relu without y
+    assert lib.sessd_nchw_channel_sum(None, 1, 8, 30, None, None, 0, None) == -1
+    assert lib.sessd_bn2d_relu_train_workspace_bytes(128) == 4096 + 128 * 16 * 2 * 8
+    assert lib.sessd_bn_relu_train_workspace_bytes(64) == 256 + 128 * 2 * 64 * 8
+    # batched packers, adjoint pack
+    assert lib.sessd_dense_pack_batch(None, 3, 10, None) == -1 and lib.sessd_sparse_pack_batch(16, 0, 10, None) == -1
+    assert lib.sessd_sparse_pack_weight_adjoint(None, 27, 24, 64, 1, None, None) == -1
+    # host box functions run here: two overlapping unit squares, one far away
+    sq = np.array([[[0, 0], [0, 1], [1, 1], [1, 0]]], dtype=np.float64)
+    qs = np.concatenate([sq + 0.5, sq + 5.0], 0)
+    out = np.zeros((1, 2), dtype=np.uint8)
+    assert lib.sessd_box_collision_host(sq.ctypes.data, 1, qs.ctypes.data, 2, 0, 1, out.ctypes.data) == 0 and out.tolist() == [[1, 0]]
+    assert lib.sessd_box_collision_host(None, 1, qs.ctypes.data, 2, 0, 1, out.ctypes.data) == -1
+    assert lib.sessd_noise_per_box_host(None, None, None, None, None, None, 2, 3, 0, None) == -1
