@@ -222,6 +222,8 @@ class TrainStep:
         self.global_step = 0
         self.graph = None
         self.repack = ops.RepackRegistry()   # packed weights of both networks, re-packed together after every update
+        self.overlap_teacher = True          # teacher forward on a second stream beside the student's
+        self._side = None
         self.direct_grads = True  # gradients handed over by autograd and packed with one multi-tensor copy (FlatParams.gather_grads)
 
     def _iteration(self, example, consistency_weight, device_schedule):
@@ -230,18 +232,34 @@ class TrainStep:
         # packed weights of both networks are kept and re-packed together at the first use after an update (two launches instead
         # of ~95); the 56 BatchNorm batch counters of the two networks: one launch at the end
         with ops.batched_repack(self.repack), ops.deferred_batch_counts():
-            with torch.no_grad():
-                teacher_preds = self.teacher.forward_preds(example, raw="voxels_raw" in example)
+            main = torch.cuda.current_stream() if self.overlap_teacher and self.flat_s.data.is_cuda else None
+            if main is not None:
+                # The two forward passes are independent until the loss: the teacher's runs on a second stream (a parallel branch
+                # of the captured graph), so that the launch-bound sparse half of one network fills the gaps of the other's dense
+                # half. The packed weights are refreshed BEFORE the fork (both branches read them).
+                if self.repack is not None:
+                    self.repack.ensure_fresh()
+                if self._side is None:
+                    self._side = torch.cuda.Stream()
+                self._side.wait_stream(main)
+                with torch.cuda.stream(self._side), torch.no_grad():
+                    teacher_preds = self.teacher.forward_preds(example, raw="voxels_raw" in example)
+            else:
+                with torch.no_grad():
+                    teacher_preds = self.teacher.forward_preds(example, raw="voxels_raw" in example)
             if self.direct_grads:
                 self.flat_s.release_grads()
             else:
                 self.flat_s.zero_grad()
-            if self.loss_fn is None:
-                losses = self.student(example, is_ema=[False, teacher_preds], return_loss=True)
+            student_preds = self.student.forward_preds(example)
+            if main is not None:
+                main.wait_stream(self._side)
+            if self.loss_fn is None:     # VoxelNet.forward(example, is_ema=[False, teacher_preds], return_loss=True) after its forward
+                losses = self.student.bbox_head.loss(example, student_preds, teacher_preds)
                 loss = losses["loss"][0] + losses["consistency_loss"][0][0] * consistency_weight
                 self.last_losses = losses
             else:
-                loss = self.loss_fn(example, self.student.forward_preds(example), teacher_preds, consistency_weight)
+                loss = self.loss_fn(example, student_preds, teacher_preds, consistency_weight)
         with ops.batched_repack(self.repack):
             loss.backward()
         if self.direct_grads:
