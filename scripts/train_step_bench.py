@@ -20,6 +20,7 @@ ap.add_argument("--batch", type=int, default=4)
 ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--graph", action="store_true", help="also capture the iteration as ONE hipGraph (capacity-form inputs) and time replays")
+ap.add_argument("--replays-only", type=int, default=0, help="profiling target: ONE eager warm-up iteration, the capture, then this many replays and nothing else")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 VG = configs.VOXEL_GENERATOR
@@ -39,6 +40,18 @@ r = ops.voxelize_batch([torch.from_numpy(f).to(dev) for f in frames], VG["voxel_
 m = int(r["prefix"][args.batch].item())
 ex = dict(voxels=r["voxels"][:m], coordinates=r["coors"][:m], num_points=r["num_points"][:m],
           num_voxels=torch.tensor(np.diff(r["prefix"].cpu().numpy())), shape=[[1408, 1600, 40]] * args.batch)
+if args.replays_only:
+    cap_ex = strain.capacity_example(ex, (int(m * 1.08) + 4095) // 4096 * 4096)
+    step.capture(cap_ex, warmup=1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.replays_only):
+        step.replay()
+    torch.cuda.synchronize()
+    print(json.dumps({"what": "captured SE-SSD training iteration, replays only", "replays": args.replays_only,
+                      "graph_ms_per_iter": (time.perf_counter() - t0) / args.replays_only * 1e3,
+                      "graph_overflow_flag": int(step.student.backbone.last_err.item())}))
+    sys.exit(0)
 for _ in range(3):
     step(ex)
 torch.cuda.synchronize()
