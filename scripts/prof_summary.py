@@ -1,9 +1,11 @@
 """Summarise a rocprofv3 --kernel-trace rocpd database (*_results.db) into a per-kernel table.
 
-    python scripts/prof_summary.py DB [FRAMES] [ROWS]
+    python scripts/prof_summary.py DB [FRAMES] [ROWS] [MARKER]
 
-FRAMES > 0: only the kernels of the LAST `FRAMES` frames are counted (a frame starts at each vox_insert_kernel launch),
-i.e. the timed region of bench.py without model set-up, BatchNorm calibration and autotuning; per-frame figures."""
+FRAMES > 0: only the kernels of the LAST `FRAMES` frames are counted (a frame starts at each launch of the marker kernel: the
+frame's clear launch by default; `sparse_pack_batch_kernel` for replays of the captured training iteration), i.e. the timed region
+without model set-up, BatchNorm calibration and autotuning; per-frame figures. The last line gives the share of kernels that are
+not ours (at::native, rocclr, MIOpen, rocBLAS)."""
 import sqlite3
 import sys
 from collections import defaultdict
@@ -14,7 +16,10 @@ nrows = int(sys.argv[3]) if len(sys.argv) > 3 else 45
 rows = list(db.execute("select name, start, end from kernels order by start"))
 div = 1.0
 if frames > 0:
-    marker = "fill_multi_kernel" if any("fill_multi_kernel" in r[0] for r in rows) else "vox_insert_kernel"  # a frame's first launch
+    if len(sys.argv) > 4:
+        marker = sys.argv[4]
+    else:
+        marker = "fill_multi_kernel" if any("fill_multi_kernel" in r[0] for r in rows) else "vox_insert_kernel"  # a frame's first launch
     starts = [i for i, r in enumerate(rows) if marker in r[0]]
     rows = rows[starts[-frames]:]
     div = float(frames)
@@ -35,3 +40,7 @@ else:
 print("%-100s %9s %11s %9s %9s %9s %6s" % ("kernel", "calls/fr" if frames else "calls", "us/frame" if frames else "total_us", "avg_us", "min_us", "max_us", "pct"))
 for n, a in sorted(agg.items(), key=lambda x: -x[1][1])[:nrows]:
     print("%-100s %9.1f %11.1f %9.1f %9.1f %9.1f %5.1f%%" % (n[:100], a[0] / div, a[1] / div, a[1] / a[0], a[2], a[3], 100 * a[1] / tot))
+import re
+foreign = sum(a[1] for n, a in agg.items() if re.search(r"at::native|rocclr|miopen|igemm|naive_conv|batched_transpose|SubTensor|Cijk_|rocprim|hipcub", n))
+print("# kernels not from libsessd_hip.so (at::native, rocclr, MIOpen, rocBLAS): %.1f us%s = %.2f %% of the kernel time; %d launches%s" % (
+    foreign / div, "/frame" if frames else "", 100 * foreign / tot, sum(a[0] for a in agg.values()) / div, "/frame" if frames else ""))
