@@ -7,7 +7,8 @@ from sessd_hip import ops
 
 dev = torch.device("cuda:0")
 out = []
-for (B, C, H, W) in [(4, 128, 200, 176), (4, 256, 100, 88), (1, 128, 200, 176)]:
+SHAPES = [(4, 128, 200, 176), (4, 256, 100, 88), (1, 128, 200, 176)]
+for (B, C, H, W) in ([SHAPES[int(a)] for a in sys.argv[1:]] or SHAPES):   # optional arguments: indices into SHAPES
     x = torch.randn(B, C, H, W, device=dev)
     g = torch.randn(B, C, H, W, device=dev)
     row = {"shape": [B, C, H, W]}
