@@ -458,6 +458,14 @@ int sessd_deconv2d_s2_mfma_pair(const float* in, int batch, int cin, int hin, in
 int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
                     float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,
                     float* out, sessd_stream_t stream);
+/* The head outputs' layout change (mg_head_sessd.py:217-230: `.permute(0, 2, 3, 1).contiguous()` per 1x1 conv) for the fused
+ * head tensor: planar (batch, channels, plane) -> parts[k] (batch, plane, sizes[k]), k < n_parts <= 4, sum(sizes) == channels, in
+ * ONE launch; sessd_nhwc_merge_nchw is its adjoint for the training step (a NULL part = a zero gradient). `sizes` and `parts` are
+ * HOST arrays (of ints / device pointers). */
+int sessd_nchw_split_nhwc(const float* planar, int batch, int channels, int plane, int n_parts, const int* sizes,
+                          float* const* parts, sessd_stream_t stream);
+int sessd_nhwc_merge_nchw(float* const* parts, int n_parts, const int* sizes, int batch, int channels, int plane, float* planar,
+                          sessd_stream_t stream);
 /* The same tail in TRAIN mode (both networks of the SE-SSD step, trainer_sessd.py:250-275): the two Conv2d(channels, 1, 1,
  * bias=False) weight branches, their BatchNorm2d(1) with BATCH statistics (running statistics updated in place, unbiased
  * variance, like torch), softmax and blend -- two launches forward, two backward, instead of ~30 torch / MIOpen launches.

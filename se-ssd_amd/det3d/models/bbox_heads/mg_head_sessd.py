@@ -60,9 +60,9 @@ class Head(nn.Module):
             w = torch.cat([c.weight for c in convs], 0)
             b = torch.cat([c.bias for c in convs], 0)
             y = ops.Conv2dFunction.apply(x, w, b, False, 1)
-            parts = torch.split(y, [c.out_channels for c in convs], dim=1)
             names = ["box_preds", "cls_preds"] + (["dir_cls_preds"] if self.use_dir else []) + ["iou_preds"]
-            return {n: p.permute(0, 2, 3, 1).contiguous() for n, p in zip(names, parts)}
+            # the parts in NHWC (each conv's `.permute(0, 2, 3, 1).contiguous()` of the reference): one launch each way
+            return dict(zip(names, ops.split_nhwc(y, [c.out_channels for c in convs])))
         if self.training:  # the four 1x1 convs as torch modules
             ret = dict(box_preds=self.conv_box(x).permute(0, 2, 3, 1).contiguous(),
                        cls_preds=self.conv_cls(x).permute(0, 2, 3, 1).contiguous())

@@ -125,6 +125,8 @@ SIGNATURES = {
     "sessd_adam_ema_step_dev": (i32, [vp, vp, vp, vp, vp, sz, vp, vp, vp]),
     "sessd_sum_f32": (i32, [vp, sz, f32, vp, sz, vp, vp]),
     "sessd_nchw_channel_sum": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
+    "sessd_nchw_split_nhwc": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
+    "sessd_nhwc_merge_nchw": (i32, [vp, i32, vp, i32, i32, i32, vp, vp]),
     "sessd_box_collision_host": (i32, [vp, i32, vp, i32, i32, i32, vp]),
     "sessd_noise_per_box_host": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "sessd_dense_pack_batch": (i32, [vp, i32, i32, vp]),

@@ -1608,6 +1608,42 @@ def ssfa_fuse_train_covers(x, conv0, bn0, conv1, bn1):
                 and (x.shape[2] * x.shape[3]) % 4 == 0)
 
 
+class SplitNhwcFunction(torch.autograd.Function):
+    """planar (B, C, H, W) -> the parts of `sizes` channels each as contiguous NHWC tensors (B, H, W, size): what
+    `[p.permute(0, 2, 3, 1).contiguous() for p in torch.split(y, sizes, 1)]` gives, in one launch each way."""
+
+    @staticmethod
+    def forward(ctx, y, *sizes):
+        import ctypes
+        y = y.float().contiguous()
+        _req(y, torch.float32, "y")
+        B, C, H, W = y.shape
+        assert sum(sizes) == C and 1 <= len(sizes) <= 4
+        outs = [torch.empty((B, H, W, int(n)), dtype=torch.float32, device=y.device) for n in sizes]
+        n = len(sizes)
+        check(lib.sessd_nchw_split_nhwc(y.data_ptr(), B, C, H * W, n, (ctypes.c_int * n)(*[int(v) for v in sizes]),
+                                        (ctypes.c_void_p * n)(*[o.data_ptr() for o in outs]), _stream()), "nchw_split_nhwc")
+        ctx.meta = (tuple(int(v) for v in sizes), tuple(y.shape))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        import ctypes
+        sizes, shape = ctx.meta
+        B, C, H, W = shape
+        gs = [None if g is None else g.float().contiguous() for g in grads]
+        dev = next(g.device for g in gs if g is not None)
+        gy = torch.empty(shape, dtype=torch.float32, device=dev)
+        n = len(sizes)
+        check(lib.sessd_nhwc_merge_nchw((ctypes.c_void_p * n)(*[None if g is None else g.data_ptr() for g in gs]), n,
+                                        (ctypes.c_int * n)(*sizes), B, C, H * W, gy.data_ptr(), _stream()), "nhwc_merge_nchw")
+        return (gy,) + (None,) * n
+
+
+def split_nhwc(y, sizes):
+    return SplitNhwcFunction.apply(y, *[int(v) for v in sizes])
+
+
 def ssfa_fuse_head(x0, x1, w0, w1, s0, t0, s1, t1, head_w, head_b, head_out=None, out=None, score_thresh=0.0, keys=None,
                    key_count=None):
     """ssfa_fuse + the 1x1 heads in one launch: head_w (22, C) row-major, head_b (22) or None -> head_out (B, 22, H*W) planar.

@@ -150,3 +150,22 @@ def test_winograd_forward_at_the_last_pixel(dev):
     for cfg in (None, 20, 22):
         got = ops.conv2d(x.to(dev), pc, None, None, False, tile_cfg=cfg)
         _close(got, want, "tile_cfg %s" % cfg)
+
+
+def test_split_nhwc_and_its_adjoint(dev):
+    """ops.split_nhwc (sessd_nchw_split_nhwc / sessd_nhwc_merge_nchw) == [p.permute(0, 2, 3, 1).contiguous() for p in split]: the
+    same bits forward, the same gradient, a part without a gradient contributes zeros."""
+    g = torch.Generator().manual_seed(2)
+    y = torch.randn(3, 22, 10, 12, generator=g).to(dev)
+    sizes = [14, 2, 4, 2]
+    a = y.clone().requires_grad_(True)
+    b = y.clone().requires_grad_(True)
+    pa = ops.split_nhwc(a, sizes)
+    pb = [p.permute(0, 2, 3, 1).contiguous() for p in torch.split(b, sizes, dim=1)]
+    assert all(u.is_contiguous() and torch.equal(u, v) for u, v in zip(pa, pb))
+    ws = [torch.randn(p.shape, generator=g).to(dev) for p in pb]
+    (pa[0] * ws[0]).sum().add((pa[2] * ws[2]).sum()).add((pa[3] * ws[3]).sum()).backward()     # part 1 unused
+    (pb[0] * ws[0]).sum().add((pb[2] * ws[2]).sum()).add((pb[3] * ws[3]).sum()).backward()
+    assert torch.equal(a.grad, b.grad) and float(a.grad[:, 14:16].abs().sum()) == 0
+    one = ops.split_nhwc(y, [22])
+    assert torch.equal(one[0], y.permute(0, 2, 3, 1).contiguous())
