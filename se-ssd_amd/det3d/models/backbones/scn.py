@@ -41,6 +41,18 @@ class SpMiddleFHD(nn.Module):
     def init_weights(self, pretrained=None):
         pass
 
+    def __deepcopy__(self, memo):
+        """A copy (the EMA teacher is a deep copy of the student) must not inherit the per-module chain plan -- its tables are
+        keyed by id() of THIS module's layers, so a copied plan silently sends the copy down the slow per-layer path and shares
+        no buffers safely -- nor the overflow flag buffer."""
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k not in ("_plan", "_err_buf", "last_err"):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
+
     def forward(self, voxel_features, coors, batch_size, input_shape, n_dev=None):
         """n_dev (ours; device int32[1]): the first n_dev[0] rows of voxel_features / coors are voxels, the tables are
         capacity-sized and no count is read back (spconv capacity mode: a capturable iteration). `self.last_err` then holds

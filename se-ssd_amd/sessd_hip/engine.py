@@ -174,13 +174,17 @@ class InferenceEngine:
                 jobs.append((li, li + 1, ks, st, pd))
                 li += 1
         chain_bytes = ops.SparseChain.workspace_bytes(self.sparse_shape, steps, [L["cap"] for L in self.levels[1:]], B)
-        # control words + the chain's occupancy maps, cleared to 0 by the frame's one clear launch: prefix[B+1] | err |
+        # control words + the chain's occupancy maps, cleared to 0 by the frame's one clear launch: prefix[B+1] | (unused) |
         # key_count[B] (candidates of the score filter that runs inside the head launch) | maps
         n_ctrl = (2 * B + 2 + 63) // 64 * 64
         self.zero_arena = torch.zeros((n_ctrl + (chain_bytes + 3) // 4,), dtype=i32, device=dev)
         self.ctrl = self.zero_arena[:n_ctrl]
         self.prefix = self.ctrl[:B + 1]
-        self.err = self.ctrl[B + 1:B + 2]
+        # overflow flag of the sparse levels: OUTSIDE the per-frame clear arena, so that it is STICKY across frames (kernels only
+        # ever OR into it) -- a pipeline that reads it once per fetch / per job still sees an overflow of any earlier frame
+        # (round-3 advisor finding: inside the arena the next frame's clear erased it). results() / the pipeline clear it when
+        # they raise.
+        self.err = torch.zeros((1,), dtype=i32, device=dev)
         self.key_count = self.ctrl[B + 2:2 * B + 2]
         self.chain = ops.SparseChain(self.sparse_shape, steps, [L["cap"] for L in self.levels[1:]], B, jobs, dev,
                                      workspace_tensor=self.zero_arena[n_ctrl:].view(torch.uint8))
@@ -716,6 +720,7 @@ class InferenceEngine:
         """Synchronising read-back: list of dict(box3d_lidar, scores, label_preds) numpy per frame; raises on overflow."""
         cnt = self.out["count"].cpu().numpy()
         if int(self.err.item()) != 0:
+            self.err.zero_()  # sticky flag: reported once, then re-armed
             raise RuntimeError("sparse level capacity overflow: raise `growth` or max_voxels")
         res = []
         for b in range(self.B):

@@ -831,11 +831,14 @@ class Bn2dReluTrainFunction(torch.autograd.Function):
         return dx, dg, db, None, None, None, None, None
 
 
+BN2D_MAX_CHANNELS = 1024  # csrc/bn_train.hip: per-channel arrival counters of the finisher block
+
+
 def bn2d_relu_train(x, bn, relu=True):
     """x (B, C, H, W) float32 on the device; bn: a torch.nn.BatchNorm2d in train mode with affine parameters (running statistics
     updated in place, num_batches_tracked incremented). Falls back to the torch module where the kernel's layout assumption
-    (H * W divisible by 4) does not hold."""
-    if (x.shape[2] * x.shape[3]) % 4 or bn.weight is None:
+    (H * W divisible by 4, at most BN2D_MAX_CHANNELS = 1024 channels) does not hold."""
+    if (x.shape[2] * x.shape[3]) % 4 or bn.weight is None or x.shape[1] > BN2D_MAX_CHANNELS:
         y = bn(x)
         return torch.relu(y) if relu else y
     mom = _bn_momentum(bn)
@@ -1414,9 +1417,9 @@ class _SumAll(torch.autograd.Function):
 
 def channel_sum(x):
     """(B, C, H, W) float32 on the device -> (C,) sums over images and pixels (a conv's bias gradient) on sessd_nchw_channel_sum;
-    torch's own reduction where the kernel's layout assumption (H * W % 4 == 0) does not hold."""
+    torch's own reduction where the kernel's layout assumptions (H * W % 4 == 0, C <= 1024) do not hold."""
     B, C, H, W = x.shape
-    if (H * W) % 4 or not x.is_cuda:
+    if (H * W) % 4 or not x.is_cuda or C > BN2D_MAX_CHANNELS:
         return x.sum((0, 2, 3))
     xc = x.float().contiguous()
     out = torch.empty((C,), dtype=torch.float32, device=x.device)

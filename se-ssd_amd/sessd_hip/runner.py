@@ -43,23 +43,47 @@ class HostFedPipeline:
                 h2d=[None] * self.ring, consumed=[None] * self.ring, submitted=0, fetched=0,
                 host_rec=[torch.empty((self.fetch_every, self.post_max, 9), dtype=torch.float32).pin_memory() for _ in range(2)],
                 host_cnt=[torch.empty((self.fetch_every,), dtype=torch.int32).pin_memory() for _ in range(2)],
+                host_err=[torch.zeros((1,), dtype=torch.int32).pin_memory() for _ in range(2)],
                 pending=[]))  # (event, buffer index, first frame of the engine, number of frames)
         self._n = 0
         self._out = {}
         self._next_out = 0
+        self._base = 0      # frames submitted before the last restart (submit() returns job-global indices)
+        self._idle = True   # nothing in flight: the next submit() checks the device cursors against the host's ring state
 
     def reset(self):
-        """Start a new job: zero the device cursors (the engines must be idle)."""
+        """Start a new job: zero the device cursors and the sticky overflow flags (the engines must be idle). MANDATORY after
+        InferenceEngine.capture() or any eager use of the engines (both advance the device cursor the host ring arithmetic
+        mirrors); submit() does it by itself when it finds the pipeline idle with a cursor that is not where it left it."""
         for e, st in zip(self.engines, self._st):
             e.record_cursor.zero_()
+            e.err.zero_()
             st.update(submitted=0, fetched=0, pending=[], h2d=[None] * self.ring, consumed=[None] * self.ring)
         self._n, self._out, self._next_out = 0, {}, 0
+        self._idle, self._base = False, 0
         torch.cuda.synchronize(self.dev)
+
+    def _sync_cursors(self):
+        """First submit() of a job (after construction, capture(), eager use of the engines, or finish()): the host ring
+        arithmetic (slot = frames of this engine so far % capacity) assumes the device cursor equals the number of frames this
+        pipeline submitted to the engine. capture() runs warm-up enqueues that advance the cursor, and finish() may leave
+        `fetched` off a multiple of fetch_every -- so an idle pipeline restarts from a clean state instead of silently reading
+        other frames' slots (round-3 advisor finding)."""
+        self._idle = False
+        dirty = any(int(e.record_cursor.item()) != st["submitted"] or st["fetched"] % self.fetch_every
+                    for e, st in zip(self.engines, self._st))
+        if dirty:
+            assert not self._out, "finish() drains every frame before the pipeline goes idle"
+            base = self._base + self._n   # submit() keeps returning job-global indices across the restart
+            self.reset()
+            self._base = base
 
     # ------------------------------------------------------------------
     def submit(self, points):
         """points: (P,4) float32 host array / CPU tensor (pinned memory is used in place, anything else goes through the
         pipeline's own pinned ring). Returns the frame's index; never blocks on the frame itself."""
+        if self._n == 0 or self._idle:
+            self._sync_cursors()
         i = self._n
         ei = i % len(self.engines)
         e, st, stream = self.engines[ei], self._st[ei], self.streams[ei]
@@ -98,7 +122,7 @@ class HostFedPipeline:
             if st["submitted"] - st["fetched"] == self.fetch_every:
                 self._fetch(ei)
         self._n += 1
-        return i
+        return self._base + i
 
     def _fetch(self, ei):
         """D2H of the frames of engine ei that are on its ring and not yet fetched (on its stream, asynchronous)."""
@@ -117,6 +141,7 @@ class HostFedPipeline:
         with torch.cuda.stream(stream):
             st["host_rec"][buf][:cnt].copy_(e.records[s0:s0 + cnt], non_blocking=True)
             st["host_cnt"][buf][:cnt].copy_(e.record_counts[s0:s0 + cnt], non_blocking=True)
+            st["host_err"][buf].copy_(e.err, non_blocking=True)  # the STICKY overflow flag as of the newest fetched frame
             ev = torch.cuda.Event()
             ev.record(stream)
         st["pending"].append((ev, buf, lo, cnt))
@@ -126,6 +151,12 @@ class HostFedPipeline:
         st = self._st[ei]
         ev, buf, lo, cnt = st["pending"].pop(0)
         ev.synchronize()
+        if int(st["host_err"][buf][0]) != 0:
+            # a sparse level overflowed in one of the frames up to this fetch: their rows were dropped, the detections are not
+            # to be handed out. The flag is sticky on the device; clear it so that a new job can start after reset().
+            self.engines[ei].err.zero_()
+            raise RuntimeError("sparse level capacity overflow in a frame of engine %d up to its frame %d (job frames <= %d): "
+                               "raise `growth` or max_voxels" % (ei, lo + cnt - 1, self._base + (lo + cnt - 1) * len(self.engines) + ei))
         rec, c = st["host_rec"][buf].numpy(), st["host_cnt"][buf].numpy()
         E = len(self.engines)
         for j in range(cnt):
@@ -155,6 +186,8 @@ class HostFedPipeline:
             while st["pending"]:
                 self._collect(ei)
         for e in self.engines:
-            if int(e.err.item()) != 0:
+            if int(e.err.item()) != 0:  # (every fetch carries the flag; this is the belt to those braces)
+                e.err.zero_()
                 raise RuntimeError("sparse level capacity overflow: raise `growth` or max_voxels")
+        self._idle = True
         return self._drain()

@@ -97,6 +97,11 @@ class ChainPlan:
         self.key = ChainPlan.key_of(x)
         self.chain = ops.SparseChain(x.spatial_shape, steps, caps, x.batch_size, jobs, x.indices.device)
         self.chain.bind_tables(int(x.indices.shape[0]))
+        # The tables are allocated ONCE and rewritten by every run() through raw pointers (no autograd version bump), while
+        # IndiceConvFunction saves them for backward: a second forward of the same backbone before the first one's backward
+        # (gradient accumulation over two views) would silently differentiate the first pass with the second pass's tables.
+        # Every run() bumps `generation`; a backward whose tables were overwritten raises (round-3 advisor finding).
+        self.generation = 0
 
     @staticmethod
     def key_of(x):
@@ -105,6 +110,7 @@ class ChainPlan:
     def run(self, x):
         h, n = x._hash()
         self.chain.run(x.indices, n.data_ptr(), int(x.indices.shape[0]), h, x.err, clear=True)
+        self.generation += 1
         x.indice_dict["__chain__"] = self
 
     def tables(self, conv):
@@ -135,7 +141,9 @@ class IndiceConvFunction(torch.autograd.Function):
     GEMM kernel (sessd_sparse_conv_wgrad), db = column sums. Deterministic (no atomics on floats)."""
 
     @staticmethod
-    def forward(ctx, feats, weight, bias, nbr, tm, n_out, n_in=None, subm=False):
+    def forward(ctx, feats, weight, bias, nbr, tm, n_out, n_in=None, subm=False, guard=None):
+        """guard: (ChainPlan, generation) when nbr / tm are the plan's shared buffers -- checked again in backward."""
+        ctx.guard = guard
         cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
         out = ops.sparse_conv(feats, nbr, tm, n_out, ops.packed_sparse_weight(weight, "fwd"), cin, cout, None, bias, relu=False)
         if n_in is None:
@@ -149,6 +157,10 @@ class IndiceConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         feats, weight, nbr, tm, n_out = ctx.saved_tensors[:5]
+        if ctx.guard is not None and ctx.guard[0].generation != ctx.guard[1]:
+            raise RuntimeError("the neighbour tables of this pass were overwritten by a later forward of the same backbone "
+                               "(spconv.ChainPlan reuses one set of buffers): run backward before the next forward, or set "
+                               "SpMiddleFHD.chain_tables = False for passes that must stay alive")
         cin, cout = int(weight.shape[-2]), int(weight.shape[-1])
         kv = nbr.shape[0]
         g = grad_out.float().contiguous()
@@ -170,7 +182,7 @@ class IndiceConvFunction(torch.autograd.Function):
             gw = ops.sparse_conv_wgrad(feats, g, nbr, tm, n_out, cin, cout).view_as(weight)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = g.sum(0)
-        return gx, gw, gb, None, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None, None
 
 
 class SparseConvolution(SparseModule):
@@ -261,7 +273,7 @@ class SparseConvolution(SparseModule):
         if torch.is_grad_enabled() and (feats.requires_grad or self.weight.requires_grad):
             subm_sym = self.subm and all(k % 2 == 1 for k in self.kernel_size)
             out.features = IndiceConvFunction.apply(feats, self.weight, self.bias, nbr, tm, n_out, n_in if x.n_dev is not None else None,
-                                                    subm_sym)
+                                                    subm_sym, (plan, plan.generation) if plan is not None else None)
         else:
             out.features = ops.sparse_conv(feats, nbr, tm, n_out, self._wpk(), self.in_channels, self.out_channels, None,
                                            self.bias, relu=False)

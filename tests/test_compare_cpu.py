@@ -119,18 +119,43 @@ def test_pairs_and_forced_entry_points_equal_the_plain_one():
 
 
 def test_box_tolerance_is_absolute_for_the_pose_and_relative_for_large_sizes():
-    """Centres and yaw: 2e-3 absolute. Sizes: 2e-3 * max(1, size) -- a size is exp(code) * anchor size, so the float32 error of
-    the network output is a RELATIVE error of the size (the random benchmark weights decode boxes of kilometres)."""
+    """Centres and yaw: 2e-3 absolute. Sizes under rule "synthetic": 2e-3 * max(1, size) -- a size is exp(code) * anchor size, so
+    the float32 error of the network output is a RELATIVE error of the size (the random benchmark weights decode boxes of
+    kilometres); under the DEFAULT rule "strict" (real KITTI weights) sizes are absolute like the pose."""
     want = dict(box3d_lidar=np.array([[10.0, -3.0, -1.0, 1.6, 3.9, 1.5, 0.3], [19.2, -14.8, -1.2, 5946.9, 0.236, 26.578, 3.97]], np.float32),
                 scores=np.array([0.9, 0.5], np.float32))
     ok = copy.deepcopy(want)
     ok["box3d_lidar"][1, 3] = 5950.8   # 6.6e-4 relative: the case bench.py's parity gate found
     ok["box3d_lidar"][0, 4] += 1.5e-3  # within 2e-3 * max(1, 3.9)
-    assert same_detections(ok, want) is None
+    assert same_detections(ok, want, relative_sizes=True) is None
+    assert same_detections(ok, want) is not None                 # the strict default does not excuse the kilometre box
+    dbg = dict(near_pairs=np.zeros((0, 2), np.int64))
+    assert compare_detections(ok, want, dbg, rule="synthetic")["rule"] == "synthetic"
+    with pytest.raises(AssertionError):
+        compare_detections(ok, want, dbg)                        # rule="strict"
     for row, col, delta in ((0, 0, 3e-3), (1, 1, 3e-3), (0, 3, 5e-3), (1, 3, 20.0), (1, 4, 3e-3), (0, 6, 3e-3)):
         bad = copy.deepcopy(want)
         bad["box3d_lidar"][row, col] += delta
+        assert same_detections(bad, want, relative_sizes=True) is not None, (row, col)
         assert same_detections(bad, want) is not None, (row, col)
+    car = copy.deepcopy(want)
+    car["box3d_lidar"][0, 4] += 1.5e-3     # a car-sized box 1.5 mm off: fine under both rule sets
+    car["box3d_lidar"] = car["box3d_lidar"][:1]
+    car["scores"] = car["scores"][:1]
+    one = dict(box3d_lidar=want["box3d_lidar"][:1], scores=want["scores"][:1])
+    assert same_detections(car, one) is None and same_detections(car, one, relative_sizes=True) is None
     nan = copy.deepcopy(want)
     nan["box3d_lidar"][0, 3] = np.nan
     assert same_detections(nan, want) is not None
+
+
+def test_strict_rule_allows_fewer_listed_decisions():
+    from oracle.compare import RULES
+    assert RULES["strict"] == dict(relative_sizes=False, max_pairs=6) and RULES["synthetic"]["max_pairs"] == 10
+    want = dict(box3d_lidar=np.zeros((1, 7), np.float32), scores=np.array([0.5], np.float32))
+    got = dict(box3d_lidar=np.zeros((0, 7), np.float32), scores=np.zeros((0,), np.float32))
+    dbg = dict(near_pairs=np.stack([np.arange(8), np.arange(8) + 1], 1), rerun=lambda forced: want)
+    with pytest.raises(AssertionError, match="too many"):
+        compare_detections(got, want, dbg)                       # 8 listed decisions > 6
+    with pytest.raises(AssertionError, match="NO assignment"):
+        compare_detections(got, want, dbg, rule="synthetic")     # 8 <= 10: explored, and none matches

@@ -129,3 +129,27 @@ def test_dense_layout_channel_is_c_times_d_plus_z():
         assert float(v[0, c * 2 + 1, 2, 3]) == float(feat[0, c])
         assert float(v[1, c * 2 + 0, 0, 0]) == float(feat[1, c])
     assert float(v.abs().sum()) == float(feat.abs().sum())
+
+
+def test_out_spatial_equals_the_reference_held_shape_annotations():
+    """The one pin the reference itself holds for spconv's output-size rule: the shapes its author annotated next to the four
+    strided convs (scn.py:113,122,134,146; parsed from source by tests/golden/make_golden_scn_shapes.py). The oracle's rule
+    `(D + 2p - k)//s + 1` must reproduce every annotated output shape from the annotated input shape and the constructor
+    arguments on that line, the annotations must chain, they must be the geometry the tests above pin (STRIDED), and the
+    product's layer table (sessd_hip.engine.SPMIDDLE_LAYERS) must carry the same arguments."""
+    import json
+    import os
+    from sessd_hip.engine import SPMIDDLE_LAYERS
+    L = lambda v: [int(v)] * 3 if isinstance(v, int) else [int(x) for x in v]
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scn_shapes.json")))
+    rows = g["rows"]
+    assert [r["line"] for r in rows] == [113, 122, 134, 146]
+    assert rows[0]["in_shape"] == [41, 1600, 1408]          # scn.py:179: input_shape[::-1] + [1, 0, 0]
+    ours = [lay for lay in SPMIDDLE_LAYERS if lay[0] == "conv"]
+    for r, (ks, st, pd), lay in zip(rows, STRIDED, ours):
+        assert (L(r["ksize"]), L(r["stride"]), L(r["padding"])) == (L(ks), L(st), L(pd))
+        assert (lay[1], lay[2], L(lay[3]), L(lay[4]), L(lay[5])) == (r["cin"], r["cout"], L(ks), L(st), L(pd))
+        assert sc.out_spatial(r["in_shape"], r["ksize"], r["stride"], r["padding"]) == r["out_shape"], r
+    for a, b in zip(rows[:-1], rows[1:]):
+        assert a["out_shape"] == b["in_shape"]
+    assert rows[-1]["out_shape"] == [2, 200, 176]           # scn.py:186-187: view(B, 64 * 2, 200, 176)
