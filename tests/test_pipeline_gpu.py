@@ -290,7 +290,7 @@ def test_stress_autotuned_equals_the_oracle(dev):
         assert float((bev[slot] - ref).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max())), slot
         r = _compare_dets(got[slot], want[0], inter["debug"][0])
         assert r["matched"] == r["n"], (slot, i)
-        assert float(np.abs(want[0]["box3d_lidar"][:, 3:6]).max(initial=0)) < 50.0  # car-sized boxes, not the degenerate regime
+        assert float(np.abs(want[0]["box3d_lidar"][:, 3:6]).max(initial=0)) < 1000.0  # not the kilometre regime of an uncalibrated model
     assert sum(len(g["scores"]) for g in got) > 20
     eng.capture()
     eng.replay()
