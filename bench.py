@@ -68,6 +68,9 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-io", action="store_true", help="skip the informational host-buffer legs (kernel traces of the timed region)")
     ap.add_argument("--no-sequential", action="store_true", help="skip the informational one-frame-at-a-time leg")
+    ap.add_argument("--no-train-step", action="store_true",
+                    help="skip the `train_step` leg (BASELINE configs[2]: the captured SE-SSD training iteration with the reference loss)")
+    ap.add_argument("--train-replays", type=int, default=20, help="timed replays of the captured training iteration")
     ap.add_argument("--sk-workgroups", type=int, default=0,
                     help="persistent workgroups of the stream-K Winograd launches (multiple of 8; 0 = the kernel's default, all CUs). "
                          "224 with two frames in flight leaves 32 CUs to the other stream's small kernels: +2 % frames/s, but the "
@@ -394,6 +397,8 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
             host_io_legs(args, out, engines, streams, frames_np, dev)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
+        if not args.no_train_step and world == 1 and not args.stress and args.batch == 1 and engine_factory is None:
+            train_step_leg(args, out, engines, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
@@ -476,6 +481,22 @@ def roofline_legs(args, out, eng, batch_of):
                                         "`mfma`: per-layer HIP-event times of the sparse convs alone and their EXECUTED f32 "
                                         "MFMA rate (active 16-site tile x offset steps x 16 x Cin x Cout x 2 FLOP) against the "
                                         "157.3 TFLOP/s peak; counters and HBM traffic: profiles/r2_sparse_pmc_after.txt"}
+
+
+def train_step_leg(args, out, engines, dev):
+    """BASELINE.json configs[2] next to the metric line (informational, never `value`): one SE-SSD training iteration -- teacher
+    forward, student forward, MultiGroupHead.loss + consistency loss (the capacity-form device op sessd_head_loss), backward,
+    fused clip / Adam / EMA -- captured as ONE hipGraph on a labelled synthetic batch of 4, ms per replay
+    (sessd_hip.trainbench). The inference engines are released first."""
+    from sessd_hip import trainbench
+    for e in engines:
+        e.graph = None
+    torch.cuda.synchronize()
+    try:
+        res, _ = trainbench.measure(dev, batch=4, steps=args.train_replays, real_loss=True)
+        out["train_step"] = res
+    except Exception as ex:  # the inference line must not die with the informational leg
+        out["train_step"] = {"error": repr(ex)[:300]}
 
 
 def host_io_legs(args, out, engines, streams, frames_np, dev):

@@ -359,6 +359,29 @@ int sessd_conv3x3_wgrad_winograd(const float* input, int batch, int cin, int h, 
  * 2 * sum(weights * term) / batch_size. */
 int sessd_odiou3d(const float* gboxes, const float* qboxes, int n, float* term, float* grad_q, sessd_stream_t stream);
 
+/* ---- The SE-SSD training loss in capacity form (BASELINE configs[2]): values AND the gradient with respect to
+ * the student's four head outputs in six launches, every count on the device -- replaces, for the single-task car head,
+ * det3d/models/bbox_heads/mg_head_sessd.py:706-808 (MultiGroupHead.loss), :810-890 (get_model_ema_loss), :618-704
+ * (consistency_loss), :573-607 (nn_distance '10'), :525-571 (prepare_loss_weights, NormByNumPositives), the loss classes of
+ * det3d/models/losses/losses.py:146-203,364-418,489-531, odiou_3D (losses/odious.py:837-900), boxes_aligned_iou3d_gpu /
+ * boxes_iou_bev_gpu (core/iou3d/iou3d_utils.py:32-52,197-252) and trainer_sessd.py:267 (loss += consistency * weight).
+ * student / teacher: head outputs + targets (the teacher's are labels_raw / reg_targets_raw / anchors_raw; log terms only).
+ * anchors0 (A,7): example["anchors"][0][0], with which the consistency loss decodes every sample (mg_head_sessd.py:649-650).
+ * transformation (B,5) device float32 [flipped, cos(noise_rotation), sin(noise_rotation), noise_rotation, noise_scale];
+ * consistency_weight: one device float. grad_* (device, same shapes as the student's head outputs) are WRITTEN:
+ * d(loss + consistency_weight * consistency) / d(head output). record: 64 device floats --
+ *   [0] total loss, [1] loss without consistency, [2] cls_loss_reduced, [3] loc_loss_reduced (logged only), [4] dir loss,
+ *   [5] iou_pred_loss, [6] ious_loss (ODIoU), [7] consistency_loss (unweighted), [8] cls_pos_loss, [9] cls_neg_loss,
+ *   [10..16] loc_loss_elem, [17] num_pos, [18] num_neg (sample 0), [19..21] box / score / IoU consistency parts, [22] matched boxes;
+ *   [24] loss_ema, [26..42] the teacher's [2..18]; [48] overflow flags (1: positives, 2: candidates), [49] / [50] positives of
+ *   the batch (student / teacher), [51] / [52] most consistency candidates in one sample (student / teacher).
+ * Deterministic (ordered sums, no float atomics); no host synchronisation: capturable in a hipGraph. */
+size_t sessd_head_loss_workspace_bytes(const sessd_head_loss_cfg_t* cfg);
+int sessd_head_loss(const sessd_head_loss_cfg_t* cfg, const sessd_head_loss_net_t* student, const sessd_head_loss_net_t* teacher,
+                    const float* anchors0, const float* transformation, const float* consistency_weight, float* grad_box,
+                    float* grad_cls, float* grad_dir, float* grad_iou, float* record, void* workspace, size_t workspace_bytes,
+                    sessd_stream_t stream);
+
 /* ---- anchor target assignment: det3d/datasets/pipelines/preprocess.py:236-358 (AssignTarget) ->
  * det3d/core/anchor/target_assigner.py:68-136 -> det3d/core/anchor/target_ops_v3.py:11-137 (create_target_np) with the
  * nearest-IoU similarity (region_similarity.py:85-98) and second_box_encode (box_np_ops.py:52-110). anchors (n,7), gt_boxes

@@ -44,4 +44,29 @@ typedef struct {
   int32_t kernel_volume, cin, cout, adjoint, reverse_k, block_start;
 } sessd_sparse_pack_job_t;
 
+/* The head outputs and targets of ONE network (student or EMA teacher) as sessd_head_loss reads them: A anchors per sample in
+ * the reference's order (anchor = (y * W + x) * 2 + rotation), B samples. box / dir / iou / cls are the NHWC tensors that
+ * MultiGroupHead.forward returns (mg_head_sessd.py:217-230), viewed as (B, A, 7) / (B, A, 2) / (B, A) / (B, A). */
+typedef struct {
+  const float* box;          /* (B, A, 7) box codes */
+  const float* cls;          /* (B, A) class logits (one class) */
+  const float* dir;          /* (B, A, 2) direction logits */
+  const float* iou;          /* (B, A) IoU predictions */
+  const void* labels;        /* (B, A) int32 or int64 (cfg.labels_i64): -1 ignore, 0 negative, > 0 positive */
+  const float* reg_targets;  /* (B, A, 7) encoded regression targets */
+  const float* anchors;      /* (B, A, 7) [x, y, z, w, l, h, r] */
+} sessd_head_loss_net_t;
+
+/* Shapes, capacities and the constants of examples/second/configs/config.py that sessd_head_loss needs. */
+typedef struct {
+  int32_t batch, num_anchors, labels_i64;
+  int32_t pos_capacity;      /* positive anchors of the whole batch kept per network (more: flagged in record[48], dropped) */
+  int32_t cons_capacity;     /* consistency candidates kept per sample and network (score >= score_thresh inside center_range) */
+  float pos_cls_weight, neg_cls_weight;             /* loss_norm (NormByNumPositives) */
+  float focal_alpha, focal_gamma, smooth_l1_sigma;  /* loss_cls, loss_bbox.sigma */
+  float cls_loss_weight, loc_loss_weight, dir_loss_weight, direction_offset;
+  float score_thresh, match_iou_thresh;             /* 0.3 (mg_head_sessd.py:653) and 0.7 (:573) */
+  float center_range[6];                            /* post_center_range (mg_head_sessd.py:484) */
+} sessd_head_loss_cfg_t;
+
 #endif

@@ -21,6 +21,9 @@ ap.add_argument("--steps", type=int, default=10)
 ap.add_argument("--cpu", action="store_true")
 ap.add_argument("--graph", action="store_true", help="also capture the iteration as ONE hipGraph (capacity-form inputs) and time replays")
 ap.add_argument("--replays-only", type=int, default=0, help="profiling target: ONE eager warm-up iteration, the capture, then this many replays and nothing else")
+ap.add_argument("--real-loss", action="store_true",
+                help="BASELINE configs[2]: labelled batch (sessd_hip.trainbench.labelled_batch), the reference loss as the capacity-form "
+                     "device op (MultiGroupHead.loss + consistency loss through sessd_head_loss) inside the captured iteration")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 VG = configs.VOXEL_GENERATOR
@@ -33,6 +36,39 @@ def loss_fn(ex, s, t, w):
             + w * M((p["cls_preds"] - q["cls_preds"]).pow(2)))
 
 
+if args.real_loss:
+    from sessd_hip import trainbench
+    if args.replays_only:
+        model = configs.build_synthetic_detector(dev, seed=0)
+        step = strain.TrainStep(model, None, total_steps=1000)
+        ex, cap_ex = trainbench.labelled_batch(dev, args.batch)
+        step.capture(cap_ex, warmup=1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.replays_only):
+            step.replay()
+        torch.cuda.synchronize()
+        print(json.dumps({"what": "captured SE-SSD training iteration with the reference loss (sessd_head_loss), replays only",
+                          "replays": args.replays_only, "graph_ms_per_iter": (time.perf_counter() - t0) / args.replays_only * 1e3,
+                          "graph_overflow_flag": int(step.student.backbone.last_err.item()),
+                          "loss_overflow_flags": int(step.last_record[ops.HEAD_LOSS_RECORD["overflow"]])}))
+        sys.exit(0)
+    real, step_r = trainbench.measure(dev, args.batch, steps=args.steps, real_loss=True)
+    # the same batch eagerly (capacity form, device schedule) and with the round-3 stand-in loss, for comparison
+    ex, cap_ex = trainbench.labelled_batch(dev, args.batch)
+    for _ in range(3):
+        step_r(cap_ex, device_schedule=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step_r(cap_ex, device_schedule=True)
+    torch.cuda.synchronize()
+    real["capacity_form_eager_ms_per_iter"] = (time.perf_counter() - t0) / args.steps * 1e3
+    del step_r
+    stand, _ = trainbench.measure(dev, args.batch, steps=args.steps, real_loss=False, standin_loss_fn=loss_fn)
+    real["standin_loss_graph_ms_per_iter"] = stand["ms_per_iter"]
+    print(json.dumps(real))
+    sys.exit(0)
 model = configs.build_synthetic_detector(dev, seed=0)
 step = strain.TrainStep(model, loss_fn, total_steps=1000)
 frames = [synth.make_frame(50 + i, 20000) for i in range(args.batch)]

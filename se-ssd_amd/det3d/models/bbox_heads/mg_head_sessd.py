@@ -320,6 +320,86 @@ class MultiGroupHead(nn.Module):
         ret.update(ema)
         return ret
 
+    # ------------------------------------------------------------------ the same loss as ONE capacity-form device op
+    def device_loss_covers(self, example, preds_dicts):
+        """sessd_head_loss (csrc/head_loss.hip) covers the configuration of examples/second/configs/config.py: one task, one
+        class, NormByNumPositives, sigmoid focal loss, codewise smooth-L1 without code weights, sin-encoded yaw, softmax
+        direction classifier, head outputs on the HIP device."""
+        p = preds_dicts[0]
+        return (len(preds_dicts) == 1 and len(self.num_classes) == 1 and self.num_classes[0] == 1 and self.encode_background_as_zeros
+                and self.loss_norm["type"] == "NormByNumPositives" and self.encode_rad_error_by_sin and self.use_direction_classifier
+                and type(self.loss_cls).__name__ == "SigmoidFocalLoss" and self.loss_cls._alpha is not None
+                and type(self.loss_reg).__name__ == "WeightedSmoothL1Loss" and self.loss_reg._codewise
+                and getattr(self.loss_aux, "_logit_scale", 1.0) == 1.0 and self.box_n_dim == 7 and p["box_preds"].is_cuda
+                and all(k in example for k in ("labels", "reg_targets", "anchors", "labels_raw", "reg_targets_raw", "anchors_raw")))
+
+    @staticmethod
+    def transformation_tensor(example, device):
+        """(B, 5) float32 [flipped, cos, sin, noise_rotation, noise_scale] of example['transformation'] (the global augmentation
+        recorded by Preprocess, mg_head_sessd.py:670-674); a captured iteration carries it as example['transformation_dev']."""
+        import math
+        rows = [[1.0 if t["flipped"] else 0.0, math.cos(float(t["noise_rotation"])), math.sin(float(t["noise_rotation"])),
+                 float(t["noise_rotation"]), float(t["noise_scale"])] for t in example["transformation"]]
+        return torch.tensor(rows, dtype=torch.float32).to(device)
+
+    def loss_device(self, example, preds_dicts, preds_ema, consistency_weight=1.0, unit_grad=False, pos_capacity=None,
+                    cons_capacity=2048):
+        """MultiGroupHead.loss + trainer_sessd.py:267 as one device op: returns (total, record) -- total = loss + consistency_weight
+        * consistency_loss as an autograd scalar of the student's head outputs (its backward hands over the kernel's gradients),
+        record = the 64-float device log (ops.HEAD_LOSS_RECORD names its entries; nothing is read back here).
+        consistency_weight: float or a device float32 scalar tensor (a captured iteration passes the tensor and refills it)."""
+        p, q = preds_dicts[0], preds_ema[0]
+        B = p["box_preds"].shape[0]
+        dev = p["box_preds"].device
+        A = p["box_preds"].numel() // (B * 7)
+        labels = example["labels"][0]
+        key = (B, A, str(dev), labels.dtype, pos_capacity, cons_capacity)
+        run = getattr(self, "_device_loss", None)
+        if run is None or run[0] != key:
+            cfg = dict(pos_cls_weight=self.loss_norm["pos_cls_weight"], neg_cls_weight=self.loss_norm["neg_cls_weight"],
+                       focal_alpha=self.loss_cls._alpha, focal_gamma=self.loss_cls._gamma or 0.0, smooth_l1_sigma=self.loss_reg._sigma,
+                       cls_loss_weight=self.loss_cls._loss_weight, loc_loss_weight=self.loss_reg._loss_weight,
+                       dir_loss_weight=self.loss_aux._loss_weight, direction_offset=self.direction_offset, score_thresh=self.thresh,
+                       match_iou_thresh=0.7, center_range=self.post_center_range)
+            run = (key, ops.HeadLoss(B, A, dev, labels.dtype == torch.int64, cfg, pos_capacity, cons_capacity))
+            self._device_loss = run
+        run = run[1]
+        C = lambda t: t if t.is_contiguous() else t.contiguous()
+        F = lambda t: C(t if t.dtype == torch.float32 else t.float())
+        lab = lambda t: C(t if t.dtype in (torch.int32, torch.int64) else t.long())
+        stu = dict(labels=lab(labels), reg_targets=F(example["reg_targets"][0]), anchors=F(example["anchors"][0]))
+        tea = dict(box=F(q["box_preds"].detach()), cls=F(q["cls_preds"].detach()), dir=F(q["dir_cls_preds"].detach()),
+                   iou=F(q["iou_preds"].detach()), labels=lab(example["labels_raw"][0]), reg_targets=F(example["reg_targets_raw"][0]),
+                   anchors=F(example["anchors_raw"][0]))
+        if tea["labels"].dtype != stu["labels"].dtype:
+            tea["labels"] = tea["labels"].to(stu["labels"].dtype)
+        anchors0 = F(example["anchors"][0][0])
+        trans = example.get("transformation_dev")
+        if trans is None:
+            trans = self.transformation_tensor(example, dev)
+        if not torch.is_tensor(consistency_weight):
+            consistency_weight = torch.tensor(float(consistency_weight), dtype=torch.float32, device=dev)
+        total, rec = ops.HeadLossFunction.apply(F(p["box_preds"]), F(p["cls_preds"]), F(p["dir_cls_preds"]), F(p["iou_preds"]), run, stu,
+                                               tea, anchors0, F(trans), consistency_weight.reshape(()), unit_grad)
+        return total, rec
+
+    def record_to_dict(self, rec):
+        """The device log record as the dict MultiGroupHead.loss returns (one host read of 64 floats; every N iterations)."""
+        r = rec.detach().cpu()
+        R = ops.HEAD_LOSS_RECORD
+        T = lambda k: r[R[k]].clone()
+        out = {k: [T(k)] for k in ("loss", "cls_loss_reduced", "loc_loss_reduced", "dir_loss_reduced", "iou_pred_loss", "cls_pos_loss",
+                                   "cls_neg_loss", "ious_loss", "loss_ema", "cls_loss_reduced_ema", "loc_loss_reduced_ema",
+                                   "dir_loss_reduced_ema", "iou_pred_loss_ema", "cls_pos_loss_ema", "cls_neg_loss_ema")}
+        out["consistency_loss"] = [T("consistency_loss").reshape(1)]
+        out["loc_loss_elem"] = [[v for v in r[R["loc_loss_elem"]]]]
+        out["loc_loss_elem_ema"] = [[v for v in r[R["loc_loss_elem_ema"]]]]
+        for k in ("num_pos", "num_neg", "num_pos_ema", "num_neg_ema"):
+            out[k] = [T(k).long()]
+        out["total"] = [T("total")]
+        out["overflow"] = int(r[R["overflow"]])
+        return out
+
     @torch.no_grad()
     def predict(self, example, preds_dicts, test_cfg, **kwargs):
         """Same contract as the reference: list (per sample) of dict(box3d_lidar, scores, label_preds, metadata).

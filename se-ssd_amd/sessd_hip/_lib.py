@@ -30,9 +30,24 @@ class RulebookJob(C.Structure):
                 ("nbr", vp), ("tile_mask", vp)]
 
 
+class HeadLossNet(C.Structure):
+    """sessd_head_loss_net_t (include/sessd_hip_types.h)"""
+    _fields_ = [("box", vp), ("cls", vp), ("dir", vp), ("iou", vp), ("labels", vp), ("reg_targets", vp), ("anchors", vp)]
+
+
+class HeadLossCfg(C.Structure):
+    """sessd_head_loss_cfg_t (include/sessd_hip_types.h)"""
+    _fields_ = [("batch", i32), ("num_anchors", i32), ("labels_i64", i32), ("pos_capacity", i32), ("cons_capacity", i32),
+                ("pos_cls_weight", f32), ("neg_cls_weight", f32), ("focal_alpha", f32), ("focal_gamma", f32),
+                ("smooth_l1_sigma", f32), ("cls_loss_weight", f32), ("loc_loss_weight", f32), ("dir_loss_weight", f32),
+                ("direction_offset", f32), ("score_thresh", f32), ("match_iou_thresh", f32), ("center_range", f32 * 6)]
+
+
 # name -> (restype, argtypes). Kept in step with include/sessd_hip.h (tests/test_abi.py checks it).
 SIGNATURES = {
     "sessd_version": (C.c_char_p, []),
+    "sessd_head_loss_workspace_bytes": (sz, [vp]),
+    "sessd_head_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_fill_u32": (i32, [vp, u32, sz, vp]),
     "sessd_fill_u32_multi": (i32, [i32, vp, vp, vp, vp]),
     "sessd_set_external_clear": (None, [i32]),

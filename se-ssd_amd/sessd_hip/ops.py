@@ -1398,6 +1398,101 @@ def odiou_3d_loss(gboxes, qboxes, weights, batch_size):
     return OdiouFunction.apply(gboxes, qboxes, weights, batch_size)
 
 
+HEAD_LOSS_RECORD = {  # names of the floats of sessd_head_loss's record (include/sessd_hip.h)
+    "total": 0, "loss": 1, "cls_loss_reduced": 2, "loc_loss_reduced": 3, "dir_loss_reduced": 4, "iou_pred_loss": 5, "ious_loss": 6,
+    "consistency_loss": 7, "cls_pos_loss": 8, "cls_neg_loss": 9, "loc_loss_elem": slice(10, 17), "num_pos": 17, "num_neg": 18,
+    "consistency_box": 19, "consistency_score": 20, "consistency_iou": 21, "matched_boxes": 22,
+    "loss_ema": 24, "cls_loss_reduced_ema": 26, "loc_loss_reduced_ema": 27, "dir_loss_reduced_ema": 28, "iou_pred_loss_ema": 29,
+    "cls_pos_loss_ema": 32, "cls_neg_loss_ema": 33, "loc_loss_elem_ema": slice(34, 41), "num_pos_ema": 41, "num_neg_ema": 42,
+    "overflow": 48, "positives": 49, "positives_ema": 50, "candidates": 51, "candidates_ema": 52}
+
+
+class HeadLoss:
+    """The SE-SSD loss of MultiGroupHead.loss / consistency_loss / get_model_ema_loss (mg_head_sessd.py:573-890) as ONE device
+    op in capacity form (csrc/head_loss.hip: six launches, every count on the device, nothing read back): value, log record and
+    the gradient with respect to the student's four head outputs. Static buffers (allocated here, once): usable inside a
+    captured iteration. One object per (batch, anchors) shape and device."""
+
+    def __init__(self, batch, num_anchors, device, labels_i64, cfg, pos_capacity=None, cons_capacity=2048):
+        from ._lib import HeadLossCfg
+        self.B, self.A, self.dev = int(batch), int(num_anchors), device
+        c = HeadLossCfg()
+        c.batch, c.num_anchors, c.labels_i64 = self.B, self.A, 1 if labels_i64 else 0
+        c.pos_capacity = int(pos_capacity or 1024 * self.B)
+        c.cons_capacity = int(cons_capacity)
+        for k in ("pos_cls_weight", "neg_cls_weight", "focal_alpha", "focal_gamma", "smooth_l1_sigma", "cls_loss_weight",
+                  "loc_loss_weight", "dir_loss_weight", "direction_offset", "score_thresh", "match_iou_thresh"):
+            setattr(c, k, float(cfg[k]))
+        for i, v in enumerate(cfg["center_range"]):
+            c.center_range[i] = float(v)
+        self.cfg = c
+        import ctypes as C
+        self._cfg_p = C.addressof(c)
+        need = int(lib.sessd_head_loss_workspace_bytes(self._cfg_p))
+        if need == 0:
+            raise ValueError("sessd_head_loss does not cover this configuration")
+        f = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=device)
+        self.ws = torch.zeros(need, dtype=torch.uint8, device=device)
+        self.g_box, self.g_cls, self.g_dir, self.g_iou = f(self.B, self.A, 7), f(self.B, self.A), f(self.B, self.A, 2), f(self.B, self.A)
+        self.record = f(64)
+
+    def run(self, stu, tea, anchors0, transformation, cons_weight):
+        """stu / tea: dict(box, cls, dir, iou, labels, reg_targets, anchors) of contiguous device tensors (shapes of
+        sessd_head_loss_net_t); anchors0 (A,7); transformation (B,5) float32; cons_weight: device float32 scalar tensor.
+        Returns the record tensor (64 floats, device); the gradients are in self.g_*."""
+        from ._lib import HeadLossNet
+        import ctypes as C
+        nets = []
+        for d in (stu, tea):
+            n = HeadLossNet()
+            for k in ("box", "cls", "dir", "iou", "reg_targets", "anchors"):
+                t = d[k]
+                _req(t, torch.float32, k)
+                setattr(n, k, t.data_ptr())
+            lab = d["labels"]
+            want = torch.int64 if self.cfg.labels_i64 else torch.int32
+            if lab.dtype != want or not lab.is_contiguous() or not lab.is_cuda:
+                raise ValueError("labels must be contiguous %s device tensors" % want)
+            if lab.numel() != self.B * self.A or d["box"].numel() != self.B * self.A * 7 or d["cls"].numel() != self.B * self.A \
+                    or d["dir"].numel() != self.B * self.A * 2 or d["iou"].numel() != self.B * self.A \
+                    or d["reg_targets"].numel() != self.B * self.A * 7 or d["anchors"].numel() != self.B * self.A * 7:
+                raise ValueError("head-loss tensors do not have the (batch %d, anchors %d) shape" % (self.B, self.A))
+            n.labels = lab.data_ptr()
+            nets.append(n)
+        _req(anchors0, torch.float32, "anchors0")
+        _req(transformation, torch.float32, "transformation")
+        _req(cons_weight, torch.float32, "cons_weight")
+        if anchors0.numel() != self.A * 7 or transformation.numel() != self.B * 5:
+            raise ValueError("anchors0 must be (A,7), transformation (B,5)")
+        check(lib.sessd_head_loss(self._cfg_p, C.addressof(nets[0]), C.addressof(nets[1]), anchors0.data_ptr(), transformation.data_ptr(),
+                                  cons_weight.data_ptr(), self.g_box.data_ptr(), self.g_cls.data_ptr(), self.g_dir.data_ptr(),
+                                  self.g_iou.data_ptr(), self.record.data_ptr(), self.ws.data_ptr(), self.ws.numel(), _stream()),
+              "head_loss")
+        return self.record
+
+
+class HeadLossFunction(torch.autograd.Function):
+    """loss = HeadLoss record[0] as a differentiable scalar of the student's head outputs. unit_grad=True: backward returns the
+    kernel's gradients as they are (valid when the scalar itself is what `.backward()` is called on -- the training step; no
+    extra launches); otherwise they are scaled by the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, box, cls, dirp, iou, runner, stu, tea, anchors0, transformation, cons_weight, unit_grad):
+        stu = dict(stu, box=box.detach(), cls=cls.detach(), dir=dirp.detach(), iou=iou.detach())
+        rec = runner.run(stu, tea, anchors0, transformation, cons_weight)
+        ctx.runner, ctx.unit, ctx.shapes = runner, bool(unit_grad), (box.shape, cls.shape, dirp.shape, iou.shape)
+        ctx.mark_non_differentiable(rec)
+        return rec[0].clone(), rec
+
+    @staticmethod
+    def backward(ctx, g, _g_rec):
+        r = ctx.runner
+        gs = [t.view(sh) for t, sh in zip((r.g_box, r.g_cls, r.g_dir, r.g_iou), ctx.shapes)]
+        if not ctx.unit:
+            gs = [t * g for t in gs]
+        return (*gs, None, None, None, None, None, None, None)
+
+
 class _SumAll(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, scale):

@@ -75,6 +75,19 @@ def make_frame(seed=0, num_points=20000, supersample=1):
     return np.ascontiguousarray(out)
 
 
+def frame_cars(seed=0):
+    """The 15 car-sized boxes make_frame(seed) places in its scene, as KITTI lidar boxes (15, 7) [x, y, z, w, l, h, r] (the same
+    random draws in the same order as make_frame: six walls first). Ground-truth stand-ins of the training benchmark."""
+    rng = np.random.RandomState(seed)
+    for _ in range(6):
+        rng.uniform(15, 65); rng.uniform(-0.7, 0.7); rng.uniform(6, 25); rng.uniform(-math.pi, math.pi)
+    out = np.zeros((15, 7), np.float32)
+    for i in range(15):
+        x, y = rng.uniform(5, 60), rng.uniform(-25, 25)
+        out[i] = [x, y, -1.73 + 0.78, 1.6, 3.9, 1.56, rng.uniform(-math.pi, math.pi)]
+    return out
+
+
 def kitti_calib():
     """A KITTI-typical calibration (P2 fx=fy=721.5377, cx=609.5593, cy=172.854; image 375x1242)."""
     P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884],

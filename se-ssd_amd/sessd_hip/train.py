@@ -176,6 +176,12 @@ def capacity_example(example, voxel_capacity, device=None):
         v[:n], c[:n], p[:n] = vox.to(dev), coo.to(dev).int(), npt.to(dev).int()
         out["voxels" + suffix], out["coordinates" + suffix], out["num_points" + suffix] = v, c, p
         out["num_voxels_dev" + suffix] = torch.tensor([n], dtype=torch.int32, device=dev)
+    if "transformation" in example and "transformation_dev" not in example:
+        # the recorded global augmentation (flip / rotation / scale) the consistency loss maps the teacher's boxes with, as a
+        # (B, 5) device tensor: [flipped, cos, sin, noise_rotation, noise_scale]
+        from det3d.models.bbox_heads.mg_head_sessd import MultiGroupHead
+        dev = device if device is not None else example["voxels"].device
+        out["transformation_dev"] = MultiGroupHead.transformation_tensor(example, dev)
     return out
 
 
@@ -225,6 +231,13 @@ class TrainStep:
         self.overlap_teacher = True          # teacher forward on a second stream beside the student's
         self._side = None
         self.direct_grads = True  # gradients handed over by autograd and packed with one multi-tensor copy (FlatParams.gather_grads)
+        # loss_fn=None: the reference loss as the capacity-form device op (MultiGroupHead.loss_device -> sessd_head_loss); False
+        # keeps the eager torch restatement (MultiGroupHead.loss: boolean masks, host reads -- not capturable)
+        self.device_loss = True
+        self.pos_capacity, self.cons_capacity = None, 2048
+        self.cw_dev = None        # consistency weight as a device scalar (a captured iteration reads it from here)
+        self._cw_host = None
+        self.last_record = None
 
     def _iteration(self, example, consistency_weight, device_schedule):
         self.student.train()
@@ -254,8 +267,17 @@ class TrainStep:
             student_preds = self.student.forward_preds(example)
             if main is not None:
                 main.wait_stream(self._side)
-            if self.loss_fn is None:     # VoxelNet.forward(example, is_ema=[False, teacher_preds], return_loss=True) after its forward
-                losses = self.student.bbox_head.loss(example, student_preds, teacher_preds)
+            head = self.student.bbox_head
+            if self.loss_fn is None and self.device_loss and head.device_loss_covers(example, student_preds):
+                # the reference loss (MultiGroupHead.loss + trainer_sessd.py:267) as one capacity-form device op: six launches,
+                # no host read -- the form that can sit inside the captured iteration. The log terms stay on the device
+                # (self.last_record; head.record_to_dict(rec) reads them, every N iterations).
+                self._cw_dev(consistency_weight, example)
+                loss, self.last_record = head.loss_device(example, student_preds, teacher_preds, self.cw_dev, unit_grad=True,
+                                                          pos_capacity=self.pos_capacity, cons_capacity=self.cons_capacity)
+                self.last_losses = None
+            elif self.loss_fn is None:   # VoxelNet.forward(example, is_ema=[False, teacher_preds], return_loss=True) after its forward
+                losses = head.loss(example, student_preds, teacher_preds)
                 loss = losses["loss"][0] + losses["consistency_loss"][0][0] * consistency_weight
                 self.last_losses = losses
             else:
@@ -272,6 +294,15 @@ class TrainStep:
         self.opt.step(lr, mom, self.global_step)
         return loss.detach(), lr, mom
 
+    def _cw_dev(self, consistency_weight, example):
+        """The consistency weight of trainer_sessd.py:306-312 (a host float that changes once per epoch) as a device scalar;
+        refilled only when it changes and never while capturing (capture() fills it before the capture begins)."""
+        if self.cw_dev is None:
+            self.cw_dev = torch.zeros((), dtype=torch.float32, device=self.flat_s.data.device)
+        if self._cw_host != float(consistency_weight) and not torch.cuda.is_current_stream_capturing():
+            self.cw_dev.fill_(float(consistency_weight))
+            self._cw_host = float(consistency_weight)
+
     def __call__(self, example, consistency_weight=1.0, device_schedule=False):
         """One eager iteration. device_schedule=True evaluates the OneCycle schedule and the Adam constants on the device from
         the device iteration counter (the arithmetic a captured iteration replays) instead of passing host scalars."""
@@ -286,10 +317,11 @@ class TrainStep:
     # ------------------------------------------------------------------ the iteration as ONE hipGraph
     def capture(self, example, consistency_weight=1.0, warmup=2):
         """Capture teacher forward + student forward / backward + all-reduce + fused update on `example` as one graph. `example`
-        must be in capacity form (capacity_example: fixed shapes, device-side voxel counts) and the loss free of host reads
-        (a `loss_fn` on the head outputs; the reference loss selects anchors by boolean masks, i.e. with host-read shapes, and
-        stays eager). Runs `warmup` real iterations first (they count: parameters and the step counter advance). Later batches
-        are copied INTO the example's tensors before replay()."""
+        must be in capacity form (capacity_example: fixed shapes, device-side voxel counts, `transformation_dev`) and the loss
+        free of host reads: with loss_fn=None that is the reference loss as the capacity-form device op (sessd_head_loss; round 3
+        had only the eager torch restatement, whose boolean masks read shapes back), or a custom `loss_fn` on the head outputs.
+        Runs `warmup` real iterations first (they count: parameters and the step counter advance). Later batches are copied INTO
+        the example's tensors before replay(); replay(consistency_weight=...) refills the device scalar the graph reads."""
         if "num_voxels_dev" not in example:
             raise ValueError("capture() needs a capacity-form example (sessd_hip.train.capacity_example)")
         self.static_example = example
@@ -318,8 +350,12 @@ class TrainStep:
         self.graph = g
         return g
 
-    def replay(self):
-        """One captured iteration on whatever the static example's tensors hold now. Returns the (device) loss tensor."""
+    def replay(self, consistency_weight=None):
+        """One captured iteration on whatever the static example's tensors hold now. Returns the (device) loss tensor; with the
+        device loss, `self.last_record` is the 64-float device log of that iteration."""
+        if consistency_weight is not None and self.cw_dev is not None and float(consistency_weight) != self._cw_host:
+            self.cw_dev.fill_(float(consistency_weight))
+            self._cw_host = float(consistency_weight)
         self.graph.replay()
         self.global_step += 1
         self.opt.steps += 1

@@ -139,3 +139,26 @@ def test_round3_training_entry_points_reject_bad_arguments_before_touching_the_d
     assert lib.sessd_box_collision_host(sq.ctypes.data, 1, qs.ctypes.data, 2, 0, 1, out.ctypes.data) == 0 and out.tolist() == [[1, 0]]
     assert lib.sessd_box_collision_host(None, 1, qs.ctypes.data, 2, 0, 1, out.ctypes.data) == -1
     assert lib.sessd_noise_per_box_host(None, None, None, None, None, None, 2, 3, 0, None) == -1
+
+
+def test_head_loss_entry_point_checks_its_arguments():
+    """sessd_head_loss (round 4): configuration and pointer checks come before any device call (no GPU here)."""
+    import ctypes as C
+    import sessd_hip
+    from sessd_hip._lib import HeadLossCfg, HeadLossNet
+    lib = sessd_hip.lib
+    c = HeadLossCfg()
+    assert lib.sessd_head_loss_workspace_bytes(C.addressof(c)) == 0          # batch 0
+    c.batch, c.num_anchors, c.pos_capacity, c.cons_capacity = 4, 70400, 4096, 2048
+    c.pos_cls_weight = c.neg_cls_weight = 1.0
+    c.smooth_l1_sigma = 3.0
+    need = lib.sessd_head_loss_workspace_bytes(C.addressof(c))
+    # counts per block + 12 doubles per block + the positive / candidate lists: a few MB, growing with the capacities
+    assert 1 << 19 < need < 64 << 20
+    c.cons_capacity = 4096
+    assert lib.sessd_head_loss_workspace_bytes(C.addressof(c)) > need
+    n = HeadLossNet()
+    assert lib.sessd_head_loss(C.addressof(c), C.addressof(n), C.addressof(n), None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert lib.sessd_head_loss(None, None, None, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    c.batch = 65
+    assert lib.sessd_head_loss_workspace_bytes(C.addressof(c)) == 0

@@ -47,3 +47,140 @@ def test_head_loss_matches_reference_run(dev, golden_dir):
         got = stu[k].grad.cpu().numpy()
         assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max(), (k, np.abs(got - want).max(), np.abs(want).max())
         assert np.array_equal(got != 0, want != 0) or np.abs(got - want).max() < 1e-6  # same support (positives / matched boxes)
+
+
+def _example_from(g, dev):
+    T = lambda k: torch.from_numpy(np.asarray(g[k])).to(dev)
+    B = g["labels"].shape[0]
+    trans = [dict(flipped=bool(g["trans_flipped"][b]), noise_rotation=float(g["trans_rot"][b]), noise_scale=float(g["trans_scale"][b]))
+             for b in range(B)]
+    example = dict(anchors=[T("anchors")], anchors_raw=[T("anchors")], labels=[T("labels")], reg_targets=[T("reg_targets")],
+                   labels_raw=[T("labels_raw")], reg_targets_raw=[T("reg_targets_raw")], metadata=[{}] * B, transformation=trans)
+    stu = {k: T(k + "_stu").clone().requires_grad_(True) for k in ("box", "cls", "dir", "iou")}
+    preds = [dict(box_preds=stu["box"], cls_preds=stu["cls"], dir_cls_preds=stu["dir"], iou_preds=stu["iou"])]
+    ema = [dict(box_preds=T("box_tea"), cls_preds=T("cls_tea"), dir_cls_preds=T("dir_tea"), iou_preds=T("iou_tea"))]
+    return example, stu, preds, ema
+
+
+def _head(dev):
+    from det3d.models import build_detector
+    return build_detector(configs.kitti_car_model(), train_cfg=None, test_cfg=configs.TEST_CFG).bbox_head.to(dev)
+
+
+def test_device_head_loss_matches_reference_run(dev, golden_dir):
+    """The SAME golden (the reference's own mg_head_sessd.py / losses.py / odious.py run from source) through the capacity-form
+    device op sessd_head_loss (csrc/head_loss.hip: six launches, no host read): every returned term and the gradient with
+    respect to the four head outputs, same tolerances as the torch restatement above."""
+    g = np.load(os.path.join(golden_dir, "head_loss_ref.npz"))
+    head = _head(dev)
+    example, stu, preds, ema = _example_from(g, dev)
+    assert head.device_loss_covers(example, preds)
+    total, rec = head.loss_device(example, preds, ema, consistency_weight=1.0)
+    ret = head.record_to_dict(rec)
+    assert ret["overflow"] == 0
+    val = lambda k: float(ret[k][0].sum())
+    for k, tol in (("loss", 1e-3), ("cls_loss_reduced", 5e-4), ("loc_loss_reduced", 5e-4), ("dir_loss_reduced", 5e-4),
+                   ("iou_pred_loss", 5e-4), ("ious_loss", 2e-3), ("cls_pos_loss", 5e-4), ("cls_neg_loss", 5e-4), ("loss_ema", 5e-4),
+                   ("cls_loss_reduced_ema", 5e-4), ("iou_pred_loss_ema", 5e-4), ("dir_loss_reduced_ema", 5e-4)):
+        want = float(g["ret_" + k])
+        assert abs(val(k) - want) <= tol * max(1e-3, abs(want)), (k, val(k), want)
+    want_c = float(g["ret_consistency_loss"][0])
+    assert abs(val("consistency_loss") - want_c) <= 5e-4 * want_c and want_c > 0
+    assert int(ret["num_pos"][0]) == int(g["ret_num_pos"])
+    assert abs(float(total) - (float(g["ret_loss"]) + want_c)) <= 1e-3 * abs(float(total))
+    total.backward()
+    for k in ("box", "cls", "dir", "iou"):
+        want = g["grad_" + k]
+        got = stu[k].grad.cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max(), (k, np.abs(got - want).max(), np.abs(want).max())
+        assert np.array_equal(got != 0, want != 0) or np.abs(got - want).max() < 1e-6
+
+
+def _big_case(seed, B, A):
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("mk_head_loss", os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                                                              "make_golden_head_loss.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)   # only its case generator is used: nothing of /root/reference is touched
+    c = m.make_case(seed=seed, B=B, A=A)
+    for b in range(2, B):
+        c["anchors"][b] = c["anchors"][0]
+    c["trans_flipped"] = np.array([t["flipped"] for t in c["trans"]])
+    c["trans_rot"] = np.array([t["noise_rotation"] for t in c["trans"]])
+    c["trans_scale"] = np.array([t["noise_scale"] for t in c["trans"]])
+    # a second matching sample with a real rotation + flip + scale: the student's boxes are the teacher's mapped by it
+    return c
+
+
+@pytest.mark.parametrize("labels_dtype", [torch.int64, torch.int32])
+def test_device_head_loss_equals_the_torch_restatement_at_full_size(dev, labels_dtype):
+    """Batch 4 x 70400 anchors (BASELINE configs[2]): the device op against MultiGroupHead.loss (the torch restatement that is
+    pinned to the reference run above) on the same inputs -- every log term 2e-4 relative, the gradients of
+    loss + 0.7 * consistency 2e-3 of the largest entry, identical support; two runs of the device op are bit-identical."""
+    B, A = 4, 70400
+    g = _big_case(3, B, A)
+    head = _head(dev)
+    example, stu, preds, ema = _example_from(g, dev)
+    for k in ("labels", "labels_raw"):
+        example[k] = [example[k][0].to(labels_dtype)]
+    cw = 0.7
+    total, rec = head.loss_device(example, preds, ema, consistency_weight=cw)
+    rec1 = rec.clone()
+    total.backward()
+    got = {k: stu[k].grad.clone() for k in stu}
+    dev_ret = head.record_to_dict(rec1)
+    assert dev_ret["overflow"] == 0
+    for k in stu:
+        stu[k].grad = None
+    for k in ("labels", "labels_raw"):
+        example[k] = [example[k][0].long()]
+    ref = head.loss(example, preds, ema)
+    (ref["loss"][0] + cw * ref["consistency_loss"][0].sum()).backward()
+    val = lambda d, k: float(d[k][0].detach().sum()) if torch.is_tensor(d[k][0]) else float(d[k][0])
+    for k in ("loss", "cls_loss_reduced", "loc_loss_reduced", "dir_loss_reduced", "iou_pred_loss", "ious_loss", "cls_pos_loss",
+              "cls_neg_loss", "consistency_loss", "loss_ema", "cls_loss_reduced_ema", "loc_loss_reduced_ema", "dir_loss_reduced_ema",
+              "iou_pred_loss_ema", "cls_pos_loss_ema", "cls_neg_loss_ema"):
+        a, b = val(dev_ret, k), val(ref, k)
+        assert abs(a - b) <= 2e-4 * max(1e-3, abs(b)), (k, a, b)
+    for i in range(7):
+        assert abs(float(dev_ret["loc_loss_elem"][0][i]) - float(ref["loc_loss_elem"][0][i])) <= 2e-4 * max(1e-3, abs(float(ref["loc_loss_elem"][0][i])))
+    for k in ("num_pos", "num_neg", "num_pos_ema", "num_neg_ema"):
+        assert int(dev_ret[k][0]) == int(ref[k][0]), k
+    assert val(ref, "consistency_loss") > 0 and float(rec1[ops_record("matched_boxes")]) > 10
+    assert abs(float(rec1[0]) - (val(ref, "loss") + cw * val(ref, "consistency_loss"))) <= 2e-4 * abs(float(rec1[0]))
+    for k in stu:
+        w, gk = stu[k].grad, got[k]
+        assert float((gk - w).abs().max()) <= 2e-3 * float(w.abs().max()), (k, float((gk - w).abs().max()), float(w.abs().max()))
+        assert int(((gk != 0) != (w != 0)).sum()) <= 2, k   # same support (an element whose gradient is exactly 0 on one side aside)
+    # deterministic: a second run gives the same bits
+    total2, rec2 = head.loss_device(example, preds, ema, consistency_weight=cw)
+    assert torch.equal(rec2, rec1)
+    r = head._device_loss[1]
+    assert torch.equal(r.g_box.view_as(got["box"]), got["box"]) and torch.equal(r.g_cls.view_as(got["cls"]), got["cls"])
+
+
+def ops_record(name):
+    from sessd_hip import ops
+    return ops.HEAD_LOSS_RECORD[name]
+
+
+def test_device_head_loss_reports_capacity_overflow(dev, golden_dir):
+    """Positives beyond pos_capacity / candidates beyond cons_capacity are dropped and FLAGGED in the record (bit 0 / bit 1):
+    never silent. With room for everything the flags are zero and an empty case (no positives, no candidates) gives finite terms."""
+    g = dict(np.load(os.path.join(golden_dir, "head_loss_ref.npz")))
+    head = _head(dev)
+    example, stu, preds, ema = _example_from(g, dev)
+    _, rec = head.loss_device(example, preds, ema, pos_capacity=8, cons_capacity=2048)
+    assert int(rec[ops_record("overflow")]) == 1
+    _, rec = head.loss_device(example, preds, ema, pos_capacity=4096, cons_capacity=4)
+    assert int(rec[ops_record("overflow")]) == 2
+    # nothing positive, nothing above the score threshold
+    g["labels"] = np.zeros_like(g["labels"]); g["labels_raw"] = np.zeros_like(g["labels_raw"])
+    g["cls_stu"] = np.full_like(g["cls_stu"], -6.0); g["cls_tea"] = np.full_like(g["cls_tea"], -6.0)
+    example, stu, preds, ema = _example_from(g, dev)
+    total, rec = head.loss_device(example, preds, ema, pos_capacity=4096, cons_capacity=2048)
+    r = rec.cpu().numpy()
+    assert np.all(np.isfinite(r)) and r[ops_record("overflow")] == 0 and r[ops_record("ious_loss")] == 0 and r[ops_record("consistency_loss")] == 0
+    assert r[ops_record("num_pos")] == 0 and r[ops_record("cls_loss_reduced")] > 0
+    total.backward()
+    assert float(stu["box"].grad.abs().max()) == 0 and float(stu["cls"].grad.abs().max()) > 0
