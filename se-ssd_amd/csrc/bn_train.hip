@@ -38,6 +38,9 @@ struct BnFinal {                      // what the finishing block writes
   float* save_invstd;
   float* dgamma;                      // backward
   float* dbeta;
+  double* sums;                       // SyncBN form (not NULL): the finishing block ALSO / INSTEAD writes the raw totals here --
+                                      // forward: [sum x (C), sum x^2 (C), rows]; backward: [sum dz (C), sum dz * xhat (C)] -- to be
+                                      // all-reduced over the ranks before the apply launch (det3d/torchie/apis/train_sessd.py:286-294)
 };
 
 // Partial sums travel between workgroups (possibly on different XCDs, each with its own L2) as agent-scope relaxed atomic
@@ -151,6 +154,13 @@ __global__ __launch_bounds__(NT) void bn_stats_kernel(const float* __restrict__ 
   if (tid >= C) return;
   t0 = sm[0][tid];
   t1 = sm[1][tid];
+  if (F.sums) {   // SyncBN: the totals of THIS rank; mean / invstd / running statistics follow the all-reduce (bn_sync_finalize)
+    F.sums[c] = t0;
+    F.sums[C + c] = t1;
+    if (!BWD && c == 0) F.sums[2 * C] = (double)n;
+    if (BWD) { F.dbeta[c] = (float)t0; F.dgamma[c] = (float)t1; }   // the parameter gradients stay local (averaged with all others)
+    return;
+  }
   if (!BWD) {
     const double m = n > 0 ? t0 / n : 0.0;
     double var = n > 0 ? t1 / n - m * m : 0.0;
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
                                                        int C, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
                                                        const float* __restrict__ dgamma, const float* __restrict__ dbeta, int relu,
-                                                       float* __restrict__ out) {
+                                                       float* __restrict__ out, const float* __restrict__ inv_n_sync) {
   const size_t i = ((size_t)blockIdx.x * NT + threadIdx.x) * VEC;
   if (i >= (size_t)n_cap * C) return;
   const int n = min(n_dev[0], n_cap);
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const float* __restrict__ 
       xv[0] = x[i];
       if (BWD) { dz[0] = dy[i]; if (relu) yv[0] = y_in[i]; }
     }
-    const float inv_n = 1.f / (float)n;
+    const float inv_n = inv_n_sync ? inv_n_sync[0] : 1.f / (float)n;   // SyncBN: 1 / rows of ALL ranks
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const int c = c0 + v;
@@ -242,7 +252,7 @@ int sessd_bn_relu_train_fwd(const float* x, const int* n_dev, int n_cap, int cha
   if (workspace_bytes < sessd_bn_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
   unsigned* counter = (unsigned*)workspace;
   double* partial = (double*)((char*)workspace + BN_COUNTER_BYTES);
-  BnFinal F{eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
+  BnFinal F{eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr, nullptr};
   const size_t total = (size_t)n_cap * channels;
   const float* nf = nullptr;
   if (channels % 4 == 0) {
@@ -250,13 +260,13 @@ int sessd_bn_relu_train_fwd(const float* x, const int* n_dev, int n_cap, int cha
                  partial, counter, F);
     SESSD_CHECK_LAUNCH();
     SESSD_LAUNCH((bn_apply_kernel<false, 4>), dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, stream, x, nf, nf, n_dev,
-                 n_cap, channels, gamma, beta, (const float*)save_mean, (const float*)save_invstd, nf, nf, relu, y);
+                 n_cap, channels, gamma, beta, (const float*)save_mean, (const float*)save_invstd, nf, nf, relu, y, nf);
   } else {
     SESSD_LAUNCH((bn_stats_kernel<false, 1>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, nf, nf, nf, nf, n_dev, n_cap, channels, 0,
                  partial, counter, F);
     SESSD_CHECK_LAUNCH();
     SESSD_LAUNCH((bn_apply_kernel<false, 1>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, x, nf, nf, n_dev, n_cap,
-                 channels, gamma, beta, (const float*)save_mean, (const float*)save_invstd, nf, nf, relu, y);
+                 channels, gamma, beta, (const float*)save_mean, (const float*)save_invstd, nf, nf, relu, y, nf);
   }
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -271,7 +281,7 @@ int sessd_bn_relu_train_bwd(const float* dy, const float* x, const float* y, con
   if (workspace_bytes < sessd_bn_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
   unsigned* counter = (unsigned*)workspace;
   double* partial = (double*)((char*)workspace + BN_COUNTER_BYTES);
-  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta, nullptr};
   const size_t total = (size_t)n_cap * channels;
   const float* nf = nullptr;
   if (channels % 4 == 0) {
@@ -279,13 +289,13 @@ int sessd_bn_relu_train_bwd(const float* dy, const float* x, const float* y, con
                  channels, relu, partial, counter, F);
     SESSD_CHECK_LAUNCH();
     SESSD_LAUNCH((bn_apply_kernel<true, 4>), dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, n_dev,
-                 n_cap, channels, gamma, nf, save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, relu, dx);
+                 n_cap, channels, gamma, nf, save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, relu, dx, nf);
   } else {
     SESSD_LAUNCH((bn_stats_kernel<true, 1>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, n_dev, n_cap,
                  channels, relu, partial, counter, F);
     SESSD_CHECK_LAUNCH();
     SESSD_LAUNCH((bn_apply_kernel<true, 1>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, n_dev, n_cap,
-                 channels, gamma, nf, save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, relu, dx);
+                 channels, gamma, nf, save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta, relu, dx, nf);
   }
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
@@ -386,6 +396,13 @@ __global__ __launch_bounds__(NT) void bn2d_stats_kernel(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < BN2D_SPLIT; ++k) { t0 += a0[k]; t1 += a1[k]; }
   __hip_atomic_store(counters + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (F.sums && MODE != 2) {   // SyncBN: this rank's totals (see BnFinal); the rest follows the all-reduce
+    F.sums[c] = t0;
+    F.sums[C + c] = t1;
+    if (MODE == 0 && c == 0) F.sums[2 * C] = (double)B * (double)plane;
+    if (MODE == 1) { F.dbeta[c] = (float)t0; F.dgamma[c] = (float)t1; }
+    return;
+  }
   if (MODE == 0) {
     const double n = (double)B * (double)plane;
     const double m = t0 / n;
@@ -411,9 +428,11 @@ __global__ __launch_bounds__(NT) void bn2d_apply_kernel(const float* __restrict_
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
                                                          const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                                         float inv_n, int relu, float* __restrict__ out, size_t total_quads) {
+                                                         float inv_n, int relu, float* __restrict__ out, size_t total_quads,
+                                                         const float* __restrict__ inv_n_sync) {
   const size_t i = (size_t)blockIdx.x * NT + threadIdx.x;
   if (i >= total_quads) return;
+  if (inv_n_sync) inv_n = inv_n_sync[0];   // SyncBN: 1 / (pixels of ALL ranks)
   const int c = (int)((i / (size_t)(plane >> 2)) % (size_t)C);
   const float mu = mean[c], is = invstd[c], g = gamma ? gamma[c] : 1.f;
   const float4 xv = *reinterpret_cast<const float4*>(x + 4 * i);
@@ -464,7 +483,7 @@ int sessd_nchw_channel_sum(const float* x, int batch, int channels, int plane, f
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
   unsigned* counters = (unsigned*)workspace;
   double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
-  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, out};
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, out, nullptr};
   const float* nf = nullptr;
   SESSD_LAUNCH((bn2d_stats_kernel<2>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, nf, nf, batch, channels, plane, 0,
                partial, counters, F);
@@ -482,7 +501,7 @@ int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane
   if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
   unsigned* counters = (unsigned*)workspace;
   double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
-  BnFinal F{eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr};
+  BnFinal F{eps, momentum, running_mean, running_var, save_mean, save_invstd, nullptr, nullptr, nullptr};
   const float* nf = nullptr;
   SESSD_LAUNCH((bn2d_stats_kernel<0>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, nf, nf, batch, channels, plane, 0,
                partial, counters, F);
@@ -490,7 +509,7 @@ int sessd_bn2d_relu_train_fwd(const float* x, int batch, int channels, int plane
   const size_t quads = (size_t)batch * channels * (plane >> 2);
   SESSD_LAUNCH((bn2d_apply_kernel<false>), dim3((unsigned)((quads + NT - 1) / NT)), dim3(NT), 0, stream, x, (const float*)nullptr,
                (const float*)nullptr, channels, plane, gamma, beta, save_mean, save_invstd, (const float*)nullptr,
-               (const float*)nullptr, 0.f, relu, y, quads);
+               (const float*)nullptr, 0.f, relu, y, quads, (const float*)nullptr);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -504,14 +523,14 @@ static int bn2d_bwd_launch(const float* dy, const float* x, const float* y, int 
   if (!dgamma || !dbeta) return SESSD_EINVAL;
   unsigned* counters = (unsigned*)workspace;
   double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
-  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta};
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta, nullptr};
   SESSD_LAUNCH((bn2d_stats_kernel<1>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, gamma, beta,
                batch, channels, plane, relu, partial, counters, F);
   SESSD_CHECK_LAUNCH();
   const size_t quads = (size_t)batch * channels * (plane >> 2);
   SESSD_LAUNCH((bn2d_apply_kernel<true>), dim3((unsigned)((quads + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, channels, plane,
                gamma, beta, save_mean, save_invstd, (const float*)dgamma, (const float*)dbeta,
-               1.f / (float)((long long)batch * plane), relu, dx, quads);
+               1.f / (float)((long long)batch * plane), relu, dx, quads, (const float*)nullptr);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -531,6 +550,206 @@ int sessd_bn2d_relu_train_bwd_x(const float* dy, const float* x, int batch, int 
                                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, hipStream_t stream) {
   return bn2d_bwd_launch(dy, x, nullptr, batch, channels, plane, gamma, beta, save_mean, save_invstd, relu, dx, dgamma, dbeta,
                          workspace, workspace_bytes, stream);
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------ SyncBN form (world size > 1)
+// The reference's distributed path converts every BatchNorm to SyncBN (det3d/torchie/apis/train_sessd.py:286-294: apex
+// convert_syncbn_model; the in-tree twin det3d/ops/syncbn/syncbn.py:37-103): batch statistics over the batches of ALL ranks.
+// Each pass is split at the point where the ranks must talk:
+//   *_stats      the statistics launch above; its finishing block writes this rank's raw totals (float64) instead of finalising
+//   [host]       ONE all-reduce (sum) of those 2C + 1 / 2C doubles over RCCL
+//   *_apply      bn_sync_finalize (one block: mean / invstd / running statistics, or the global gradient sums and 1 / N) + the
+//                apply launch above
+// With one rank the two forms give the same bits (same sums, same finalisation arithmetic).
+namespace {
+
+// forward: sums = [sum x (C), sum x^2 (C), N] over all ranks. backward: sums = [sum dz (C), sum dz * xhat (C)], n_total = fwd N.
+template <bool BWD>
+__global__ void bn_sync_finalize_kernel(const double* __restrict__ sums, const double* __restrict__ fwd_sums, int C, float eps,
+                                        float momentum, float* running_mean, float* running_var, float* save_mean,
+                                        float* save_invstd, float* g_dbeta, float* g_dgamma, float* inv_n) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (!BWD) {
+    const double n = sums[2 * C];
+    const double m = n > 0 ? sums[c] / n : 0.0;
+    double var = n > 0 ? sums[C + c] / n - m * m : 0.0;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)m;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean && n > 0) {
+      const double unbiased = n > 1 ? var * n / (n - 1) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * m);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  } else {
+    g_dbeta[c] = (float)sums[c];
+    g_dgamma[c] = (float)sums[C + c];
+    if (c == 0) inv_n[0] = (float)(1.0 / fwd_sums[2 * C]);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+// scratch of the *_apply calls after the counters / partials: global dbeta, dgamma (C floats each) and 1 / N
+size_t sessd_bn_sync_scratch_bytes(int channels) { return ((size_t)2 * channels + 4) * sizeof(float); }
+
+int sessd_bn_relu_train_stats(const float* x, const int* n_dev, int n_cap, int channels, double* sums, void* workspace,
+                              size_t workspace_bytes, hipStream_t stream) {
+  if (n_cap <= 0 || !channels_ok(channels) || !sums) return SESSD_EINVAL;
+  if (workspace_bytes < sessd_bn_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
+  unsigned* counter = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + BN_COUNTER_BYTES);
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sums};
+  const float* nf = nullptr;
+  if (channels % 4 == 0)
+    SESSD_LAUNCH((bn_stats_kernel<false, 4>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, nf, nf, nf, nf, n_dev, n_cap, channels, 0,
+                 partial, counter, F);
+  else
+    SESSD_LAUNCH((bn_stats_kernel<false, 1>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, nf, nf, nf, nf, n_dev, n_cap, channels, 0,
+                 partial, counter, F);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// sums: the all-reduced totals [sum x, sum x^2, N]
+int sessd_bn_relu_train_apply(const float* x, const int* n_dev, int n_cap, int channels, const float* gamma, const float* beta,
+                              float eps, float momentum, int relu, const double* sums, float* running_mean, float* running_var,
+                              float* y, float* save_mean, float* save_invstd, hipStream_t stream) {
+  if (n_cap <= 0 || !channels_ok(channels) || !sums || !save_mean || !save_invstd) return SESSD_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SESSD_EINVAL;
+  SESSD_LAUNCH((bn_sync_finalize_kernel<false>), dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, sums, (const double*)nullptr,
+               channels, eps, momentum, running_mean, running_var, save_mean, save_invstd, (float*)nullptr, (float*)nullptr,
+               (float*)nullptr);
+  SESSD_CHECK_LAUNCH();
+  const size_t total = (size_t)n_cap * channels;
+  const float* nf = nullptr;
+  if (channels % 4 == 0)
+    SESSD_LAUNCH((bn_apply_kernel<false, 4>), dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, stream, x, nf, nf, n_dev,
+                 n_cap, channels, gamma, beta, (const float*)save_mean, (const float*)save_invstd, nf, nf, relu, y, nf);
+  else
+    SESSD_LAUNCH((bn_apply_kernel<false, 1>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, x, nf, nf, n_dev, n_cap,
+                 channels, gamma, beta, (const float*)save_mean, (const float*)save_invstd, nf, nf, relu, y, nf);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// this rank's sums [sum dz, sum dz * xhat] into `sums` (to be all-reduced) and into dgamma / dbeta (the parameter gradients: local)
+int sessd_bn_relu_train_bwd_stats(const float* dy, const float* x, const float* y, const int* n_dev, int n_cap, int channels,
+                                  const float* save_mean, const float* save_invstd, int relu, float* dgamma, float* dbeta,
+                                  double* sums, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+  if (n_cap <= 0 || !channels_ok(channels) || !dgamma || !dbeta || !sums) return SESSD_EINVAL;
+  if (workspace_bytes < sessd_bn_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
+  unsigned* counter = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + BN_COUNTER_BYTES);
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta, sums};
+  if (channels % 4 == 0)
+    SESSD_LAUNCH((bn_stats_kernel<true, 4>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, n_dev, n_cap,
+                 channels, relu, partial, counter, F);
+  else
+    SESSD_LAUNCH((bn_stats_kernel<true, 1>), dim3(BN_BLOCKS), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, n_dev, n_cap,
+                 channels, relu, partial, counter, F);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// sums: all-reduced [sum dz, sum dz * xhat]; fwd_sums: the forward's all-reduced totals (its last entry is N of all ranks);
+// scratch: sessd_bn_sync_scratch_bytes(channels) bytes
+int sessd_bn_relu_train_bwd_apply(const float* dy, const float* x, const float* y, const int* n_dev, int n_cap, int channels,
+                                  const float* gamma, const float* save_mean, const float* save_invstd, int relu, const double* sums,
+                                  const double* fwd_sums, float* dx, void* scratch, size_t scratch_bytes, hipStream_t stream) {
+  if (n_cap <= 0 || !channels_ok(channels) || !sums || !fwd_sums || !scratch) return SESSD_EINVAL;
+  if (scratch_bytes < sessd_bn_sync_scratch_bytes(channels)) return SESSD_EWORKSPACE;
+  float* gdb = (float*)scratch;
+  float* gdg = gdb + channels;
+  float* inv_n = gdg + channels;
+  SESSD_LAUNCH((bn_sync_finalize_kernel<true>), dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, sums, fwd_sums, channels, 0.f, 0.f,
+               (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, gdb, gdg, inv_n);
+  SESSD_CHECK_LAUNCH();
+  const size_t total = (size_t)n_cap * channels;
+  const float* nf = nullptr;
+  if (channels % 4 == 0)
+    SESSD_LAUNCH((bn_apply_kernel<true, 4>), dim3((unsigned)((total / 4 + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, n_dev, n_cap,
+                 channels, gamma, nf, save_mean, save_invstd, (const float*)gdg, (const float*)gdb, relu, dx, (const float*)inv_n);
+  else
+    SESSD_LAUNCH((bn_apply_kernel<true, 1>), dim3((unsigned)((total + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, n_dev, n_cap,
+                 channels, gamma, nf, save_mean, save_invstd, (const float*)gdg, (const float*)gdb, relu, dx, (const float*)inv_n);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// ---- the same four for the dense (batch, channels, plane) layout
+int sessd_bn2d_relu_train_stats(const float* x, int batch, int channels, int plane, double* sums, void* workspace,
+                                size_t workspace_bytes, hipStream_t stream) {
+  if (batch <= 0 || channels <= 0 || channels > BN2D_MAX_CHANNELS || plane <= 0 || (plane & 3) || !sums) return SESSD_EINVAL;
+  if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
+  unsigned* counters = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sums};
+  const float* nf = nullptr;
+  SESSD_LAUNCH((bn2d_stats_kernel<0>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, nf, nf, nf, nf, nf, nf, batch, channels, plane, 0,
+               partial, counters, F);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+int sessd_bn2d_relu_train_apply(const float* x, int batch, int channels, int plane, const float* gamma, const float* beta, float eps,
+                                float momentum, int relu, const double* sums, float* running_mean, float* running_var, float* y,
+                                float* save_mean, float* save_invstd, hipStream_t stream) {
+  if (batch <= 0 || channels <= 0 || channels > BN2D_MAX_CHANNELS || plane <= 0 || (plane & 3) || !sums || !save_mean || !save_invstd)
+    return SESSD_EINVAL;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return SESSD_EINVAL;
+  SESSD_LAUNCH((bn_sync_finalize_kernel<false>), dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, sums, (const double*)nullptr,
+               channels, eps, momentum, running_mean, running_var, save_mean, save_invstd, (float*)nullptr, (float*)nullptr,
+               (float*)nullptr);
+  SESSD_CHECK_LAUNCH();
+  const size_t quads = (size_t)batch * channels * (plane >> 2);
+  SESSD_LAUNCH((bn2d_apply_kernel<false>), dim3((unsigned)((quads + NT - 1) / NT)), dim3(NT), 0, stream, x, (const float*)nullptr,
+               (const float*)nullptr, channels, plane, gamma, beta, (const float*)save_mean, (const float*)save_invstd,
+               (const float*)nullptr, (const float*)nullptr, 0.f, relu, y, quads, (const float*)nullptr);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// y == NULL: the ReLU mask from x (needs beta), as sessd_bn2d_relu_train_bwd_x
+int sessd_bn2d_relu_train_bwd_stats(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
+                                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                    float* dgamma, float* dbeta, double* sums, void* workspace, size_t workspace_bytes,
+                                    hipStream_t stream) {
+  if (batch <= 0 || channels <= 0 || channels > BN2D_MAX_CHANNELS || plane <= 0 || (plane & 3) || !dgamma || !dbeta || !sums)
+    return SESSD_EINVAL;
+  if (workspace_bytes < sessd_bn2d_relu_train_workspace_bytes(channels)) return SESSD_EWORKSPACE;
+  unsigned* counters = (unsigned*)workspace;
+  double* partial = (double*)((char*)workspace + BN2D_COUNTER_BYTES);
+  BnFinal F{0.f, 0.f, nullptr, nullptr, nullptr, nullptr, dgamma, dbeta, sums};
+  SESSD_LAUNCH((bn2d_stats_kernel<1>), dim3(channels, BN2D_SPLIT), dim3(NT), 0, stream, x, dy, y, save_mean, save_invstd, gamma, beta,
+               batch, channels, plane, relu, partial, counters, F);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+int sessd_bn2d_relu_train_bwd_apply(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
+                                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                    const double* sums, const double* fwd_sums, float* dx, void* scratch, size_t scratch_bytes,
+                                    hipStream_t stream) {
+  if (batch <= 0 || channels <= 0 || channels > BN2D_MAX_CHANNELS || plane <= 0 || (plane & 3) || !sums || !fwd_sums || !scratch)
+    return SESSD_EINVAL;
+  if (scratch_bytes < sessd_bn_sync_scratch_bytes(channels)) return SESSD_EWORKSPACE;
+  float* gdb = (float*)scratch;
+  float* gdg = gdb + channels;
+  float* inv_n = gdg + channels;
+  SESSD_LAUNCH((bn_sync_finalize_kernel<true>), dim3(sessd_divup(channels, 64)), dim3(64), 0, stream, sums, fwd_sums, channels, 0.f, 0.f,
+               (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, gdb, gdg, inv_n);
+  SESSD_CHECK_LAUNCH();
+  const size_t quads = (size_t)batch * channels * (plane >> 2);
+  SESSD_LAUNCH((bn2d_apply_kernel<true>), dim3((unsigned)((quads + NT - 1) / NT)), dim3(NT), 0, stream, x, dy, y, channels, plane, gamma,
+               beta, save_mean, save_invstd, (const float*)gdg, (const float*)gdb, 0.f, relu, dx, quads, (const float*)inv_n);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
 }
 
 }  // extern "C"
