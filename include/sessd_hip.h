@@ -242,6 +242,39 @@ int sessd_bn2d_relu_train_bwd(const float* dy, const float* x, const float* y, i
 int sessd_bn2d_relu_train_bwd_x(const float* dy, const float* x, int batch, int channels, int plane, const float* gamma,
                                 const float* beta, const float* save_mean, const float* save_invstd, int relu, float* dx,
                                 float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+/* ---- SyncBN form of the four passes above, for world size > 1: the reference's distributed path converts every BatchNorm to SyncBN
+ * (det3d/torchie/apis/train_sessd.py:286-294, apex convert_syncbn_model; in-tree twin det3d/ops/syncbn/syncbn.py:37-103) -- batch
+ * statistics over the batches of ALL ranks. Each pass is split where the ranks must talk: *_stats writes THIS rank's float64 totals
+ * (forward: [sum x (C), sum x^2 (C), N]; backward: [sum dz (C), sum dz * xhat (C)], and the LOCAL dgamma / dbeta, which are averaged
+ * with all other parameter gradients), the caller all-reduces (sums) them over RCCL, *_apply finalises (mean / invstd / running
+ * statistics with the global N; backward: dx with the global sums and 1 / N_global) and runs the apply launch. fwd_sums of
+ * *_bwd_apply = the forward's all-reduced totals. Same workspace contract as above; scratch: sessd_bn_sync_scratch_bytes(channels).
+ * With one rank the result equals the fused form bit for bit. */
+size_t sessd_bn_sync_scratch_bytes(int channels);
+int sessd_bn_relu_train_stats(const float* x, const int32_t* n_dev, int n_cap, int channels, double* sums, void* workspace,
+                              size_t workspace_bytes, sessd_stream_t stream);
+int sessd_bn_relu_train_apply(const float* x, const int32_t* n_dev, int n_cap, int channels, const float* gamma, const float* beta,
+                              float eps, float momentum, int relu, const double* sums, float* running_mean, float* running_var,
+                              float* y, float* save_mean, float* save_invstd, sessd_stream_t stream);
+int sessd_bn_relu_train_bwd_stats(const float* dy, const float* x, const float* y, const int32_t* n_dev, int n_cap, int channels,
+                                  const float* save_mean, const float* save_invstd, int relu, float* dgamma, float* dbeta,
+                                  double* sums, void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+int sessd_bn_relu_train_bwd_apply(const float* dy, const float* x, const float* y, const int32_t* n_dev, int n_cap, int channels,
+                                  const float* gamma, const float* save_mean, const float* save_invstd, int relu, const double* sums,
+                                  const double* fwd_sums, float* dx, void* scratch, size_t scratch_bytes, sessd_stream_t stream);
+int sessd_bn2d_relu_train_stats(const float* x, int batch, int channels, int plane, double* sums, void* workspace,
+                                size_t workspace_bytes, sessd_stream_t stream);
+int sessd_bn2d_relu_train_apply(const float* x, int batch, int channels, int plane, const float* gamma, const float* beta, float eps,
+                                float momentum, int relu, const double* sums, float* running_mean, float* running_var, float* y,
+                                float* save_mean, float* save_invstd, sessd_stream_t stream);
+int sessd_bn2d_relu_train_bwd_stats(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
+                                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                    float* dgamma, float* dbeta, double* sums, void* workspace, size_t workspace_bytes,
+                                    sessd_stream_t stream);
+int sessd_bn2d_relu_train_bwd_apply(const float* dy, const float* x, const float* y, int batch, int channels, int plane,
+                                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int relu,
+                                    const double* sums, const double* fwd_sums, float* dx, void* scratch, size_t scratch_bytes,
+                                    sessd_stream_t stream);
 
 /* ---- training data path, point-level work -----------------------------------------------------------
  * replaces det3d/core/bbox/geometry.py:215-276 points_in_convex_polygon_3d_jit (numba) as used by

@@ -46,6 +46,15 @@ class HeadLossCfg(C.Structure):
 # name -> (restype, argtypes). Kept in step with include/sessd_hip.h (tests/test_abi.py checks it).
 SIGNATURES = {
     "sessd_version": (C.c_char_p, []),
+    "sessd_bn_sync_scratch_bytes": (sz, [i32]),
+    "sessd_bn_relu_train_stats": (i32, [vp, vp, i32, i32, vp, vp, sz, vp]),
+    "sessd_bn_relu_train_apply": (i32, [vp, vp, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "sessd_bn_relu_train_bwd_stats": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "sessd_bn_relu_train_bwd_apply": (i32, [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "sessd_bn2d_relu_train_stats": (i32, [vp, i32, i32, i32, vp, vp, sz, vp]),
+    "sessd_bn2d_relu_train_apply": (i32, [vp, i32, i32, i32, vp, vp, f32, f32, i32, vp, vp, vp, vp, vp, vp, vp]),
+    "sessd_bn2d_relu_train_bwd_stats": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
+    "sessd_bn2d_relu_train_bwd_apply": (i32, [vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
     "sessd_head_loss_workspace_bytes": (sz, [vp]),
     "sessd_head_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "sessd_fill_u32": (i32, [vp, u32, sz, vp]),

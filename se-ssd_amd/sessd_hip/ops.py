@@ -783,7 +783,130 @@ def bn_relu_train(x, n_dev, bn, relu=True):
     """x (cap, C) float32 on the device, rows < n_dev[0] valid; bn: a torch.nn.BatchNorm1d in train mode (its running statistics are
     updated in place, num_batches_tracked incremented)."""
     mom = _bn_momentum(bn)
+    if sync_bn_active():
+        return SyncBnReluTrainFunction.apply(x, n_dev, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
     return BnReluTrainFunction.apply(x, n_dev, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
+
+
+# ---------------------------------------------------------------------------------------------------------------- SyncBN
+# The reference's distributed training converts every BatchNorm to SyncBN (det3d/torchie/apis/train_sessd.py:286-294; semantics
+# det3d/ops/syncbn/syncbn.py:37-103): batch statistics over the batches of ALL ranks. set_sync_bn(True) switches the fused
+# train-mode BatchNorm passes (sparse tables and dense maps) to their split form -- statistics launch, ONE all-reduce of the
+# float64 totals (2C + 1 numbers forward, 2C backward), finalise + apply -- in every process group of more than one rank; with
+# one rank the all-reduce is skipped and the result equals the fused form bit for bit.
+_SYNC_BN = {"on": False, "group": None, "reduce": None}
+
+
+def set_sync_bn(on=True, group=None, reduce_fn=None):
+    """reduce_fn(tensor) (tests): replaces dist.all_reduce on the float64 totals."""
+    _SYNC_BN.update(on=bool(on), group=group, reduce=reduce_fn)
+
+
+def sync_bn_active():
+    return _SYNC_BN["on"]
+
+
+def _sync_reduce(t):
+    if _SYNC_BN["reduce"] is not None:
+        _SYNC_BN["reduce"](t)
+        return
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_BN["group"]) > 1:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("SyncBN all-reduces cannot be captured in a hipGraph here: run the iteration eagerly at world size > 1 "
+                               "(TrainStep.capture refuses it), or switch SyncBN off (rank-local statistics)")
+        dist.all_reduce(t, group=_SYNC_BN["group"])
+
+
+class SyncBnReluTrainFunction(torch.autograd.Function):
+    """BnReluTrainFunction with the statistics of ALL ranks (sessd_bn_relu_train_stats / _apply / _bwd_stats / _bwd_apply)."""
+
+    @staticmethod
+    def forward(ctx, x, n_dev, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = x.float().contiguous()
+        _req(x, torch.float32, "x")
+        cap, C = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        ws = zeroed_workspace(lib.sessd_bn_relu_train_workspace_bytes(C), dev, "bn")
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        check(lib.sessd_bn_relu_train_stats(x.data_ptr(), n_dev.data_ptr(), cap, C, sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+              "bn_relu_train_stats")
+        _sync_reduce(sums)
+        check(lib.sessd_bn_relu_train_apply(x.data_ptr(), n_dev.data_ptr(), cap, C, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
+                                            1 if relu else 0, sums.data_ptr(), _p(running_mean), _p(running_var), y.data_ptr(),
+                                            mean.data_ptr(), invstd.data_ptr(), _stream()), "bn_relu_train_apply")
+        ctx.save_for_backward(x, y, g, mean, invstd, n_dev, sums)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, g, mean, invstd, n_dev, fwd_sums = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        cap, C = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ws = zeroed_workspace(lib.sessd_bn_relu_train_workspace_bytes(C), dev, "bn")
+        scratch = torch.empty(int(lib.sessd_bn_sync_scratch_bytes(C)), dtype=torch.uint8, device=dev)
+        check(lib.sessd_bn_relu_train_bwd_stats(dy.data_ptr(), x.data_ptr(), y.data_ptr(), n_dev.data_ptr(), cap, C, mean.data_ptr(),
+                                                invstd.data_ptr(), 1 if ctx.relu else 0, dg.data_ptr(), db.data_ptr(), sums.data_ptr(),
+                                                ws.data_ptr(), ws.numel(), _stream()), "bn_relu_train_bwd_stats")
+        _sync_reduce(sums)
+        check(lib.sessd_bn_relu_train_bwd_apply(dy.data_ptr(), x.data_ptr(), y.data_ptr(), n_dev.data_ptr(), cap, C, g.data_ptr(),
+                                                mean.data_ptr(), invstd.data_ptr(), 1 if ctx.relu else 0, sums.data_ptr(),
+                                                fwd_sums.data_ptr(), dx.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream()),
+              "bn_relu_train_bwd_apply")
+        return dx, None, dg, db, None, None, None, None, None
+
+
+class SyncBn2dReluTrainFunction(torch.autograd.Function):
+    """Bn2dReluTrainFunction with the statistics of ALL ranks (the dense layout's split entry points; ReLU mask from x)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, eps, momentum, relu):
+        x = x.float().contiguous()
+        _req(x, torch.float32, "x")
+        B, C, H, W = x.shape
+        dev = x.device
+        y = torch.empty_like(x)
+        mean, invstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        sums = torch.empty(2 * C + 1, dtype=torch.float64, device=dev)
+        ws = zeroed_workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), dev, "bn2d")
+        g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+        check(lib.sessd_bn2d_relu_train_stats(x.data_ptr(), B, C, H * W, sums.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+              "bn2d_relu_train_stats")
+        _sync_reduce(sums)
+        check(lib.sessd_bn2d_relu_train_apply(x.data_ptr(), B, C, H * W, g.data_ptr(), b.data_ptr(), float(eps), float(momentum),
+                                              1 if relu else 0, sums.data_ptr(), _p(running_mean), _p(running_var), y.data_ptr(),
+                                              mean.data_ptr(), invstd.data_ptr(), _stream()), "bn2d_relu_train_apply")
+        ctx.save_for_backward(x, g, b, mean, invstd, sums)
+        ctx.relu = bool(relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b, mean, invstd, fwd_sums = ctx.saved_tensors
+        dy = dy.float().contiguous()
+        B, C, H, W = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        dg, db = torch.empty(C, device=dev), torch.empty(C, device=dev)
+        sums = torch.empty(2 * C, dtype=torch.float64, device=dev)
+        ws = zeroed_workspace(lib.sessd_bn2d_relu_train_workspace_bytes(C), dev, "bn2d")
+        scratch = torch.empty(int(lib.sessd_bn_sync_scratch_bytes(C)), dtype=torch.uint8, device=dev)
+        check(lib.sessd_bn2d_relu_train_bwd_stats(dy.data_ptr(), x.data_ptr(), 0, B, C, H * W, g.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                                                  invstd.data_ptr(), 1 if ctx.relu else 0, dg.data_ptr(), db.data_ptr(), sums.data_ptr(),
+                                                  ws.data_ptr(), ws.numel(), _stream()), "bn2d_relu_train_bwd_stats")
+        _sync_reduce(sums)
+        check(lib.sessd_bn2d_relu_train_bwd_apply(dy.data_ptr(), x.data_ptr(), 0, B, C, H * W, g.data_ptr(), b.data_ptr(), mean.data_ptr(),
+                                                  invstd.data_ptr(), 1 if ctx.relu else 0, sums.data_ptr(), fwd_sums.data_ptr(),
+                                                  dx.data_ptr(), scratch.data_ptr(), scratch.numel(), _stream()), "bn2d_relu_train_bwd_apply")
+        return dx, dg, db, None, None, None, None, None
 
 
 BN_MASK_FROM_X = os.environ.get("SESSD_BN_MASK_FROM_Y", "0") == "0"   # dense train-mode BatchNorm backward: ReLU mask from x, not y
@@ -842,6 +965,8 @@ def bn2d_relu_train(x, bn, relu=True):
         y = bn(x)
         return torch.relu(y) if relu else y
     mom = _bn_momentum(bn)
+    if sync_bn_active():
+        return SyncBn2dReluTrainFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
     return Bn2dReluTrainFunction.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps, mom, relu)
 
 
@@ -1698,7 +1823,7 @@ def ssfa_fuse_train_covers(x, conv0, bn0, conv1, bn1):
                    and c.stride == (1, 1) and c.padding == (0, 0) for c in (conv0, conv1))
     bns_ok = all(type(b) is nn.BatchNorm2d and b.training and b.weight is not None and b.momentum is not None and b.num_features == 1
                  for b in (bn0, bn1))
-    if not (convs_ok and bns_ok):
+    if not (convs_ok and bns_ok) or sync_bn_active():   # SyncBN: the tail's two BatchNorm2d(1) take the split (all-reduce) passes
         return False
     same = bn0.eps == bn1.eps and bn0.momentum == bn1.momentum and (bn0.running_mean is None) == (bn1.running_mean is None)
     C = x.shape[1]

@@ -235,17 +235,36 @@ class TrainStep:
         # keeps the eager torch restatement (MultiGroupHead.loss: boolean masks, host reads -- not capturable)
         self.device_loss = True
         self.pos_capacity, self.cons_capacity = None, 2048
+        # SyncBN (apis/train_sessd.py:286-294): None = like the reference, on exactly when the process group has more than one
+        # rank; True / False force it (True with one rank runs the split passes without a collective: same bits as the fused ones)
+        self.sync_bn = None
         self.cw_dev = None        # consistency weight as a device scalar (a captured iteration reads it from here)
         self._cw_host = None
         self.last_record = None
 
-    def _iteration(self, example, consistency_weight, device_schedule):
+    def _world(self):
+        return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _fwd_bwd(self, example, consistency_weight):
+        """Teacher forward, student forward, loss, backward, gradients packed into the flat buffer -- everything of an iteration
+        BEFORE the ranks exchange gradients. Returns the loss tensor."""
         self.student.train()
         self.teacher.train()  # trainer_sessd.py:321-322: both nets in train mode
+        # SyncBN like the reference's distributed path (apis/train_sessd.py:286-294): statistics over the batches of all ranks
+        prev_sync = ops.sync_bn_active()
+        ops.set_sync_bn(self.sync_bn if self.sync_bn is not None else self._world() > 1)
+        try:
+            return self._fwd_bwd_body(example, consistency_weight)
+        finally:
+            ops.set_sync_bn(prev_sync)
+
+    def _fwd_bwd_body(self, example, consistency_weight):
         # packed weights of both networks are kept and re-packed together at the first use after an update (two launches instead
         # of ~95); the 56 BatchNorm batch counters of the two networks: one launch at the end
         with ops.batched_repack(self.repack), ops.deferred_batch_counts():
-            main = torch.cuda.current_stream() if self.overlap_teacher and self.flat_s.data.is_cuda else None
+            # with SyncBN both networks issue collectives: they stay on one stream, in one order on every rank
+            main = torch.cuda.current_stream() if (self.overlap_teacher and self.flat_s.data.is_cuda
+                                                   and not (ops.sync_bn_active() and self._world() > 1)) else None
             if main is not None:
                 # The two forward passes are independent until the loss: the teacher's runs on a second stream (a parallel branch
                 # of the captured graph), so that the launch-bound sparse half of one network fills the gaps of the other's dense
@@ -286,13 +305,22 @@ class TrainStep:
             loss.backward()
         if self.direct_grads:
             self.flat_s.gather_grads()
-        allreduce_flat(self.flat_s.grad)
+        return loss.detach()
+
+    def _update(self, device_schedule):
+        """Clip + Adam + EMA on the (all-reduced) flat gradient. Returns (lr, momentum) of a host-scheduled step."""
         if device_schedule:
             self.opt.step_dev(self.total_steps, **self.sched)
-            return loss.detach(), None, None
+            return None, None
         lr, mom = one_cycle(self.global_step, self.total_steps, **self.sched)  # lr_scheduler.step(global_step) first
         self.opt.step(lr, mom, self.global_step)
-        return loss.detach(), lr, mom
+        return lr, mom
+
+    def _iteration(self, example, consistency_weight, device_schedule):
+        loss = self._fwd_bwd(example, consistency_weight)
+        allreduce_flat(self.flat_s.grad)
+        lr, mom = self._update(device_schedule)
+        return loss, lr, mom
 
     def _cw_dev(self, consistency_weight, example):
         """The consistency weight of trainer_sessd.py:306-312 (a host float that changes once per epoch) as a device scalar;
@@ -324,6 +352,11 @@ class TrainStep:
         the example's tensors before replay(); replay(consistency_weight=...) refills the device scalar the graph reads."""
         if "num_voxels_dev" not in example:
             raise ValueError("capture() needs a capacity-form example (sessd_hip.train.capacity_example)")
+        if self._world() > 1 and (self.sync_bn if self.sync_bn is not None else True):
+            raise RuntimeError("TrainStep.capture() at world size %d with SyncBN: the BatchNorm all-reduces sit inside the forward and "
+                               "backward passes and cannot be captured; run the iteration eagerly (step(example)) or set "
+                               "step.sync_bn = False (rank-local BatchNorm statistics) to capture it as two graphs around the "
+                               "gradient all-reduce" % self._world())
         self.static_example = example
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -341,6 +374,24 @@ class TrainStep:
         if self.repack is not None:
             self.repack.prepare()  # job tables of everything the warm-up iterations packed: uploaded before the capture
             self.repack.gen = -1   # the batched re-pack of all weights is the captured iteration's first two launches
+        world = self._world()
+        if world > 1:
+            # THE COLLECTIVE OF A CAPTURED ITERATION (review item): an RCCL all-reduce recorded inside a hipGraph is not something
+            # this stack lets us validate (one GPU per test box), so it is NOT captured. The iteration is captured as TWO graphs
+            # split at the one point where the ranks talk -- [teacher fwd + student fwd + loss + backward + gradient packing] and
+            # [clip + Adam + EMA] -- and replay() issues allreduce_flat (ONE collective on the flat gradient) eagerly between
+            # them. SyncBN puts ~110 more collectives inside the first part: that configuration runs eagerly.
+            # (checked at the top of capture(): SyncBN off here)
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                loss = self._fwd_bwd(example, consistency_weight)
+                self.static_loss.copy_(loss)
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=ga.pool()):
+                self._update(True)
+            self.opt.steps -= 1
+            self.graph = (ga, gb)
+            return self.graph
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             loss, _, _ = self._iteration(example, consistency_weight, True)
@@ -356,7 +407,12 @@ class TrainStep:
         if consistency_weight is not None and self.cw_dev is not None and float(consistency_weight) != self._cw_host:
             self.cw_dev.fill_(float(consistency_weight))
             self._cw_host = float(consistency_weight)
-        self.graph.replay()
+        if isinstance(self.graph, tuple):   # world size > 1: two graphs around the eager gradient all-reduce (capture())
+            self.graph[0].replay()
+            allreduce_flat(self.flat_s.grad)
+            self.graph[1].replay()
+        else:
+            self.graph.replay()
         self.global_step += 1
         self.opt.steps += 1
         ops.bump_param_generation()  # parameters changed under the packed-weight caches of any eager code that runs next

@@ -255,23 +255,48 @@ def _rank_worker(rank, world, port, q):
     step = strain.TrainStep(model, lambda ex, s, t, w: _loss(s) + w * (s[0]["cls_preds"] - t[0]["cls_preds"]).pow(2).mean(),
                             total_steps=10)
     grads = []
+    assert step.sync_bn is None          # default: like the reference, SyncBN exactly when world size > 1
     for it in range(2):
         _, ex = _example(dev, (70 + 10 * rank + it,), 6000, 6000)  # different data per rank and iteration
         step(ex)
         grads.append(float(step.flat_s.grad.double().abs().sum()))
     torch.cuda.synchronize()
     s, t = step.flat_s.data.double(), step.flat_t.data.double()
-    q.put((rank, float(s.sum()), float(s.abs().sum()), float(t.sum()), float(t.abs().sum()), grads,
-           float(step.student.backbone.middle_conv[1].running_mean.double().sum())))
+    rm_sync = float(step.student.backbone.middle_conv[1].running_mean.double().sum())
+    rv_sync = float(step.student.neck.conv_0[1].running_var.double().sum())
+    res = [rank, float(s.sum()), float(s.abs().sum()), float(t.sum()), float(t.abs().sum()), grads, rm_sync, rv_sync]
+    # ---- the captured form at world size 2: refused with SyncBN, two graphs around the eager gradient all-reduce without it
+    cap = strain.capacity_example(_example(dev, (90 + rank,), 6000, 6000)[1], 8192)
+    try:
+        step.capture(cap, warmup=1)
+        res.append("captured with SyncBN")
+    except RuntimeError as ex:
+        res.append("refused" if "SyncBN" in str(ex) else repr(ex))
+    step.sync_bn = False
+    step.capture(cap, warmup=1)
+    assert isinstance(step.graph, tuple) and len(step.graph) == 2
+    for it in range(2):
+        nxt = strain.capacity_example(_example(dev, (95 + 10 * rank + it,), 6000, 6000)[1], 8192)
+        for k in ("voxels", "coordinates", "num_points", "num_voxels_dev"):
+            cap[k].copy_(nxt[k])
+        step.replay()
+    torch.cuda.synchronize()
+    s, t = step.flat_s.data.double(), step.flat_t.data.double()
+    res += [float(s.sum()), float(s.abs().sum()), float(t.sum()), float(t.abs().sum()),
+            float(step.student.backbone.middle_conv[1].running_mean.double().sum()), step.global_step]
+    q.put(tuple(res))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_train_step_two_ranks_identical_parameters(dev):
-    """The real TrainStep on the real VoxelNet with world_size 2 (two processes, one flat all-reduce per step over gloo,
-    apis/train_sessd.py:286-294 + dist_utils.py:45-57): different frames per rank, yet after two iterations student and
-    teacher parameters are identical on both ranks (averaged gradients, rank-local identical EMA); BatchNorm running
-    statistics are rank-local and differ (no SyncBN in this slice)."""
+    """The real TrainStep on the real VoxelNet with world_size 2 (two processes on the one GPU of the box, collectives over gloo;
+    apis/train_sessd.py:286-294 + dist_utils.py:45-57): different frames per rank, yet after two iterations student and teacher
+    parameters are identical on both ranks (one flat gradient all-reduce per step, rank-local identical EMA) and -- SyncBN, on by
+    default at world size > 1 like the reference's convert_syncbn_model -- so are the BatchNorm running statistics. Then the
+    captured form: capture() refuses SyncBN (its ~110 all-reduces sit inside the passes), and with rank-local statistics captures
+    TWO graphs around the eager gradient all-reduce: after two replays on different data per rank the parameters are again
+    identical on both ranks, the (now rank-local) running statistics differ."""
     import socket
     import torch.multiprocessing as mp
     sck = socket.socket()
@@ -283,15 +308,150 @@ def test_train_step_two_ranks_identical_parameters(dev):
     procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
+    res = sorted(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a, b = res
+    assert a[1:5] == b[1:5], "student / teacher parameters differ across ranks"
+    assert a[5] == b[5]  # the averaged flat gradient is the same buffer content on both ranks
+    assert a[6] == b[6] and a[7] == b[7], "SyncBN: the running statistics of sparse and dense layers are the same on both ranks"
+    assert a[8] == b[8] == "refused"
+    assert a[9:13] == b[9:13], "two-graph replays: parameters differ across ranks"
+    assert a[13] != b[13]    # rank-local BatchNorm statistics in the captured form
+    assert a[14] == b[14] == 5
+
+
+def _syncbn_worker(rank, world, port, q):
+    """Each rank holds ITS part of a batch; with SyncBN the statistics, outputs and input gradients must be those of the
+    single-process pass over the concatenated batch (computed here too, from the same seed)."""
+    import os
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    out = {}
+    # ---- sparse table: rank 0 holds 3000 rows, rank 1 holds 1777 (different counts per rank), capacity-padded
+    C, n0, n1 = 64, 3000, 1777
+    full = torch.randn(n0 + n1, C, device=dev) * 2 + 0.5
+    dy_full = torch.randn(n0 + n1, C, device=dev)
+    lo, hi = (0, n0) if rank == 0 else (n0, n0 + n1)
+
+    def run_sparse(x, dy, sync):
+        bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
+        cap = 4096
+        xp = torch.zeros(cap, C, device=dev); xp[:x.shape[0]] = x
+        xp.requires_grad_(True)
+        n_dev = torch.tensor([x.shape[0]], dtype=torch.int32, device=dev)
+        ops.set_sync_bn(sync)
+        y = ops.bn_relu_train(xp, n_dev, bn, relu=True)
+        g = torch.zeros(cap, C, device=dev); g[:x.shape[0]] = dy
+        y.backward(g)
+        ops.set_sync_bn(False)
+        return y[:x.shape[0]].detach(), xp.grad[:x.shape[0]], bn.weight.grad, bn.bias.grad, bn.running_mean.clone(), bn.running_var.clone()
+
+    ys, dxs, dgs, dbs, rms, rvs = run_sparse(full[lo:hi], dy_full[lo:hi], True)
+    yf, dxf, dgf, dbf, rmf, rvf = run_sparse(full, dy_full, False)
+    out["sparse_y"] = float((ys - yf[lo:hi]).abs().max())
+    out["sparse_dx"] = float((dxs - dxf[lo:hi]).abs().max()) / float(dxf.abs().max())
+    out["sparse_rm"] = float((rms - rmf).abs().max())
+    out["sparse_rv"] = float((rvs - rvf).abs().max()) / float(rvf.abs().max())
+    tot = torch.stack([dgs, dbs]).double()
+    dist.all_reduce(tot)                       # local parameter gradients add up to the global ones
+    out["sparse_dg"] = float((tot[0].float() - dgf).abs().max()) / float(dgf.abs().max())
+    out["sparse_db"] = float((tot[1].float() - dbf).abs().max()) / float(dbf.abs().max())
+    # ---- dense map: 2 + 2 images of (C, 20, 24)
+    C2 = 32
+    xfull = torch.randn(4, C2, 20, 24, device=dev) + 0.3
+    dyf2 = torch.randn(4, C2, 20, 24, device=dev)
+    sl = slice(0, 2) if rank == 0 else slice(2, 4)
+
+    def run_dense(x, dy, sync):
+        bn = torch.nn.BatchNorm2d(C2, eps=1e-3, momentum=0.01).to(dev).train()
+        with torch.no_grad():
+            bn.weight.copy_(torch.linspace(0.5, 1.5, C2)); bn.bias.copy_(torch.linspace(-0.2, 0.2, C2))
+        xx = x.clone().requires_grad_(True)
+        ops.set_sync_bn(sync)
+        y = ops.bn2d_relu_train(xx, bn, True)
+        y.backward(dy)
+        ops.set_sync_bn(False)
+        return y.detach(), xx.grad, bn.running_mean.clone(), bn.running_var.clone()
+
+    ys, dxs, rms, rvs = run_dense(xfull[sl], dyf2[sl], True)
+    yf, dxf, rmf, rvf = run_dense(xfull, dyf2, False)
+    out["dense_y"] = float((ys - yf[sl]).abs().max())
+    out["dense_dx"] = float((dxs - dxf[sl]).abs().max()) / float(dxf.abs().max())
+    out["dense_rm"] = float((rms - rmf).abs().max())
+    out["dense_rv"] = float((rvs - rvf).abs().max()) / float(rvf.abs().max())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_bn_two_ranks_equal_the_concatenated_batch(dev):
+    """SyncBN (apis/train_sessd.py:286-294; det3d/ops/syncbn/syncbn.py:37-103): two ranks, each with its part of a batch (sparse
+    table: 3000 and 1777 rows; dense map: 2 + 2 images), all-reduce of the float64 totals over gloo between the statistics and
+    the apply launch -- outputs, running statistics and input gradients equal the single-process pass over the concatenated batch
+    (float64 sums in a different order: 2e-6), the local parameter gradients add up to the global ones."""
+    import socket
+    import torch.multiprocessing as mp
+    sck = socket.socket()
+    sck.bind(("127.0.0.1", 0))
+    port = sck.getsockname()[1]
+    sck.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
     res = sorted(q.get(timeout=600) for _ in range(2))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (_, s0, sa0, t0, ta0, g0, rm0), (_, s1, sa1, t1, ta1, g1, rm1) = res
-    assert s0 == s1 and sa0 == sa1, "student parameters differ across ranks"
-    assert t0 == t1 and ta0 == ta1, "teacher parameters differ across ranks"
-    assert g0 == g1  # the averaged flat gradient is the same buffer content on both ranks
-    assert rm0 != rm1  # different data: rank-local BatchNorm statistics
+    for rank, out in res:
+        for k, v in out.items():
+            assert v <= 2e-5, (rank, k, v)
+
+
+def test_sync_bn_with_one_rank_equals_the_fused_passes(dev):
+    """The split (SyncBN) form of the train-mode BatchNorm passes without a collective = the fused two-launch passes, bit for bit:
+    outputs, saved / running statistics, all gradients, sparse and dense layout."""
+    torch.manual_seed(1)
+    for C, n in ((16, 5000), (64, 777)):
+        x = torch.randn(n, C, device=dev)
+        dy = torch.randn(4096 if n < 4096 else 8192, C, device=dev)
+        res = []
+        for sync in (False, True):
+            bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
+            xp = torch.zeros(dy.shape[0], C, device=dev); xp[:n] = x
+            xp.requires_grad_(True)
+            ops.set_sync_bn(sync)
+            try:
+                y = ops.bn_relu_train(xp, torch.tensor([n], dtype=torch.int32, device=dev), bn, relu=True)
+                y.backward(dy)
+            finally:
+                ops.set_sync_bn(False)
+            res.append((y.detach(), xp.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var))
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    x = torch.randn(3, 128, 20, 44, device=dev)
+    dy = torch.randn_like(x)
+    res = []
+    for sync in (False, True):
+        bn = torch.nn.BatchNorm2d(128, eps=1e-3, momentum=0.01).to(dev).train()
+        xx = x.clone().requires_grad_(True)
+        ops.set_sync_bn(sync)
+        try:
+            y = ops.bn2d_relu_train(xx, bn, True)
+            y.backward(dy)
+        finally:
+            ops.set_sync_bn(False)
+        res.append((y.detach(), xx.grad, bn.weight.grad, bn.bias.grad, bn.running_mean, bn.running_var))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
 
 
 def test_device_schedule_equals_the_host_schedule(dev):
