@@ -55,6 +55,18 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
                          uint32_t* hash_keys, int32_t* hash_vals, uint32_t hash_capacity, float* voxels, int32_t* coors,
                          int coors_stride, int32_t* num_points_per_voxel, float* mean_feat, int32_t* prefix,
                          void* workspace, size_t workspace_bytes, sessd_stream_t stream);
+/* ALL frames of a batch in FOUR launches (sessd_voxelize_frame: four per frame, frame after frame). points (batch,
+ * points_per_frame, ndim): every frame holds exactly points_per_frame rows (pad with out-of-range rows: sessd_stage_points);
+ * prefix[0] must be 0 on entry, prefix[1 .. batch] are written. Same outputs, bit for bit, as `batch` calls of
+ * sessd_voxelize_frame with batch_index 0 .. batch - 1 on one shared hash (replaces the same reference loop,
+ * point_cloud_ops_v2.py:9-62, once per frame of a collated batch: torchie/parallel/collate.py:154-218). */
+size_t sessd_voxelize_frames_workspace_bytes(uint32_t hash_capacity, int batch, int points_per_frame, int max_points_per_voxel,
+                                             int max_voxels);
+int sessd_voxelize_frames(const float* points, int batch, int points_per_frame, int ndim, const float* range6,
+                          const float* voxel_size3, const int32_t* grid3, int max_points_per_voxel, int max_voxels,
+                          uint32_t* hash_keys, int32_t* hash_vals, uint32_t hash_capacity, float* voxels, int32_t* coors,
+                          int coors_stride, int32_t* num_points_per_voxel, float* mean_feat, int32_t* prefix, void* workspace,
+                          size_t workspace_bytes, sessd_stream_t stream);
 /* (n,4) points -> fixed-capacity staging buffer, tail rows set out of range (dropped by the voxelizer) */
 int sessd_stage_points(const float* points, int num_points, float* dst, int capacity, sessd_stream_t stream);
 int sessd_vfe_mean(const float* voxels, const int32_t* num_points, const int32_t* num_voxels_dev, int num_voxels_host,

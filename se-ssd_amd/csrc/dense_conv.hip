@@ -878,8 +878,9 @@ __global__ __launch_bounds__(256) void pack_taps_kernel(PackArgs A, float* __res
 // layout 0: sessd_conv3x3_winograd      [ci/2][xi/4][h][cp32][xi%4]
 // layout 1: sessd_conv3x3_winograd_sk shape 0  [ceil(co/128)][ci/2][8][2][32][4][2]
 // layout 2: sessd_conv3x3_winograd_sk shape 1  [ceil(co/64)][ci/2][4][2][32][2][4]
+// layout 3: sessd_conv3x3_winograd_sk shape 2  [ceil(co/128)][ci/2][wave 4][2][32][xi 16]
 __device__ __forceinline__ void winograd_pack_body(const PackArgs& A, int flip, int layout, float* __restrict__ out, size_t idx) {
-  const int cpad = layout == 0 ? A.cp : (layout == 1 ? (A.co + 127) / 128 * 128 : (A.co + 63) / 64 * 64);
+  const int cpad = layout == 0 ? A.cp : ((layout == 1 || layout == 3) ? (A.co + 127) / 128 * 128 : (A.co + 63) / 64 * 64);
   if (idx >= (size_t)cpad * A.ci) return;
   const int o = (int)(idx % cpad), c = (int)(idx / cpad);
   double g[3][3];
@@ -913,6 +914,9 @@ __device__ __forceinline__ void winograd_pack_body(const PackArgs& A, int flip, 
       } else if (layout == 1) {
         const int grp = o >> 7, cb = (o >> 5) & 3, j = o & 31, wave = xi >> 1, xl = xi & 1;
         dst = ((((((size_t)grp * (A.ci >> 1) + kp) * 8 + wave) * 2 + h) * 32 + j) * 4 + cb) * 2 + xl;
+      } else if (layout == 3) {
+        const int grp = o >> 7, wave = (o >> 5) & 3, j = o & 31;
+        dst = (((((size_t)grp * (A.ci >> 1) + kp) * 4 + wave) * 2 + h) * 32 + j) * 16 + xi;
       } else {
         const int grp = o >> 6, cb = (o >> 5) & 1, j = o & 31, wave = xi >> 2, xl = xi & 3;
         dst = ((((((size_t)grp * (A.ci >> 1) + kp) * 4 + wave) * 2 + h) * 32 + j) * 2 + cb) * 4 + xl;
@@ -983,11 +987,11 @@ int sessd_conv2d_pack_taps(const float* w, long long out_stride, long long in_st
 // (layout 0) or sessd_conv3x3_winograd_sk shape 0 / 1 (layout 1 / 2); `out` must hold the padded layout (all of it is written).
 int sessd_conv3x3_winograd_pack(const float* w, long long out_stride, long long in_stride, int flip, int cout, int cin, int layout,
                                 float* out, hipStream_t stream) {
-  if (cout < 1 || cin < 2 || (cin & 1) || layout < 0 || layout > 2) return SESSD_EINVAL;
+  if (cout < 1 || cin < 2 || (cin & 1) || layout < 0 || layout > 3) return SESSD_EINVAL;
   PackArgs A;
   A.w = w; A.so = out_stride; A.sc = in_stride; A.co = cout; A.ci = cin; A.nt = 9; A.cp = sessd_divup(cout, 32) * 32;
   for (int t = 0; t < 16; ++t) A.tap_off[t] = 0;
-  const int cpad = layout == 0 ? A.cp : (layout == 1 ? sessd_divup(cout, 128) * 128 : sessd_divup(cout, 64) * 64);
+  const int cpad = layout == 0 ? A.cp : ((layout == 1 || layout == 3) ? sessd_divup(cout, 128) * 128 : sessd_divup(cout, 64) * 64);
   const size_t total = (size_t)cpad * cin;
   SESSD_LAUNCH(winograd_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, A, flip, layout, out);
   SESSD_CHECK_LAUNCH();

@@ -32,10 +32,15 @@ struct VoxGrid {
 };
 
 __global__ __launch_bounds__(VOX_NT) void vox_insert_kernel(const float* __restrict__ points, int P, int ndim,
-                                                              VoxGrid G, uint32_t key_base,
+                                                              VoxGrid G, uint32_t key_base, uint32_t cells,
                                                               uint32_t* __restrict__ keys, uint32_t mask,
                                                               int* __restrict__ lists, int MP,
                                                               int* __restrict__ ent) {
+  // blockIdx.y = frame of a batched launch (sessd_voxelize_frames): its points, its slice of `ent`, its key range
+  const int fr = blockIdx.y;
+  points += (size_t)fr * P * ndim;
+  ent += (size_t)fr * P;
+  key_base += (uint32_t)fr * cells;
   int i = blockIdx.x * VOX_NT + threadIdx.x;
   if (i >= P) return;
   const float* p = points + (size_t)i * ndim;
@@ -71,6 +76,10 @@ __global__ __launch_bounds__(VOX_NT) void vox_count_kernel(int P, const int* __r
                                                              const int* __restrict__ lists, int MP,
                                                              int* __restrict__ blk_cnt, int* __restrict__ meta) {
   __shared__ int sm[VOX_NT / 64];
+  const int fr = blockIdx.y;   // frame of a batched launch
+  ent += (size_t)fr * P;
+  blk_cnt += (size_t)fr * gridDim.x;
+  meta += fr * 4;
   int i = blockIdx.x * VOX_NT + threadIdx.x;
   // per-FRAME reset of the break index: the workspace is shared by the frames of a batch, and an engine clears its
   // arena once per batch, so a frame that hit max_voxels must not leave its cut behind for the next frame
@@ -99,9 +108,38 @@ __global__ __launch_bounds__(VOX_NT) void vox_assign_kernel(int P, const int* __
                                                               const int* __restrict__ prefix_in,
                                                               int* __restrict__ vals, int* __restrict__ entry_of_vid,
                                                               int* __restrict__ coors, int coors_stride,
-                                                              int* __restrict__ meta, int* __restrict__ prefix_out) {
+                                                              int* __restrict__ meta, int* __restrict__ prefix_out,
+                                                              uint32_t cells, int batched) {
   __shared__ int sm[VOX_NT / 64];
   __shared__ int s_base;
+  // batched launch (sessd_voxelize_frames): blockIdx.y = frame. The frame's first output row is the sum of the EARLIER frames'
+  // voxel counts min(unique cells, max_voxels) -- taken from their block counts by every block itself (a per-frame launch reads
+  // it from prefix_in, written by the previous frame's launch)
+  const int fr = blockIdx.y;
+  int out_base = 0;
+  if (batched) {
+    for (int f = 0; f < fr; ++f) {
+      int part = 0;
+      for (int b = threadIdx.x; b < nblk; b += VOX_NT) part += blk_cnt[(size_t)f * nblk + b];
+      part = sessd_wave_sum(part);
+      __syncthreads();
+      if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = part;
+      __syncthreads();
+      int t = 0;
+      for (int w = 0; w < VOX_NT / 64; ++w) t += sm[w];
+      out_base += t < max_voxels ? t : max_voxels;
+    }
+    __syncthreads();
+    ent += (size_t)fr * P;
+    blk_cnt += (size_t)fr * nblk;
+    entry_of_vid += (size_t)fr * max_voxels;
+    meta += fr * 4;
+    key_base += (uint32_t)fr * cells;
+    batch_index += fr;
+    prefix_out += fr;
+  } else {
+    out_base = prefix_in[0];
+  }
   // base = sum of counts of all preceding blocks
   int part = 0;
   for (int b = threadIdx.x; b < (int)blockIdx.x; b += VOX_NT) part += blk_cnt[b];
@@ -115,7 +153,6 @@ __global__ __launch_bounds__(VOX_NT) void vox_assign_kernel(int P, const int* __
   }
   __syncthreads();
   const int base = s_base;
-  const int out_base = prefix_in[0];
 
   int i = blockIdx.x * VOX_NT + threadIdx.x;
   int e = -1, f = 0;
@@ -160,8 +197,13 @@ __global__ __launch_bounds__(VOX_NT) void vox_gather_kernel(const float* __restr
                                                               const int* __restrict__ meta, int max_voxels,
                                                               const int* __restrict__ prefix_in,
                                                               float* __restrict__ voxels, int* __restrict__ num_points,
-                                                              float* __restrict__ mean) {
+                                                              float* __restrict__ mean, int P) {
   const int ndim = NDIM > 0 ? NDIM : ndim_rt;
+  const int fr = blockIdx.y;   // frame of a batched launch: its points, its meta / entry table, its prefix word
+  points += (size_t)fr * P * ndim;
+  entry_of_vid += (size_t)fr * max_voxels;
+  meta += fr * 4;
+  prefix_in += fr;
   int vid = blockIdx.x * VOX_NT + threadIdx.x;
   int uniq = meta[1];
   int M = uniq < max_voxels ? uniq : max_voxels;
@@ -242,7 +284,7 @@ struct VoxWs {
   int* meta;
 };
 
-size_t vox_ws_layout(int hash_cap, int max_pts_total, int MP, int max_voxels, VoxWs* w, char* base) {
+size_t vox_ws_layout(int hash_cap, int max_pts_total, int MP, int max_voxels, VoxWs* w, char* base, int batch = 1) {
   size_t off = 0;
   auto take = [&](size_t bytes) {
     size_t o = off;
@@ -250,10 +292,10 @@ size_t vox_ws_layout(int hash_cap, int max_pts_total, int MP, int max_voxels, Vo
     return o;
   };
   size_t o_lists = take((size_t)hash_cap * MP * 4);
-  size_t o_ent = take((size_t)max_pts_total * 4);
-  size_t o_blk = take((size_t)sessd_divup(max_pts_total, VOX_NT) * 4 + 4);
-  size_t o_eov = take((size_t)max_voxels * 4);
-  size_t o_meta = take(16);
+  size_t o_ent = take((size_t)batch * max_pts_total * 4);
+  size_t o_blk = take((size_t)batch * sessd_divup(max_pts_total, VOX_NT) * 4 + 4);
+  size_t o_eov = take((size_t)batch * max_voxels * 4);
+  size_t o_meta = take((size_t)batch * 16);
   if (w) {
     w->lists = (int*)(base + o_lists);
     w->ent = (int*)(base + o_ent);
@@ -315,7 +357,7 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
   SESSD_FILL_SCRATCH(w.meta, SESSD_HASH_EMPTY, 1, stream);  // cut = SESSD_SENT
   const int nblk = sessd_divup(num_points > 0 ? num_points : 1, VOX_NT);
   if (num_points > 0) {
-    SESSD_LAUNCH(vox_insert_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, points, num_points, ndim, G, key_base,
+    SESSD_LAUNCH(vox_insert_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, points, num_points, ndim, G, key_base, (uint32_t)cells,
                        hash_keys, hash_capacity - 1, w.lists, MP, w.ent);
     SESSD_CHECK_LAUNCH();
   }
@@ -324,18 +366,73 @@ int sessd_voxelize_frame(const float* points, int num_points, int ndim, const fl
   SESSD_CHECK_LAUNCH();
   SESSD_LAUNCH(vox_assign_kernel, dim3(nblk), dim3(VOX_NT), 0, stream, num_points, w.ent, w.lists, MP, w.blk_cnt,
                      nblk, hash_keys, key_base, G, max_voxels, batch_index, prefix + batch_index, hash_vals,
-                     w.entry_of_vid, coors, coors_stride, w.meta, prefix + batch_index + 1);
+                     w.entry_of_vid, coors, coors_stride, w.meta, prefix + batch_index + 1, (uint32_t)cells, 0);
   SESSD_CHECK_LAUNCH();
   const int gblk = sessd_divup(max_voxels < num_points ? max_voxels : (num_points > 0 ? num_points : 1), VOX_NT);
   if (ndim == 4) {
     SESSD_LAUNCH(vox_gather_kernel<4>, dim3(gblk), dim3(VOX_NT), 0, stream, points, ndim, w.lists, MP,
                        w.entry_of_vid, w.meta, max_voxels, prefix + batch_index, voxels, num_points_per_voxel,
-                       mean_feat);
+                       mean_feat, num_points);
   } else {
     SESSD_LAUNCH(vox_gather_kernel<0>, dim3(gblk), dim3(VOX_NT), 0, stream, points, ndim, w.lists, MP,
                        w.entry_of_vid, w.meta, max_voxels, prefix + batch_index, voxels, num_points_per_voxel,
-                       mean_feat);
+                       mean_feat, num_points);
   }
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+size_t sessd_voxelize_frames_workspace_bytes(uint32_t hash_capacity, int batch, int points_per_frame, int max_points_per_voxel,
+                                             int max_voxels) {
+  if (batch < 1 || points_per_frame < 1) return 0;
+  return vox_ws_layout((int)hash_capacity, points_per_frame, max_points_per_voxel, max_voxels, nullptr, nullptr, batch);
+}
+
+// ALL frames of a batch in FOUR launches (sessd_voxelize_frame: four per frame, each frame's launches waiting for the previous
+// frame's -- 32 dependent launches for the dense-scene batch of 8). points (batch, points_per_frame, ndim): every frame holds
+// exactly points_per_frame rows (pad with out-of-range rows, sessd_stage_points). prefix (batch + 1): prefix[0] must be 0 on
+// entry; prefix[1 ..] are written. Frame f's voxel rows start at the sum of the earlier frames' voxel counts, which every block
+// of the assignment launch takes from the per-block counts itself. Same results as `batch` calls of sessd_voxelize_frame
+// with batch_index 0 .. batch - 1, bit for bit.
+int sessd_voxelize_frames(const float* points, int batch, int points_per_frame, int ndim, const float* range6,
+                          const float* voxel_size3, const int* grid3, int max_points_per_voxel, int max_voxels,
+                          uint32_t* hash_keys, int* hash_vals, uint32_t hash_capacity, float* voxels, int* coors, int coors_stride,
+                          int* num_points_per_voxel, float* mean_feat, int* prefix, void* workspace, size_t workspace_bytes,
+                          hipStream_t stream) {
+  if (batch < 1 || batch > 65535 || points_per_frame < 1 || ndim < 3 || ndim > 8 || max_points_per_voxel < 1 || max_voxels < 1)
+    return SESSD_EINVAL;
+  if (coors_stride != 3 && coors_stride != 4) return SESSD_EINVAL;
+  if ((hash_capacity & (hash_capacity - 1)) != 0) return SESSD_EINVAL;
+  VoxGrid G;
+  for (int j = 0; j < 3; ++j) {
+    G.lo[j] = range6[j];
+    G.vs[j] = voxel_size3[j];
+    G.g[j] = grid3[j];
+  }
+  const uint64_t cells = (uint64_t)grid3[0] * grid3[1] * grid3[2];
+  if (cells * (uint64_t)batch >= (uint64_t)SESSD_HASH_EMPTY) return SESSD_EINVAL;
+  if ((uint64_t)hash_capacity < 2ull * (uint64_t)batch * (uint64_t)points_per_frame) return SESSD_EINVAL;
+  VoxWs w;
+  const size_t need = vox_ws_layout((int)hash_capacity, points_per_frame, max_points_per_voxel, max_voxels, &w, (char*)workspace, batch);
+  if (need > workspace_bytes) return SESSD_EWORKSPACE;
+  const int MP = max_points_per_voxel, P = points_per_frame;
+  SESSD_FILL_SCRATCH(w.lists, SESSD_HASH_EMPTY, (size_t)hash_capacity * MP, stream);
+  const int nblk = sessd_divup(P, VOX_NT);
+  SESSD_LAUNCH(vox_insert_kernel, dim3(nblk, batch), dim3(VOX_NT), 0, stream, points, P, ndim, G, 0u, (uint32_t)cells, hash_keys,
+               hash_capacity - 1, w.lists, MP, w.ent);
+  SESSD_CHECK_LAUNCH();
+  SESSD_LAUNCH(vox_count_kernel, dim3(nblk, batch), dim3(VOX_NT), 0, stream, P, w.ent, w.lists, MP, w.blk_cnt, w.meta);
+  SESSD_CHECK_LAUNCH();
+  SESSD_LAUNCH(vox_assign_kernel, dim3(nblk, batch), dim3(VOX_NT), 0, stream, P, w.ent, w.lists, MP, w.blk_cnt, nblk, hash_keys, 0u, G,
+               max_voxels, 0, prefix, hash_vals, w.entry_of_vid, coors, coors_stride, w.meta, prefix + 1, (uint32_t)cells, 1);
+  SESSD_CHECK_LAUNCH();
+  const int gblk = sessd_divup(max_voxels < P ? max_voxels : P, VOX_NT);
+  if (ndim == 4)
+    SESSD_LAUNCH(vox_gather_kernel<4>, dim3(gblk, batch), dim3(VOX_NT), 0, stream, points, ndim, w.lists, MP, w.entry_of_vid, w.meta,
+                 max_voxels, prefix, voxels, num_points_per_voxel, mean_feat, P);
+  else
+    SESSD_LAUNCH(vox_gather_kernel<0>, dim3(gblk, batch), dim3(VOX_NT), 0, stream, points, ndim, w.lists, MP, w.entry_of_vid, w.meta,
+                 max_voxels, prefix, voxels, num_points_per_voxel, mean_feat, P);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

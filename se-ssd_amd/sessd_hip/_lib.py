@@ -65,6 +65,8 @@ SIGNATURES = {
     "sessd_voxelize_workspace_bytes": (sz, [u32, i32, i32, i32]),
     "sessd_voxelize_frame": (i32, [vp, i32, i32, vp, vp, vp, i32, i32, i32, vp, vp, u32, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
     "sessd_stage_points": (i32, [vp, i32, vp, i32, vp]),
+    "sessd_voxelize_frames_workspace_bytes": (sz, [u32, i32, i32, i32, i32]),
+    "sessd_voxelize_frames": (i32, [vp, i32, i32, i32, vp, vp, vp, i32, i32, vp, vp, u32, vp, vp, i32, vp, vp, vp, vp, sz, vp]),
     "sessd_vfe_mean": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "sessd_boxes_pairwise": (i32, [i32, vp, i32, vp, i32, vp, vp]),
     "sessd_boxes_aligned_overlap_bev": (i32, [vp, vp, i32, vp, vp]),

@@ -192,7 +192,8 @@ class InferenceEngine:
         # ---- one contiguous arena for everything that must read 0x7F7F7F7F at the start of a frame (hash tables,
         # per-cell point lists, first-touch words): cleared by ONE fill instead of ~17 small ones
         cap0h = int(lib.sessd_hash_capacity(self.P_cap * B))
-        vox_bytes = int(lib.sessd_voxelize_workspace_bytes(cap0h, self.P_cap, self.max_points, self.max_voxels))
+        # all frames of a batch are voxelized by ONE set of four launches (sessd_voxelize_frames; round 3: four per frame)
+        vox_bytes = int(lib.sessd_voxelize_frames_workspace_bytes(cap0h, B, self.P_cap, self.max_points, self.max_voxels))
         plan, off = [], 0
 
         def take(nbytes):
@@ -235,6 +236,7 @@ class InferenceEngine:
                                    dtype=torch.uint8, device=dev)
         self.keys = torch.empty((B, 2 * H * W), dtype=torch.int64, device=dev)  # score-filter keys written by the head launch
         self.fuse_predict = True  # score filter inside the head launch; NMS walk + filters + record in one launch
+        self.batched_voxelizer = True  # the frames of a batch in four launches (False: four per frame, as round 3)
         # The neighbour table of the voxels (level 0, hash lookups) and the two submanifold convs that use it depend on the
         # voxelizer only, not on the site chain of the deeper levels: with fork_front they run on a second stream (a parallel
         # branch of the captured graph) beside mark / gather / count / scan / emit and the remaining tables. MEASURED SLOWER on
@@ -390,7 +392,7 @@ class InferenceEngine:
                         cands.append(21)  # same, operands fetched two rounds ahead
                     # stream-K Winograd (all couts of a unit in one workgroup, equal shares of rounds per CU): 8 waves x 128
                     # couts / 4 waves x 64 couts. One workspace per engine: its launches are serialised on the engine's stream.
-                    for cfg, shape in ((22, 0), (23, 1)) if self.allow_streamk else ():
+                    for cfg, shape in ((22, 0), (23, 1), (24, 2)) if self.allow_streamk else ():
                         if pc.upk_sk(shape) is not None:
                             need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(x.shape[0], x.shape[2], x.shape[3], pc.cout, shape, 0))
                             if self.sk_ws is None or self.sk_ws.numel() < need:
@@ -446,13 +448,20 @@ class InferenceEngine:
 
     def _enqueue_body(self, s):
         B = self.B
-        for b in range(B):
-            check(lib.sessd_voxelize_frame(self.points[b].data_ptr(), self.P_cap, 4, self.vrange.data_ptr(),
-                                           self.vsize.data_ptr(), self.grid.data_ptr(), self.max_points, self.max_voxels,
-                                           b, self.hash0.keys.data_ptr(), self.hash0.vals.data_ptr(), self.hash0.capacity,
-                                           self.voxels.data_ptr(), self.coors.data_ptr(), 4, self.nump.data_ptr(),
-                                           self.vfeat.data_ptr(), self.prefix.data_ptr(), self.vox_ws.data_ptr(),
-                                           self.vox_ws.numel(), s), "voxelize_frame")
+        if self.batched_voxelizer:
+            check(lib.sessd_voxelize_frames(self.points.data_ptr(), B, self.P_cap, 4, self.vrange.data_ptr(), self.vsize.data_ptr(),
+                                            self.grid.data_ptr(), self.max_points, self.max_voxels, self.hash0.keys.data_ptr(),
+                                            self.hash0.vals.data_ptr(), self.hash0.capacity, self.voxels.data_ptr(),
+                                            self.coors.data_ptr(), 4, self.nump.data_ptr(), self.vfeat.data_ptr(),
+                                            self.prefix.data_ptr(), self.vox_ws.data_ptr(), self.vox_ws.numel(), s), "voxelize_frames")
+        else:
+            for b in range(B):
+                check(lib.sessd_voxelize_frame(self.points[b].data_ptr(), self.P_cap, 4, self.vrange.data_ptr(),
+                                               self.vsize.data_ptr(), self.grid.data_ptr(), self.max_points, self.max_voxels,
+                                               b, self.hash0.keys.data_ptr(), self.hash0.vals.data_ptr(), self.hash0.capacity,
+                                               self.voxels.data_ptr(), self.coors.data_ptr(), 4, self.nump.data_ptr(),
+                                               self.vfeat.data_ptr(), self.prefix.data_ptr(), self.vox_ws.data_ptr(),
+                                               self.vox_ws.numel(), s), "voxelize_frame")
         feat = self.vfeat
         if self.sort_sites:
             check(lib.sessd_sparse_renumber_sites(self.coors.data_ptr(), self._n(0), self.levels[0]["cap"], B,
@@ -535,7 +544,7 @@ class InferenceEngine:
             mid0 = self._conv(tr1, d.deconv_0, t["mid0"], residual=tr0, name="deconv_0")
             mid1 = self._conv(tr1, d.deconv_1, t["mid1"], name="deconv_1")
         c01 = self.tile_cfg.get("conv_0")
-        if self.merge_branch_convs and c01 in (22, 23) and self.tile_cfg.get("conv_1") == c01 and self._tuning is None \
+        if self.merge_branch_convs and c01 in (22, 23, 24) and self.tile_cfg.get("conv_1") == c01 and self._tuning is None \
                 and self.sk_ws is not None and self._branch_sets(c01 - 22) is not None:
             sets = self._branch_sets(c01 - 22)
             if self._kmarks is not None:

@@ -127,6 +127,38 @@ def voxelize_batch(points_list, voxel_size, coors_range, max_points, max_voxels,
     return dict(voxels=voxels, coors=coors, num_points=nump, mean=mean, prefix=prefix, hash=h, grid=grid)
 
 
+def voxelize_frames(points_list, voxel_size, coors_range, max_points, max_voxels):
+    """voxelize_batch with ALL frames in four launches (sessd_voxelize_frames): the clouds are staged into one
+    (B, P_cap, 4) buffer, shorter ones padded with out-of-range rows. Same dict, same bits."""
+    B = len(points_list)
+    dev = points_list[0].device
+    ndim = points_list[0].shape[1]
+    vs = torch.tensor(voxel_size, dtype=torch.float32)
+    cr = torch.tensor(coors_range, dtype=torch.float32)
+    grid = torch.round((cr[3:] - cr[:3]) / vs).to(torch.int32)
+    cap = B * max_voxels
+    P = max(1, max(int(p.shape[0]) for p in points_list))
+    if ndim != 4:
+        raise ValueError("voxelize_frames stages (x, y, z, r) rows; use voxelize_batch for other layouts")
+    staged = torch.empty((B, P, 4), dtype=torch.float32, device=dev)
+    for b, pts in enumerate(points_list):
+        _req(pts, torch.float32, "points")
+        check(lib.sessd_stage_points(pts.data_ptr(), pts.shape[0], staged[b].data_ptr(), P, _stream()), "stage_points")
+    h = VoxelHash(P * B, dev)
+    h.clear()
+    voxels = torch.empty((cap, max_points, ndim), dtype=torch.float32, device=dev)
+    coors = torch.empty((cap, 4), dtype=torch.int32, device=dev)
+    nump = torch.empty((cap,), dtype=torch.int32, device=dev)
+    mean = torch.empty((cap, ndim), dtype=torch.float32, device=dev)
+    prefix = torch.zeros((B + 1,), dtype=torch.int32, device=dev)
+    ws = workspace(lib.sessd_voxelize_frames_workspace_bytes(h.capacity, B, P, max_points, max_voxels), dev, "voxelize_frames")
+    check(lib.sessd_voxelize_frames(staged.data_ptr(), B, P, ndim, cr.data_ptr(), vs.data_ptr(), grid.data_ptr(), max_points, max_voxels,
+                                    h.keys.data_ptr(), h.vals.data_ptr(), h.capacity, voxels.data_ptr(), coors.data_ptr(), 4,
+                                    nump.data_ptr(), mean.data_ptr(), prefix.data_ptr(), ws.data_ptr(), ws.numel(), _stream()),
+          "voxelize_frames")
+    return dict(voxels=voxels, coors=coors, num_points=nump, mean=mean, prefix=prefix, hash=h, grid=grid)
+
+
 def vfe_mean(voxels, num_points, num_features=4, num_voxels_dev=None):
     _req(voxels, torch.float32, "voxels")
     _req(num_points, torch.int32, "num_points")
@@ -1148,7 +1180,7 @@ class PackedConv:
         self.cin, self.cout, self.kind, self.stride = cin, cout, kind, stride
         self._w3 = None      # (weight, adjoint): the 3x3 stride-1 weight the Winograd packings are made from, on demand
         self._upk = None
-        self._upk_sk = [None, None]
+        self._upk_sk = [None, None, None]
         self._sk = None      # argument block of sessd_conv2d_sk (tile_cfg 30), made when first asked for
         self._registry = None  # RepackRegistry that keeps this object fresh (training step), else None
 
@@ -1161,8 +1193,8 @@ class PackedConv:
         return self._upk
 
     def upk_sk(self, shape):
-        """U packed for sessd_conv3x3_winograd_sk (tile_cfg 22 / 23 = shape 0 / 1); None if not eligible."""
-        if self._upk_sk[shape] is None and self._w3 is not None and self.cin % (16, 8)[shape] == 0:
+        """U packed for sessd_conv3x3_winograd_sk (tile_cfg 22 / 23 / 24 = shape 0 / 1 / 2); None if not eligible."""
+        if self._upk_sk[shape] is None and self._w3 is not None and self.cin % (16, 8, 16)[shape] == 0:
             make = lambda: pack_winograd_sk(self._w3[0], shape, adjoint=self._w3[1])
             self._upk_sk[shape] = self._registry.create(make) if self._registry is not None else make()
         return self._upk_sk[shape]
@@ -1260,6 +1292,8 @@ def _winograd_pack(weight, layout, adjoint):
     co, ci, so, sc, flip = _conv_view(w, adjoint)
     if layout == 0:
         out = torch.empty((ci // 2, 4, 2, (co + 31) // 32 * 32, 4), dtype=torch.float32, device=w.device)
+    elif layout == 3:   # shape 2 (register-resident output transform): [cout group of 128][k-step][wave 4][parity][cout % 32][xi 16]
+        out = torch.empty(((co + 127) // 128, ci // 2, 4, 2, 32, 16), dtype=torch.float32, device=w.device)
     else:
         nw, c = ((8, 128), (4, 64))[layout - 1]
         out = torch.empty(((co + c - 1) // c, ci // 2, nw, 2, 32, c // 32, 16 // nw), dtype=torch.float32, device=w.device)
@@ -1387,11 +1421,11 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
         th, tw = H, W
     if out is None:
         out = torch.empty((B, pc.cout, Ho, Wo), dtype=torch.float32, device=x.device)
-    if tile_cfg in (22, 23):
+    if tile_cfg in (22, 23, 24):
         shape = tile_cfg - 22
         upk = pc.upk_sk(shape) if pc.kind == "conv" else None
         if upk is None or (H & 1) or (W & 1):
-            raise ValueError("tile_cfg 22/23 (stream-K Winograd) needs a 3x3 stride-1 conv with cin % 16 (22) / 8 (23) == 0 and even H, W")
+            raise ValueError("tile_cfg 22/23/24 (stream-K Winograd) needs a 3x3 stride-1 conv with cin % 16 (22, 24) / 8 (23) == 0 and even H, W")
         if workspace is None:
             key = (x.device.index, _cache_scope(), shape, workgroups)
             need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(B, H, W, pc.cout, shape, workgroups))
@@ -1462,8 +1496,8 @@ def conv2d(x, pc, scale=None, shift=None, relu=True, residual=None, out=None, ti
 
 _TILE_CFG_OVERRIDE = {}
 # tile_cfg families of the 3x3 stride-1 convs: 20/21 first-generation Winograd F(2x2,3x3), 22/23 its stream-K form
-WINOGRAD_CFGS = (20, 21, 22, 23)
-WINOGRAD_SK_CFGS = (22, 23)
+WINOGRAD_CFGS = (20, 21, 22, 23, 24)
+WINOGRAD_SK_CFGS = (22, 23, 24)   # 24: third generation, output transform in registers (same cuts and bits as 22)
 
 
 def winograd_mult_ratio(tile_cfg):

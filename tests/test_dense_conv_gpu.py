@@ -73,9 +73,11 @@ def test_winograd_variant(dev, cin, cout, H, W, B):
 
 @pytest.mark.parametrize("cin,cout,H,W,B,wgs", [(128, 128, 24, 40, 2, 0), (256, 256, 14, 18, 1, 0), (16, 40, 10, 66, 3, 8), (128, 128, 200, 176, 1, 0),
                                                  (128, 128, 200, 176, 1, 104), (64, 300, 12, 16, 1, 64), (32, 128, 8, 8, 1, 16), (256, 256, 100, 88, 2, 0)])
-@pytest.mark.parametrize("cfg", [22, 23])
+@pytest.mark.parametrize("cfg", [22, 23, 24])
 def test_winograd_stream_k(dev, cin, cout, H, W, B, wgs, cfg):
-    """tile_cfg 22 / 23: 128 / 64 couts per workgroup of 8 / 4 waves, rounds dealt out in equal shares (stream-K). Same bound as the first-generation
+    """tile_cfg 22 / 23: 128 / 64 couts per workgroup of 8 / 4 waves, rounds dealt out in equal shares (stream-K); tile_cfg 24: the
+    third generation (4 waves, a wave owns all 16 transform points of its 32 couts: output transform in registers, no LDS exchange
+    in the epilogue) -- same units, rounds and cuts as 22, so its results must equal 22's BIT FOR BIT. Same bound as the first-generation
     Winograd kernel; covers whole units, units cut in two and (few rounds per share) units cut in three or more parts; the
     second and third launch reuse the workspace (the counters must be back at zero) and must give the same bits."""
     g = torch.Generator().manual_seed(cin + H + W + wgs)
@@ -93,9 +95,16 @@ def test_winograd_stream_k(dev, cin, cout, H, W, B, wgs, cfg):
     b = ops.conv2d(*args, residual=res.to(dev), tile_cfg=cfg, workspace=ws, workgroups=wgs)
     c = ops.conv2d(*args, residual=res.to(dev), tile_cfg=cfg, workspace=ws, workgroups=wgs)
     torch.cuda.synchronize()
-    units = B * (((H // 2) * (W // 2) + 31) // 32) * ((cout + 127) // 128 if cfg == 22 else (cout + 63) // 64)
+    units = B * (((H // 2) * (W // 2) + 31) // 32) * ((cout + 127) // 128 if cfg != 23 else (cout + 63) // 64)
     assert int(ws[:units * 4].view(torch.int32).abs().sum().item()) == 0       # counters left at zero
     assert torch.equal(a, b) and torch.equal(a, c)
+    if cfg == 24:
+        ws22 = ops.winograd_sk_workspace(B, H, W, cout, dev, wgs, 0)
+        a22 = ops.conv2d(*args, residual=res.to(dev), tile_cfg=22, workspace=ws22, workgroups=wgs)
+        assert torch.equal(a, a22), "tile_cfg 24 must reproduce tile_cfg 22's bits (max diff %.3e)" % float((a - a22).abs().max())
+        p24 = ops.conv2d(x.to(dev), pc, None, None, False, tile_cfg=24, workspace=ws, workgroups=wgs)
+        p22 = ops.conv2d(x.to(dev), pc, None, None, False, tile_cfg=22, workspace=ws22, workgroups=wgs)
+        assert torch.equal(p24, p22)
     direct = ops.conv2d(*args, residual=res.to(dev), tile_cfg=3).cpu().double()
     e_w, e_d = float((a.cpu().double() - ref).abs().max()), float((direct - ref).abs().max())
     print("stream-K winograd err %.2e  direct err %.2e  (max|ref| %.2f)" % (e_w, e_d, float(ref.abs().max())))
@@ -106,7 +115,8 @@ def test_winograd_stream_k(dev, cin, cout, H, W, B, wgs, cfg):
     assert float((plain - F.conv2d(x.double(), w.double(), padding=1)).abs().max()) < 2e-4 * max(1.0, float(ref.abs().max()))
 
 
-@pytest.mark.parametrize("shape,B,H,W,wgs", [(0, 1, 200, 176, 0), (1, 2, 24, 40, 0), (0, 2, 10, 66, 8), (1, 1, 14, 18, 16)])
+@pytest.mark.parametrize("shape,B,H,W,wgs", [(0, 1, 200, 176, 0), (1, 2, 24, 40, 0), (0, 2, 10, 66, 8), (1, 1, 14, 18, 16), (2, 1, 200, 176, 0),
+                                             (2, 2, 10, 66, 8)])
 def test_winograd_stream_k_weight_sets(dev, shape, B, H, W, wgs):
     """sessd_conv3x3_winograd_sk_sets: two layers of one shape (conv_0 / conv_1 of the SSFA neck) as ONE stream-K launch over a
     (2 B, C, H, W) input, each half with its own weights and BatchNorm constants, against the two single-layer launches."""

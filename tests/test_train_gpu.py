@@ -323,6 +323,15 @@ def test_train_step_two_ranks_identical_parameters(dev):
 
 
 def _syncbn_worker(rank, world, port, q):
+    try:
+        _syncbn_worker_body(rank, world, port, q)
+    except Exception as ex:   # a crashed rank must not leave the parent waiting for its queue timeout
+        import traceback
+        q.put((rank, {"error": 1e9, "trace": traceback.format_exc()[-1500:]}))
+        raise
+
+
+def _syncbn_worker_body(rank, world, port, q):
     """Each rank holds ITS part of a batch; with SyncBN the statistics, outputs and input gradients must be those of the
     single-process pass over the concatenated batch (computed here too, from the same seed)."""
     import os
@@ -342,7 +351,7 @@ def _syncbn_worker(rank, world, port, q):
         bn = torch.nn.BatchNorm1d(C, eps=1e-3, momentum=0.01).to(dev).train()
         with torch.no_grad():
             bn.weight.copy_(torch.linspace(0.5, 1.5, C)); bn.bias.copy_(torch.linspace(-0.2, 0.2, C))
-        cap = 4096
+        cap = 8192
         xp = torch.zeros(cap, C, device=dev); xp[:x.shape[0]] = x
         xp.requires_grad_(True)
         n_dev = torch.tensor([x.shape[0]], dtype=torch.int32, device=dev)
@@ -407,11 +416,11 @@ def test_sync_bn_two_ranks_equal_the_concatenated_batch(dev):
     procs = [ctx.Process(target=_syncbn_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=600) for _ in range(2))
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
     for p in procs:
         p.join(timeout=120)
-        assert p.exitcode == 0
     for rank, out in res:
+        assert "trace" not in out, out.get("trace")
         for k, v in out.items():
             assert v <= 2e-5, (rank, k, v)
 
@@ -509,14 +518,14 @@ def test_capacity_mode_gives_the_exact_row_gradients(dev):
 
 
 def test_captured_iteration_equals_eager(dev):
-    """TrainStep.capture(): teacher forward + student forward / backward + fused update as ONE hipGraph. Two trainers from the
-    same seed, one running eager iterations (device schedule), one replaying its graph, on the same three batches (copied INTO
-    the static example): the same losses to 2e-4 (measured 1e-6 at the first replay, 1e-5 at the third: the loss of iteration k sees the parameters after k - 1 noise-carrying updates), and student /
-    teacher parameters that differ by less than ONE Adam step can move a parameter (sum of the learning rates so far): the torch /
-    MIOpen pieces of the step (the 1x1 heads' weight gradients) are not bit-reproducible from run to run, and Adam's m / sqrt(v)
-    turns a last-bit difference of a near-zero gradient into a full-size step -- measured on MI355X after three iterations: two
-    EAGER trainers 6.6e-6 ... 2.5e-4 apart, graph and eager 1.5e-5 ... 8.7e-5 (sum of learning rates 1.2e-3); the second eager
-    trainer is run to show that spread. The learning rate of a replay is the schedule's CURRENT one, not the captured one."""
+    """TrainStep.capture(): teacher forward + student forward / backward + fused update as ONE hipGraph. Three trainers from the
+    same seed -- two running eager iterations (device schedule), one replaying its graph -- on the same batches (copied INTO the
+    static example): BIT-IDENTICAL losses and parameters, eager against eager and graph against eager. (Round 3 accepted parameters
+    "less than one Adam step" apart and blamed torch / MIOpen pieces; since then the heads, BatchNorm and the SSFA tail moved onto
+    the library's own kernels, and scripts/repro_probe.py measured on MI355X: no gradient tensor differs after iteration 1, no
+    parameter after 3, graph replays included -- there are no float atomics in csrc/, every reduction has a fixed order. The
+    review asked to tighten the test or name the non-reproducible kernel: there is none.) The learning rate of a replay is the
+    schedule's CURRENT one, not the captured one."""
     def make():
         model = configs.build_synthetic_detector(dev, seed=0)
         return strain.TrainStep(model, loss_fn=lambda ex, sp, tp, w: _loss(sp) + 0.1 * w * ops.mean_all((sp[0]["cls_preds"] - tp[0]["cls_preds"]).pow(2)),
@@ -533,22 +542,18 @@ def test_captured_iteration_equals_eager(dev):
     eager(batches[0], device_schedule=True)
     eager2(batches[0], device_schedule=True)
     lrs = []
-    dist = lambda a, b: float((a - b).abs().max())
     for b in batches[1:]:                # ... then three replays / three eager iterations on batches 1..3
         load(static, b)
         lg = float(graph.replay())      # (synchronises)
         assert int(graph.student.backbone.last_err.item()) == 0
         le, _, _ = eager(b, device_schedule=True)
-        eager2(b, device_schedule=True)
+        le2, _, _ = eager2(b, device_schedule=True)
         torch.cuda.synchronize()
-        assert abs(lg - float(le)) <= 2e-4 * abs(float(le)), (lg, float(le))   # 1e-6 at the first replay, 1e-5 at the third
+        assert float(le) == float(le2) and lg == float(le), (lg, float(le), float(le2))
         assert abs(float(graph.static_loss) - lg) == 0   # the output survives other work on the device
-        print("max |graph - eager| %.3e   max |eager2 - eager| %.3e   max |param| %.3e" % (
-            float((graph.flat_s.data - eager.flat_s.data).abs().max()), float((eager2.flat_s.data - eager.flat_s.data).abs().max()),
-            float(eager.flat_s.data.abs().max())))
-        moved = sum(strain.one_cycle(s, 20)[0] for s in range(eager.global_step))   # what the iterations so far can move a parameter
-        assert dist(graph.flat_s.data, eager.flat_s.data) <= moved and dist(graph.flat_t.data, eager.flat_t.data) <= moved
-
+        assert torch.equal(eager2.flat_s.data, eager.flat_s.data) and torch.equal(eager2.flat_t.data, eager.flat_t.data)
+        assert torch.equal(graph.flat_s.data, eager.flat_s.data) and torch.equal(graph.flat_t.data, eager.flat_t.data)
+        assert torch.equal(graph.opt.exp_avg_sq, eager.opt.exp_avg_sq)
         lrs.append(float(graph.opt.lr_mom_dev[0].item()))
     assert graph.global_step == eager.global_step == 4 and int(graph.opt.global_step_dev.item()) == 4
     want = [strain.one_cycle(s, 20)[0] for s in (1, 2, 3)]
@@ -583,8 +588,8 @@ def test_captured_iteration_with_the_reference_loss(dev):
     consistency loss (the capacity-form device op sessd_head_loss), backward, fused update -- as ONE hipGraph (round 3 could only
     capture a stand-in loss: the reference loss was an eager torch restatement with host-read shapes). Replays on three further
     labelled batches (voxels, targets and the recorded augmentation copied INTO the static example) follow an eager trainer from
-    the same seed: same loss and log terms to 2e-4, parameters within what the learning rates so far can move them, the
-    consistency weight refilled between replays is the one the graph uses."""
+    the same seed BIT FOR BIT (loss, log terms, student and teacher parameters); the consistency weight refilled between replays
+    is the one the graph uses."""
     def make():
         return strain.TrainStep(configs.build_synthetic_detector(dev, seed=0), None, total_steps=20)
     batches = []
@@ -616,16 +621,15 @@ def test_captured_iteration_with_the_reference_loss(dev):
         le, _, _ = eager(b, consistency_weight=w, device_schedule=True)
         re = eager.student.bbox_head.record_to_dict(eager.last_record)
         assert rg["overflow"] == 0 and int(graph.student.backbone.last_err.item()) == 0
-        assert abs(lg - float(le)) <= 2e-4 * abs(float(le)), (lg, float(le))
+        assert lg == float(le), (lg, float(le))        # bit-identical: every kernel of the iteration has a fixed summation order
         assert abs(lg - float(rg["total"][0])) == 0
         for k in ("loss", "cls_loss_reduced", "ious_loss", "dir_loss_reduced", "iou_pred_loss", "consistency_loss", "loss_ema"):
             x, y = float(rg[k][0].sum()), float(re[k][0].sum())
-            assert abs(x - y) <= 5e-4 * max(1e-3, abs(y)), (k, x, y)
+            assert x == y, (k, x, y)
         assert int(rg["num_pos"][0]) == 40 and float(rg["ious_loss"][0]) > 0
         # the graph used the refilled consistency weight: total = loss + w * consistency
         assert abs(float(rg["total"][0]) - (float(rg["loss"][0]) + w * float(rg["consistency_loss"][0].sum()))) <= 1e-5 * abs(float(rg["total"][0]))
-        moved = sum(strain.one_cycle(s, 20)[0] for s in range(eager.global_step))
-        assert dist(graph.flat_s.data, eager.flat_s.data) <= moved and dist(graph.flat_t.data, eager.flat_t.data) <= moved
+        assert dist(graph.flat_s.data, eager.flat_s.data) == 0 and dist(graph.flat_t.data, eager.flat_t.data) == 0
     assert graph.global_step == eager.global_step == 4 and int(graph.opt.global_step_dev.item()) == 4
 
 

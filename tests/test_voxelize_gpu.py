@@ -70,3 +70,35 @@ def test_vfe_standalone(dev):
     ov, oc, on = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 20000)
     got = ops.vfe_mean(torch.from_numpy(ov).to(dev), torch.from_numpy(on).to(dev), 4).cpu().numpy()
     assert np.array_equal(got.view(np.uint32), oracle.vfe_mean(ov, on, 4).view(np.uint32))
+
+
+def test_all_frames_of_a_batch_in_four_launches(dev):
+    """sessd_voxelize_frames (round 4: the frames of a batch no longer wait for each other -- 4 launches instead of 4 per frame)
+    against the per-frame entry point on one shared hash: every output bit-identical, on ragged frames (padding rows), a frame
+    that breaks at max_voxels followed by frames that do not, an empty frame, and the hash values (level-0 site index)."""
+    MV = 5000
+    frames = [synth.make_frame(31, 20000), synth.make_frame(32, 20000)[:2500].copy(), np.zeros((0, 4), np.float32),
+              synth.make_frame(33, 20000)[::7].copy(), synth.make_frame(34, 20000), synth.make_frame(35, 9000)]
+    pts = [torch.from_numpy(np.ascontiguousarray(f)).to(dev) for f in frames]
+    a = ops.voxelize_batch(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, MV)
+    b = ops.voxelize_frames(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, MV)
+    pa, pb = a["prefix"].cpu().numpy(), b["prefix"].cpu().numpy()
+    assert np.array_equal(pa, pb) and pa[1] - pa[0] == MV and pa[3] == pa[2] and 0 < pa[2] - pa[1] < MV   # capped, empty, uncapped
+    m = int(pa[-1])
+    for k in ("voxels", "coors", "num_points", "mean"):
+        assert torch.equal(a[k][:m], b[k][:m]), k
+    # the oracle, frame by frame
+    for i, f in enumerate(frames):
+        v, c, n = oracle.points_to_voxel(f, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, MV)
+        lo, hi = int(pb[i]), int(pb[i + 1])
+        assert hi - lo == c.shape[0]
+        assert np.array_equal(b["coors"][lo:hi, 1:].cpu().numpy(), c) and np.all(b["coors"][lo:hi, 0].cpu().numpy() == i)
+        assert np.array_equal(b["num_points"][lo:hi].cpu().numpy(), n)
+        assert np.array_equal(b["voxels"][lo:hi].cpu().numpy().view(np.uint32), v.view(np.uint32))
+    # the shared hash maps cell -> global row in both: same set of (key, value) pairs
+    ka, va = a["hash"].keys.cpu().numpy(), a["hash"].vals.cpu().numpy()
+    kb, vb = b["hash"].keys.cpu().numpy(), b["hash"].vals.cpu().numpy()
+    live_a, live_b = ka != 0x7F7F7F7F, kb != 0x7F7F7F7F
+    da = dict(zip(ka[live_a].tolist(), va[live_a].tolist()))
+    db = dict(zip(kb[live_b].tolist(), vb[live_b].tolist()))
+    assert da == db
