@@ -308,7 +308,7 @@ def test_train_step_two_ranks_identical_parameters(dev):
     procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=900) for _ in range(2))
+    res = sorted(q.get(timeout=420) for _ in range(2))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
