@@ -367,7 +367,8 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
                        "gather": "one all_gather of fixed-size (frames, 100, 9) float32 records + counts per engine at the end "
                                  "of the job, inside the timed region (RCCL when n_gpus > 1; a device-side no-op at n_gpus = 1)",
                        "tuning": {"dense_tile_cfg": dict(getattr(eng, "tile_cfg", {})),
-                                  "sparse": {str(k): v for k, v in getattr(eng, "sparse_split", {}).items()}}},
+                                  "sparse": {str(k): v for k, v in getattr(eng, "sparse_split", {}).items()},
+                                  "sparse_offset_pattern_tiles": {str(k): bool(v) for k, v in getattr(eng, "sparse_sorted", {}).items()}}},
         }
         if parity is not None:
             out["parity"] = parity

@@ -210,6 +210,15 @@ int sessd_sparse_conv(const float* in_feat, int cin, const int32_t* nbr, const u
                       const int32_t* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
                       const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
                       float* dense_out, const int32_t* dense_dims3, int tuning, sessd_stream_t stream);
+/* The same with OFFSET-PATTERN TILES (perm != NULL): tile_mask = the rulebook job's tile_mask_sorted, perm = its position -> row
+ * table (sessd_rulebook_job_t, built by sessd_sparse_chain_rulebooks): inside every group of 256 consecutive rows the sites are
+ * grouped into 16-row tiles by their neighbour pattern, so fewer (tile, offset) MFMA steps multiply rows without a neighbour.
+ * Rows keep their numbers (no indirection in any lookup); per site the arithmetic is unchanged: results are bit-identical to
+ * sessd_sparse_conv on the same tables. */
+int sessd_sparse_conv_sorted(const float* in_feat, int cin, const int32_t* nbr, const uint32_t* tile_mask, int kernel_volume,
+                             const int32_t* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
+                             const float* shift, int relu, float* out_feat, int cout, const int32_t* out_indices,
+                             float* dense_out, const int32_t* dense_dims3, int tuning, const uint8_t* perm, sessd_stream_t stream);
 
 /* ---- engine-internal site renumbering (no reference counterpart: spconv numbers sites as they come) ---------------
  * EXPERIMENTAL -- compiled, not yet validated on hardware (round 1 ran out of GPU budget); off by default in the engine.

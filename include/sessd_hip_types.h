@@ -20,6 +20,14 @@ typedef struct {
   int32_t ksize[3], stride[3], pad[3];
   int32_t* nbr;        /* out: (kernel_volume, cap of out_level) input row or -1 */
   uint32_t* tile_mask; /* out: ceil(cap / 16) words, bit k = some site of the 16-site tile has a neighbour at offset k */
+  /* optional (all three or none): OFFSET-PATTERN TILES. site_mask: out, (cap) words, bit k = site has a neighbour at offset k.
+   * perm: out, ceil(cap / 256) * 256 bytes -- inside every group of 256 consecutive rows the live sites sorted by site_mask;
+   * position p of the group holds row  group * 256 + perm[group * 256 + p]. tile_mask_sorted: out, ceil(cap / 256) * 16 words,
+   * the tile masks of the 16-position tiles of that order. sessd_sparse_conv_sorted walks these tiles: sites with the same
+   * neighbour pattern share a tile, so fewer (tile, offset) steps multiply rows without a neighbour -- same results per site. */
+  uint32_t* site_mask;
+  uint8_t* perm;
+  uint32_t* tile_mask_sorted;
 } sessd_rulebook_job_t;
 
 /* One weight packing of a batched re-pack launch (sessd_dense_pack_batch): the arguments of sessd_conv2d_pack_taps (kind 0) or

@@ -61,7 +61,11 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
                                                            const float* __restrict__ shift, int relu,
                                                            float* __restrict__ out_feat,
                                                            const int* __restrict__ out_indices,
-                                                           float* __restrict__ dense_out, int dD, int dH, int dW) {
+                                                           float* __restrict__ dense_out, int dD, int dH, int dW,
+                                                           const uint8_t* __restrict__ perm) {
+  // perm != NULL: OFFSET-PATTERN TILES (sessd_sparse_chain_rulebooks: sessd_rulebook_job_t.perm / tile_mask_sorted). Tile t holds
+  // the sorted positions 16 t .. 16 t + 15 of its 256-row group; position p is row (t >> 4) * 256 + perm[16 t + p]. `tile_mask`
+  // is then the mask array of THAT order. Everything per site is unchanged (same offsets, same fmaf chain): the same bits.
   constexpr int STEPS = CIN / 4;          // MFMA k-steps per offset
   constexpr int NTILE = NTW;              // 16-wide cout tiles handled by this wave
   constexpr int NTALL = COUT / 16;        // ... of all groups
@@ -93,6 +97,9 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
                                           // below), with it the four waves of a workgroup leave together
   const int i = lane & 15, kq = lane >> 4;
   const uint32_t tmask_raw = tile_mask[tile];  // used (readfirstlane) after the neighbour rows below have been requested
+  const int gbase = (tile >> 4) << 8;          // first row of the tile's 256-row group
+  // row of position p of this tile (p < 16; positions beyond the live count map to the tile's first site: read, never written)
+#define SESSD_ROW(P) (perm ? gbase + (int)perm[(size_t)tile * 16 + (P)] : tile * 16 + (P))
 
   f32x4 acc[NTILE];
 #pragma unroll
@@ -109,15 +116,17 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
   int4 ocoord[DENSE_OUT ? 4 : 1];
   if constexpr (DENSE_OUT) {
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-      ocoord[r] = *reinterpret_cast<const int4*>(out_indices + (size_t)min(tile * 16 + kq * 4 + r, n - 1) * 4);
+    for (int r = 0; r < 4; ++r) {
+      const int p = kq * 4 + r;
+      ocoord[r] = *reinterpret_cast<const int4*>(out_indices + (size_t)(tile * 16 + p < n ? SESSD_ROW(p) : SESSD_ROW(0)) * 4);
+    }
   }
 
   // stage the tile's neighbour table: lane (i, kq) fetches offsets kq, kq+4, ... of site i (64-byte segments).
   // lanes of the last tile whose site is >= n read the tile's first site instead (their results are discarded below):
   // with a capacity that is not a multiple of 16 their own column would lie past the end of the last rulebook row
   {
-    const int* nb = nbr + tile * 16 + (tile * 16 + i < n ? i : 0);
+    const int* nb = nbr + (tile * 16 + i < n ? SESSD_ROW(i) : SESSD_ROW(0));
     int r[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -239,8 +248,8 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
     const float sc = scv[t], sh = shv[t];
 #pragma unroll
     for (int r = 0; r < (KSPLIT ? 1 : 4); ++r) {
-      const int site = tile * 16 + kq * 4 + (KSPLIT ? wv : r);
-      if (site >= n) continue;
+      const int pos = kq * 4 + (KSPLIT ? wv : r);
+      if (tile * 16 + pos >= n) continue;
       float v = fmaf(acc[t][r], sc, sh);
       if (relu) v = fmaxf(v, 0.f);
       if (DENSE_OUT) {
@@ -248,10 +257,11 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
         const int4 c = ocoord[DENSE_OUT ? r : 0];
         dense_out[(((size_t)c.x * COUT + co) * dD + c.y) * dH * dW + (size_t)c.z * dW + c.w] = v;
       } else {
-        out_feat[(size_t)site * COUT + co] = v;
+        out_feat[(size_t)SESSD_ROW(pos) * COUT + co] = v;
       }
     }
   }
+#undef SESSD_ROW
 }
 
 // Variant for levels with many tiles (tuning bit 17): the four site tiles of a workgroup walk the UNION of their active offsets in
@@ -269,7 +279,7 @@ __global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __
                                                                   const int* __restrict__ n_dev, int n_cap,
                                                                   const float* __restrict__ wpk, const float* __restrict__ scale,
                                                                   const float* __restrict__ shift, int relu,
-                                                                  float* __restrict__ out_feat) {
+                                                                  float* __restrict__ out_feat, const uint8_t* __restrict__ perm) {
   constexpr int STEPS = CIN / 4, NTILE = NTW, NTALL = COUT / 16, SG = STEPS / 4;
   static_assert(CIN % 16 == 0, "16-byte operand loads");
   constexpr int WFLOATS = NTILE * CIN * 16;   // W[k] of this workgroup's couts, in fragment order
@@ -310,8 +320,10 @@ __global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __
   f32x4 acc[NTILE];
 #pragma unroll
   for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int gbase = (tile >> 4) << 8;   // offset-pattern tiles: see sparse_conv_kernel
+#define SESSD_ROW(P) (perm ? gbase + (int)perm[(size_t)tile * 16 + (P)] : tile * 16 + (P))
   if (live) {
-    const int* nb = nbr + tile * 16 + (tile * 16 + i < n ? i : 0);
+    const int* nb = nbr + (tile * 16 + i < n ? SESSD_ROW(i) : SESSD_ROW(0));
     int r[8];
 #pragma unroll
     for (int p = 0; p < 8; ++p) {
@@ -396,13 +408,14 @@ __global__ __launch_bounds__(256) void sparse_conv_wshare_kernel(const float* __
     const float sc = scv[t], sh = shv[t];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int site = tile * 16 + kq * 4 + r;
-      if (site >= n) continue;
+      const int pos = kq * 4 + r;
+      if (tile * 16 + pos >= n) continue;
       float v = fmaf(acc[t][r], sc, sh);
       if (relu) v = fmaxf(v, 0.f);
-      out_feat[(size_t)site * COUT + co] = v;
+      out_feat[(size_t)SESSD_ROW(pos) * COUT + co] = v;
     }
   }
+#undef SESSD_ROW
 }
 
 // W (kv, cin, cout) row-major [the flattened spconv layout (kz,ky,kx,Cin,Cout)] -> fragment order
@@ -449,22 +462,22 @@ __global__ __launch_bounds__(256) void sparse_pack_batch_kernel(const sessd_spar
 template <int CIN, int COUT, int NTW, int DEPTH, bool KS = false>
 int launch_depth(bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
                  int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
-                 const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
+                 const int* out_indices, float* dense_out, const int* dd, const uint8_t* perm, hipStream_t stream) {
   const int tiles = sessd_divup(n_cap, 16);
   // per XCD: ceil(groups / 8C) runs of C groups; C <= 8, so ceil(groups / 8) + 8 positions always suffice
   dim3 grid(8 * (sessd_divup(KS ? tiles : sessd_divup(tiles, 4), 8) + 8) * (COUT / 16 / NTW)), block(256);
   if constexpr (KS) {
     SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, DEPTH, false, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
-                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0);
+                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0, perm);
     SESSD_CHECK_LAUNCH();
     return SESSD_OK;
   }
   if (dense)
     SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, DEPTH, true>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
-                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2]);
+                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd[0], dd[1], dd[2], perm);
   else
     SESSD_LAUNCH((sparse_conv_kernel<CIN, COUT, NTW, DEPTH, false>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv,
-                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0);
+                       n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, 0, 0, 0, perm);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -474,12 +487,12 @@ int launch_depth(bool dense, const float* in_feat, const int* nbr, const uint32_
 template <int CIN, int COUT, int NTW, bool KS = false>
 int launch_ntw(int depth, bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv,
                const int* n_dev, int n_cap, const float* wpk, const float* scale, const float* shift, int relu,
-               float* out_feat, const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
+               float* out_feat, const int* out_indices, float* dense_out, const int* dd, const uint8_t* perm, hipStream_t stream) {
   constexpr int SET = (CIN / 4) * (1 + NTW);
   constexpr int DMAX = SET * 4 <= 400 ? 4 : (SET * 3 <= 400 ? 3 : 2);
   if (depth <= 0) depth = 3;
   if (depth > DMAX) depth = DMAX;
-#define SESSD_ARGS2 dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
+#define SESSD_ARGS2 dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, perm, stream
   if constexpr (KS) {  // offset split: at most 7 offsets per wave -- two or three operand sets
     if constexpr (DMAX >= 3) {
       if (depth >= 3) return launch_depth<CIN, COUT, NTW, 3, true>(SESSD_ARGS2);
@@ -499,7 +512,7 @@ int launch_ntw(int depth, bool dense, const float* in_feat, const int* nbr, cons
 template <int CIN, int COUT>
 int launch(int tuning, bool dense, const float* in_feat, const int* nbr, const uint32_t* tile_mask, int kv, const int* n_dev,
            int n_cap, const float* wpk, const float* scale, const float* shift, int relu, float* out_feat,
-           const int* out_indices, float* dense_out, const int* dd, hipStream_t stream) {
+           const int* out_indices, float* dense_out, const int* dd, const uint8_t* perm, hipStream_t stream) {
   constexpr int NT = COUT / 16;
   int split = tuning & 0xFF;
   const int depth = (tuning >> 8) & 0xFF;
@@ -512,7 +525,7 @@ int launch(int tuning, bool dense, const float* in_feat, const int* nbr, const u
     if constexpr (CIN % 16 == 0 && (NTW_) * CIN >= 64) {                                                              \
       dim3 grid(8 * (sessd_divup(sessd_divup(tiles, 4), 8) + 8) * (NT / (NTW_))), block(256);                          \
       SESSD_LAUNCH((sparse_conv_wshare_kernel<CIN, COUT, (NTW_)>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv, \
-                   n_dev, n_cap, wpk, scale, shift, relu, out_feat);                                                  \
+                   n_dev, n_cap, wpk, scale, shift, relu, out_feat, perm);                                            \
       SESSD_CHECK_LAUNCH();                                                                                           \
       return SESSD_OK;                                                                                                \
     }
@@ -526,7 +539,7 @@ int launch(int tuning, bool dense, const float* in_feat, const int* nbr, const u
 #undef SESSD_WSHARE
     // not instantiable for this channel pair / split: the plain kernel (same bits)
   }
-#define SESSD_ARGS depth, dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, stream
+#define SESSD_ARGS depth, dense, in_feat, nbr, tile_mask, kv, n_dev, n_cap, wpk, scale, shift, relu, out_feat, out_indices, dense_out, dd, perm, stream
   if (ksplit) {
     if constexpr (NT % 4 == 0) {
       if (split >= 4) return launch_ntw<CIN, COUT, NT / 4, true>(SESSD_ARGS);
@@ -595,10 +608,12 @@ int sessd_sparse_pack_weight_adjoint(const float* weight, int kernel_volume, int
 // out[o] = act( (sum_k W[k]^T in[nbr[k][o]]) * scale + shift ). If dense_out != NULL the result is
 // scattered instead into the dense BEV tensor (B, cout*D, H, W) with dense_dims3 = (D,H,W) (pre-zeroed
 // by the caller) and out_feat may be NULL.
-int sessd_sparse_conv(const float* in_feat, int cin, const int* nbr, const uint32_t* tile_mask, int kernel_volume,
-                      const int* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
-                      const float* shift, int relu, float* out_feat, int cout, const int* out_indices,
-                      float* dense_out, const int* dense_dims3, int tuning, hipStream_t stream) {
+// perm != NULL: offset-pattern tiles -- `tile_mask` is the job's tile_mask_sorted, `perm` its position -> row table
+// (sessd_rulebook_job_t); NULL: tiles of 16 consecutive rows. Same results either way.
+int sessd_sparse_conv_sorted(const float* in_feat, int cin, const int* nbr, const uint32_t* tile_mask, int kernel_volume,
+                             const int* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
+                             const float* shift, int relu, float* out_feat, int cout, const int* out_indices,
+                             float* dense_out, const int* dense_dims3, int tuning, const uint8_t* perm, hipStream_t stream) {
   if (n_out_cap <= 0 || kernel_volume <= 0 || kernel_volume > 32) return SESSD_EINVAL;
   const bool dense = dense_out != nullptr;
   if (dense && (!out_indices || !dense_dims3)) return SESSD_EINVAL;
@@ -606,7 +621,7 @@ int sessd_sparse_conv(const float* in_feat, int cin, const int* nbr, const uint3
 #define SESSD_SC(CI, CO)                                                                                              \
   if (cin == CI && cout == CO)                                                                                        \
     return launch<CI, CO>(tuning, dense, in_feat, nbr, tile_mask, kernel_volume, n_out_dev, n_out_cap, packed_weight, scale,  \
-                          shift, relu, out_feat, out_indices, dense_out, dense_dims3, stream);
+                          shift, relu, out_feat, out_indices, dense_out, dense_dims3, perm, stream);
   SESSD_SC(4, 16)
   SESSD_SC(16, 16)
   SESSD_SC(16, 32)
@@ -621,6 +636,14 @@ int sessd_sparse_conv(const float* in_feat, int cin, const int* nbr, const uint3
   SESSD_SC(64, 32)
 #undef SESSD_SC
   return SESSD_EINVAL;  // channel pair not instantiated
+}
+
+int sessd_sparse_conv(const float* in_feat, int cin, const int* nbr, const uint32_t* tile_mask, int kernel_volume,
+                      const int* n_out_dev, int n_out_cap, const float* packed_weight, const float* scale,
+                      const float* shift, int relu, float* out_feat, int cout, const int* out_indices,
+                      float* dense_out, const int* dense_dims3, int tuning, hipStream_t stream) {
+  return sessd_sparse_conv_sorted(in_feat, cin, nbr, tile_mask, kernel_volume, n_out_dev, n_out_cap, packed_weight, scale, shift, relu,
+                                  out_feat, cout, out_indices, dense_out, dense_dims3, tuning, nullptr, stream);
 }
 
 }  // extern "C"

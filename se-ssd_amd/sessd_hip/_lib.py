@@ -27,7 +27,7 @@ class ChainLevel(C.Structure):
 class RulebookJob(C.Structure):
     """sessd_rulebook_job_t (include/sessd_hip_types.h)"""
     _fields_ = [("in_level", i32), ("out_level", i32), ("ksize", i32 * 3), ("stride", i32 * 3), ("pad", i32 * 3),
-                ("nbr", vp), ("tile_mask", vp)]
+                ("nbr", vp), ("tile_mask", vp), ("site_mask", vp), ("perm", vp), ("tile_mask_sorted", vp)]
 
 
 class HeadLossNet(C.Structure):
@@ -121,6 +121,7 @@ SIGNATURES = {
     "sessd_sparse_pack_weight": (i32, [vp, i32, i32, i32, vp, vp]),
     "sessd_sparse_pack_weight_adjoint": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "sessd_sparse_conv": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp]),
+    "sessd_sparse_conv_sorted": (i32, [vp, i32, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, i32, vp, vp, vp, i32, vp, vp]),
     "sessd_sparse_renumber_workspace_bytes": (sz, [i32, vp]),
     "sessd_sparse_renumber_sites": (i32, [vp, vp, i32, i32, vp, vp, i32, vp, vp, u32, vp, vp, vp, sz, vp]),
     "sessd_points_in_bodies": (i32, [vp, i32, i32, vp, i32, i32, vp, vp]),

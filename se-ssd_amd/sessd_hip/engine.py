@@ -100,7 +100,7 @@ class DensePlan:
 class InferenceEngine:
     def __init__(self, model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, batch_size=1,
                  max_points_per_frame=32768, device=None, growth=(1.5, 1.0, 0.75, 0.75), anchors=None,
-                 use_frustum=False, allow_winograd=True, sort_sites=False):
+                 use_frustum=False, allow_winograd=True, sort_sites=False, sort_tiles=True):
         """growth[i]: capacity of sparse level i+1 relative to level i (observed ratios on KITTI-like scans are
         ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results().
         sort_sites: renumber the voxels by grid row between the voxelizer and the first sparse conv
@@ -188,6 +188,9 @@ class InferenceEngine:
         self.key_count = self.ctrl[B + 2:2 * B + 2]
         self.chain = ops.SparseChain(self.sparse_shape, steps, [L["cap"] for L in self.levels[1:]], B, jobs, dev,
                                      workspace_tensor=self.zero_arena[n_ctrl:].view(torch.uint8))
+        # offset-pattern tiles: the chain also sorts the sites of every 256-row group by neighbour pattern (one more launch); a
+        # sparse layer then walks those tiles when sparse_sorted[layer] says so (autotune times both: same bits either way)
+        self.chain.sort_tiles = bool(sort_tiles)
         self.chain.bind_tables(cap0)
         # ---- one contiguous arena for everything that must read 0x7F7F7F7F at the start of a frame (hash tables,
         # per-cell point lists, first-touch words): cleared by ONE fill instead of ~17 small ones
@@ -268,6 +271,7 @@ class InferenceEngine:
         self._tuning = None
         self._kmarks = None
         self.sparse_split = {}
+        self.sparse_sorted = {}   # layer -> walk the offset-pattern tiles (default True when the chain builds them)
         self._tuning_sparse = None
 
     # ------------------------------------------------------------------ helpers
@@ -301,11 +305,16 @@ class InferenceEngine:
         Lo = self.levels[out_li]
         kv = lay["ks"][0] * lay["ks"][1] * lay["ks"][2]
         dd = self._i3(Lo["shape"]).data_ptr() if dense else 0
-        check(lib.sessd_sparse_conv(in_feat.data_ptr(), lay["cin"], nbr.data_ptr(), tm.data_ptr(), kv, self._n(out_li),
-                                    Lo["cap"], lay["wpk"].data_ptr(), lay["scale"].data_ptr(), lay["shift"].data_ptr(), 1,
-                                    0 if dense else out_feat.data_ptr(), lay["cout"],
-                                    Lo["indices"].data_ptr() if dense else 0, self.bev.data_ptr() if dense else 0, dd,
-                                    self.sparse_split.get(idx, 0), s), "sparse_conv")
+        perm = 0
+        if self.chain.sort_tiles and self.sparse_sorted.get(idx, True):
+            j = self._job_of[idx]
+            if self.chain.nbr[j] is nbr:   # the layer runs on the chain's own table: its sorted tiles
+                tm, perm = self.chain.tile_mask_sorted[j], self.chain.perm[j].data_ptr()
+        check(lib.sessd_sparse_conv_sorted(in_feat.data_ptr(), lay["cin"], nbr.data_ptr(), tm.data_ptr(), kv, self._n(out_li),
+                                           Lo["cap"], lay["wpk"].data_ptr(), lay["scale"].data_ptr(), lay["shift"].data_ptr(), 1,
+                                           0 if dense else out_feat.data_ptr(), lay["cout"],
+                                           Lo["indices"].data_ptr() if dense else 0, self.bev.data_ptr() if dense else 0, dd,
+                                           self.sparse_split.get(idx, 0), perm, s), "sparse_conv_sorted")
         if self._tuning_sparse is not None and not dense:
             self._tuning_sparse.append((idx, lay, in_feat, nbr, tm, out_li, out_feat))
 
@@ -342,6 +351,7 @@ class InferenceEngine:
         stream-K workspace of this engine's own: engines that run concurrently must not share one."""
         self.tile_cfg = dict(other.tile_cfg)
         self.sparse_split = dict(other.sparse_split)
+        self.sparse_sorted = dict(other.sparse_sorted)
         self.sk_workgroups = other.sk_workgroups
         self.merge_branch_convs = other.merge_branch_convs
         self.sk_ws = torch.zeros_like(other.sk_ws) if other.sk_ws is not None else None
@@ -365,8 +375,9 @@ class InferenceEngine:
             for split, depth, ks in cands:
                 if (lay["cout"] // 16) % split or (ks == 1 and depth == 4):
                     continue
-                if True:
+                for srt in ((True, False) if self.chain.sort_tiles else (False,)):
                     self.sparse_split[idx] = split + 256 * depth + 65536 * ks
+                    self.sparse_sorted[idx] = srt
                     for _ in range(2):
                         self._sconv(lay, in_feat, nbr, tm, out_li, out_feat, st, idx=idx)
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -377,8 +388,9 @@ class InferenceEngine:
                     torch.cuda.synchronize()
                     t = e0.elapsed_time(e1) / reps
                     if t < best[1]:
-                        best = (split + 256 * depth + 65536 * ks, t)
-            self.sparse_split[idx] = best[0]
+                        best = (split + 256 * depth + 65536 * ks + (1 << 24 if srt else 0), t)
+            self.sparse_split[idx] = best[0] & 0xFFFFFF
+            self.sparse_sorted[idx] = bool(best[0] >> 24)
             self.tune_report["sparse%d" % idx] = best
         for name, x, layer, out, relu, residual in todo:
             pc, scale, shift = layer
@@ -678,7 +690,9 @@ class InferenceEngine:
             n = ns[out_li]
             kv = lay["ks"][0] * lay["ks"][1] * lay["ks"][2]
             pairs = int((nbr[:kv, :n] >= 0).sum().item())
-            masks = tm[:(n + 15) // 16]
+            srt = bool(self.chain.sort_tiles and self.sparse_sorted.get(idx, True))
+            # the tiles the launch really walks: offset-pattern tiles (all masks beyond the live groups are zero) or 16 consecutive rows
+            masks = self.chain.tile_mask_sorted[self._job_of[idx]] if srt else tm[:(n + 15) // 16]
             steps = int(sum(int(((masks >> k) & 1).sum().item()) for k in range(kv)))
             if in_feat is None:  # last layer: input = output of the previous one
                 in_feat, dense = feat_last, True
@@ -695,6 +709,7 @@ class InferenceEngine:
             ms = e0.elapsed_time(e1) / reps
             use, exe = 2.0 * pairs * lay["cin"] * lay["cout"] / 1e9, 2.0 * steps * 16 * lay["cin"] * lay["cout"] / 1e9
             rows.append(dict(layer=idx, kind=lay["kind"], cin=lay["cin"], cout=lay["cout"], sites=n, pairs=pairs, tile_steps=steps,
+                             sorted_tiles=srt,
                              ms=round(ms, 5), useful_gflop=round(use, 4), executed_gflop=round(exe, 4),
                              executed_tflops=round(exe / ms, 2) if ms > 0 else 0.0))
             tot_ms, tot_use, tot_exe = tot_ms + ms, tot_use + use, tot_exe + exe

@@ -433,6 +433,10 @@ class SparseChain:
         assert self.ws.numel() >= self.ws_bytes
         self.jobs = (RulebookJob * len(jobs))()
         self.nbr, self.tile_mask = [], []
+        # offset-pattern tiles (sessd_rulebook_job_t.perm): per job the sites' offset patterns, the position -> row table of the
+        # sorted 256-row groups and the tile masks of that order; built by one more launch of run_rulebooks when sort_tiles is set
+        self.sort_tiles = False
+        self.site_mask, self.perm, self.tile_mask_sorted = [None] * len(jobs), [None] * len(jobs), [None] * len(jobs)
         for j, (li, lo, ks, st, pd) in enumerate(jobs):
             ks, st, pd = _t3(ks), _t3(st), _t3(pd)
             cap = None if lo == 0 else self.caps[lo - 1]
@@ -465,6 +469,13 @@ class SparseChain:
             self.nbr[j] = torch.empty((kv, cap), dtype=torch.int32, device=self.dev)
             self.tile_mask[j] = torch.empty(((cap + 15) // 16,), dtype=torch.int32, device=self.dev)
             self.jobs[j].nbr, self.jobs[j].tile_mask = self.nbr[j].data_ptr(), self.tile_mask[j].data_ptr()
+            if self.sort_tiles:
+                groups = (cap + 255) // 256
+                self.site_mask[j] = torch.zeros((cap,), dtype=torch.int32, device=self.dev)
+                self.perm[j] = torch.zeros((groups * 256,), dtype=torch.uint8, device=self.dev)
+                self.tile_mask_sorted[j] = torch.zeros((groups * 16,), dtype=torch.int32, device=self.dev)
+                self.jobs[j].site_mask, self.jobs[j].perm = self.site_mask[j].data_ptr(), self.perm[j].data_ptr()
+                self.jobs[j].tile_mask_sorted = self.tile_mask_sorted[j].data_ptr()
 
     def run(self, indices0, n0_dev_ptr, n0_cap, hash0, err_flag, clear=True, stream=None):
         self.run_sites(indices0, n0_dev_ptr, n0_cap, err_flag, clear, stream)
@@ -698,8 +709,9 @@ def sparse_pack_weight_adjoint(weight, reverse_offsets):
 
 
 def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, scale=None, shift=None, relu=True,
-                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0, offset_split=0, share_w=0):
-    """cout_split (0 heuristic | 1, 2, 4) and depth (0 default | 2..4 operand sets in flight) only tune the launch: results are
+                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0, offset_split=0, share_w=0, perm=None):
+    """perm (with tile_mask = the job's tile_mask_sorted): offset-pattern tiles of a SparseChain built with sort_tiles -- the same
+    bits as the plain tiles. cout_split (0 heuristic | 1, 2, 4) and depth (0 default | 2..4 operand sets in flight) only tune the launch: results are
     bit-identical for every choice. offset_split = 1 (small levels; ignored with dense_out): the four waves of a workgroup split
     the kernel offsets of a tile by k % 4 -- the same bits for every cout_split / depth, last-bit differences from offset_split 0.
     share_w = 1 (large levels; ignored with dense_out or where cin % 16 != 0): the four tiles of a workgroup share W[k] through LDS --
@@ -712,10 +724,11 @@ def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, sc
             out = torch.empty((cap, cout), dtype=torch.float32, device=in_feat.device)
     else:
         dd = _i3(dense_dims)
-    check(lib.sessd_sparse_conv(in_feat.data_ptr(), cin, nbr.data_ptr(), tile_mask.data_ptr(), kv, n_out_dev.data_ptr(),
-                                cap, packed_weight.data_ptr(), _p(scale), _p(shift), 1 if relu else 0, _p(out), cout,
-                                _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(), int(cout_split) + 256 * int(depth) + 65536 * int(bool(offset_split)) + 131072 * int(bool(share_w)),
-                                _stream()),
+    check(lib.sessd_sparse_conv_sorted(in_feat.data_ptr(), cin, nbr.data_ptr(), tile_mask.data_ptr(), kv, n_out_dev.data_ptr(),
+                                       cap, packed_weight.data_ptr(), _p(scale), _p(shift), 1 if relu else 0, _p(out), cout,
+                                       _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(),
+                                       int(cout_split) + 256 * int(depth) + 65536 * int(bool(offset_split)) + 131072 * int(bool(share_w)),
+                                       _p(perm), _stream()),
           "sparse_conv")
     return out if dense_out is None else dense_out
 

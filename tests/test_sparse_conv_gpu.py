@@ -183,3 +183,55 @@ def test_every_tuning_is_bit_identical(dev, cin, cout, n, cap):
     ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, True, dense_out=d, out_indices=out_idx,
                     dense_dims=[5, 12, 10], cout_split=1, depth=2, offset_split=1)
     assert torch.equal(d, dref)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 16), (32, 32), (64, 64)])
+@pytest.mark.parametrize("n", [5000, 1501, 300, 7])
+def test_offset_pattern_tiles_give_the_same_bits(dev, cin, cout, n):
+    """sessd_sparse_conv_sorted with the chain's perm / tile_mask_sorted (sites of every 256-row group grouped into tiles by their
+    neighbour pattern; rows keep their numbers) against the plain tiles on the same tables: BIT-IDENTICAL for the submanifold
+    table, the strided table and the dense-output layer, in the plain kernel, the offset split and the shared-W variant -- and
+    fewer executed (tile, offset) steps."""
+    from oracle import sparse_conv as osc_
+    rng = np.random.RandomState(cin + n)
+    B, shape0 = 2, [9, 48, 40]
+    steps = [(3, 2, 1)]
+    idx = _random_sites(rng, B, [8, 48, 40], n)
+    cap0 = (n + 63) // 64 * 64 + 64
+    d_idx = torch.zeros((cap0, 4), dtype=torch.int32, device=dev)
+    d_idx[:n] = torch.from_numpy(idx).to(dev)
+    n_dev = torch.tensor([n], dtype=torch.int32, device=dev)
+    h0 = ops.sparse_hash_build(d_idx, n_dev, [8, 48, 40])
+    oshape = osc_.out_spatial(shape0, 3, 2, 1)
+    cap1 = min(8 * cap0, B * int(np.prod(oshape)))
+    jobs = [(0, 0, 3, 1, 1), (0, 1, 3, 2, 1)]
+    err = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ch = ops.SparseChain(shape0, steps, [cap1], B, jobs, dev)
+    ch.sort_tiles = True
+    ch.run(d_idx, n_dev.data_ptr(), cap0, h0, err)
+    torch.cuda.synchronize()
+    assert int(err.item()) == 0
+    feat = torch.zeros((cap0, cin), device=dev)
+    feat[:n] = torch.randn(n, cin, generator=torch.Generator().manual_seed(1)).to(dev)
+    w = (torch.randn(3, 3, 3, cin, cout, generator=torch.Generator().manual_seed(2)) * 0.2).to(dev)
+    wpk = ops.sparse_pack_weight(w)
+    scale, shift = (torch.rand(cout) + 0.5).to(dev), (torch.randn(cout) * 0.1).to(dev)
+    n1 = ch.n_dev[0]
+    m = int(n1.item())
+    for j, (nd, rows) in enumerate(((n_dev, n), (n1, m))):
+        nbr, tm, tms, perm = ch.nbr[j], ch.tile_mask[j], ch.tile_mask_sorted[j], ch.perm[j]
+        kv = nbr.shape[0]
+        plain_steps = sum(int(((tm[:(rows + 15) // 16] >> k) & 1).sum()) for k in range(kv))
+        sorted_steps = sum(int(((tms >> k) & 1).sum()) for k in range(kv))
+        assert sorted_steps <= plain_steps
+        for kw in (dict(), dict(offset_split=1), dict(share_w=1), dict(cout_split=1, depth=2), dict(cout_split=2, depth=4)):
+            a = ops.sparse_conv(feat, nbr, tm, nd, wpk, cin, cout, scale, shift, True, **kw)
+            b = ops.sparse_conv(feat, nbr, tms, nd, wpk, cin, cout, scale, shift, True, perm=perm, **kw)
+            assert torch.equal(a[:rows], b[:rows]), (j, kw)
+        assert float(a[:rows].abs().max()) > 0 or rows == 0
+    # the dense-output layer on the strided table
+    da, db = torch.zeros((B, cout * oshape[0], oshape[1], oshape[2]), device=dev), torch.zeros((B, cout * oshape[0], oshape[1], oshape[2]), device=dev)
+    ops.sparse_conv(feat, ch.nbr[1], ch.tile_mask[1], n1, wpk, cin, cout, scale, shift, True, dense_out=da, out_indices=ch.indices[0], dense_dims=oshape)
+    ops.sparse_conv(feat, ch.nbr[1], ch.tile_mask_sorted[1], n1, wpk, cin, cout, scale, shift, True, dense_out=db, out_indices=ch.indices[0],
+                    dense_dims=oshape, perm=ch.perm[1])
+    assert torch.equal(da, db) and float(da.abs().max()) > 0

@@ -76,6 +76,7 @@ def test_chain_sites_and_rulebooks(dev, B, shape0, n, clustered, seed):
         jobs.append((l, l + 1) + tuple(STEPS[l]))          # strided table into level l + 1
     err = torch.zeros((1,), dtype=torch.int32, device=dev)
     ch = ops.SparseChain(shape0, STEPS, caps, B, jobs, dev)
+    ch.sort_tiles = True     # offset-pattern tiles next to the plain tables (checked at the end)
     ch.run(d_idx, n_dev.data_ptr(), cap0, h0, err)
     torch.cuda.synchronize()
     assert int(err.item()) == 0
@@ -108,6 +109,26 @@ def test_chain_sites_and_rulebooks(dev, B, shape0, n, clustered, seed):
             hit = (nbr[:, t * 16:min(m, t * 16 + 16)] >= 0).any(1)
             assert int(tm[t]) == sum(1 << k for k in range(kv) if hit[k]), (j, t)
         assert not tm[(m + 15) // 16:].any()
+        # ---- offset-pattern tiles (sessd_rulebook_job_t.site_mask / perm / tile_mask_sorted)
+        sm = ch.site_mask[j].cpu().numpy().view(np.uint32)[:m]
+        want_sm = np.zeros(m, np.uint32)
+        for k in range(kv):
+            want_sm |= ((nbr[k, :m] >= 0).astype(np.uint32) << np.uint32(k))
+        assert np.array_equal(sm, want_sm), j
+        perm = ch.perm[j].cpu().numpy()
+        tms = ch.tile_mask_sorted[j].cpu().numpy().view(np.uint32)
+        for g in range((m + 255) // 256):
+            live = min(256, m - g * 256)
+            p = perm[g * 256:g * 256 + 256].astype(np.int64)
+            assert sorted(p.tolist()) == list(range(256)), (j, g)            # a permutation of the group's 256 rows
+            assert set(p[:live].tolist()) == set(range(live))                 # the live rows first ...
+            keys = (sm[g * 256 + p[:live]].astype(np.int64) << 8) | p[:live]
+            assert np.all(np.diff(keys) > 0), (j, g)                          # ... ordered by (pattern, row)
+            for t in range(16):
+                rows = p[t * 16:min(live, t * 16 + 16)]
+                want_t = np.bitwise_or.reduce(sm[g * 256 + rows]) if len(rows) else 0
+                assert int(tms[g * 16 + t]) == int(want_t), (j, g, t)
+        assert not tms[((m + 255) // 256) * 16:].any()
 
 
 def test_capacity_overflow_is_flagged(dev):
