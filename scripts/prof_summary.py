@@ -44,3 +44,14 @@ import re
 foreign = sum(a[1] for n, a in agg.items() if re.search(r"at::native|rocclr|miopen|igemm|naive_conv|batched_transpose|SubTensor|Cijk_|rocprim|hipcub", n))
 print("# kernels not from libsessd_hip.so (at::native, rocclr, MIOpen, rocBLAS): %.1f us%s = %.2f %% of the kernel time; %d launches%s" % (
     foreign / div, "/frame" if frames else "", 100 * foreign / tot, sum(a[0] for a in agg.values()) / div, "/frame" if frames else ""))
+
+# the launches around the longest instance of a kernel (argument 5: a name fragment), to see WHICH call it is
+if len(sys.argv) > 5:
+    frag = sys.argv[5]
+    hits = [(e - s_, i) for i, (n, s_, e) in enumerate(rows) if frag in n]
+    if hits:
+        _, at = max(hits)
+        print("# around the longest %s launch:" % frag)
+        for i in range(max(0, at - 4), min(len(rows), at + 4)):
+            n, s_, e = rows[i]
+            print("#   %s %8.1f us  %s" % ("->" if i == at else "  ", (e - s_) / 1e3, n[:110]))

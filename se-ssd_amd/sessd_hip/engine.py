@@ -100,7 +100,7 @@ class DensePlan:
 class InferenceEngine:
     def __init__(self, model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, batch_size=1,
                  max_points_per_frame=32768, device=None, growth=(1.5, 1.0, 0.75, 0.75), anchors=None,
-                 use_frustum=False, allow_winograd=True, sort_sites=False, sort_tiles=True):
+                 use_frustum=False, allow_winograd=True, sort_sites=False, sort_tiles=False):
         """growth[i]: capacity of sparse level i+1 relative to level i (observed ratios on KITTI-like scans are
         ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results().
         sort_sites: renumber the voxels by grid row between the voxelizer and the first sparse conv
@@ -188,8 +188,12 @@ class InferenceEngine:
         self.key_count = self.ctrl[B + 2:2 * B + 2]
         self.chain = ops.SparseChain(self.sparse_shape, steps, [L["cap"] for L in self.levels[1:]], B, jobs, dev,
                                      workspace_tensor=self.zero_arena[n_ctrl:].view(torch.uint8))
-        # offset-pattern tiles: the chain also sorts the sites of every 256-row group by neighbour pattern (one more launch); a
-        # sparse layer then walks those tiles when sparse_sorted[layer] says so (autotune times both: same bits either way)
+        # offset-pattern tiles (sort_tiles=True): the chain also sorts the sites of every 256-row group by neighbour pattern (one
+        # more launch); a sparse layer then walks those tiles when sparse_sorted[layer] says so (autotune times both: same bits
+        # either way). MEASURED ON MI355X AND OFF BY DEFAULT: useful MFMA rows 57 -> 73 % (batch 1) / 63 -> 80 % (dense scene), yet
+        # the autotune kept the plain tiles for EVERY layer at both scales -- the position -> row byte table adds a dependent load
+        # to each tile's prologue and epilogue and the 16 sites of a tile gather from scattered rows -- and the sort launch cost
+        # 0.09 ms of the dense-scene batch (profiles/r4_offset_pattern_tiles.txt)
         self.chain.sort_tiles = bool(sort_tiles)
         self.chain.bind_tables(cap0)
         # ---- one contiguous arena for everything that must read 0x7F7F7F7F at the start of a frame (hash tables,
@@ -404,7 +408,9 @@ class InferenceEngine:
                         cands.append(21)  # same, operands fetched two rounds ahead
                     # stream-K Winograd (all couts of a unit in one workgroup, equal shares of rounds per CU): 8 waves x 128
                     # couts / 4 waves x 64 couts. One workspace per engine: its launches are serialised on the engine's stream.
-                    for cfg, shape in ((22, 0), (23, 1), (24, 2)) if self.allow_streamk else ():
+                    # (tile_cfg 24, the third generation with the output transform in registers, is selectable but not a candidate:
+                    # measured 81 / 96 us against 63 / 66 us for 22 / 23 on the two SSFA shapes, profiles/r4_wino_rk_probe.json)
+                    for cfg, shape in ((22, 0), (23, 1)) if self.allow_streamk else ():
                         if pc.upk_sk(shape) is not None:
                             need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(x.shape[0], x.shape[2], x.shape[3], pc.cout, shape, 0))
                             if self.sk_ws is None or self.sk_ws.numel() < need:

@@ -301,8 +301,8 @@ def test_stress_autotuned_equals_the_oracle(dev):
 
 
 def test_offset_pattern_tiles_do_not_change_the_frame(dev, model):
-    """InferenceEngine(sort_tiles=True) (default: the chain groups the sites of every 256-row group into 16-row tiles by neighbour
-    pattern, the sparse convs walk those tiles) against sort_tiles=False: the SAME BEV map and detections, bit for bit, at batch 1
+    """InferenceEngine(sort_tiles=True) (the chain groups the sites of every 256-row group into 16-row tiles by neighbour pattern,
+    the sparse convs walk those tiles; measured slower on MI355X and therefore not the default) against sort_tiles=False: the SAME BEV map and detections, bit for bit, at batch 1
     and 2, and a higher share of executed MFMA rows that carry a pair."""
     for B, seeds in ((1, (51,)), (2, (52, 53))):
         frames = [torch.from_numpy(synth.make_frame(s, 20000)).to(dev) for s in seeds]
