@@ -318,13 +318,14 @@ struct PosLds {
   float pa[SESSD_IOU_MAXPTS][64];
 };
 
+// eight lanes per positive: lane c < 7 carries d ODIoU / d q[c] (odiou_core.hpp), lane 0 also does the IoU-prediction term
 __global__ __launch_bounds__(64) void hl_pos_kernel(sessd_head_loss_net_t S, sessd_head_loss_net_t T, sessd_head_loss_cfg_t P, Work W,
                                                      float* __restrict__ g_box, float* __restrict__ g_iou) {
   __shared__ PosLds L;
   const int s = blockIdx.y, B = P.batch, A = P.num_anchors;
   const sessd_head_loss_net_t& N = s ? T : S;
   const int n = min(W.counts[s], P.pos_capacity);
-  const int r = blockIdx.x * 64 + threadIdx.x;
+  const int r = blockIdx.x * 8 + (threadIdx.x >> 3), c = threadIdx.x & 7;
   if (r >= n) return;
   const size_t i = (size_t)W.pos_list[(size_t)s * P.pos_capacity + r];
   const int b = (int)(i / A);
@@ -334,36 +335,41 @@ __global__ __launch_bounds__(64) void hl_pos_kernel(sessd_head_loss_net_t S, ses
   for (int k = 0; k < 7; ++k) { code[k] = N.box[i * 7 + k]; tg[k] = N.reg_targets[i * 7 + k]; an[k] = N.anchors[i * 7 + k]; }
   decode_box(code, an, q);
   decode_box(tg, an, g);
-  // ---- IoU-prediction target 2 * IoU3D(q, g) - 1 (iou3d_utils.py:197-252: rotated BEV overlap x height overlap)
-  sessd_rect RQ, RG;
-  sessd_rect_init(RQ, q[0] - q[3] / 2, q[1] - q[4] / 2, q[0] + q[3] / 2, q[1] + q[4] / 2, q[6]);
-  sessd_rect_init(RG, g[0] - g[3] / 2, g[1] - g[4] / 2, g[0] + g[3] / 2, g[1] + g[4] / 2, g[6]);
-  sessd_ptlist PL = {&L.px[0][threadIdx.x], &L.py[0][threadIdx.x], &L.pa[0][threadIdx.x], 64};
-  const float ov = sessd_rect_overlap_f32(RQ, RG, PL);
-  const float qlo = q[2] - q[5] / 2, qhi = q[2] + q[5] / 2, glo = g[2] - g[5] / 2, ghi = g[2] + g[5] / 2;
-  const float oh = fmaxf(fminf(qhi, ghi) - fmaxf(qlo, glo), 0.f);
-  const float o3 = ov * oh;
-  const float iou3d = o3 / fmaxf(q[3] * q[4] * q[5] + g[3] * g[4] * g[5] - o3, 1e-7f);
-  const float target = 2.f * iou3d - 1.f;
-  const float s2 = P.smooth_l1_sigma * P.smooth_l1_sigma;
-  float d;
-  const float v = sl1(N.iou[i] - target, s2, &d);
   float* terms = W.pos_terms + ((size_t)s * P.pos_capacity + r) * 2;
-  terms[0] = v * reg_w;
-  terms[1] = 0.f;
+  if (c == 0) {
+    // ---- IoU-prediction target 2 * IoU3D(q, g) - 1 (iou3d_utils.py:197-252: rotated BEV overlap x height overlap)
+    sessd_rect RQ, RG;
+    sessd_rect_init(RQ, q[0] - q[3] / 2, q[1] - q[4] / 2, q[0] + q[3] / 2, q[1] + q[4] / 2, q[6]);
+    sessd_rect_init(RG, g[0] - g[3] / 2, g[1] - g[4] / 2, g[0] + g[3] / 2, g[1] + g[4] / 2, g[6]);
+    sessd_ptlist PL = {&L.px[0][threadIdx.x], &L.py[0][threadIdx.x], &L.pa[0][threadIdx.x], 64};
+    const float ov = sessd_rect_overlap_f32(RQ, RG, PL);
+    const float qlo = q[2] - q[5] / 2, qhi = q[2] + q[5] / 2, glo = g[2] - g[5] / 2, ghi = g[2] + g[5] / 2;
+    const float oh = fmaxf(fminf(qhi, ghi) - fmaxf(qlo, glo), 0.f);
+    const float o3 = ov * oh;
+    const float iou3d = o3 / fmaxf(q[3] * q[4] * q[5] + g[3] * g[4] * g[5] - o3, 1e-7f);
+    const float target = 2.f * iou3d - 1.f;
+    const float s2 = P.smooth_l1_sigma * P.smooth_l1_sigma;
+    float d;
+    const float v = sl1(N.iou[i] - target, s2, &d);
+    terms[0] = v * reg_w;
+    if (s != 0) terms[1] = 0.f;
+    else g_iou[i] = d * reg_w / (float)B;
+  }
   if (s != 0) return;
-  g_iou[i] = d * reg_w / (float)B;
   // ---- ODIoU (odious.py:837-900): loss 2 * sum(w * term) / B; gradient through the box decoding (diagonal Jacobian)
-  double gd[7], qd[7], term, grad[7];
+  double gd[7], qd[7], term, grad;
 #pragma unroll
   for (int k = 0; k < 7; ++k) { gd[k] = (double)g[k]; qd[k] = (double)q[k]; }
-  odiou_eval(gd, qd, &term, grad);
-  terms[1] = (float)term * reg_w;
-  float jac[7];
-  decode_jac(q, an, jac);
-  const float sc = 2.0f * reg_w / (float)B;
-#pragma unroll
-  for (int k = 0; k < 7; ++k) g_box[i * 7 + k] = (float)grad[k] * sc * jac[k];
+  const int comp = c < 7 ? c : 6;
+  odiou_eval(gd, qd, comp, &term, &grad);
+  if (c == 0) terms[1] = (float)term * reg_w;
+  if (c < 7) {
+    float jac[7];
+    decode_jac(q, an, jac);
+    const float jc = c == 0 ? jac[0] : c == 1 ? jac[1] : c == 2 ? jac[2] : c == 3 ? jac[3] : c == 4 ? jac[4] : c == 5 ? jac[5] : jac[6];
+    const float sc = 2.0f * reg_w / (float)B;
+    g_box[i * 7 + c] = (float)grad * sc * jc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------- launch 4
@@ -615,7 +621,7 @@ int sessd_head_loss(const sessd_head_loss_cfg_t* cfg, const sessd_head_loss_net_
   SESSD_LAUNCH(hl_anchor_kernel, dim3(nblk, B, 2), dim3(NT), 0, stream, *student, *teacher, P, anchors0, transformation, W, nblk,
                grad_box, grad_cls, grad_dir, grad_iou);
   SESSD_CHECK_LAUNCH();
-  SESSD_LAUNCH(hl_pos_kernel, dim3(sessd_divup(P.pos_capacity, 64), 2), dim3(64), 0, stream, *student, *teacher, P, W, grad_box,
+  SESSD_LAUNCH(hl_pos_kernel, dim3(sessd_divup(P.pos_capacity, 8), 2), dim3(64), 0, stream, *student, *teacher, P, W, grad_box,
                grad_iou);
   SESSD_CHECK_LAUNCH();
   SESSD_LAUNCH(hl_match_kernel, dim3(sessd_divup(P.cons_capacity, NT / 64), B), dim3(NT), 0, stream, P, W);

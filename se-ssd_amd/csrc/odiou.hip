@@ -18,17 +18,17 @@
 
 namespace {
 
+// eight lanes per pair: lane c < 7 carries d / d q[c], all eight compute the value (lane 7 repeats component 6 and writes nothing)
 __global__ __launch_bounds__(64) void odiou_kernel(const float* __restrict__ gboxes, const float* __restrict__ qboxes, int n,
                                                     float* __restrict__ term_out, float* __restrict__ grad_out) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int i = blockIdx.x * 8 + (threadIdx.x >> 3), c = threadIdx.x & 7;
   if (i >= n) return;
-  double g[ND], qv[ND], term, grad[ND];
+  double g[NB], qv[NB], term, grad;
 #pragma unroll
-  for (int k = 0; k < ND; ++k) { g[k] = (double)gboxes[(size_t)i * ND + k]; qv[k] = (double)qboxes[(size_t)i * ND + k]; }
-  odiou_eval(g, qv, &term, grad);
-  term_out[i] = (float)term;
-#pragma unroll
-  for (int k = 0; k < ND; ++k) grad_out[(size_t)i * ND + k] = (float)grad[k];
+  for (int k = 0; k < NB; ++k) { g[k] = (double)gboxes[(size_t)i * NB + k]; qv[k] = (double)qboxes[(size_t)i * NB + k]; }
+  odiou_eval(g, qv, c < NB ? c : NB - 1, &term, &grad);
+  if (c == 0) term_out[i] = (float)term;
+  if (c < NB) grad_out[(size_t)i * NB + c] = (float)grad;
 }
 
 }  // namespace
@@ -40,7 +40,7 @@ extern "C" {
 int sessd_odiou3d(const float* gboxes, const float* qboxes, int n, float* term, float* grad_q, hipStream_t stream) {
   if (n < 0) return SESSD_EINVAL;
   if (n == 0) return SESSD_OK;
-  SESSD_LAUNCH(odiou_kernel, dim3(sessd_divup(n, 64)), dim3(64), 0, stream, gboxes, qboxes, n, term, grad_q);
+  SESSD_LAUNCH(odiou_kernel, dim3(sessd_divup(n, 8)), dim3(64), 0, stream, gboxes, qboxes, n, term, grad_q);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

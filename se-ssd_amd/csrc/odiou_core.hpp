@@ -5,7 +5,10 @@
 
 namespace {
 
-constexpr int ND = 7;
+constexpr int NB = 7;   // box parameters [x, y, z, w, l, h, r]
+constexpr int ND = 1;   // partial derivatives carried per LANE: lane c of a pair's group of eight differentiates with respect to box
+                        // parameter c (round 4: one thread carrying all seven was a 140 us serial float64 chain; per component the
+                        // formulas -- and therefore the bits -- are the same)
 constexpr double PI_REF = 3.1415926;
 
 struct Dual {
@@ -20,9 +23,9 @@ __device__ __forceinline__ Dual dconst(double v) {
   for (int i = 0; i < ND; ++i) r.d[i] = 0.0;
   return r;
 }
-__device__ __forceinline__ Dual dvar(double v, int k) {
+__device__ __forceinline__ Dual dvar(double v) {   // the variable this lane differentiates with respect to
   Dual r = dconst(v);
-  r.d[k] = 1.0;
+  r.d[0] = 1.0;
   return r;
 }
 __device__ __forceinline__ Dual operator+(const Dual& a, const Dual& b) {
@@ -255,22 +258,23 @@ __device__ Dual mbr_diag(const P2* pts) {
   return dsqrt(bex * bex + bey * bey);
 }
 
-// term and d term / d q of ONE pair: g, qv = [x, y, z, w, l, h, r] (float64 copies of the float32 boxes). odious.py:851-899.
-__device__ void odiou_eval(const double* g_in, const double* qv, double* term_out, double* grad_out) {
-  double g[ND];
+// term and d term / d q[comp] of ONE pair: g, qv = [x, y, z, w, l, h, r] (float64 copies of the float32 boxes), comp in 0..6 the
+// box parameter this lane differentiates with respect to. odious.py:851-899.
+__device__ void odiou_eval(const double* g_in, const double* qv, int comp, double* term_out, double* grad_out) {
+  double g[NB];
 #pragma unroll
-  for (int k = 0; k < ND; ++k) g[k] = g_in[k];
+  for (int k = 0; k < NB; ++k) g[k] = g_in[k];
   if (!(g[3] > 0 && g[4] > 0 && g[5] > 0 && qv[3] > 0 && qv[4] > 0 && qv[5] > 0)) {  // :851-853 indicator
     *term_out = 0.0;
-#pragma unroll
-    for (int k = 0; k < ND; ++k) grad_out[k] = 0.0;
+    *grad_out = 0.0;
     return;
   }
-  Dual q[ND];
+  Dual q[NB];
 #pragma unroll
-  for (int k = 0; k < ND; ++k) {  // torch.clamp(-200, 200) :855-856: identity gradient inside, zero outside
+  for (int k = 0; k < NB; ++k) {  // torch.clamp(-200, 200) :855-856: identity gradient inside, zero outside
     g[k] = fmin(fmax(g[k], -200.0), 200.0);
-    q[k] = (qv[k] >= -200.0 && qv[k] <= 200.0) ? dvar(qv[k], k) : dconst(fmin(fmax(qv[k], -200.0), 200.0));
+    q[k] = dconst(fmin(fmax(qv[k], -200.0), 200.0));
+    if (k == comp && qv[k] >= -200.0 && qv[k] <= 200.0) q[k].d[0] = 1.0;
   }
   const Dual angle = (dconst(1.0) - dabs(dcos(q[6] + (-g[6])))) * 1.25;
   P2 c[8];
@@ -298,8 +302,7 @@ __device__ void odiou_eval(const double* g_in, const double* qv, double* term_ou
   const Dual iou = inc / (vol_q + vol_g - inc);
   const Dual term = dconst(1.0) - iou + dist2 / diag3d2 + angle;
   *term_out = term.v;
-#pragma unroll
-  for (int k = 0; k < ND; ++k) grad_out[k] = term.d[k];
+  *grad_out = term.d[0];
 }
 
 }  // namespace
