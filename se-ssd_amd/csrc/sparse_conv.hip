@@ -264,6 +264,178 @@ __global__ __launch_bounds__(256) void sparse_conv_kernel(const float* __restric
 #undef SESSD_ROW
 }
 
+// Variant for levels with many tiles (tuning bits 20-21: TPW = 2 or 4 tiles per wave). Round 4 measured that a sparse layer's time
+// does not follow its MFMA steps (offset-pattern tiles: 18 - 25 % fewer steps, +2 ... +8 % time, profiles/r4_sorted_tiles_probe.json):
+// a wave's life is the dependent chain  tile mask + neighbour rows -> operand rows -> MFMAs -> stores,  paid once per 16-site tile.
+// Here a wave takes TPW tiles (the same position of TPW consecutive 64-site groups) and fetches the NEXT tile's mask and neighbour
+// rows right after publishing the current tile's table, i.e. under the current tile's whole MFMA walk; the BatchNorm constants are
+// loaded once per wave. Per site the arithmetic is the plain kernel's: identical bits. Only for levels with many more tiles than
+// wave slots (the dense-scene batch): at batch 1 it would thin out the already scarce waves.
+template <int CIN, int COUT, int NTW, int DEPTH, int TPW>
+__global__ __launch_bounds__(256) void sparse_conv_mt_kernel(const float* __restrict__ in_feat, const int* __restrict__ nbr,
+                                                              const uint32_t* __restrict__ tile_mask, int kv,
+                                                              const int* __restrict__ n_dev, int n_cap, const float* __restrict__ wpk,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              int relu, float* __restrict__ out_feat) {
+  constexpr int STEPS = CIN / 4, NTILE = NTW, NTALL = COUT / 16;
+  constexpr int G = STEPS < 4 ? STEPS : 4;
+  constexpr int SG = STEPS / G;
+  constexpr int NGRP = COUT / 16 / NTW;
+  __shared__ int s_nbr[4][32][16];
+  const int n = min(n_dev[0], n_cap);
+  const int xcd = (int)(blockIdx.x & 7u), j = (int)(blockIdx.x >> 3);
+  const int groups64 = (n + 63) >> 6;
+  const int groups = (groups64 + TPW - 1) / TPW;   // unit of the XCD mapping: TPW consecutive 64-site groups
+  const int lg = groups >= 4096 ? 3 : (groups >= 2048 ? 2 : (groups >= 512 ? 1 : 0));
+  const int t_local = j / NGRP;
+  const int group = ((((t_local >> lg) << 3) + xcd) << lg) + (t_local & ((1 << lg) - 1));
+  if (group >= groups) return;
+  const int tbase = (j - t_local * NGRP) * NTW;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  int tile = (group * TPW) * 4 + wv;       // wave-uniform; the wave's later tiles are tile + 4, + 8, ...
+  if (tile * 16 >= n) return;
+  const int i = lane & 15, kq = lane >> 4;
+  float scv[NTILE], shv[NTILE];
+#pragma unroll
+  for (int t = 0; t < NTILE; ++t) {
+    const int co = (tbase + t) * 16 + i;
+    scv[t] = scale ? scale[co] : 1.f;
+    shv[t] = shift ? shift[co] : 0.f;
+  }
+  const rsrc_t fr = make_rsrc(in_feat, 0x7FFFFFFFu);
+  const rsrc_t wrs = make_rsrc(wpk, (unsigned)kv * NTALL * STEPS * 64u * 4u);
+  // neighbour rows + mask of the first tile
+  uint32_t mcur = tile_mask[tile];
+  int rcur[8];
+  {
+    const int* nb = nbr + tile * 16 + (tile * 16 + i < n ? i : 0);
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const int k = p * 4 + kq;
+      rcur[p] = k < kv ? nb[(size_t)k * n_cap] : -1;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 8; ++p) s_nbr[wv][p * 4 + kq][i] = rcur[p];
+  uint32_t tmask = __builtin_amdgcn_readfirstlane(mcur);
+#pragma unroll 1
+  for (int tt = 0; tt < TPW; ++tt) {
+    __builtin_amdgcn_wave_barrier();
+    // the NEXT tile's table: requested now, published (LDS) after this tile's MFMA walk and BEFORE its output stores -- a wait
+    // placed after the stores would be a wait for the stores (unconditional loads: a wave without a next tile re-reads its own)
+    const int tile_n = tile + 4;
+    const bool more = (tt + 1 < TPW) && (tile_n * 16 < n);   // wave-uniform
+    const int tile_f = more ? tile_n : tile;
+    uint32_t mnext = tile_mask[tile_f];
+    int rnext[8];
+    {
+      const int* nb = nbr + tile_f * 16 + (tile_f * 16 + i < n ? i : 0);
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        const int k = p * 4 + kq;
+        rnext[p] = k < kv ? nb[(size_t)k * n_cap] : -1;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc[NTILE];
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float a[DEPTH][STEPS], bw[DEPTH][NTILE][STEPS];
+    uint32_t rest = tmask;
+    const int remaining = __builtin_popcount(tmask);
+    int kn = 0, rn = -1;
+#define SESSD_FETCH()                                        \
+  {                                                          \
+    const bool more_ = rest != 0u;                           \
+    if (more_) {                                             \
+      kn = __builtin_ctz(rest);                              \
+      rest &= rest - 1;                                      \
+    }                                                        \
+    const int rr = s_nbr[wv][kn][i];                         \
+    rn = more_ ? rr : -1;                                    \
+  }
+#define SESSD_LOADAB(SET, K, ROW)                                                                  \
+  {                                                                                                \
+    const unsigned ao = (ROW) >= 0 ? (unsigned)(((ROW)*CIN + kq * STEPS) * 4) : SESSD_OOB;          \
+    const unsigned ws = (unsigned)(K) * (NTALL * STEPS * 64 * 4);                                  \
+    if (G == 4) {                                                                                  \
+      _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                             \
+        const f32x4 v = bufload4(fr, ao + 16u * g, 0);                                             \
+        a[SET][4 * g] = v.x; a[SET][4 * g + 1] = v.y; a[SET][4 * g + 2] = v.z; a[SET][4 * g + 3] = v.w; \
+      }                                                                                            \
+      _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
+        _Pragma("unroll") for (int g = 0; g < SG; ++g) {                                           \
+          const f32x4 v = bufload4(wrs, (unsigned)lane * 16u + (unsigned)((tbase + t) * SG + g) * 1024u, ws); \
+          bw[SET][t][4 * g] = v.x; bw[SET][t][4 * g + 1] = v.y; bw[SET][t][4 * g + 2] = v.z; bw[SET][t][4 * g + 3] = v.w; \
+        }                                                                                          \
+    } else {                                                                                       \
+      _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2) a[SET][s2] = bufload1(fr, ao + 4u * s2, 0); \
+      _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
+        _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2)                                       \
+          bw[SET][t][s2] = bufload1(wrs, ((unsigned)((tbase + t) * SG) * 64u + lane) * (G * 4u) + 4u * s2, ws); \
+    }                                                                                              \
+  }
+#define SESSD_MMA(SET)                                                                             \
+  {                                                                                                \
+    _Pragma("unroll") for (int s2 = 0; s2 < STEPS; ++s2)                                           \
+      _Pragma("unroll") for (int t = 0; t < NTILE; ++t)                                            \
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[SET][s2], bw[SET][t][s2], acc[t], 0, 0, 0); \
+  }
+    if (remaining > 0) {
+#pragma unroll
+      for (int d = 0; d < DEPTH - 1; ++d) {
+        SESSD_FETCH()
+        SESSD_LOADAB(d, kn, rn)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      SESSD_FETCH()
+      __builtin_amdgcn_sched_barrier(0);
+#define SESSD_STEP(CUR)                                                                            \
+  {                                                                                                \
+    SESSD_LOADAB((CUR + DEPTH - 1) % DEPTH, kn, rn)                                                \
+    SESSD_FETCH()                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    SESSD_MMA(CUR)                                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+  }
+      const int iters = (remaining + DEPTH - 1) / DEPTH;
+      for (int it = 0; it < iters; ++it) {
+        SESSD_STEP(0)
+        SESSD_STEP(1)
+        if constexpr (DEPTH >= 3) SESSD_STEP(2)
+        if constexpr (DEPTH >= 4) SESSD_STEP(3)
+      }
+#undef SESSD_STEP
+    }
+#undef SESSD_FETCH
+#undef SESSD_LOADAB
+#undef SESSD_MMA
+    // this tile's table has been read for the last time: publish the next one
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 8; ++p) s_nbr[wv][p * 4 + kq][i] = rnext[p];
+    const uint32_t tmask_n = __builtin_amdgcn_readfirstlane(mnext);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < NTILE; ++t) {
+      const int co = (tbase + t) * 16 + i;
+      const float sc = scv[t], sh = shv[t];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int site = tile * 16 + kq * 4 + r;
+        if (site >= n) continue;
+        float v = fmaf(acc[t][r], sc, sh);
+        if (relu) v = fmaxf(v, 0.f);
+        out_feat[(size_t)site * COUT + co] = v;
+      }
+    }
+    if (!more) break;
+    tmask = tmask_n;
+    tile = tile_n;
+  }
+}
+
 // Variant for levels with many tiles (tuning bit 17): the four site tiles of a workgroup walk the UNION of their active offsets in
 // step and share W[k] through LDS. Without it every wave streams its own copy of W[k] (Cin x Cout/split floats per 16-site tile
 // and offset: 2/3 of the operand bytes), and at scale the kernel is bound by that L1/L2 traffic, not by the matrix cores
@@ -518,6 +690,37 @@ int launch(int tuning, bool dense, const float* in_feat, const int* nbr, const u
   const int depth = (tuning >> 8) & 0xFF;
   if (split <= 0) split = (n_cap / 16 < 4096) ? (NT >= 4 ? 4 : (NT >= 2 ? 2 : 1)) : 1;  // fill 1024 SIMDs on small levels
   const bool ksplit = ((tuning >> 16) & 1) && !dense;
+  const int tpw_sel = (tuning >> 20) & 3;   // 1: two, 2: four tiles per wave (sparse_conv_mt_kernel); plain tiles, not dense / split / shared-W
+  if (tpw_sel && !dense && !ksplit && !((tuning >> 17) & 1) && !perm) {
+    const int tiles = sessd_divup(n_cap, 16);
+    int depth_mt = depth <= 0 ? 3 : depth;
+#define SESSD_MT(NTW_, DEPTH_, TPW_)                                                                                        \
+    {                                                                                                                       \
+      dim3 grid(8 * (sessd_divup(sessd_divup(sessd_divup(tiles, 4), (TPW_)), 8) + 8) * (NT / (NTW_))), block(256);           \
+      SESSD_LAUNCH((sparse_conv_mt_kernel<CIN, COUT, (NTW_), (DEPTH_), (TPW_)>), grid, block, 0, stream, in_feat, nbr, tile_mask, kv, \
+                   n_dev, n_cap, wpk, scale, shift, relu, out_feat);                                                        \
+      SESSD_CHECK_LAUNCH();                                                                                                 \
+      return SESSD_OK;                                                                                                      \
+    }
+#define SESSD_MT_NTW(NTW_)                                                                   \
+    {                                                                                        \
+      constexpr int SET_ = (CIN / 4) * (1 + (NTW_));                                         \
+      if (depth_mt >= 3 && SET_ * 3 <= 400) {                                                \
+        if (tpw_sel == 1) SESSD_MT(NTW_, 3, 2) else SESSD_MT(NTW_, 3, 4)                     \
+      } else {                                                                               \
+        if (tpw_sel == 1) SESSD_MT(NTW_, 2, 2) else SESSD_MT(NTW_, 2, 4)                     \
+      }                                                                                      \
+    }
+    if constexpr (NT % 4 == 0) {
+      if (split >= 4) SESSD_MT_NTW(NT / 4)
+    }
+    if constexpr (NT % 2 == 0) {
+      if (split >= 2) SESSD_MT_NTW(NT / 2)
+    }
+    SESSD_MT_NTW(NT)
+#undef SESSD_MT_NTW
+#undef SESSD_MT
+  }
   if (((tuning >> 17) & 1) && !dense) {
     // shared-W variant: needs 16-byte A loads and at least one 16-byte W load per thread
     const int tiles = sessd_divup(n_cap, 16);

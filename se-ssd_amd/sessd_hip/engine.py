@@ -376,6 +376,10 @@ class InferenceEngine:
             best = (None, 1e30)
             cands = [(a, b, c) for c in ((0, 1) if self.allow_offset_split else (0,)) for a in (1, 2, 4) for b in (2, 3, 4)]
             cands += [(a, 2, 2) for a in (1, 2, 4)]  # mode 2: W[k] shared through LDS by the four tiles of a workgroup (same bits)
+            # modes 16 / 32: two / four tiles per wave, the next tile's neighbour rows fetched under the current tile's MFMAs (same
+            # bits); only where a level has several tiles per wave slot (the dense-scene batch)
+            if self.levels[out_li]["cap"] >= 65536:
+                cands += [(a, b, c) for c in (16, 32) for a in (1, 2, 4) for b in (2, 3)]
             for split, depth, ks in cands:
                 if (lay["cout"] // 16) % split or (ks == 1 and depth == 4):
                     continue

@@ -709,8 +709,9 @@ def sparse_pack_weight_adjoint(weight, reverse_offsets):
 
 
 def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, scale=None, shift=None, relu=True,
-                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0, offset_split=0, share_w=0, perm=None):
-    """perm (with tile_mask = the job's tile_mask_sorted): offset-pattern tiles of a SparseChain built with sort_tiles -- the same
+                out=None, dense_out=None, out_indices=None, dense_dims=None, cout_split=0, depth=0, offset_split=0, share_w=0, perm=None, tiles_per_wave=1):
+    """tiles_per_wave = 2 / 4 (large levels; plain tiles only): a wave walks that many tiles and fetches the next tile's neighbour
+    rows under the current tile's MFMAs -- the same bits. perm (with tile_mask = the job's tile_mask_sorted): offset-pattern tiles of a SparseChain built with sort_tiles -- the same
     bits as the plain tiles. cout_split (0 heuristic | 1, 2, 4) and depth (0 default | 2..4 operand sets in flight) only tune the launch: results are
     bit-identical for every choice. offset_split = 1 (small levels; ignored with dense_out): the four waves of a workgroup split
     the kernel offsets of a tile by k % 4 -- the same bits for every cout_split / depth, last-bit differences from offset_split 0.
@@ -727,8 +728,8 @@ def sparse_conv(in_feat, nbr, tile_mask, n_out_dev, packed_weight, cin, cout, sc
     check(lib.sessd_sparse_conv_sorted(in_feat.data_ptr(), cin, nbr.data_ptr(), tile_mask.data_ptr(), kv, n_out_dev.data_ptr(),
                                        cap, packed_weight.data_ptr(), _p(scale), _p(shift), 1 if relu else 0, _p(out), cout,
                                        _p(out_indices), _p(dense_out), 0 if dd is None else dd.data_ptr(),
-                                       int(cout_split) + 256 * int(depth) + 65536 * int(bool(offset_split)) + 131072 * int(bool(share_w)),
-                                       _p(perm), _stream()),
+                                       int(cout_split) + 256 * int(depth) + 65536 * int(bool(offset_split)) + 131072 * int(bool(share_w))
+                                       + ({1: 0, 2: 1, 4: 2}[int(tiles_per_wave)] << 20), _p(perm), _stream()),
           "sparse_conv")
     return out if dense_out is None else dense_out
 

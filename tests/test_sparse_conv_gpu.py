@@ -157,6 +157,16 @@ def test_every_tuning_is_bit_identical(dev, cin, cout, n, cap):
             ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, True, dense_out=d, out_indices=out_idx,
                             dense_dims=[5, 12, 10], cout_split=split, depth=depth)
             assert torch.equal(d, dref), (cin, cout, split, depth)
+    # two / four tiles per wave (the next tile's neighbour rows fetched under the current tile's MFMAs): the plain kernel's bits
+    for tpw in (2, 4):
+        for split in (0, 1, 2, 4):
+            if split > 1 and (cout // 16) % split:
+                continue
+            for depth in (0, 2, 3):
+                a = ops.sparse_conv(feat, nbr, tm, n_dev, wpk, cin, cout, scale, shift, True, cout_split=split, depth=depth, tiles_per_wave=tpw)
+                assert torch.equal(a[:n], ref[:n]), (cin, cout, split, depth, tpw)
+                b = ops.sparse_conv(feat, nbr2, tm2, n_out, wpk, cin, cout, scale, shift, False, cout_split=split, depth=depth, tiles_per_wave=tpw)
+                assert torch.equal(b[:m], ref2[:m]), (cin, cout, split, depth, tpw)
     # shared-W variant (the four tiles of a workgroup walk the union of their offsets): the plain kernel's bits
     for split in (0, 1, 2, 4):
         if split > 1 and (cout // 16) % split:
