@@ -66,15 +66,33 @@ static __device__ __forceinline__ uint32_t sessd_hash_u32(uint32_t k) {
   return k;
 }
 
+// Home slot and probe sequence (round 4). The 8 cells of an aligned run along x (the fastest axis of the linear cell key) share
+// one 32-byte BUCKET: slot = bucket(hash(key >> 3)) * 8 + (key & 7). A rulebook looks up x-1, x, x+1 of nine (z, y) rows per
+// site: with a slot per hashed cell those were 27 random cache lines (dense-scene batch: 2.05 GB fetched by one
+// chain_rulebook launch, profiles/r4_sparse_pmc.txt), now the three of a row are one line. A taken slot sends the key to the SAME
+// offset of the next bucket (so a displaced run stays a run); after a whole lap of that offset class the sequence moves to the
+// next offset: every slot of the table is visited once, insert and find walk the same sequence.
+static __device__ __forceinline__ uint32_t sessd_hash_home(uint32_t key, uint32_t mask) {
+  return ((sessd_hash_u32(key >> 3) << 3) | (key & 7u)) & mask;
+}
+#define SESSD_HASH_ADVANCE(slot, lap, mask)  \
+  {                                          \
+    (slot) = ((slot) + 8u) & (mask);         \
+    if ((slot) == (lap)) {                   \
+      (slot) = ((slot) + 1u) & (mask);       \
+      (lap) = (slot);                        \
+    }                                        \
+  }
+
 // Insert-or-find. Returns the slot that holds `key`, or SESSD_HASH_FULL when every slot is taken by other keys
 // (the probe sequence is bounded by the table size: a full table is reported, never spun on).
 #define SESSD_HASH_FULL 0xFFFFFFFFu
 static __device__ __forceinline__ uint32_t sessd_hash_insert(uint32_t* keys, uint32_t mask, uint32_t key) {
-  uint32_t slot = sessd_hash_u32(key) & mask;
+  uint32_t slot = sessd_hash_home(key, mask), lap = slot;
   for (uint32_t probes = 0; probes <= mask; ++probes) {
     uint32_t prev = atomicCAS(&keys[slot], SESSD_HASH_EMPTY, key);
     if (prev == SESSD_HASH_EMPTY || prev == key) return slot;
-    slot = (slot + 1) & mask;
+    SESSD_HASH_ADVANCE(slot, lap, mask)
   }
   return SESSD_HASH_FULL;
 }
@@ -83,7 +101,7 @@ static __device__ __forceinline__ uint32_t sessd_hash_insert(uint32_t* keys, uin
 static __device__ __forceinline__ int sessd_hash_find(const uint32_t* __restrict__ keys,
                                                       const int* __restrict__ vals, uint32_t mask,
                                                       uint32_t key) {
-  uint32_t slot = sessd_hash_u32(key) & mask;
+  uint32_t slot = sessd_hash_home(key, mask), lap = slot;
   for (uint32_t probes = 0; probes <= mask; ++probes) {
     uint32_t k = keys[slot];
     if (k == key) {
@@ -91,7 +109,7 @@ static __device__ __forceinline__ int sessd_hash_find(const uint32_t* __restrict
       return v == SESSD_SENT ? -1 : v;
     }
     if (k == SESSD_HASH_EMPTY) return -1;
-    slot = (slot + 1) & mask;
+    SESSD_HASH_ADVANCE(slot, lap, mask)
   }
   return -1;  // full table without the key
 }

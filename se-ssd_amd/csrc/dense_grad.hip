@@ -14,6 +14,7 @@
 //                  columns outside the image get an out-of-range buffer offset (the hardware returns 0 = zero padding)
 // One wave owns a 32x32 (co, ci) tile with all taps (9 accumulators) over one chunk of output rows; the <= 64 chunk
 // partials are summed in order by a second kernel: deterministic, no float atomics.
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -201,6 +202,139 @@ __global__ __launch_bounds__(64) void conv1x1_wgrad_partial_kernel(WgArgs A) {
     }
 }
 
+// 3x3 stride-2 layers with cout, cin % 64 == 0 (b1.0 of the SSFA neck and, roles swapped, its two transposed convs), round 4:
+// the kernel above gives every wave private operands -- a 32-ci input strip is fetched by each of the cout / 32 waves that
+// need it, 7 x 16-byte + 3 x 4-byte loads per lane in front of every 36 MFMAs, two register sets deep: 71 TFLOP/s, the matrix
+// cores 45 % busy (profiles/r4_kernel_trace_train_replay.txt: 293 us per launch). Here the operands of a step go through LDS
+// ONCE per workgroup:
+//   workgroup = 4 waves, a 64 co x 64 ci block (wave (m, n) owns co 32 m.., ci 32 n.. with all 9 taps: 9 accumulators)
+//   stage     = 8 output pixels of one output row: A = gout[64 co][8 px] (128 x 16-byte loads), B = the three input rows
+//               2y-1 .. 2y+1, 64 ci x 24 columns 2 x0 - 4 .. 2 x0 + 19 (1152 aligned 16-byte loads; rows / columns outside the
+//               image by out-of-range buffer offsets = zero padding). A thread's <= 6 loads of stage s+1 are issued before the 36
+//               MFMAs of stage s and written to the other LDS buffer after them: one barrier per stage.
+//   MFMA step = pixel pair {2c, 2c+1}: a = A[co][2c + h], b_tap = B[ky][ci][2 (2c + h) + kx + 3] (odd row pitches: the 32 rows
+//               of a wave hit 32 banks)
+// Row chunks and their ordered sum as above (same partial layout, same reduce kernel). Workgroup id -> (chunk, block) keeps the
+// blocks of one chunk on ONE XCD (id % 8 = chunk % 8): the chunk's rows are fetched into that XCD's L2 once.
+constexpr int WL_PA = 9, WL_PB = 25;                       // LDS row pitches (floats)
+constexpr int WL_A = 64 * WL_PA, WL_B = 3 * 64 * WL_PB;    // floats per buffer
+__global__ __launch_bounds__(256, 2) void conv3x3s2_wgrad_lds_kernel(WgArgs A, int nchunks, int tiles) {
+  __shared__ float sA[2][WL_A];
+  __shared__ float sB[2][WL_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, h = lane >> 5, wm = wave >> 1, wn = wave & 1;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int tile = local % tiles, chunk = xcd + 8 * (local / tiles);
+  if (chunk >= nchunks) return;
+  const int cob = tile / A.cib_n, cib = tile - cob * A.cib_n;
+  const int co0 = cob * 64, ci0 = cib * 64;
+  const int R = A.batch * A.ho;
+  const int r0 = chunk * A.rows_per_chunk, r1 = min(R, r0 + A.rows_per_chunk);
+  const int spr = A.wo >> 3;                               // stages per row
+  const int S = (r1 - r0) * spr;
+  const rsrc_t gr = make_rsrc(A.gout, (unsigned)((size_t)A.batch * A.co * A.ho * A.wo * 4));
+  const rsrc_t xr = make_rsrc(A.inp, (unsigned)((size_t)A.batch * A.ci * A.hi * A.wi * 4));
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  // this thread's load slots: A (tid < 128): co = tid >> 1, 4-pixel half = tid & 1; B slot k: e = tid + 256 k < 1152 ->
+  // row e / 384, ci (e % 384) / 6, 4-column chunk (e % 384) % 6
+  const int a_co = tid >> 1, a_c = tid & 1;
+  int b_row[5], b_ci[5], b_c[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int e = tid + 256 * k;
+    b_row[k] = e / 384;
+    const int rem = e - b_row[k] * 384;
+    b_ci[k] = rem / 6;
+    b_c[k] = rem - b_ci[k] * 6;
+  }
+  // Two register sets: the loads of stage s + 2 / s + 3 are in flight while stage s computes (one stage of 36 MFMAs is shorter
+  // than a memory round trip; with a single set in flight the kernel ran at the private-operand kernel's 290 us). The loader
+  // walks (batch, row, x0) incrementally; stages past the chunk load zeros.
+  f32x4 ra[2], rb[2][5];
+  int l_b = r0 / A.ho, l_y = r0 - l_b * A.ho, l_x = 0, l_left = S;
+#define SESSD_WL_LOAD(SET)                                                                                          \
+  {                                                                                                                 \
+    const bool live_ = l_left > 0;                                                                                  \
+    ra[SET] = ld4(gr, (live_ && tid < 128)                                                                          \
+                          ? (unsigned)(((((size_t)l_b * A.co + co0 + a_co) * A.ho + l_y) * A.wo + l_x + 4 * a_c) * 4) \
+                          : SESSD_OOB);                                                                             \
+    _Pragma("unroll") for (int k = 0; k < 5; ++k) {                                                                 \
+      const int yin = 2 * l_y + b_row[k] - 1, xin = 2 * l_x - 4 + 4 * b_c[k];                                       \
+      const bool ok = live_ && (k < 4 || tid < 128) && yin >= 0 && yin < A.hi && xin >= 0 && xin < A.wi;            \
+      rb[SET][k] = ld4(xr, ok ? (unsigned)(((((size_t)l_b * A.ci + ci0 + b_ci[k]) * A.hi + yin) * A.wi + xin) * 4) : SESSD_OOB); \
+    }                                                                                                               \
+    --l_left;                                                                                                       \
+    l_x += 8;                                                                                                       \
+    if (l_x == A.wo) {                                                                                              \
+      l_x = 0;                                                                                                      \
+      if (++l_y == A.ho) { l_y = 0; ++l_b; }                                                                        \
+    }                                                                                                               \
+  }
+#define SESSD_WL_STORE(BUF, SET)                                                                                    \
+  {                                                                                                                 \
+    if (tid < 128) {                                                                                                \
+      float* d = &sA[BUF][a_co * WL_PA + 4 * a_c];                                                                  \
+      d[0] = ra[SET].x; d[1] = ra[SET].y; d[2] = ra[SET].z; d[3] = ra[SET].w;                                       \
+    }                                                                                                               \
+    _Pragma("unroll") for (int k = 0; k < 5; ++k)                                                                   \
+      if (k < 4 || tid < 128) {                                                                                     \
+        float* d = &sB[BUF][(b_row[k] * 64 + b_ci[k]) * WL_PB + 4 * b_c[k]];                                        \
+        d[0] = rb[SET][k].x; d[1] = rb[SET][k].y; d[2] = rb[SET][k].z; d[3] = rb[SET][k].w;                         \
+      }                                                                                                             \
+  }
+#define SESSD_WL_MMA(BUF)                                                                                           \
+  {                                                                                                                 \
+    const float* pa = &sA[BUF][(wm * 32 + i) * WL_PA + h];                                                          \
+    const float* pb = &sB[BUF][(wn * 32 + i) * WL_PB + 2 * h + 3];                                                  \
+    _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                                 \
+      const float a = pa[2 * c];                                                                                    \
+      _Pragma("unroll") for (int ky = 0; ky < 3; ++ky)                                                              \
+        _Pragma("unroll") for (int kx = 0; kx < 3; ++kx) {                                                          \
+          const float bq = pb[ky * 64 * WL_PB + 4 * c + kx];                                                        \
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bq, acc[ky * 3 + kx], 0, 0, 0);                \
+        }                                                                                                           \
+    }                                                                                                               \
+  }
+// LDS-only barrier: __syncthreads() is a workgroup-scope fence and hipcc puts s_waitcnt vmcnt(0) in front of it, i.e. it would
+// wait for the loads that are meant to stay in flight across it
+#define SESSD_WL_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  SESSD_WL_LOAD(0)
+  SESSD_WL_LOAD(1)
+  SESSD_WL_STORE(0, 0)
+  SESSD_WL_LOAD(0)
+  SESSD_WL_BARRIER();
+  for (int s = 0; s < S; s += 2) {
+    SESSD_WL_MMA(0)
+    __builtin_amdgcn_sched_barrier(0);
+    SESSD_WL_STORE(1, 1)
+    SESSD_WL_LOAD(1)
+    SESSD_WL_BARRIER();
+    if (s + 1 < S) SESSD_WL_MMA(1)
+    __builtin_amdgcn_sched_barrier(0);
+    SESSD_WL_STORE(0, 0)
+    SESSD_WL_LOAD(0)
+    SESSD_WL_BARRIER();
+  }
+#undef SESSD_WL_LOAD
+#undef SESSD_WL_STORE
+#undef SESSD_WL_MMA
+#undef SESSD_WL_BARRIER
+  // D layout: column (ci) = lane & 31, row (co) = (e & 3) + 8 * (e >> 2) + 4 * h
+  float* dst = A.partial + (size_t)chunk * A.co * A.ci * 9;
+  const int ci = ci0 + wn * 32 + i;
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int cor = co0 + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      dst[((size_t)cor * A.ci + ci) * 9 + t] = acc[t][e];
+    }
+}
+
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int nchunks, int total,
                                                                  float* __restrict__ gw) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -257,6 +391,24 @@ int sessd_conv2d_wgrad(const float* input, int batch, int cin, int hin, int win,
     SESSD_LAUNCH(conv1x1_wgrad_partial_kernel, dim3(tiles, nchunks), dim3(64), 0, stream, A);
     SESSD_CHECK_LAUNCH();
     const int total = cout * cin;
+    SESSD_LAUNCH(conv_wgrad_reduce_kernel, dim3(sessd_divup(total, 256)), dim3(256), 0, stream, (const float*)workspace, nchunks,
+                 total, grad_weight);
+    SESSD_CHECK_LAUNCH();
+    return SESSD_OK;
+  }
+  // SESSD_WGRAD_S2_LDS=0 keeps the private-operand kernel for A/B measurements
+  static const bool s2_lds = !(getenv("SESSD_WGRAD_S2_LDS") && atoi(getenv("SESSD_WGRAD_S2_LDS")) == 0);
+  if (s2_lds && ksize == 3 && stride == 2 && cout % 64 == 0 && cin % 64 == 0) {
+    A.cib_n = cin / 64;
+    const int tiles = (cout / 64) * A.cib_n, rows = batch * hout;
+    int nchunks = 512 / tiles;   // two workgroups per CU
+    nchunks = nchunks < 8 ? 8 : (nchunks > WG_MAX_CHUNKS ? WG_MAX_CHUNKS : nchunks);
+    if (nchunks > rows) nchunks = rows;
+    A.rows_per_chunk = sessd_divup(rows, nchunks);
+    nchunks = sessd_divup(rows, A.rows_per_chunk);
+    SESSD_LAUNCH(conv3x3s2_wgrad_lds_kernel, dim3(tiles * ((nchunks + 7) / 8 * 8)), dim3(256), 0, stream, A, nchunks, tiles);
+    SESSD_CHECK_LAUNCH();
+    const int total = cout * cin * 9;
     SESSD_LAUNCH(conv_wgrad_reduce_kernel, dim3(sessd_divup(total, 256)), dim3(256), 0, stream, (const float*)workspace, nchunks,
                  total, grad_weight);
     SESSD_CHECK_LAUNCH();

@@ -28,12 +28,12 @@ __device__ __forceinline__ uint32_t lin_key4(const int4& c, int D, int H, int W)
 
 // slot of an existing key (the key IS in the table: every site was inserted when the level was built); ~0u if absent
 __device__ __forceinline__ uint32_t slot_of(const uint32_t* __restrict__ keys, uint32_t mask, uint32_t key) {
-  uint32_t slot = sessd_hash_u32(key) & mask;
+  uint32_t slot = sessd_hash_home(key, mask), lap = slot;
   for (uint32_t probes = 0; probes <= mask; ++probes) {
     const uint32_t k = keys[slot];
     if (k == key) return slot;
     if (k == SESSD_HASH_EMPTY) return 0xFFFFFFFFu;
-    slot = (slot + 1) & mask;
+    SESSD_HASH_ADVANCE(slot, lap, mask)
   }
   return 0xFFFFFFFFu;
 }

@@ -114,8 +114,8 @@ __global__ __launch_bounds__(NT) void down_insert_unordered_kernel(const int* __
   uint32_t slot = 0;
   if (active) {
     const uint32_t key = lin_key(b, o[0], o[1], o[2], G.out_dims);
-    slot = sessd_hash_u32(key) & mask;
-    uint32_t probes = 0;
+    slot = sessd_hash_home(key, mask);
+    uint32_t probes = 0, lap = slot;
     for (; probes <= mask; ++probes) {
       const uint32_t prev = atomicCAS(&keys[slot], SESSD_HASH_EMPTY, key);
       if (prev == SESSD_HASH_EMPTY) {  // this thread created the cell
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(NT) void down_insert_unordered_kernel(const int* __
         break;
       }
       if (prev == key) break;
-      slot = (slot + 1) & mask;
+      SESSD_HASH_ADVANCE(slot, lap, mask)
     }
     if (probes > mask) atomicOr(err_flag, 1);  // table full (a cloud far sparser than the growth factors assume)
   }
@@ -270,7 +270,7 @@ __global__ __launch_bounds__(NT) void rulebook_kernel(const int* __restrict__ ou
       if (z >= 0 && z < G.in_dims[0] && y >= 0 && y < G.in_dims[1] && x >= 0 && x < G.in_dims[2]) {
         want[p] = true;
         key[p] = lin_key(c.x, z, y, x, G.in_dims);
-        slot[p] = sessd_hash_u32(key[p]) & mask;
+        slot[p] = sessd_hash_home(key[p], mask);
       }
     }
   }

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(NT) void chain_rulebook_kernel(JobsDev Q) {
         const int x = x0 + kx;
         want[pass][kx] = kx < ksx && rowok[pass] && x >= 0 && x < J.in_dims[2];
         key[pass][kx] = cell0[pass] + (unsigned)kx;
-        slot[pass][kx] = sessd_hash_u32(key[pass][kx]) & J.mask;
+        slot[pass][kx] = sessd_hash_home(key[pass][kx], J.mask);
       }
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass)

@@ -27,7 +27,9 @@ CASES = [
     ("conv", 128, 128, 1, 1, 40, 48, False),   # 1x1 with >= 64 channels: the 64 x 64 wave-tile weight-gradient kernel
     ("conv", 64, 160, 1, 1, 12, 24, True),    # ... with a ragged channel block
     ("deconv", 32, 16, 3, 2, 12, 24, False),
-    ("deconv", 256, 128, 3, 2, 20, 16, False),
+    ("deconv", 256, 128, 3, 2, 20, 16, False),   # cin, cout % 64 == 0: the LDS-staged stride-2 weight-gradient kernel
+    ("conv", 128, 256, 3, 2, 40, 48, False),     # ... called directly (b1.0 of the neck), 7 row chunks of ragged length
+    ("conv", 64, 64, 3, 2, 16, 16, True),
 ]
 
 
