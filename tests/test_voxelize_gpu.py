@@ -102,3 +102,21 @@ def test_all_frames_of_a_batch_in_four_launches(dev):
     da = dict(zip(ka[live_a].tolist(), va[live_a].tolist()))
     db = dict(zip(kb[live_b].tolist(), vb[live_b].tolist()))
     assert da == db
+
+
+def test_a_wall_across_the_x_axis_fills_one_offset_class_of_the_hash(dev):
+    """The hash keeps the 8 cells of an aligned x-run in one bucket: slot = bucket * 8 + (x & 7), and a taken slot sends the key
+    to the same offset of the next bucket. A plane x = const puts EVERY cell into one offset class (an eighth of the table);
+    with more cells than that class holds the probe sequence must move on to the next offset -- not report a full table.
+    6000 distinct cells, capacity 2 * 6000 -> 16384 slots -> 2048 per class."""
+    rng = np.random.RandomState(3)
+    ny, nz = 150, 40
+    yy, zz = np.meshgrid(np.arange(ny), np.arange(nz), indexing="ij")
+    pts = np.stack([np.full(ny * nz, 20.0 + 0.025), -3.0 + 0.05 * yy.ravel() + 0.025, -3.0 + 0.1 * zz.ravel() + 0.05,
+                    rng.rand(ny * nz)], 1).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    v, c, n, mean = _run(pts, 5, 16000, dev, coors4=True)
+    ov, oc, on = oracle.points_to_voxel(pts, synth.KITTI_VOXEL, synth.KITTI_RANGE, 5, 16000)
+    assert oc.shape[0] == ny * nz and len(np.unique(oc[:, 2])) == 1
+    assert np.array_equal(c[:, 1:], oc) and np.array_equal(n, on)
+    assert np.array_equal(v.view(np.uint32), ov.view(np.uint32))
