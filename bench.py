@@ -481,7 +481,7 @@ def roofline_legs(args, out, eng, batch_of):
                                         "batch 1 the stage is launch/latency-bound, see --stress for the meaningful case. "
                                         "`mfma`: per-layer HIP-event times of the sparse convs alone and their EXECUTED f32 "
                                         "MFMA rate (active 16-site tile x offset steps x 16 x Cin x Cout x 2 FLOP) against the "
-                                        "157.3 TFLOP/s peak; counters and HBM traffic: profiles/r2_sparse_pmc_after.txt"}
+                                        "157.3 TFLOP/s peak; counters and HBM traffic per kernel: profiles/r4_sparse_pmc.txt"}
 
 
 def train_step_leg(args, out, engines, dev):
