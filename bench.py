@@ -459,7 +459,7 @@ def roofline_legs(args, out, eng, batch_of):
                        "traffic": None}
     # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
     # under profiles/; it cannot be collected inside this process
-    cands = ["r3_wino_sk_traffic.json", "r2_wino_sk_traffic.json"] if streamk else ["r1_winograd_traffic.json"]
+    cands = ["r4_wino_sk_traffic.json", "r3_wino_sk_traffic.json", "r2_wino_sk_traffic.json"] if streamk else ["r1_winograd_traffic.json"]
     cands = cands if wino else ["r1_conv_traffic.json"]
     for nm in cands:
         tpath = os.path.join(ROOT, "profiles", nm)
