@@ -45,7 +45,10 @@ void sessd_set_external_clear(int on);
  *          det3d/models/readers/voxel_encoder.py:215-220 VoxelFeatureExtractorV3.forward (mean_feat).
  * Bit-exact with the reference's serial first-come-first-served loop, including the `break`
  * at max_voxels and the <= max_points_per_voxel rule. The hash (keys/vals) afterwards maps
- * cell -> output row and is reused as the level-0 site index of SpMiddleFHD. */
+ * cell -> output row and is reused as the level-0 site index of SpMiddleFHD.
+ * The slot layout of keys/vals is PRIVATE to the library (open addressing in 32-byte buckets: the 8 cells of an aligned run
+ * along x share a bucket, csrc/common.hpp sessd_hash_home): a table is only ever filled by sessd_voxelize_frame(s) or
+ * sessd_sparse_hash_build and read by the entry points that take (keys, vals, capacity); callers own the memory, not the layout. */
 uint32_t sessd_hash_capacity(int max_items);
 int sessd_hash_clear(uint32_t* keys, int32_t* vals, uint32_t capacity, sessd_stream_t stream);
 size_t sessd_voxelize_workspace_bytes(uint32_t hash_capacity, int max_points_in_frame, int max_points_per_voxel,
