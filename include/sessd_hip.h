@@ -501,6 +501,27 @@ int sessd_conv3x3_winograd_sk(const float* in, int batch, int cin, int h, int w,
 int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int cin, int h, int w, const float* upk, float* out,
                                    int cout, const float* scale, const float* shift, int relu, const float* residual,
                                    void* workspace, size_t workspace_bytes, int shape, int workgroups, sessd_stream_t stream);
+/* ACTIVE-TILE mode of the stream-K kernel (csrc/dense_wino_sk.hip, LIST = true; csrc/dense_active.hip). The BEV map entering the
+ * neck (`.dense()` of the last sparse level, det3d/models/backbones/scn.py:179-183) is zero outside the sparse backbone's sites, so
+ * the first three layers of bottom_up_block_0 (rpn_v1.py:135-148) compute the same per-channel constant in every 2x2-output tile
+ * whose 4x4 input patch holds no non-constant pixel (82 % / 71 % / 61 % of the tiles on a 20 k-point scan):
+ *   sessd_bev_tile_activity     tile masks + ordered tile lists (entry image * (h/2 * w/2) + tile) + device counts of the first
+ *                               n_layers (<= 4) layers, from the (image, z, y, x) rows of the last sparse level
+ *   sessd_fill_inactive_tiles   out[b][co][tile] = value[co] (the layer's constant, computed by the host from the folded weights)
+ *                               in the tiles nobody computes, up to 4 layers per launch
+ *   sessd_conv3x3_winograd_sk_active   sessd_conv3x3_winograd_sk over the listed tiles only (same packed U, same workspace; the
+ *                               shares of the round list are sized on the device, workgroups beyond rounds / min_rounds exit)
+ * Results equal the dense layer's to float32 rounding (tests/test_dense_active_gpu.py); replaces nothing in the reference -- it is
+ * how this path avoids arithmetic on constants that ATen's dense conv performs. */
+size_t sessd_bev_tile_activity_workspace_bytes(int batch, int n_layers);
+int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_cap, int batch, int h, int w, int n_layers,
+                            uint8_t* tile_mask, int32_t* tile_list, int32_t* n_list, int list_cap, void* workspace,
+                            size_t workspace_bytes, sessd_stream_t stream);
+int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, int h, int w, sessd_stream_t stream);
+int sessd_conv3x3_winograd_sk_active(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
+                                     const float* scale, const float* shift, int relu, const float* residual,
+                                     const int32_t* tile_list, const int32_t* n_list, int list_cap, int min_rounds, void* workspace,
+                                     size_t workspace_bytes, int shape, int workgroups, sessd_stream_t stream);
 /* The convolutions that are NOT 3x3 stride 1 (stride-2 3x3, 1x1, the four output-parity classes of the stride-2 transposed conv;
  * rpn_v1.py:150-210) as an LDS-tiled implicit GEMM, stream-K over `workgroups` persistent workgroups (a multiple of 8, 0 = one
  * per CU): csrc/dense_conv_sk.hip, tile_cfg 30 of ops.conv2d. nclass (1..4) convolutions that share input, shapes and epilogue

@@ -43,6 +43,14 @@ typedef struct {
   int32_t block_start, pad_;
 } sessd_dense_pack_job_t;
 
+/* One layer of sessd_fill_inactive_tiles: out (batch, cout, h, w), value[cout], tile_mask[batch][h/2 * w/2] (1 = computed tile). */
+typedef struct {
+  float* out;
+  const float* value;
+  const uint8_t* tile_mask;
+  int32_t cout, pad_;
+} sessd_fill_tiles_job_t;
+
 /* One sparse-conv weight packing of sessd_sparse_pack_batch: sessd_sparse_pack_weight (adjoint 0) or
  * sessd_sparse_pack_weight_adjoint (adjoint 1; reverse_k = its reverse_offsets); cin / cout are those of the STORED weight
  * (kernel_volume, cin, cout); a job takes ceil(kernel_volume * cin * cout / 256) blocks. */

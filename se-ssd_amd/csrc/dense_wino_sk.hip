@@ -66,12 +66,16 @@ struct WinoArgs {
   int bper;               // batch elements per weight set (several layers of one shape in one launch: set = b / bper)
   int ss_stride;          // floats between the sets' scale / shift vectors (0 with one set)
   long long upk_stride;   // floats between the sets' packed U
+  // active-tile mode (LIST kernels): entries image * ntiles + tile, their count on the device
+  const int* tile_list;
+  const int* n_list;
+  int list_cap, min_rounds, batch;
 };
 
 // VAR: measured code variants of the main loop (same arithmetic, same results; `SESSD_WINO_VAR` selects one at launch for
 // A/B runs, 0 ships): bit 0 = the patch transform with scalar adds instead of packed v_pk_add_f32 (MI355X_MICROARCH.md
 // measures packed adds beside MFMAs as an anti-lever), bit 1 = s_setprio around the MFMA groups.
-template <int NW, int CBN, int VAR = 0>
+template <int NW, int CBN, int VAR = 0, bool LIST = false>
 __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(WinoArgs A) {
   constexpr int XW = 16 / NW;                          // transform points per wave
   static_assert(XW * CBN == 8, "8 accumulators per wave");
@@ -86,11 +90,24 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int j = lane & 31, h = lane >> 5;
-  const int G = gridDim.x;
+  int G = gridDim.x;
+  long long R = A.total_rounds;
+  int n_list = 0;
+  if constexpr (LIST) {
+    // ACTIVE-TILE mode (sessd_conv3x3_winograd_sk_active): the tiles are the entries (image * ntiles + tile) of a device list,
+    // their number is on the device, so the round list is sized HERE. A sparse frame leaves fewer rounds than the launch has
+    // workgroups could usefully cut: shares of at least `min_rounds` rounds, the workgroups beyond that leave at once.
+    n_list = __builtin_amdgcn_readfirstlane(min(A.n_list[0], A.list_cap));
+    R = (long long)((n_list + 31) >> 5) * A.ngroups * A.rpu;
+    if (R == 0) return;
+    long long g = R / A.min_rounds;
+    g = g < 1 ? 1 : (g > G ? G : g);
+    G = (int)(g >= 8 ? (g & ~7LL) : g);
+    if ((G & 7) ? ((int)blockIdx.x >= G) : ((int)(blockIdx.x >> 3) >= (G >> 3))) return;
+  }
   // share w of the round list; consecutive shares on one XCD (workgroup b runs on XCD b % 8): neighbouring units share
   // input rows through that XCD's L2
   const int w = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
-  const long long R = A.total_rounds;
   int r = (int)((long long)w * R / G);
   const int r_stop = (int)((long long)(w + 1) * R / G);
   const int in_plane = A.hin * A.win;
@@ -140,10 +157,18 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     float* outb = Fp->out + (size_t)pend_b * e_cout * out_plane;                                   \
     const float* resb = Fp->residual ? Fp->residual + (size_t)pend_b * e_cout * out_plane : nullptr; \
     const int tl = tid & 31, col0 = tid >> 5;                                                      \
-    const int tt = pend_tbase + tl;                                                                \
-    const bool tok = tt < Fp->ntiles;                                                              \
+    int tt = pend_tbase + tl;                                                                      \
+    bool tok = tt < Fp->ntiles;                                                                    \
+    size_t pix = 0;                                                                                \
+    if constexpr (LIST) {                                                                          \
+      const int fe = tt < n_list ? Fp->tile_list[tt] : -1;                                         \
+      tok = fe >= 0;                                                                               \
+      const int fb = tok ? fe / Fp->ntiles : 0;                                                    \
+      tt = tok ? fe - fb * Fp->ntiles : 0;                                                         \
+      pix = (size_t)fb * e_cout * out_plane;                                                       \
+    }                                                                                              \
     const int oty = tok ? tt / f_tw : 0, otx = tok ? tt - (tt / f_tw) * f_tw : 0;                  \
-    const size_t pix = (size_t)(2 * oty) * e_win + 2 * otx;                                        \
+    pix += (size_t)(2 * oty) * e_win + 2 * otx;                                                    \
     _Pragma("unroll 1") for (int cb = 0; cb < CBN; ++cb) {                                         \
       f32x4v ysum[NPT];                                                                            \
       _Pragma("unroll") for (int n = 0; n < NPT; ++n) ysum[n] = 0.f;                               \
@@ -174,22 +199,34 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     const int r1 = __builtin_amdgcn_readfirstlane(min(r_stop - u * A.rpu, A.rpu));
     r = u * A.rpu + r1;
     const int cg = __builtin_amdgcn_readfirstlane(u % A.ngroups), ub = u / A.ngroups;
-    const int tb = __builtin_amdgcn_readfirstlane(ub % A.tblocks), b = __builtin_amdgcn_readfirstlane(ub / A.tblocks);
+    // LIST: the tile blocks run over the whole list (a block may span images: the image is part of every lane's offsets), one
+    // weight set
+    const int tb = LIST ? __builtin_amdgcn_readfirstlane(ub) : __builtin_amdgcn_readfirstlane(ub % A.tblocks);
+    const int b = LIST ? 0 : __builtin_amdgcn_readfirstlane(ub / A.tblocks);
     const int t_base = tb * 32, m_base = cg * (CBN * 32);
-    const rsrc_t xr = make_rsrc(A.in + (size_t)b * A.cin * in_plane, (unsigned)A.cin * in_plane * 4u);
-    const int wset = __builtin_amdgcn_readfirstlane(b / A.bper);
+    const rsrc_t xr = LIST ? make_rsrc(A.in, (unsigned)A.batch * (unsigned)A.cin * (unsigned)in_plane * 4u)
+                           : make_rsrc(A.in + (size_t)b * A.cin * in_plane, (unsigned)A.cin * in_plane * 4u);
+    const int wset = LIST ? 0 : __builtin_amdgcn_readfirstlane(b / A.bper);
     const rsrc_t wr = make_rsrc(A.upk + (size_t)wset * A.upk_stride + (size_t)cg * (A.cin >> 1) * (WSTEP / 4), (unsigned)(A.cin >> 1) * WSTEP);
 
     // ---- transform role: lane = (tile j, channel parity h)
-    const int t = t_base + j;
-    const bool tlive = t < A.ntiles;
+    int t = t_base + j;
+    bool tlive = t < A.ntiles;
+    unsigned img_off = 0;   // LIST: byte offset of the lane's image
+    if constexpr (LIST) {
+      const int e = t < n_list ? A.tile_list[t] : -1;
+      tlive = e >= 0;
+      const int bl = tlive ? e / A.ntiles : 0;
+      t = tlive ? e - bl * A.ntiles : 0;
+      img_off = (unsigned)bl * (unsigned)A.cin * (unsigned)in_plane * 4u;
+    }
     const int ty = tlive ? t / A.tw : 0, tx = tlive ? t - (t / A.tw) * A.tw : 0;
     const int y0 = 2 * ty - 1, x0 = 2 * tx - 1;
     unsigned ro[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int y = y0 + q;
-      ro[q] = (tlive && y >= 0 && y < A.hin) ? (unsigned)((h * in_plane + y * A.win + max(x0, 0)) * 4) : SESSD_OOB;
+      ro[q] = (tlive && y >= 0 && y < A.hin) ? img_off + (unsigned)((h * in_plane + y * A.win + max(x0, 0)) * 4) : SESSD_OOB;
     }
     const bool mask_l = (tx == 0), mask_r = (tx == A.tw - 1);
     const bool edge = __builtin_amdgcn_ballot_w64(tlive && (mask_l || mask_r)) != 0;
@@ -341,10 +378,18 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     const float* resb = Ep->residual ? Ep->residual + (size_t)b * e_cout * out_plane : nullptr;
     // this thread's (cout, tile) pairs: tile tl = tid & 31 in every pass, cout = m_base + cb * 32 + (tid >> 5) + (NT / 32) * n
     const int tl = tid & 31, col0 = tid >> 5;
-    const int tt = t_base + tl;
-    const bool tok = tt < e_ntiles;
+    int tt = t_base + tl;
+    bool tok = tt < e_ntiles;
+    size_t pix = 0;
+    if constexpr (LIST) {
+      const int ee = tt < n_list ? Ep->tile_list[tt] : -1;
+      tok = ee >= 0;
+      const int eb = tok ? ee / e_ntiles : 0;
+      tt = tok ? ee - eb * e_ntiles : 0;
+      pix = (size_t)eb * e_cout * out_plane;
+    }
     const int oty = tok ? tt / e_tw : 0, otx = tok ? tt - (tt / e_tw) * e_tw : 0;
-    const size_t pix = (size_t)(2 * oty) * e_win + 2 * otx;
+    pix += (size_t)(2 * oty) * e_win + 2 * otx;
     // parts of unit u = the shares that intersect its rounds; share of round q = ((q + 1) G - 1) / R
     const int w_first = (int)((((long long)u * Ep->rpu + 1) * G - 1) / R);
     const int w_last = (int)((((long long)u * Ep->rpu + Ep->rpu) * G - 1) / R);
@@ -812,6 +857,7 @@ int launch_rk(const float* in, int batch, int nsets, int cin, int h, int w, cons
   A.rpu = cin / 16;
   A.bper = batch / nsets; A.ss_stride = nsets > 1 ? cout : 0;
   A.upk_stride = nsets > 1 ? (long long)sessd_divup(cout, 128) * (cin >> 1) * (4 * 2 * 32 * 16) : 0;
+  A.tile_list = nullptr; A.n_list = nullptr; A.list_cap = 0; A.min_rounds = 1; A.batch = batch;
   const long long units = (long long)batch * A.tblocks * A.ngroups;
   if (units * A.rpu > 0x7fffffffLL) return SESSD_EINVAL;
   A.total_rounds = (int)(units * A.rpu);
@@ -828,9 +874,10 @@ int launch_rk(const float* in, int batch, int nsets, int cin, int h, int w, cons
 template <int NW, int CBN>
 int launch_sk(const float* in, int batch, int nsets, int cin, int h, int w, const float* upk, float* out, int cout, const float* scale,
               const float* shift, int relu, const float* residual, void* workspace, size_t workspace_bytes, int workgroups,
-              hipStream_t stream) {
+              hipStream_t stream, const int* tile_list = nullptr, const int* n_list = nullptr, int list_cap = 0, int min_rounds = 1) {
   constexpr int SLOT = CBN * 32 * 32 * 4;
   if (cin % (2 * NW)) return SESSD_EINVAL;
+  if (tile_list && (nsets != 1 || !n_list || list_cap < 1 || (size_t)batch * cin * h * w * 4 >= 0xFFFFFFFFull)) return SESSD_EINVAL;
   WinoArgs A;
   A.in = in; A.upk = upk; A.out = out; A.scale = scale; A.shift = shift; A.residual = residual;
   A.cin = cin; A.hin = h; A.win = w; A.cout = cout; A.relu = relu;
@@ -838,6 +885,7 @@ int launch_sk(const float* in, int batch, int nsets, int cin, int h, int w, cons
   A.rpu = cin / (2 * NW);
   A.bper = batch / nsets; A.ss_stride = nsets > 1 ? cout : 0;
   A.upk_stride = nsets > 1 ? (long long)sessd_divup(cout, CBN * 32) * (cin >> 1) * (NW * 2 * 32 * 32 / 4) : 0;
+  A.tile_list = tile_list; A.n_list = n_list; A.list_cap = list_cap; A.min_rounds = min_rounds < 1 ? 1 : min_rounds; A.batch = batch;
   const long long units = (long long)batch * A.tblocks * A.ngroups;
   if (units * A.rpu > 0x7fffffffLL) return SESSD_EINVAL;
   A.total_rounds = (int)(units * A.rpu);
@@ -847,6 +895,11 @@ int launch_sk(const float* in, int batch, int nsets, int cin, int h, int w, cons
   if (workgroups > A.total_rounds) workgroups = A.total_rounds >= 8 ? (A.total_rounds & ~7) : A.total_rounds;
   A.counters = (unsigned*)workspace;
   A.scratch = (float*)((char*)workspace + sessd_align((size_t)units * 4, 256));
+  if (tile_list) {   // active-tile mode: the same kernel over a device list of tiles (shares are sized on the device)
+    SESSD_LAUNCH((conv3x3s1_winograd_sk_kernel<NW, CBN, 0, true>), dim3(workgroups), dim3(NW * 64), 0, stream, A);
+    SESSD_CHECK_LAUNCH();
+    return SESSD_OK;
+  }
   static const int var = [] { const char* e = getenv("SESSD_WINO_VAR"); return e ? atoi(e) & 3 : 0; }();
   switch (var) {
     case 1: SESSD_LAUNCH((conv3x3s1_winograd_sk_kernel<NW, CBN, 1>), dim3(workgroups), dim3(NW * 64), 0, stream, A); break;
@@ -903,6 +956,29 @@ int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int ci
   if (shape == 1)
     return launch_sk<4, 2>(in, batch, nsets, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream);
   return launch_sk<8, 4>(in, batch, nsets, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream);
+}
+
+// ACTIVE-TILE mode of the same kernel (round 4; the first layers of the SSFA neck, rpn_v1.py:135-160, on a BEV map that is zero
+// outside the sparse backbone's sites): only the 2x2-output tiles listed in tile_list[0 .. min(*n_list, list_cap)) are computed
+// and written -- entries image * (h/2 * w/2) + tile in any fixed order, count on the device (sessd_bev_tile_activity builds both).
+// The other tiles of `out` are the caller's (sessd_fill_inactive_tiles writes the layer's constant there). Workgroups beyond
+// rounds / min_rounds leave at once. Same packed U, same workspace (sized for the dense layer) as sessd_conv3x3_winograd_sk.
+int sessd_conv3x3_winograd_sk_active(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
+                                     const float* scale, const float* shift, int relu, const float* residual,
+                                     const int32_t* tile_list, const int32_t* n_list, int list_cap, int min_rounds, void* workspace,
+                                     size_t workspace_bytes, int shape, int workgroups, hipStream_t stream) {
+  if ((h & 1) || (w & 1) || batch < 1 || cout < 1 || workgroups < 0 || (workgroups & 7) || shape < 0 || shape > 1 || !tile_list ||
+      !n_list || list_cap < 1)
+    return SESSD_EINVAL;
+  if (workgroups == 0) {
+    const int rc = default_workgroups(shape, &workgroups);
+    if (rc != SESSD_OK) return rc;
+  }
+  if (shape == 1)
+    return launch_sk<4, 2>(in, batch, 1, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups,
+                           stream, tile_list, n_list, list_cap, min_rounds);
+  return launch_sk<8, 4>(in, batch, 1, cin, h, w, upk, out, cout, scale, shift, relu, residual, workspace, workspace_bytes, workgroups,
+                         stream, tile_list, n_list, list_cap, min_rounds);
 }
 
 int sessd_conv3x3_winograd_sk(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,

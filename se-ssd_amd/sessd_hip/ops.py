@@ -1368,6 +1368,53 @@ def conv2d_winograd_sk_sets(x, upk_sets, nsets, cout, scale, shift, relu, out, s
     return out
 
 
+def conv2d_winograd_sk_active(x, upk, cout, scale, shift, relu, out, shape, workspace, tile_list, n_list, workgroups=0, residual=None,
+                              min_rounds=2):
+    """sessd_conv3x3_winograd_sk_active: the stream-K Winograd layer over the listed 2x2-output tiles only (entries image *
+    (H/2 * W/2) + tile, count on the device: bev_tile_activity); the other tiles of `out` are left alone."""
+    _req(x, torch.float32, "x"); _req(tile_list, torch.int32, "tile_list"); _req(n_list, torch.int32, "n_list")
+    B, ci, H, W = x.shape
+    check(lib.sessd_conv3x3_winograd_sk_active(x.data_ptr(), B, ci, H, W, upk.data_ptr(), out.data_ptr(), int(cout), _p(scale), _p(shift),
+                                               1 if relu else 0, _p(residual), tile_list.data_ptr(), n_list.data_ptr(),
+                                               tile_list.numel(), int(min_rounds), workspace.data_ptr(), workspace.numel(), int(shape),
+                                               int(workgroups), _stream()), "conv3x3_winograd_sk_active")
+    return out
+
+
+class TileActivity:
+    """Buffers + launches of sessd_bev_tile_activity / sessd_fill_inactive_tiles for `n_layers` 3x3 stride-1 layers over
+    (batch, ., H, W) maps: tile_mask (n_layers, batch, H/2 * W/2) uint8, tile_list (n_layers, batch * H/2 * W/2) int32,
+    n_list (n_layers,) int32."""
+
+    def __init__(self, batch, H, W, n_layers, device):
+        self.batch, self.H, self.W, self.n_layers = int(batch), int(H), int(W), int(n_layers)
+        tiles = (H // 2) * (W // 2)
+        self.tile_mask = torch.zeros((n_layers, batch, tiles), dtype=torch.uint8, device=device)
+        self.tile_list = torch.zeros((n_layers, batch * tiles), dtype=torch.int32, device=device)
+        self.n_list = torch.zeros(n_layers, dtype=torch.int32, device=device)
+        self.ws = torch.zeros(max(256, int(lib.sessd_bev_tile_activity_workspace_bytes(batch, n_layers))), dtype=torch.uint8, device=device)
+        self._jobs = None
+
+    def run(self, indices, n_dev, n_cap):
+        _req(indices, torch.int32, "indices"); _req(n_dev, torch.int32, "n_dev")
+        check(lib.sessd_bev_tile_activity(indices.data_ptr(), n_dev.data_ptr(), int(n_cap), self.batch, self.H, self.W, self.n_layers,
+                                          self.tile_mask.data_ptr(), self.tile_list.data_ptr(), self.n_list.data_ptr(),
+                                          self.tile_list.shape[1], self.ws.data_ptr(), self.ws.numel(), _stream()), "bev_tile_activity")
+
+    def fill(self, outs, values):
+        """outs[l] (batch, cout, H, W) <- values[l][cout] in the tiles layer l does not compute (one launch)."""
+        from ._lib import FillTilesJob
+        key = tuple((o.data_ptr(), v.data_ptr()) for o, v in zip(outs, values))
+        if self._jobs is None or self._jobs[0] != key:
+            arr = (FillTilesJob * len(outs))()
+            for l, (o, v) in enumerate(zip(outs, values)):
+                _req(o, torch.float32, "out"); _req(v, torch.float32, "value")
+                arr[l].out, arr[l].value, arr[l].tile_mask, arr[l].cout = o.data_ptr(), v.data_ptr(), self.tile_mask[l].data_ptr(), o.shape[1]
+            self._jobs = (key, arr)
+        arr = self._jobs[1]
+        check(lib.sessd_fill_inactive_tiles(arr, len(outs), self.batch, self.H, self.W, _stream()), "fill_inactive_tiles")
+
+
 def pack_winograd(weight, adjoint=False):
     """U = G g G^T of a 3x3 conv weight (Cout,Cin,3,3) for sessd_conv3x3_winograd, packed
     [Cin/2][xi/4][channel parity][Cout_pad][xi%4]. One launch (sessd_conv3x3_winograd_pack)."""

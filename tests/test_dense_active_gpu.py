@@ -1,0 +1,151 @@
+"""Active-tile mode of the first SSFA layers (csrc/dense_active.hip + conv3x3s1_winograd_sk_kernel<.., LIST>): on a BEV map that is
+zero outside the sparse sites (scn.py:179-183 `.dense()`), the three conv + BatchNorm + ReLU layers of rpn_v1.py:135-148 are
+computed only where they are not constant. Checks: the tile masks / lists against a numpy restatement of the rule, and the chain
+fill + active conv against the DENSE kernels on the same input (float32 rounding: 1e-5 of the layer's largest value; the first
+layer's filled tiles bit-equal)."""
+import numpy as np
+import pytest
+import torch
+
+from sessd_hip import ops
+
+pytestmark = pytest.mark.gpu
+H, W = 200, 176
+
+
+def _sites(seed, batch, n):
+    rng = np.random.RandomState(seed)
+    rows = []
+    for b in range(batch):
+        # clustered like a scan: a few blobs + scattered pixels, two z slices
+        cy, cx = rng.randint(10, H - 10, 12), rng.randint(10, W - 10, 12)
+        y = np.clip(np.concatenate([rng.normal(cy[i], 4, n // 16) for i in range(12)] + [rng.randint(0, H, n // 4)]).astype(int), 0, H - 1)
+        x = np.clip(np.concatenate([rng.normal(cx[i], 6, n // 16) for i in range(12)] + [rng.randint(0, W, n // 4)]).astype(int), 0, W - 1)
+        z = rng.randint(0, 2, len(y))
+        u = np.unique(np.stack([np.full(len(y), b), z, y, x], 1), axis=0)
+        rows.append(u)
+    return np.concatenate(rows).astype(np.int32)
+
+
+def _masks_numpy(idx, batch, n_layers):
+    """The rule of csrc/dense_active.hip restated: tile active iff its 4x4 input patch touches a non-constant pixel (+ the border
+    ring from the second layer on); a layer's output is non-constant exactly in its active tiles."""
+    out = []
+    for b in range(batch):
+        nc = np.zeros((H, W), bool)
+        s = idx[idx[:, 0] == b]
+        nc[s[:, 2], s[:, 3]] = True
+        per = []
+        for l in range(n_layers):
+            p = np.pad(nc, 1)
+            tm = np.zeros((H // 2, W // 2), bool)
+            for dy in range(4):
+                for dx in range(4):
+                    tm |= p[dy:dy + H:2, dx:dx + W:2][:H // 2, :W // 2]
+            if l > 0:
+                tm[0, :] = tm[-1, :] = True
+                tm[:, 0] = tm[:, -1] = True
+            per.append(tm.reshape(-1).copy())
+            nc = tm.repeat(2, 0).repeat(2, 1)
+        out.append(per)
+    return out
+
+
+@pytest.mark.parametrize("batch", [1, 3])
+def test_tile_masks_and_lists(dev, batch):
+    idx = _sites(1, batch, 1600)
+    ta = ops.TileActivity(batch, H, W, 3, dev)
+    n = torch.tensor([len(idx)], dtype=torch.int32, device=dev)
+    cap = len(idx) + 100
+    buf = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
+    buf[:len(idx)] = torch.from_numpy(idx).to(dev)
+    ta.run(buf, n, cap)
+    want = _masks_numpy(idx, batch, 3)
+    tiles = (H // 2) * (W // 2)
+    tm, tl, nl = ta.tile_mask.cpu().numpy(), ta.tile_list.cpu().numpy(), ta.n_list.cpu().numpy()
+    for l in range(3):
+        ref = np.concatenate([np.nonzero(want[b][l])[0] + b * tiles for b in range(batch)])
+        for b in range(batch):
+            assert np.array_equal(tm[l, b].astype(bool), want[b][l]), (l, b)
+        assert nl[l] == len(ref)
+        assert np.array_equal(tl[l, :nl[l]], ref)     # ascending (image, tile): deterministic order
+    assert 0.05 < nl[0] / (batch * tiles) < 0.6 and nl[0] < nl[1] < nl[2]
+
+
+def _layer(seed, c):
+    g = torch.Generator().manual_seed(seed)
+    w = torch.randn(c, c, 3, 3, generator=g) * (1.0 / (3.0 * c ** 0.5))
+    scale = 0.5 + torch.rand(c, generator=g)
+    shift = torch.randn(c, generator=g) * 0.3
+    return w, scale, shift
+
+
+def _constants(layers):
+    """value of a layer's output where its input is the previous layer's constant (float64, then float32)"""
+    c = torch.zeros(layers[0][0].shape[1], dtype=torch.float64)
+    out = []
+    for w, scale, shift in layers:
+        c = torch.relu(scale.double() * (w.double().sum((2, 3)) @ c) + shift.double())
+        out.append(c.float())
+    return out
+
+
+@pytest.mark.parametrize("batch,shape,min_rounds", [(1, 0, 2), (1, 1, 2), (2, 0, 1), (2, 1, 4), (1, 0, 8)])
+def test_active_chain_equals_the_dense_layers(dev, batch, shape, min_rounds):
+    C = 128
+    idx = _sites(2 + batch, batch, 1600)
+    x = torch.zeros(batch, C, H, W)
+    g = torch.Generator().manual_seed(7)
+    vals = torch.randn(len(idx), C // 2, generator=g)
+    for (b, z, y, xx), v in zip(idx, vals):
+        x[b, z * (C // 2):(z + 1) * (C // 2), y, xx] = v
+    x = x.to(dev)
+    layers = [_layer(10 + l, C) for l in range(3)]
+    consts = [c.to(dev) for c in _constants(layers)]
+    ta = ops.TileActivity(batch, H, W, 3, dev)
+    n = torch.tensor([len(idx)], dtype=torch.int32, device=dev)
+    ta.run(torch.from_numpy(idx).to(dev), n, len(idx))
+    outs = [torch.full((batch, C, H, W), float("nan"), device=dev) for _ in range(3)]
+    ta.fill(outs, consts)
+    ws = torch.zeros(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(batch, H, W, C, shape, 0)), dtype=torch.uint8, device=dev)
+    cur_a, cur_d = x, x
+    for l, (w, scale, shift) in enumerate(layers):
+        pc = ops.pack_conv2d(w.to(dev))
+        sc, sh = scale.to(dev), shift.to(dev)
+        dense = ops.conv2d(cur_d, pc, sc, sh, True, None, None, 22 + shape)
+        ops.conv2d_winograd_sk_active(cur_a, pc.upk_sk(shape), C, sc, sh, True, outs[l], shape, ws, ta.tile_list[l], ta.n_list[l:l + 1],
+                                      min_rounds=min_rounds)
+        torch.cuda.synchronize()
+        got = outs[l]
+        assert torch.isfinite(got).all(), "layer %d: a tile neither filled nor computed" % l
+        ref = float(dense.abs().max())
+        err = float((got - dense).abs().max())
+        assert err <= 1e-5 * ref, (l, err, ref)
+        if l == 0:
+            # filled tiles of the first layer: relu(shift) exactly, as 0 * U gives
+            tm = ta.tile_mask[0].view(batch, 1, H // 2, W // 2).bool().repeat_interleave(2, 2).repeat_interleave(2, 3).expand(-1, C, -1, -1)
+            assert torch.equal(got[~tm], dense[~tm])
+        cur_a, cur_d = got, dense
+    # the workspace counters are left zero (the next launch relies on it)
+    units = batch * ((H // 2) * (W // 2) + 31) // 32 * (C // (128 if shape == 0 else 64))
+    assert int(ws[:units * 4].view(torch.int32).abs().sum()) == 0
+
+
+def test_active_layer_is_repeatable(dev):
+    """same list, same launch configuration -> same bits (shares are a function of the device count only)"""
+    C = 128
+    idx = _sites(9, 1, 1600)
+    x = torch.zeros(1, C, H, W)
+    x[0, :, idx[:, 2], idx[:, 3]] = torch.randn(C, len(idx), generator=torch.Generator().manual_seed(1))
+    x = x.to(dev)
+    w, scale, shift = _layer(3, C)
+    pc = ops.pack_conv2d(w.to(dev))
+    ta = ops.TileActivity(1, H, W, 1, dev)
+    ta.run(torch.from_numpy(idx).to(dev), torch.tensor([len(idx)], dtype=torch.int32, device=dev), len(idx))
+    ws = torch.zeros(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(1, H, W, C, 0, 0)), dtype=torch.uint8, device=dev)
+    outs = []
+    for _ in range(3):
+        o = torch.zeros(1, C, H, W, device=dev)
+        ops.conv2d_winograd_sk_active(x, pc.upk_sk(0), C, scale.to(dev), shift.to(dev), True, o, 0, ws, ta.tile_list[0], ta.n_list[0:1])
+        outs.append(o)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
