@@ -68,6 +68,9 @@ def parse(argv=None):
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-io", action="store_true", help="skip the informational host-buffer legs (kernel traces of the timed region)")
     ap.add_argument("--no-sequential", action="store_true", help="skip the informational one-frame-at-a-time leg")
+    ap.add_argument("--no-active-tiles", action="store_true",
+                    help="A/B: the first three SSFA layers over the whole BEV map (round 3) instead of only the tiles whose input is not "
+                         "constant (csrc/dense_active.hip)")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the `train_step` leg (BASELINE configs[2]: the captured SE-SSD training iteration with the reference loss)")
     ap.add_argument("--train-replays", type=int, default=20, help="timed replays of the captured training iteration")
@@ -112,7 +115,8 @@ def default_engine_factory(args, dev):
     VG = configs.VOXEL_GENERATOR
     model = configs.build_synthetic_detector(dev, seed=0, max_voxels=args.max_voxels, num_points=args.points, supersample=args.supersample)
     engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], args.max_voxels,
-                               configs.TEST_CFG, batch_size=args.batch, max_points_per_frame=args.points, device=dev)
+                               configs.TEST_CFG, batch_size=args.batch, max_points_per_frame=args.points, device=dev,
+                               active_tiles=not getattr(args, "no_active_tiles", False))
                for _ in range(max(1, args.streams))]
     for e in engines:
         e.fork_front = bool(args.fork)
@@ -368,7 +372,9 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
                                  "of the job, inside the timed region (RCCL when n_gpus > 1; a device-side no-op at n_gpus = 1)",
                        "tuning": {"dense_tile_cfg": dict(getattr(eng, "tile_cfg", {})),
                                   "sparse": {str(k): v for k, v in getattr(eng, "sparse_split", {}).items()},
-                                  "sparse_offset_pattern_tiles": {str(k): bool(v) for k, v in getattr(eng, "sparse_sorted", {}).items()}}},
+                                  "sparse_offset_pattern_tiles": {str(k): bool(v) for k, v in getattr(eng, "sparse_sorted", {}).items()},
+                                  "active_tiles": {"b0.%d" % l: {"streamk_shape": v[0], "min_rounds": v[1]}
+                                                   for l, v in getattr(eng, "active_cfg", {}).items()}}},
         }
         if parity is not None:
             out["parity"] = parity
@@ -425,12 +431,21 @@ def roofline_legs(args, out, eng, batch_of):
     lt = eng.dense_layer_times(reps=20)
     # conv_0 + conv_1 may run as ONE launch of twice the work (engine.merge_branch_convs): per-launch figures are averages
     # over the launches that carry the seven layers
-    times = [lt[nm] for nm in names if nm in lt] + ([lt["conv_0+conv_1"]] if "conv_0+conv_1" in lt else [])
-    nlayers = sum(1 for nm in names if nm in lt) + (2 if "conv_0+conv_1" in lt else 0)
+    # layers in ACTIVE-TILE mode (block 0, csrc/dense_active.hip) compute only a share of the map's tiles: their FLOPs count with that
+    # share (engine.active_tile_fractions(): device counts of the frame just timed). Per-launch figures are totals over the
+    # launches that carry the seven layers divided by their number.
+    act = eng.active_tile_fractions() if hasattr(eng, "active_tile_fractions") else {}
+    per = [(nm, lt[nm], 1, act.get(nm, 1.0)) for nm in names if nm in lt]
+    if "conv_0+conv_1" in lt:
+        per.append(("conv_0+conv_1", lt["conv_0+conv_1"], 2, 1.0))
+    times = [p[1] for p in per]
+    nlayers = sum(p[2] for p in per)
     assert nlayers == len(names)
     kms = sum(times) / len(times)
-    flops = CONV_FLOPS * args.batch * nlayers / len(times)
+    flops = CONV_FLOPS * args.batch * sum(p[2] * p[3] for p in per) / len(times)
     ach = flops / (kms * 1e-3) / 1e12
+    full = [p for p in per if p[3] == 1.0]
+    ach_full = (CONV_FLOPS * args.batch * sum(p[2] for p in full) / (sum(p[1] for p in full) * 1e-3) / 1e12) if full else 0.0
     log("roofline kernel: %.3f ms per launch in sequence" % kms)
     # executed matrix-core FLOPs per algorithmic FLOP: direct 1, Winograd F(2x2,3x3) 16/36, F(4x4,3x3) 36/144
     exe_ratio = sum(ops.winograd_mult_ratio(c if c is not None else (20 if ops.USE_WINOGRAD else 0)) for c in cfgs) / len(cfgs)
@@ -446,6 +461,13 @@ def roofline_legs(args, out, eng, batch_of):
                        "frac_definition": "EXECUTED matrix-core FLOPs (what SQ_INSTS_MFMA counts: 16/36 of the direct-"
                                           "convolution count for Winograd F(2x2,3x3)) / launch time / dense f32 MFMA peak",
                        "avg_launch_ms": kms,
+                       "active_tile_fraction": act,
+                       "frac_full_map_launches": ach_full * exe_ratio / F32_MFMA_PEAK_TFLOPS,
+                       "active_tile_note": ("layers listed in active_tile_fraction run over the listed 2x2-output tiles only (the BEV map is "
+                                            "zero outside the sparse sites: the other tiles hold a per-channel constant, written by one fill "
+                                            "launch); their FLOPs count with that share, the activity + fill launches are in "
+                                            "dense_launch_ms['tile_activity+fill']; frac_full_map_launches = the same figure over the "
+                                            "launches that cover the whole map (comparable with earlier rounds)") if act else None,
                        "avg_launch_source": "HIP events before / after each of the kernel's %d launches inside 20 whole frames " % len(times) +
                                             "(eager enqueue; same stream as the kernels; one frame in flight, the same "
                                             "launch configuration as the timed region unless --sk-workgroups says otherwise)",

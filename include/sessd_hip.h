@@ -515,7 +515,7 @@ int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int ci
  * how this path avoids arithmetic on constants that ATen's dense conv performs. */
 size_t sessd_bev_tile_activity_workspace_bytes(int batch, int n_layers);
 int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_cap, int batch, int h, int w, int n_layers,
-                            uint8_t* tile_mask, int32_t* tile_list, int32_t* n_list, int list_cap, void* workspace,
+                            uint64_t* tile_mask, int32_t* tile_list, int32_t* n_list, int list_cap, void* workspace,
                             size_t workspace_bytes, sessd_stream_t stream);
 int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, int h, int w, sessd_stream_t stream);
 int sessd_conv3x3_winograd_sk_active(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,

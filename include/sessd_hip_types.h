@@ -43,11 +43,12 @@ typedef struct {
   int32_t block_start, pad_;
 } sessd_dense_pack_job_t;
 
-/* One layer of sessd_fill_inactive_tiles: out (batch, cout, h, w), value[cout], tile_mask[batch][h/2 * w/2] (1 = computed tile). */
+/* One layer of sessd_fill_inactive_tiles: out (batch, cout, h, w), value[cout], tile_mask[batch][h/2][2] 64-bit words (bit tx of a
+ * row's 128 bits set = computed tile), as sessd_bev_tile_activity writes them. */
 typedef struct {
   float* out;
   const float* value;
-  const uint8_t* tile_mask;
+  const uint64_t* tile_mask;
   int32_t cout, pad_;
 } sessd_fill_tiles_job_t;
 

@@ -74,6 +74,15 @@ class DensePlan:
 
         b0, b1 = neck.bottom_up_block_0, neck.bottom_up_block_1
         self.b0 = [cbr(b0, 1, 2), cbr(b0, 4, 5), cbr(b0, 7, 8)]  # index 0 is ZeroPad2d(1) + unpadded conv == pad 1
+        # What the three layers of block 0 compute where their input is CONSTANT (the BEV map is zero outside the sparse sites):
+        # c_0 = 0, c_{l+1}[co] = relu(scale * sum_ci c_l[ci] * sum_k W[co][ci][k] + shift), float64 over the folded weights. The
+        # engine writes c_{l+1} into the tiles of layer l it does not compute (active-tile mode, csrc/dense_active.hip).
+        c = torch.zeros(b0[1].weight.shape[1], dtype=torch.float64)
+        self.b0_const = []
+        for (ci, bi) in ((1, 2), (4, 5), (7, 8)):
+            s_, t_ = fold_bn(b0[bi])
+            c = torch.relu(s_.double().cpu() * (b0[ci].weight.detach().double().cpu().sum((2, 3)) @ c) + t_.double().cpu())
+            self.b0_const.append(c.float().to(device).contiguous())
         self.b1 = [cbr(b1, 0, 1), cbr(b1, 3, 4), cbr(b1, 6, 7)]
         self.trans_0 = cbr(neck.trans_0, 0, 1)
         self.trans_1 = cbr(neck.trans_1, 0, 1)
@@ -100,7 +109,7 @@ class DensePlan:
 class InferenceEngine:
     def __init__(self, model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, batch_size=1,
                  max_points_per_frame=32768, device=None, growth=(1.5, 1.0, 0.75, 0.75), anchors=None,
-                 use_frustum=False, allow_winograd=True, sort_sites=False, sort_tiles=False):
+                 use_frustum=False, allow_winograd=True, sort_sites=False, sort_tiles=False, active_tiles=True):
         """growth[i]: capacity of sparse level i+1 relative to level i (observed ratios on KITTI-like scans are
         ~1.05-1.25, 0.5, 0.4, 0.85; the worst case is 8 / 8 / 8 / 2). Exceeding a capacity raises in results().
         sort_sites: renumber the voxels by grid row between the voxelizer and the first sparse conv
@@ -252,6 +261,13 @@ class InferenceEngine:
         # critical path, and with two engines the four streams serialise against each other.
         self.fork_front = False
         self.side_stream = torch.cuda.Stream(device=dev)
+        # Active-tile mode of bottom_up_block_0 (round 4): the BEV map is zero outside the last sparse level's sites, so its three
+        # layers are computed only in the 2x2-output tiles whose input patch is not constant (18 / 29 / 39 % of the tiles on a
+        # 20 k-point scan) and the rest is filled with the layer's constant. Applies to the layers the autotune put on the
+        # stream-K Winograd kernel (tile_cfg 22 / 23).
+        self.active_tiles = bool(active_tiles)
+        self.active_cfg = {}   # layer of block 0 -> (stream-K shape, min_rounds), chosen by autotune(); empty = dense launches
+        self.ta = ops.TileActivity(B, H, W, 3, dev) if self.active_tiles and H * W <= 40960 and H % 2 == 0 and W % 2 == 0 else None
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -337,8 +353,28 @@ class InferenceEngine:
                                     shift=torch.stack([t0, t1]).contiguous()) if ok else None)
         return getattr(self, key)
 
-    def _conv(self, x, layer, out, relu=True, residual=None, name=None):
+    def _active_layers(self):
+        """indices of the block-0 layers that run in active-tile mode in this configuration"""
+        if self.ta is None or self._tuning is not None or self.sk_ws is None:
+            return []
+        return sorted(self.active_cfg)
+
+    def _conv(self, x, layer, out, relu=True, residual=None, name=None, active=None):
         pc, scale, shift = layer
+        if active is not None:
+            # active-tile mode: the listed tiles only (the others were filled with the layer's constant at the head of the stage)
+            shape, min_rounds = self.active_cfg[active]
+            call = lambda: ops.conv2d_winograd_sk_active(x, pc.upk_sk(shape), pc.cout, scale, shift, relu, out, shape, self.sk_ws,
+                                                         self.ta.tile_list[active], self.ta.n_list[active:active + 1],
+                                                         workgroups=self.sk_workgroups, residual=residual, min_rounds=min_rounds)
+            if self._kmarks is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                r = call()
+                e1.record()
+                self._kmarks.append((name, e0, e1))
+                return r
+            return call()
         if self._tuning is not None:
             self._tuning.append((name, x, layer, out, relu, residual))
         if self._kmarks is not None:  # per-launch HIP events inside a whole eager frame (dense_layer_times)
@@ -354,6 +390,7 @@ class InferenceEngine:
         """Take another engine's tuned configuration (per-layer tilings, sparse variants, stream-K workgroup count) with a
         stream-K workspace of this engine's own: engines that run concurrently must not share one."""
         self.tile_cfg = dict(other.tile_cfg)
+        self.active_cfg = dict(other.active_cfg) if self.ta is not None else {}
         self.sparse_split = dict(other.sparse_split)
         self.sparse_sorted = dict(other.sparse_sorted)
         self.sk_workgroups = other.sk_workgroups
@@ -449,9 +486,64 @@ class InferenceEngine:
                     best = (cfg, t)
             self.tile_cfg[name] = best[0]
             self.tune_report[name] = best
+        self._autotune_active_tiles(reps)
         self.enqueue()  # leave every buffer consistent with the chosen configuration
         torch.cuda.synchronize()
         return self.tune_report
+
+    def _autotune_active_tiles(self, reps):
+        """Block 0 in active-tile mode (csrc/dense_active.hip) where that is faster on the staged frame: per layer the stream-K
+        shape and the minimum share length, then the whole set against the cost of the activity + fill launches."""
+        self.active_cfg = {}
+        if self.ta is None or not self.allow_streamk or not self.allow_winograd:
+            return
+        def timed(fn):
+            for _ in range(2):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+        L4, d, t = self.levels[-1], self.dn, self.t
+        bufs, ins = (t["a"], t["b"], t["x0"]), (self.bev, t["a"], t["b"])
+        self.ta.run(L4["indices"], L4["n"], L4["cap"])
+        pick, gain = {}, 0.0
+        for l in range(3):
+            pc, scale, shift = d.b0[l]
+            best = (None, 1e30)
+            for shape in (0, 1):
+                if pc.upk_sk(shape) is None:
+                    continue
+                need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(self.B, self.H, self.W, pc.cout, shape, 0))
+                if self.sk_ws is None or self.sk_ws.numel() < need:
+                    self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+                for mr in (1, 2, 4):
+                    tt = timed(lambda: ops.conv2d_winograd_sk_active(ins[l], pc.upk_sk(shape), pc.cout, scale, shift, True, bufs[l], shape,
+                                                                     self.sk_ws, self.ta.tile_list[l], self.ta.n_list[l:l + 1],
+                                                                     workgroups=self.sk_workgroups, min_rounds=mr))
+                    if tt < best[1]:
+                        best = ((shape, mr), tt)
+            dense_t = self.tune_report.get("b0.%d" % l, (None, 0.0))[1]
+            if best[0] is not None and best[1] < dense_t:
+                pick[l] = best
+                gain += dense_t - best[1]
+        over = timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]),
+                              self.ta.fill([bufs[l] for l in sorted(pick)], [d.b0_const[l] for l in sorted(pick)], layers=sorted(pick)))) if pick else 0.0
+        if pick and gain > over:
+            self.active_cfg = {l: pick[l][0] for l in pick}
+        # (choice, gain ms per frame over the dense launches, ms of the activity + fill launches, per-layer ms): a tuple like the others
+        self.tune_report["active_tiles"] = (dict(self.active_cfg), gain - over, over, {l: pick[l][1] for l in pick})
+
+    def active_tile_fractions(self):
+        """name -> share of the 2x2-output tiles the layer computed in the LAST enqueued batch (layers in active-tile mode only)"""
+        if not self._active_layers():
+            return {}
+        n = self.ta.n_list.cpu().numpy()
+        tiles = self.B * (self.H // 2) * (self.W // 2)
+        return {"b0.%d" % l: float(n[l]) / tiles for l in self._active_layers()}
 
     # ------------------------------------------------------------------ the frame
     def enqueue(self):
@@ -542,9 +634,21 @@ class InferenceEngine:
         self._mark("spmiddle")
         # ---- SSFA (a9) rpn_v1.py:220-235
         t, h, d = self.t, self.h, self.dn
-        x = self._conv(self.bev, d.b0[0], t["a"], name="b0.0")
-        x = self._conv(x, d.b0[1], t["b"], name="b0.1")
-        x0 = self._conv(x, d.b0[2], t["x0"], name="b0.2")
+        act = self._active_layers()
+        if act:
+            L4 = self.levels[-1]
+            if self._kmarks is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            self.ta.run(L4["indices"], L4["n"], L4["cap"])
+            bufs = (t["a"], t["b"], t["x0"])
+            self.ta.fill([bufs[l] for l in act], [d.b0_const[l] for l in act], layers=act)
+            if self._kmarks is not None:
+                e1.record()
+                self._kmarks.append(("tile_activity+fill", e0, e1))
+        x = self._conv(self.bev, d.b0[0], t["a"], name="b0.0", active=0 if 0 in act else None)
+        x = self._conv(x, d.b0[1], t["b"], name="b0.1", active=1 if 1 in act else None)
+        x0 = self._conv(x, d.b0[2], t["x0"], name="b0.2", active=2 if 2 in act else None)
         y = self._conv(x0, d.b1[0], h["a"], name="b1.0")
         y = self._conv(y, d.b1[1], h["b"], name="b1.1")
         x1 = self._conv(y, d.b1[2], h["x1"], name="b1.2")

@@ -1383,13 +1383,13 @@ def conv2d_winograd_sk_active(x, upk, cout, scale, shift, relu, out, shape, work
 
 class TileActivity:
     """Buffers + launches of sessd_bev_tile_activity / sessd_fill_inactive_tiles for `n_layers` 3x3 stride-1 layers over
-    (batch, ., H, W) maps: tile_mask (n_layers, batch, H/2 * W/2) uint8, tile_list (n_layers, batch * H/2 * W/2) int32,
-    n_list (n_layers,) int32."""
+    (batch, ., H, W) maps: tile_mask (n_layers, batch, H/2, 2) int64 -- bit tx of a row's 128 bits = tile (ty, tx) is computed --,
+    tile_list (n_layers, batch * H/2 * W/2) int32, n_list (n_layers,) int32."""
 
     def __init__(self, batch, H, W, n_layers, device):
         self.batch, self.H, self.W, self.n_layers = int(batch), int(H), int(W), int(n_layers)
         tiles = (H // 2) * (W // 2)
-        self.tile_mask = torch.zeros((n_layers, batch, tiles), dtype=torch.uint8, device=device)
+        self.tile_mask = torch.zeros((n_layers, batch, H // 2, 2), dtype=torch.int64, device=device)
         self.tile_list = torch.zeros((n_layers, batch * tiles), dtype=torch.int32, device=device)
         self.n_list = torch.zeros(n_layers, dtype=torch.int32, device=device)
         self.ws = torch.zeros(max(256, int(lib.sessd_bev_tile_activity_workspace_bytes(batch, n_layers))), dtype=torch.uint8, device=device)
@@ -1401,15 +1401,23 @@ class TileActivity:
                                           self.tile_mask.data_ptr(), self.tile_list.data_ptr(), self.n_list.data_ptr(),
                                           self.tile_list.shape[1], self.ws.data_ptr(), self.ws.numel(), _stream()), "bev_tile_activity")
 
-    def fill(self, outs, values):
-        """outs[l] (batch, cout, H, W) <- values[l][cout] in the tiles layer l does not compute (one launch)."""
+    def mask_bool(self, layer):
+        """(batch, H/2, W/2) bool of the layer's computed tiles (tests / reports)"""
+        import numpy as np
+        m = self.tile_mask[layer].cpu().numpy().view("uint64")
+        tx = np.arange(self.W // 2)
+        return torch.from_numpy(((m[:, :, tx >> 6] >> (tx & 63).astype("uint64")) & np.uint64(1)).astype(bool))
+
+    def fill(self, outs, values, layers=None):
+        """outs[i] (batch, cout, H, W) <- values[i][cout] in the tiles layer layers[i] (default i) does not compute (one launch)."""
         from ._lib import FillTilesJob
-        key = tuple((o.data_ptr(), v.data_ptr()) for o, v in zip(outs, values))
+        layers = list(range(len(outs))) if layers is None else list(layers)
+        key = tuple((o.data_ptr(), v.data_ptr(), l) for o, v, l in zip(outs, values, layers))
         if self._jobs is None or self._jobs[0] != key:
             arr = (FillTilesJob * len(outs))()
-            for l, (o, v) in enumerate(zip(outs, values)):
+            for i, (o, v, l) in enumerate(zip(outs, values, layers)):
                 _req(o, torch.float32, "out"); _req(v, torch.float32, "value")
-                arr[l].out, arr[l].value, arr[l].tile_mask, arr[l].cout = o.data_ptr(), v.data_ptr(), self.tile_mask[l].data_ptr(), o.shape[1]
+                arr[i].out, arr[i].value, arr[i].tile_mask, arr[i].cout = o.data_ptr(), v.data_ptr(), self.tile_mask[l].data_ptr(), o.shape[1]
             self._jobs = (key, arr)
         arr = self._jobs[1]
         check(lib.sessd_fill_inactive_tiles(arr, len(outs), self.batch, self.H, self.W, _stream()), "fill_inactive_tiles")

@@ -62,11 +62,12 @@ def test_tile_masks_and_lists(dev, batch):
     ta.run(buf, n, cap)
     want = _masks_numpy(idx, batch, 3)
     tiles = (H // 2) * (W // 2)
-    tm, tl, nl = ta.tile_mask.cpu().numpy(), ta.tile_list.cpu().numpy(), ta.n_list.cpu().numpy()
+    tl, nl = ta.tile_list.cpu().numpy(), ta.n_list.cpu().numpy()
     for l in range(3):
         ref = np.concatenate([np.nonzero(want[b][l])[0] + b * tiles for b in range(batch)])
+        tm = ta.mask_bool(l).numpy().reshape(batch, -1)
         for b in range(batch):
-            assert np.array_equal(tm[l, b].astype(bool), want[b][l]), (l, b)
+            assert np.array_equal(tm[b], want[b][l]), (l, b)
         assert nl[l] == len(ref)
         assert np.array_equal(tl[l, :nl[l]], ref)     # ascending (image, tile): deterministic order
     assert 0.05 < nl[0] / (batch * tiles) < 0.6 and nl[0] < nl[1] < nl[2]
@@ -123,7 +124,7 @@ def test_active_chain_equals_the_dense_layers(dev, batch, shape, min_rounds):
         assert err <= 1e-5 * ref, (l, err, ref)
         if l == 0:
             # filled tiles of the first layer: relu(shift) exactly, as 0 * U gives
-            tm = ta.tile_mask[0].view(batch, 1, H // 2, W // 2).bool().repeat_interleave(2, 2).repeat_interleave(2, 3).expand(-1, C, -1, -1)
+            tm = ta.mask_bool(0).to(dev).view(batch, 1, H // 2, W // 2).repeat_interleave(2, 2).repeat_interleave(2, 3).expand(-1, C, -1, -1)
             assert torch.equal(got[~tm], dense[~tm])
         cur_a, cur_d = got, dense
     # the workspace counters are left zero (the next launch relies on it)
