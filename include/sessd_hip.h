@@ -505,19 +505,21 @@ int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int ci
  * neck (`.dense()` of the last sparse level, det3d/models/backbones/scn.py:179-183) is zero outside the sparse backbone's sites, so
  * the first three layers of bottom_up_block_0 (rpn_v1.py:135-148) compute the same per-channel constant in every 2x2-output tile
  * whose 4x4 input patch holds no non-constant pixel (82 % / 71 % / 61 % of the tiles on a 20 k-point scan):
- *   sessd_bev_tile_activity     tile masks + ordered tile lists (entry image * (h/2 * w/2) + tile) + device counts of the first
- *                               n_layers (<= 4) layers, from the (image, z, y, x) rows of the last sparse level
+ *   sessd_bev_tile_activity     tile masks + ordered tile lists (entry image * tiles + tile) + device counts of a chain of 3x3 layers
+ *                               given as HOST steps (0 = stride-1 layer taking the next of <= 6 slots, 1 = stride-2 layer computed
+ *                               everywhere: rpn_v1.py:135-160 is {0, 0, 0, 1, 0, 0}), from the (image, z, y, x) rows of the last
+ *                               sparse level
  *   sessd_fill_inactive_tiles   out[b][co][tile] = value[co] (the layer's constant, computed by the host from the folded weights)
- *                               in the tiles nobody computes, up to 4 layers per launch
+ *                               in the tiles nobody computes, up to 6 layers per launch
  *   sessd_conv3x3_winograd_sk_active   sessd_conv3x3_winograd_sk over the listed tiles only (same packed U, same workspace; the
  *                               shares of the round list are sized on the device, workgroups beyond rounds / min_rounds exit)
  * Results equal the dense layer's to float32 rounding (tests/test_dense_active_gpu.py); replaces nothing in the reference -- it is
  * how this path avoids arithmetic on constants that ATen's dense conv performs. */
 size_t sessd_bev_tile_activity_workspace_bytes(int batch, int n_layers);
-int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_cap, int batch, int h, int w, int n_layers,
-                            uint64_t* tile_mask, int32_t* tile_list, int32_t* n_list, int list_cap, void* workspace,
+int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_cap, int batch, int h, int w, const int32_t* steps,
+                            int n_steps, uint64_t* tile_mask, int32_t* tile_list, int32_t* n_list, int list_cap, void* workspace,
                             size_t workspace_bytes, sessd_stream_t stream);
-int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, int h, int w, sessd_stream_t stream);
+int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, sessd_stream_t stream);
 int sessd_conv3x3_winograd_sk_active(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
                                      const float* scale, const float* shift, int relu, const float* residual,
                                      const int32_t* tile_list, const int32_t* n_list, int list_cap, int min_rounds, void* workspace,

@@ -43,13 +43,13 @@ typedef struct {
   int32_t block_start, pad_;
 } sessd_dense_pack_job_t;
 
-/* One layer of sessd_fill_inactive_tiles: out (batch, cout, h, w), value[cout], tile_mask[batch][h/2][2] 64-bit words (bit tx of a
- * row's 128 bits set = computed tile), as sessd_bev_tile_activity writes them. */
+/* One layer of sessd_fill_inactive_tiles: out (batch, cout, h, w), value[cout], tile_mask[batch][mask_th][2] 64-bit words (bit tx of
+ * a row's 128 bits set = computed tile; mask_th >= h/2 rows per image), as sessd_bev_tile_activity writes them. */
 typedef struct {
   float* out;
   const float* value;
   const uint64_t* tile_mask;
-  int32_t cout, pad_;
+  int32_t cout, h, w, mask_th;
 } sessd_fill_tiles_job_t;
 
 /* One sparse-conv weight packing of sessd_sparse_pack_batch: sessd_sparse_pack_weight (adjoint 0) or

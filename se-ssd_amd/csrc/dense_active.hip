@@ -14,6 +14,9 @@
 //                       launch at batch 1; with more images a second launch numbers the lists (an image's base is the sum of the
 //                       earlier images' counts). (First version: byte maps walked by one workgroup -- 104 us.)
 //   fill_inactive_tiles the layers' constants into the tiles nobody computes (<= 4 layers per launch).
+//   The walk continues THROUGH the stride-2 conv that opens bottom_up_block_1 (rpn_v1.py:150-152: computed over the whole map; an
+//   output pixel is constant iff its 3x3 stride-2 window is, zero padding enters at the top / left border only) into that block's
+//   two 3x3 stride-1 layers at half resolution: a "step program" of conv layers (each with a mask / list slot) and transitions.
 // The convolutions themselves: conv3x3s1_winograd_sk_kernel<.., LIST = true> (dense_wino_sk.hip) over the list.
 // The constants come from the host (float64 over the folded weights: sessd_hip.engine); a computed tile and a filled tile agree
 // to float32 rounding of that chain (1e-7 relative), bit-exactly for the first layer (0 * U = 0).
@@ -22,19 +25,23 @@
 
 namespace {
 
-constexpr int NT = 256;
+constexpr int NT = 1024;
 constexpr int MAX_H = 256, MAX_W = 192;   // one image's pixel rows as 3 x 64-bit words in LDS; a thread pair per tile row
-constexpr int MAX_LAYERS = 4;
+constexpr int MAX_SLOTS = 6, MAX_STEPS = 8;
 typedef unsigned long long u64;
 
 struct ActArgs {
   const int* indices;   // (n, 4) rows (image, z, y, x) of the last sparse level
   const int* n_dev;
-  int n_cap, batch, h, w, th, tw, n_layers, list_cap;
-  u64* tile_mask;       // [n_layers][batch][th][2]: bit tx of the row's 128-bit word = tile (ty, tx) is computed
-  int* tile_list;       // [n_layers][list_cap]
-  int* n_list;          // [n_layers]
-  int* counts;          // [n_layers][batch]
+  int n_cap, batch, h, w;
+  int n_steps, n_slots;
+  int kind[MAX_STEPS];        // 0: 3x3 stride-1 layer (takes the next slot), 1: 3x3 stride-2 transition (halves the map)
+  int slot_th[MAX_SLOTS], slot_tw[MAX_SLOTS];
+  int list_cap, mask_th;      // rows of a (slot, image) block of tile_mask = h / 2 (the first resolution's)
+  u64* tile_mask;       // [n_slots][batch][mask_th][2]: bit tx of the row's 128-bit word = tile (ty, tx) is computed
+  int* tile_list;       // [n_slots][list_cap]
+  int* n_list;          // [n_slots]
+  int* counts;          // [n_slots][batch]
 };
 
 // bits 0, 2, 4, .. of x -> bits 0 .. 31
@@ -57,6 +64,11 @@ __device__ __forceinline__ u64 double_bits(unsigned v) {
   x = (x | (x << 1)) & 0x5555555555555555ull;
   return x | (x << 1);
 }
+// the valid bits of a row of `n` bits over two words
+__device__ __forceinline__ void valid_bits(int n, u64& v0, u64& v1) {
+  v0 = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+  v1 = n > 64 ? (n >= 128 ? ~0ull : ((1ull << (n - 64)) - 1ull)) : 0ull;
+}
 
 // entries of one 64-bit word of a tile row, ascending, starting at list[at]
 __device__ __forceinline__ void emit_word(u64 m, int first, int at, int* list, int list_cap) {
@@ -69,72 +81,116 @@ __device__ __forceinline__ void emit_word(u64 m, int first, int at, int* list, i
 }
 
 // One workgroup per image. Pixel rows and tile rows are bit vectors: a tile row is OR of four pixel rows, shifted-OR over the four
-// patch columns, every second bit kept -- one thread per tile row and layer.
+// patch columns, every second bit kept -- a thread pair per tile row and layer.
 __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
-  __shared__ u64 nc[MAX_H][3];            // non-constant pixels of the current layer's input
-  __shared__ u64 tmb[MAX_H / 2][2];       // computed tiles of the current layer
+  __shared__ u64 nc[MAX_H][3];            // non-constant pixels of the current step's input
+  __shared__ u64 tmb[MAX_H / 2][2];       // computed tiles of the current layer / rows of a transition
   __shared__ int s_scan[NT / 64];
-  const int b = blockIdx.x, H = A.h, W = A.w, TH = A.th, TW = A.tw;
+  const int b = blockIdx.x;
+  int H = A.h, W = A.w;
   for (int i = threadIdx.x; i < H * 3; i += NT) (&nc[0][0])[i] = 0ull;
   __syncthreads();
   const int n = min(A.n_dev[0], A.n_cap);
-  for (int i = threadIdx.x; i < n; i += NT) {
-    const int4 c = *reinterpret_cast<const int4*>(A.indices + (size_t)i * 4);
-    if (c.x == b && c.z >= 0 && c.z < H && c.w >= 0 && c.w < W) atomicOr(&nc[c.z][c.w >> 6], 1ull << (c.w & 63));
+  // the site rows of ALL images are walked by every workgroup (they are few); eight independent loads per thread and round
+  for (int base = 0; base < n; base += NT * 8) {
+    int4 c[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int i = base + k * NT + (int)threadIdx.x;
+      c[k] = i < n ? *reinterpret_cast<const int4*>(A.indices + (size_t)i * 4) : make_int4(-1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (c[k].x == b && c[k].z >= 0 && c[k].z < H && c[k].w >= 0 && c[k].w < W) atomicOr(&nc[c[k].z][c[k].w >> 6], 1ull << (c[k].w & 63));
   }
   __syncthreads();
-  // valid tile bits of a row: TW bits over two words
-  const u64 v0 = TW >= 64 ? ~0ull : ((1ull << TW) - 1ull), v1 = TW > 64 ? ((1ull << (TW - 64)) - 1ull) : 0ull;
-  for (int l = 0; l < A.n_layers; ++l) {
-    const int row = threadIdx.x >> 1, half = threadIdx.x & 1;   // thread pair = one tile row; each thread owns one 64-bit word of it
-    u64 mine = 0ull;
-    if (row < TH) {
-      u64 r0 = 0ull, r1 = 0ull, r2 = 0ull;
-      for (int y = max(2 * row - 1, 0); y <= min(2 * row + 2, H - 1); ++y) { r0 |= nc[y][0]; r1 |= nc[y][1]; r2 |= nc[y][2]; }
-      // patch columns 2 tx - 1 .. 2 tx + 2 at bit 2 tx: r | r << 1 | r >> 1 | r >> 2 over the 192-bit row
-      const u64 h0 = r0 | (r0 << 1) | (r0 >> 1) | (r1 << 63) | (r0 >> 2) | (r1 << 62);
-      const u64 h1 = r1 | (r1 << 1) | (r0 >> 63) | (r1 >> 1) | (r2 << 63) | (r1 >> 2) | (r2 << 62);
-      const u64 h2 = r2 | (r2 << 1) | (r1 >> 63) | (r2 >> 1) | (r2 >> 2);
-      u64 t0 = (u64)even_bits(h0) | ((u64)even_bits(h1) << 32), t1 = (u64)even_bits(h2);
-      // from the second layer on the input constant is not zero: zero padding makes the border ring a computed region
-      if (l > 0) {
-        if (row == 0 || row == TH - 1) { t0 = ~0ull; t1 = ~0ull; }
-        t0 |= 1ull;
-        if (TW - 1 < 64) t0 |= 1ull << (TW - 1); else t1 |= 1ull << (TW - 1 - 64);
+  bool zero_input = true;   // the map's constant is zero: zero padding does not show at the border
+  int slot = 0;
+  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+  for (int st = 0; st < A.n_steps; ++st) {
+    if (A.kind[st] == 0) {
+      // ---- 3x3 stride-1 layer: tile (ty, tx) is computed iff its 4x4 input patch rows 2ty-1 .. 2ty+2, cols 2tx-1 .. 2tx+2 holds a
+      // non-constant pixel (or, with a non-zero constant, lies on the border ring)
+      const int TH = H >> 1, TW = W >> 1;
+      u64 v0, v1;
+      valid_bits(TW, v0, v1);
+      u64 mine = 0ull;
+      if (row < TH) {
+        u64 r0 = 0ull, r1 = 0ull, r2 = 0ull;
+        for (int y = max(2 * row - 1, 0); y <= min(2 * row + 2, H - 1); ++y) { r0 |= nc[y][0]; r1 |= nc[y][1]; r2 |= nc[y][2]; }
+        // r | r << 1 | r >> 1 | r >> 2 over the 192-bit row, read at the even bits
+        const u64 h0 = r0 | (r0 << 1) | (r0 >> 1) | (r1 << 63) | (r0 >> 2) | (r1 << 62);
+        const u64 h1 = r1 | (r1 << 1) | (r0 >> 63) | (r1 >> 1) | (r2 << 63) | (r1 >> 2) | (r2 << 62);
+        const u64 h2 = r2 | (r2 << 1) | (r1 >> 63) | (r2 >> 1) | (r2 >> 2);
+        u64 t0 = (u64)even_bits(h0) | ((u64)even_bits(h1) << 32), t1 = (u64)even_bits(h2);
+        if (!zero_input) {
+          if (row == 0 || row == TH - 1) { t0 = ~0ull; t1 = ~0ull; }
+          t0 |= 1ull;
+          if (TW - 1 < 64) t0 |= 1ull << (TW - 1); else t1 |= 1ull << (TW - 1 - 64);
+        }
+        t0 &= v0; t1 &= v1;
+        mine = half ? t1 : t0;
+        A.tile_mask[(((size_t)slot * A.batch + b) * A.mask_th + row) * 2 + half] = mine;
       }
-      t0 &= v0; t1 &= v1;
-      mine = half ? t1 : t0;
-      tmb[row][half] = mine;
-      A.tile_mask[(((size_t)l * A.batch + b) * TH + row) * 2 + half] = mine;
+      int total;   // (the scan's barriers also separate this step's reads of nc from the writes below)
+      const int at = sessd_block_exscan<NT>(__popcll(mine), s_scan, &total);   // thread order = (row, word) = ascending tile order
+      if (A.batch == 1) {
+        if (row < TH) emit_word(mine, row * TW + 64 * half, at, A.tile_list + (size_t)slot * A.list_cap, A.list_cap);
+        if (threadIdx.x == 0) A.n_list[slot] = total;
+      } else if (threadIdx.x == 0) {
+        A.counts[slot * A.batch + b] = total;
+      }
+      // the layer's output is non-constant exactly in its computed tiles: pixel rows 2 ty, 2 ty + 1 = the tile row, every bit twice
+      // (each thread of the pair writes the words that come from its own half)
+      if (row < TH) {
+        if (half == 0) {
+          const u64 p0 = double_bits((unsigned)mine), p1 = double_bits((unsigned)(mine >> 32));
+          nc[2 * row][0] = p0; nc[2 * row][1] = p1;
+          nc[2 * row + 1][0] = p0; nc[2 * row + 1][1] = p1;
+        } else {
+          const u64 p2 = double_bits((unsigned)mine);
+          nc[2 * row][2] = p2;
+          nc[2 * row + 1][2] = p2;
+        }
+      }
+      __syncthreads();
+      zero_input = false;   // (a layer's own constant relu(shift) is not zero in general)
+      ++slot;
+    } else {
+      // ---- 3x3 stride-2 conv, padding 1, computed everywhere: output pixel (Y, X) is constant iff rows 2Y-1 .. 2Y+1, cols 2X-1 ..
+      // 2X+1 are; the padding enters at Y = 0 / X = 0 only (2Y+1 <= H-1 for even H)
+      const int H2 = H >> 1, W2 = W >> 1;
+      u64 v0, v1;
+      valid_bits(W2, v0, v1);
+      if (row < H2 && half == 0) {
+        u64 r0 = 0ull, r1 = 0ull, r2 = 0ull;
+        for (int y = max(2 * row - 1, 0); y <= min(2 * row + 1, H - 1); ++y) { r0 |= nc[y][0]; r1 |= nc[y][1]; r2 |= nc[y][2]; }
+        const u64 h0 = r0 | (r0 << 1) | (r0 >> 1) | (r1 << 63);
+        const u64 h1 = r1 | (r1 << 1) | (r0 >> 63) | (r1 >> 1) | (r2 << 63);
+        const u64 h2 = r2 | (r2 << 1) | (r1 >> 63) | (r2 >> 1);
+        u64 t0 = (u64)even_bits(h0) | ((u64)even_bits(h1) << 32), t1 = (u64)even_bits(h2);
+        if (!zero_input) {
+          if (row == 0) { t0 = ~0ull; t1 = ~0ull; }
+          t0 |= 1ull;
+        }
+        tmb[row][0] = t0 & v0; tmb[row][1] = t1 & v1;
+      }
+      __syncthreads();
+      if (row < H2 && half == 0) { nc[row][0] = tmb[row][0]; nc[row][1] = tmb[row][1]; nc[row][2] = 0ull; }
+      __syncthreads();
+      H = H2; W = W2;
     }
-    int total;
-    const int at = sessd_block_exscan<NT>(__popcll(mine), s_scan, &total);   // thread order = (row, word) = ascending tile order
-    if (A.batch == 1) {
-      if (row < TH) emit_word(mine, row * TW + 64 * half, at, A.tile_list + (size_t)l * A.list_cap, A.list_cap);
-      if (threadIdx.x == 0) A.n_list[l] = total;
-    } else if (threadIdx.x == 0) {
-      A.counts[l * A.batch + b] = total;
-    }
-    __syncthreads();
-    // the layer's output is non-constant exactly in its computed tiles: pixel rows 2 ty, 2 ty + 1 = the tile row, every bit twice
-    if (row < TH && half == 0) {
-      const u64 t0 = tmb[row][0], t1 = tmb[row][1];
-      const u64 p0 = double_bits((unsigned)t0), p1 = double_bits((unsigned)(t0 >> 32)), p2 = double_bits((unsigned)t1);
-      nc[2 * row][0] = p0; nc[2 * row][1] = p1; nc[2 * row][2] = p2;
-      nc[2 * row + 1][0] = p0; nc[2 * row + 1][1] = p1; nc[2 * row + 1][2] = p2;
-    }
-    __syncthreads();
   }
 }
 
-// batch > 1: number the lists (grid = (batch, n_layers)); an image's entries follow those of the earlier images
+// batch > 1: number the lists (grid = (batch, n_slots)); an image's entries follow those of the earlier images
 __global__ __launch_bounds__(NT) void bev_tile_list_kernel(ActArgs A) {
   __shared__ int s_scan[NT / 64];
-  const int b = blockIdx.x, l = blockIdx.y, TH = A.th, TW = A.tw, tiles = TH * TW;
+  const int b = blockIdx.x, l = blockIdx.y, TH = A.slot_th[l < MAX_SLOTS ? l : 0], TW = A.slot_tw[l < MAX_SLOTS ? l : 0], tiles = TH * TW;
   int base = 0;
   for (int q = 0; q < b; ++q) base += A.counts[l * A.batch + q];
   const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
-  const u64 mine = row < TH ? A.tile_mask[(((size_t)l * A.batch + b) * TH + row) * 2 + half] : 0ull;
+  const u64 mine = row < TH ? A.tile_mask[(((size_t)l * A.batch + b) * A.mask_th + row) * 2 + half] : 0ull;
   int total;
   const int at = base + sessd_block_exscan<NT>(__popcll(mine), s_scan, &total);
   if (row < TH) emit_word(mine, b * tiles + row * TW + 64 * half, at, A.tile_list + (size_t)l * A.list_cap, A.list_cap);
@@ -143,28 +199,44 @@ __global__ __launch_bounds__(NT) void bev_tile_list_kernel(ActArgs A) {
 
 struct FillJobs {
   int njobs;
-  sessd_fill_tiles_job_t J[MAX_LAYERS];
+  int blk_off[MAX_SLOTS + 1];   // first block of every job (a job = tile-pair chunks of 256 x cout x batch blocks)
+  sessd_fill_tiles_job_t J[MAX_SLOTS];
 };
 
-// grid = (tile chunks of 256, cout, batch * njobs): thread = one 2x2 tile of one channel; adjacent threads = adjacent tiles of a row
-__global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, int batch, int h, int w) {
-  const int th = h >> 1, tw = w >> 1, tiles = th * tw;
-  const int j = blockIdx.z / batch, b = blockIdx.z - j * batch;
-  // static-index copy (a dynamically indexed kernel-argument array goes to scratch)
-  sessd_fill_tiles_job_t J = Q.J[0];
+// One block = 256 threads = 256 pairs of adjacent tiles (2 tx, 2 tx + 1) of one (job, image, channel): a thread writes up to two
+// 16-byte rows-of-four-pixels twice. Only blocks that have tiles are launched.
+__global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, int batch) {
+  int j = 0;
 #pragma unroll
-  for (int q = 1; q < MAX_LAYERS; ++q)
-    if (q == j) J = Q.J[q];
-  const int co = blockIdx.y;
-  if (co >= J.cout) return;
-  const int t = blockIdx.x * 256 + threadIdx.x;
-  if (t >= tiles) return;
-  const int ty = t / tw, tx = t - ty * tw;
-  if ((J.tile_mask[((size_t)b * th + ty) * 2 + (tx >> 6)] >> (tx & 63)) & 1ull) return;
+  for (int q = 1; q < MAX_SLOTS; ++q)
+    if (q < Q.njobs && (int)blockIdx.x >= Q.blk_off[q]) j = q;
+  // static-index copies (a dynamically indexed kernel-argument array goes to scratch)
+  sessd_fill_tiles_job_t J = Q.J[0];
+  int off = Q.blk_off[0];
+#pragma unroll
+  for (int q = 1; q < MAX_SLOTS; ++q)
+    if (q == j) { J = Q.J[q]; off = Q.blk_off[q]; }
+  const int h = J.h, w = J.w, th = h >> 1, tw = w >> 1, pairs = th * (tw >> 1);
+  const int chunks = sessd_divup(pairs, 256);
+  int r = (int)blockIdx.x - off;
+  const int chunk = r % chunks; r /= chunks;
+  const int co = r % J.cout, b = r / J.cout;
+  const int p = chunk * 256 + threadIdx.x;
+  if (p >= pairs) return;
+  const int ty = p / (tw >> 1), tx = 2 * (p - ty * (tw >> 1));
+  const u64 word = J.tile_mask[((size_t)b * J.mask_th + ty) * 2 + (tx >> 6)];   // tx even: both bits in one word
+  const bool on0 = (word >> (tx & 63)) & 1ull, on1 = (word >> ((tx & 63) + 1)) & 1ull;
+  if (on0 && on1) return;
   const float c = J.value[co];
   float* o = J.out + (((size_t)b * J.cout + co) * h + 2 * ty) * w + 2 * tx;
-  *reinterpret_cast<float2*>(o) = make_float2(c, c);
-  *reinterpret_cast<float2*>(o + w) = make_float2(c, c);
+  if (!on0 && !on1) {
+    *reinterpret_cast<float4*>(o) = make_float4(c, c, c, c);
+    *reinterpret_cast<float4*>(o + w) = make_float4(c, c, c, c);
+  } else {
+    float* q = on0 ? o + 2 : o;
+    *reinterpret_cast<float2*>(q) = make_float2(c, c);
+    *reinterpret_cast<float2*>(q + w) = make_float2(c, c);
+  }
 }
 
 }  // namespace
@@ -172,50 +244,75 @@ __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, in
 extern "C" {
 
 // bytes of the `counts` scratch of sessd_bev_tile_activity
-size_t sessd_bev_tile_activity_workspace_bytes(int batch, int n_layers) {
-  if (batch < 1 || n_layers < 1 || n_layers > MAX_LAYERS) return 0;
-  return sessd_align((size_t)batch * n_layers * sizeof(int), 256);
+size_t sessd_bev_tile_activity_workspace_bytes(int batch, int n_slots) {
+  if (batch < 1 || n_slots < 1 || n_slots > MAX_SLOTS) return 0;
+  return sessd_align((size_t)batch * n_slots * sizeof(int), 256);
 }
 
-// Active 2x2-output tiles of the first `n_layers` 3x3 stride-1 layers over an (h, w) map that is zero except at the pixels
-// (y, x) of `indices` rows (image, z, y, x) -- the last sparse level of SpMiddleFHD, count on the device.
-//   tile_mask [n_layers][batch][h/2][2] 64-bit words (bit tx of a row's 128 bits = tile (ty, tx) is computed), tile_list [n_layers][list_cap] entries image * (h/2 * w/2) + tile in ascending
-//   order, n_list [n_layers]; list_cap >= batch * h/2 * w/2 never truncates.
-int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_cap, int batch, int h, int w, int n_layers,
-                            uint64_t* tile_mask, int32_t* tile_list, int32_t* n_list, int list_cap, void* workspace,
+// Computed 2x2-output tiles of a chain of 3x3 layers over an (h, w) map that is zero except at the pixels (y, x) of `indices` rows
+// (image, z, y, x) -- the last sparse level of SpMiddleFHD, count on the device. steps[n_steps] (HOST ints): 0 = a 3x3 stride-1
+// layer (conv + BatchNorm + ReLU), which takes the next slot; 1 = a 3x3 stride-2 padding-1 layer computed over the whole map (the
+// resolution halves). Per slot s (n_slots of them, <= 6):
+//   tile_mask [n_slots][batch][h/2][2] 64-bit words: bit tx of row ty's 128 bits = tile (ty, tx) of that layer is computed (rows
+//   beyond the layer's own h_s / 2 unused), tile_list [n_slots][list_cap] entries image * tiles_s + tile in ascending order,
+//   n_list [n_slots]; list_cap >= batch * h/2 * w/2 never truncates.
+int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_cap, int batch, int h, int w, const int32_t* steps,
+                            int n_steps, uint64_t* tile_mask, int32_t* tile_list, int32_t* n_list, int list_cap, void* workspace,
                             size_t workspace_bytes, hipStream_t stream) {
-  if (!indices || !n_dev || n_cap < 1 || batch < 1 || h < 2 || w < 2 || (h & 1) || (w & 1) || n_layers < 1 ||
-      n_layers > MAX_LAYERS || !tile_mask || !tile_list || !n_list || list_cap < 1 || h > MAX_H || w > MAX_W)
+  if (!indices || !n_dev || n_cap < 1 || batch < 1 || h < 2 || w < 2 || !steps || n_steps < 1 || n_steps > MAX_STEPS || !tile_mask ||
+      !tile_list || !n_list || list_cap < 1 || h > MAX_H || w > MAX_W)
     return SESSD_EINVAL;
-  if (batch > 1 && (!workspace || workspace_bytes < sessd_bev_tile_activity_workspace_bytes(batch, n_layers))) return SESSD_EWORKSPACE;
   ActArgs A;
-  A.indices = indices; A.n_dev = n_dev; A.n_cap = n_cap; A.batch = batch; A.h = h; A.w = w; A.th = h / 2; A.tw = w / 2;
-  A.n_layers = n_layers; A.list_cap = list_cap; A.tile_mask = (u64*)tile_mask; A.tile_list = tile_list; A.n_list = n_list;
-  A.counts = (int*)workspace;
+  A.indices = indices; A.n_dev = n_dev; A.n_cap = n_cap; A.batch = batch; A.h = h; A.w = w;
+  A.n_steps = n_steps; A.n_slots = 0; A.list_cap = list_cap; A.mask_th = h / 2;
+  int ch = h, cw = w;
+  for (int s = 0; s < MAX_STEPS; ++s) A.kind[s] = 0;
+  for (int s = 0; s < MAX_SLOTS; ++s) A.slot_th[s] = A.slot_tw[s] = 0;
+  for (int s = 0; s < n_steps; ++s) {
+    if ((ch & 1) || (cw & 1) || ch < 2 || cw < 2) return SESSD_EINVAL;   // every step works on 2x2 tiles / halves the map
+    A.kind[s] = steps[s];
+    if (steps[s] == 0) {
+      if (A.n_slots == MAX_SLOTS) return SESSD_EINVAL;
+      A.slot_th[A.n_slots] = ch / 2; A.slot_tw[A.n_slots] = cw / 2;
+      ++A.n_slots;
+    } else if (steps[s] == 1) {
+      ch /= 2; cw /= 2;
+    } else {
+      return SESSD_EINVAL;
+    }
+  }
+  if (A.n_slots < 1) return SESSD_EINVAL;
+  if (batch > 1 && (!workspace || workspace_bytes < sessd_bev_tile_activity_workspace_bytes(batch, A.n_slots))) return SESSD_EWORKSPACE;
+  A.tile_mask = (u64*)tile_mask; A.tile_list = tile_list; A.n_list = n_list; A.counts = (int*)workspace;
   SESSD_LAUNCH(bev_tile_activity_kernel, dim3(batch), dim3(NT), 0, stream, A);
   SESSD_CHECK_LAUNCH();
   if (batch > 1) {
-    SESSD_LAUNCH(bev_tile_list_kernel, dim3(batch, n_layers), dim3(NT), 0, stream, A);
+    SESSD_LAUNCH(bev_tile_list_kernel, dim3(batch, A.n_slots), dim3(NT), 0, stream, A);
     SESSD_CHECK_LAUNCH();
   }
   return SESSD_OK;
 }
 
-// out[b][co][tile pixels] = value[co] for every tile with tile_mask[b][tile] == 0, for up to 4 (out, value, tile_mask, cout) jobs
-// over (batch, ., h, w) maps in one launch.
-int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, int h, int w, hipStream_t stream) {
-  if (!jobs || n_jobs < 1 || n_jobs > MAX_LAYERS || batch < 1 || h < 2 || w < 2 || (h & 1) || (w & 1)) return SESSD_EINVAL;
+// out[b][co][tile pixels] = value[co] for every tile of job j whose bit in tile_mask is 0, for up to 6 jobs (out (batch, cout, h, w),
+// value[cout], tile_mask (batch, mask_th, 2) words, cout, h, w, mask_th) in one launch.
+int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, hipStream_t stream) {
+  if (!jobs || n_jobs < 1 || n_jobs > MAX_SLOTS || batch < 1) return SESSD_EINVAL;
   FillJobs Q;
   Q.njobs = n_jobs;
-  int cmax = 0;
+  int blk = 0;
   for (int j = 0; j < n_jobs; ++j) {
-    if (!jobs[j].out || !jobs[j].value || !jobs[j].tile_mask || jobs[j].cout < 1) return SESSD_EINVAL;
-    Q.J[j] = jobs[j];
-    cmax = jobs[j].cout > cmax ? jobs[j].cout : cmax;
+    const sessd_fill_tiles_job_t& S = jobs[j];
+    // (w % 4 == 0: a thread owns two adjacent tiles = 16-byte aligned rows of four pixels)
+    if (!S.out || !S.value || !S.tile_mask || S.cout < 1 || S.h < 2 || S.w < 4 || (S.h & 1) || (S.w & 3) || S.mask_th < S.h / 2 ||
+        S.w / 2 > 128)
+      return SESSD_EINVAL;
+    Q.J[j] = S;
+    Q.blk_off[j] = blk;
+    blk += sessd_divup((S.h / 2) * (S.w / 4), 256) * S.cout * batch;
   }
-  for (int j = n_jobs; j < MAX_LAYERS; ++j) Q.J[j] = jobs[0];
-  const int tiles = (h / 2) * (w / 2);
-  SESSD_LAUNCH(fill_inactive_tiles_kernel, dim3(sessd_divup(tiles, 256), cmax, batch * n_jobs), dim3(256), 0, stream, Q, batch, h, w);
+  for (int j = n_jobs; j < MAX_SLOTS; ++j) { Q.J[j] = jobs[0]; Q.blk_off[j] = blk; }
+  Q.blk_off[MAX_SLOTS] = blk;
+  SESSD_LAUNCH(fill_inactive_tiles_kernel, dim3(blk), dim3(256), 0, stream, Q, batch);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }

@@ -32,7 +32,7 @@ class RulebookJob(C.Structure):
 
 class FillTilesJob(C.Structure):
     """sessd_fill_tiles_job_t (include/sessd_hip_types.h)"""
-    _fields_ = [("out", vp), ("value", vp), ("tile_mask", vp), ("cout", i32), ("pad_", i32)]
+    _fields_ = [("out", vp), ("value", vp), ("tile_mask", vp), ("cout", i32), ("h", i32), ("w", i32), ("mask_th", i32)]
 
 
 class HeadLossNet(C.Structure):
@@ -93,8 +93,8 @@ SIGNATURES = {
     "sessd_conv3x3_winograd_sk": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, sz, i32, i32, vp]),
     "sessd_conv3x3_winograd_sk_active": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, vp, sz, i32, i32, vp]),
     "sessd_bev_tile_activity_workspace_bytes": (sz, [i32, i32]),
-    "sessd_bev_tile_activity": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, vp, sz, vp]),
-    "sessd_fill_inactive_tiles": (i32, [vp, i32, i32, i32, i32, vp]),
+    "sessd_bev_tile_activity": (i32, [vp, vp, i32, i32, i32, i32, vp, i32, vp, vp, vp, i32, vp, sz, vp]),
+    "sessd_fill_inactive_tiles": (i32, [vp, i32, i32, vp]),
     "sessd_conv2d_sk_workspace_bytes": (sz, [i32, i32, i32, i32, i32, i32]),
     "sessd_conv2d_sk_pack": (i32, [vp, i64, i64, vp, i32, i32, i32, vp, vp]),
     "sessd_conv2d_sk": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp,

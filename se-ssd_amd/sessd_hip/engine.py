@@ -74,15 +74,18 @@ class DensePlan:
 
         b0, b1 = neck.bottom_up_block_0, neck.bottom_up_block_1
         self.b0 = [cbr(b0, 1, 2), cbr(b0, 4, 5), cbr(b0, 7, 8)]  # index 0 is ZeroPad2d(1) + unpadded conv == pad 1
-        # What the three layers of block 0 compute where their input is CONSTANT (the BEV map is zero outside the sparse sites):
-        # c_0 = 0, c_{l+1}[co] = relu(scale * sum_ci c_l[ci] * sum_k W[co][ci][k] + shift), float64 over the folded weights. The
-        # engine writes c_{l+1} into the tiles of layer l it does not compute (active-tile mode, csrc/dense_active.hip).
+        # What the first six layers compute where their input is CONSTANT (the BEV map is zero outside the sparse sites):
+        # c_0 = 0, c_{l+1}[co] = relu(scale * sum_ci c_l[ci] * sum_k W[co][ci][k] + shift), float64 over the folded weights (the
+        # stride-2 layer that opens block 1 included: away from the top / left border its window of a constant map is constant).
+        # The engine writes them into the tiles it does not compute (active-tile mode, csrc/dense_active.hip): slots 0-2 = block 0,
+        # 3-4 = the second and third layer of block 1.
         c = torch.zeros(b0[1].weight.shape[1], dtype=torch.float64)
-        self.b0_const = []
-        for (ci, bi) in ((1, 2), (4, 5), (7, 8)):
-            s_, t_ = fold_bn(b0[bi])
-            c = torch.relu(s_.double().cpu() * (b0[ci].weight.detach().double().cpu().sum((2, 3)) @ c) + t_.double().cpu())
-            self.b0_const.append(c.float().to(device).contiguous())
+        chain = []
+        for seq, ci, bi in ((b0, 1, 2), (b0, 4, 5), (b0, 7, 8), (b1, 0, 1), (b1, 3, 4), (b1, 6, 7)):
+            s_, t_ = fold_bn(seq[bi])
+            c = torch.relu(s_.double().cpu() * (seq[ci].weight.detach().double().cpu().sum((2, 3)) @ c) + t_.double().cpu())
+            chain.append(c.float().to(device).contiguous())
+        self.act_const = [chain[0], chain[1], chain[2], chain[4], chain[5]]
         self.b1 = [cbr(b1, 0, 1), cbr(b1, 3, 4), cbr(b1, 6, 7)]
         self.trans_0 = cbr(neck.trans_0, 0, 1)
         self.trans_1 = cbr(neck.trans_1, 0, 1)
@@ -261,13 +264,17 @@ class InferenceEngine:
         # critical path, and with two engines the four streams serialise against each other.
         self.fork_front = False
         self.side_stream = torch.cuda.Stream(device=dev)
-        # Active-tile mode of bottom_up_block_0 (round 4): the BEV map is zero outside the last sparse level's sites, so its three
-        # layers are computed only in the 2x2-output tiles whose input patch is not constant (18 / 29 / 39 % of the tiles on a
-        # 20 k-point scan) and the rest is filled with the layer's constant. Applies to the layers the autotune put on the
-        # stream-K Winograd kernel (tile_cfg 22 / 23).
+        # Active-tile mode of bottom_up_block_0 and of the stride-1 layers of bottom_up_block_1 (round 4): the BEV map is zero
+        # outside the last sparse level's sites, so these layers are computed only in the 2x2-output tiles whose input patch is
+        # not constant (14 / 26 / 36 % of the tiles of block 0, 54 / 68 % of block 1's on a 20 k-point scan) and the rest is filled
+        # with the layer's constant. ACTIVE_SLOTS: slot -> (layer name, layer, input buffer, output buffer).
         self.active_tiles = bool(active_tiles)
-        self.active_cfg = {}   # layer of block 0 -> (stream-K shape, min_rounds), chosen by autotune(); empty = dense launches
-        self.ta = ops.TileActivity(B, H, W, 3, dev) if self.active_tiles and H * W <= 40960 and H % 2 == 0 and W % 2 == 0 else None
+        self.active_cfg = {}   # slot -> (stream-K shape, min_rounds), chosen by autotune(); empty = dense launches
+        ok = self.active_tiles and H <= 256 and W <= 192 and H % 4 == 0 and W % 4 == 0
+        self.ta = ops.TileActivity(B, H, W, [0, 0, 0, 1, 0, 0], dev) if ok else None
+        self.ACTIVE_SLOTS = {0: ("b0.0", self.dn.b0[0], self.bev, self.t["a"]), 1: ("b0.1", self.dn.b0[1], self.t["a"], self.t["b"]),
+                             2: ("b0.2", self.dn.b0[2], self.t["b"], self.t["x0"]), 3: ("b1.1", self.dn.b1[1], self.h["a"], self.h["b"]),
+                             4: ("b1.2", self.dn.b1[2], self.h["b"], self.h["x1"])}
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -354,7 +361,7 @@ class InferenceEngine:
         return getattr(self, key)
 
     def _active_layers(self):
-        """indices of the block-0 layers that run in active-tile mode in this configuration"""
+        """slots (ACTIVE_SLOTS) of the layers that run in active-tile mode in this configuration"""
         if self.ta is None or self._tuning is not None or self.sk_ws is None:
             return []
         return sorted(self.active_cfg)
@@ -507,43 +514,43 @@ class InferenceEngine:
             e1.record()
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / reps
-        L4, d, t = self.levels[-1], self.dn, self.t
-        bufs, ins = (t["a"], t["b"], t["x0"]), (self.bev, t["a"], t["b"])
+        L4, d = self.levels[-1], self.dn
         self.ta.run(L4["indices"], L4["n"], L4["cap"])
         pick, gain = {}, 0.0
-        for l in range(3):
-            pc, scale, shift = d.b0[l]
+        for l, (name, (pc, scale, shift), x_in, x_out) in self.ACTIVE_SLOTS.items():
             best = (None, 1e30)
             for shape in (0, 1):
                 if pc.upk_sk(shape) is None:
                     continue
-                need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(self.B, self.H, self.W, pc.cout, shape, 0))
+                need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(self.B, x_in.shape[2], x_in.shape[3], pc.cout, shape, 0))
                 if self.sk_ws is None or self.sk_ws.numel() < need:
                     self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
                 for mr in (1, 2, 4):
-                    tt = timed(lambda: ops.conv2d_winograd_sk_active(ins[l], pc.upk_sk(shape), pc.cout, scale, shift, True, bufs[l], shape,
+                    tt = timed(lambda: ops.conv2d_winograd_sk_active(x_in, pc.upk_sk(shape), pc.cout, scale, shift, True, x_out, shape,
                                                                      self.sk_ws, self.ta.tile_list[l], self.ta.n_list[l:l + 1],
                                                                      workgroups=self.sk_workgroups, min_rounds=mr))
                     if tt < best[1]:
                         best = ((shape, mr), tt)
-            dense_t = self.tune_report.get("b0.%d" % l, (None, 0.0))[1]
+            dense_t = self.tune_report.get(name, (None, 0.0))[1]
             if best[0] is not None and best[1] < dense_t:
                 pick[l] = best
                 gain += dense_t - best[1]
+        sl = sorted(pick)
         over = timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]),
-                              self.ta.fill([bufs[l] for l in sorted(pick)], [d.b0_const[l] for l in sorted(pick)], layers=sorted(pick)))) if pick else 0.0
+                              self.ta.fill([self.ACTIVE_SLOTS[l][3] for l in sl], [d.act_const[l] for l in sl], layers=sl))) if pick else 0.0
         if pick and gain > over:
             self.active_cfg = {l: pick[l][0] for l in pick}
         # (choice, gain ms per frame over the dense launches, ms of the activity + fill launches, per-layer ms): a tuple like the others
-        self.tune_report["active_tiles"] = (dict(self.active_cfg), gain - over, over, {l: pick[l][1] for l in pick})
+        self.tune_report["active_tiles"] = ({self.ACTIVE_SLOTS[l][0]: v for l, v in self.active_cfg.items()}, gain - over, over,
+                                            {self.ACTIVE_SLOTS[l][0]: pick[l][1] for l in pick})
 
     def active_tile_fractions(self):
         """name -> share of the 2x2-output tiles the layer computed in the LAST enqueued batch (layers in active-tile mode only)"""
-        if not self._active_layers():
+        act = self._active_layers()
+        if not act:
             return {}
         n = self.ta.n_list.cpu().numpy()
-        tiles = self.B * (self.H // 2) * (self.W // 2)
-        return {"b0.%d" % l: float(n[l]) / tiles for l in self._active_layers()}
+        return {self.ACTIVE_SLOTS[l][0]: float(n[l]) / (self.B * (self.ta.dims[l][0] // 2) * (self.ta.dims[l][1] // 2)) for l in act}
 
     # ------------------------------------------------------------------ the frame
     def enqueue(self):
@@ -641,8 +648,7 @@ class InferenceEngine:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             self.ta.run(L4["indices"], L4["n"], L4["cap"])
-            bufs = (t["a"], t["b"], t["x0"])
-            self.ta.fill([bufs[l] for l in act], [d.b0_const[l] for l in act], layers=act)
+            self.ta.fill([self.ACTIVE_SLOTS[l][3] for l in act], [d.act_const[l] for l in act], layers=act)
             if self._kmarks is not None:
                 e1.record()
                 self._kmarks.append(("tile_activity+fill", e0, e1))
@@ -650,8 +656,8 @@ class InferenceEngine:
         x = self._conv(x, d.b0[1], t["b"], name="b0.1", active=1 if 1 in act else None)
         x0 = self._conv(x, d.b0[2], t["x0"], name="b0.2", active=2 if 2 in act else None)
         y = self._conv(x0, d.b1[0], h["a"], name="b1.0")
-        y = self._conv(y, d.b1[1], h["b"], name="b1.1")
-        x1 = self._conv(y, d.b1[2], h["x1"], name="b1.2")
+        y = self._conv(y, d.b1[1], h["b"], name="b1.1", active=3 if 3 in act else None)
+        x1 = self._conv(y, d.b1[2], h["x1"], name="b1.2", active=4 if 4 in act else None)
         tr0 = self._conv(x0, d.trans_0, t["tr0"], name="trans_0")
         tr1 = self._conv(x1, d.trans_1, h["tr1"], name="trans_1")
         cd = self.tile_cfg.get("deconv_0")

@@ -1382,34 +1382,46 @@ def conv2d_winograd_sk_active(x, upk, cout, scale, shift, relu, out, shape, work
 
 
 class TileActivity:
-    """Buffers + launches of sessd_bev_tile_activity / sessd_fill_inactive_tiles for `n_layers` 3x3 stride-1 layers over
-    (batch, ., H, W) maps: tile_mask (n_layers, batch, H/2, 2) int64 -- bit tx of a row's 128 bits = tile (ty, tx) is computed --,
-    tile_list (n_layers, batch * H/2 * W/2) int32, n_list (n_layers,) int32."""
+    """Buffers + launches of sessd_bev_tile_activity / sessd_fill_inactive_tiles for a chain of 3x3 layers over (batch, ., H, W) maps.
+    steps: 0 = a 3x3 stride-1 layer (takes the next slot), 1 = a 3x3 stride-2 layer computed everywhere (the map halves);
+    an int n means n stride-1 layers. Per slot s: dims[s] = (h, w) of the layer, tile_mask[s] (batch, H/2, 2) int64 -- bit tx of a
+    row's 128 bits = tile (ty, tx) is computed; rows beyond h/2 unused --, tile_list[s] (batch * H/2 * W/2,) int32, n_list[s]."""
 
-    def __init__(self, batch, H, W, n_layers, device):
-        self.batch, self.H, self.W, self.n_layers = int(batch), int(H), int(W), int(n_layers)
+    def __init__(self, batch, H, W, steps, device):
+        import ctypes
+        steps = [0] * steps if isinstance(steps, int) else [int(v) for v in steps]
+        self.batch, self.H, self.W, self.steps = int(batch), int(H), int(W), steps
+        self.dims, h, w = [], H, W
+        for k in steps:
+            if k == 0:
+                self.dims.append((h, w))
+            else:
+                h, w = h // 2, w // 2
+        self.n_slots = self.n_layers = len(self.dims)
+        self._steps = (ctypes.c_int32 * len(steps))(*steps)
         tiles = (H // 2) * (W // 2)
-        self.tile_mask = torch.zeros((n_layers, batch, H // 2, 2), dtype=torch.int64, device=device)
-        self.tile_list = torch.zeros((n_layers, batch * tiles), dtype=torch.int32, device=device)
-        self.n_list = torch.zeros(n_layers, dtype=torch.int32, device=device)
-        self.ws = torch.zeros(max(256, int(lib.sessd_bev_tile_activity_workspace_bytes(batch, n_layers))), dtype=torch.uint8, device=device)
+        self.tile_mask = torch.zeros((self.n_slots, batch, H // 2, 2), dtype=torch.int64, device=device)
+        self.tile_list = torch.zeros((self.n_slots, batch * tiles), dtype=torch.int32, device=device)
+        self.n_list = torch.zeros(self.n_slots, dtype=torch.int32, device=device)
+        self.ws = torch.zeros(max(256, int(lib.sessd_bev_tile_activity_workspace_bytes(batch, self.n_slots))), dtype=torch.uint8, device=device)
         self._jobs = None
 
     def run(self, indices, n_dev, n_cap):
         _req(indices, torch.int32, "indices"); _req(n_dev, torch.int32, "n_dev")
-        check(lib.sessd_bev_tile_activity(indices.data_ptr(), n_dev.data_ptr(), int(n_cap), self.batch, self.H, self.W, self.n_layers,
-                                          self.tile_mask.data_ptr(), self.tile_list.data_ptr(), self.n_list.data_ptr(),
+        check(lib.sessd_bev_tile_activity(indices.data_ptr(), n_dev.data_ptr(), int(n_cap), self.batch, self.H, self.W, self._steps,
+                                          len(self.steps), self.tile_mask.data_ptr(), self.tile_list.data_ptr(), self.n_list.data_ptr(),
                                           self.tile_list.shape[1], self.ws.data_ptr(), self.ws.numel(), _stream()), "bev_tile_activity")
 
-    def mask_bool(self, layer):
-        """(batch, H/2, W/2) bool of the layer's computed tiles (tests / reports)"""
+    def mask_bool(self, slot):
+        """(batch, h/2, w/2) bool of the slot's computed tiles (tests / reports)"""
         import numpy as np
-        m = self.tile_mask[layer].cpu().numpy().view("uint64")
-        tx = np.arange(self.W // 2)
+        h, w = self.dims[slot]
+        m = self.tile_mask[slot].cpu().numpy().view("uint64")[:, :h // 2]
+        tx = np.arange(w // 2)
         return torch.from_numpy(((m[:, :, tx >> 6] >> (tx & 63).astype("uint64")) & np.uint64(1)).astype(bool))
 
     def fill(self, outs, values, layers=None):
-        """outs[i] (batch, cout, H, W) <- values[i][cout] in the tiles layer layers[i] (default i) does not compute (one launch)."""
+        """outs[i] (batch, cout, h, w) <- values[i][cout] in the tiles slot layers[i] (default i) does not compute (one launch)."""
         from ._lib import FillTilesJob
         layers = list(range(len(outs))) if layers is None else list(layers)
         key = tuple((o.data_ptr(), v.data_ptr(), l) for o, v, l in zip(outs, values, layers))
@@ -1417,10 +1429,12 @@ class TileActivity:
             arr = (FillTilesJob * len(outs))()
             for i, (o, v, l) in enumerate(zip(outs, values, layers)):
                 _req(o, torch.float32, "out"); _req(v, torch.float32, "value")
+                assert tuple(o.shape[2:]) == tuple(self.dims[l]) and o.shape[0] == self.batch
                 arr[i].out, arr[i].value, arr[i].tile_mask, arr[i].cout = o.data_ptr(), v.data_ptr(), self.tile_mask[l].data_ptr(), o.shape[1]
+                arr[i].h, arr[i].w, arr[i].mask_th = o.shape[2], o.shape[3], self.H // 2
             self._jobs = (key, arr)
         arr = self._jobs[1]
-        check(lib.sessd_fill_inactive_tiles(arr, len(outs), self.batch, self.H, self.W, _stream()), "fill_inactive_tiles")
+        check(lib.sessd_fill_inactive_tiles(arr, len(outs), self.batch, _stream()), "fill_inactive_tiles")
 
 
 def pack_winograd(weight, adjoint=False):

@@ -27,50 +27,69 @@ def _sites(seed, batch, n):
     return np.concatenate(rows).astype(np.int32)
 
 
-def _masks_numpy(idx, batch, n_layers):
-    """The rule of csrc/dense_active.hip restated: tile active iff its 4x4 input patch touches a non-constant pixel (+ the border
-    ring from the second layer on); a layer's output is non-constant exactly in its active tiles."""
+def _masks_numpy(idx, batch, steps):
+    """The rule of csrc/dense_active.hip restated. Step 0 (3x3 stride-1 layer): tile computed iff its 4x4 input patch touches a
+    non-constant pixel (+ the border ring once the input constant is not zero, i.e. from the second layer on); the layer's output
+    is non-constant exactly in its computed tiles. Step 1 (3x3 stride-2 layer, padding 1, computed everywhere): output pixel
+    non-constant iff its 3x3 window is (+ the top row / left column, where the padding enters). Returns per image the list of the
+    layers' tile masks (flattened)."""
+    steps = [0] * steps if isinstance(steps, int) else steps
     out = []
     for b in range(batch):
         nc = np.zeros((H, W), bool)
         s = idx[idx[:, 0] == b]
         nc[s[:, 2], s[:, 3]] = True
-        per = []
-        for l in range(n_layers):
+        per, zero_input = [], True
+        for k in steps:
+            h, w = nc.shape
             p = np.pad(nc, 1)
-            tm = np.zeros((H // 2, W // 2), bool)
-            for dy in range(4):
-                for dx in range(4):
-                    tm |= p[dy:dy + H:2, dx:dx + W:2][:H // 2, :W // 2]
-            if l > 0:
-                tm[0, :] = tm[-1, :] = True
-                tm[:, 0] = tm[:, -1] = True
-            per.append(tm.reshape(-1).copy())
-            nc = tm.repeat(2, 0).repeat(2, 1)
+            if k == 0:
+                tm = np.zeros((h // 2, w // 2), bool)
+                for dy in range(4):
+                    for dx in range(4):
+                        tm |= p[dy:dy + h:2, dx:dx + w:2][:h // 2, :w // 2]
+                if not zero_input:
+                    tm[0, :] = tm[-1, :] = True
+                    tm[:, 0] = tm[:, -1] = True
+                per.append(tm.reshape(-1).copy())
+                nc = tm.repeat(2, 0).repeat(2, 1)
+                zero_input = False
+            else:
+                o = np.zeros((h // 2, w // 2), bool)
+                for dy in range(3):
+                    for dx in range(3):
+                        o |= p[dy:dy + h:2, dx:dx + w:2][:h // 2, :w // 2]
+                if not zero_input:
+                    o[0, :] = True
+                    o[:, 0] = True
+                nc = o
         out.append(per)
     return out
 
 
-@pytest.mark.parametrize("batch", [1, 3])
-def test_tile_masks_and_lists(dev, batch):
-    idx = _sites(1, batch, 1600)
-    ta = ops.TileActivity(batch, H, W, 3, dev)
+@pytest.mark.parametrize("batch,steps", [(1, 3), (3, 3), (1, [0, 0, 0, 1, 0, 0]), (2, [0, 0, 0, 1, 0, 0])])
+def test_tile_masks_and_lists(dev, batch, steps):
+    idx = _sites(1, batch, 1600 if isinstance(steps, int) else 500)
+    ta = ops.TileActivity(batch, H, W, steps, dev)
     n = torch.tensor([len(idx)], dtype=torch.int32, device=dev)
     cap = len(idx) + 100
     buf = torch.zeros((cap, 4), dtype=torch.int32, device=dev)
     buf[:len(idx)] = torch.from_numpy(idx).to(dev)
     ta.run(buf, n, cap)
-    want = _masks_numpy(idx, batch, 3)
-    tiles = (H // 2) * (W // 2)
+    want = _masks_numpy(idx, batch, steps)
     tl, nl = ta.tile_list.cpu().numpy(), ta.n_list.cpu().numpy()
-    for l in range(3):
+    for l in range(ta.n_slots):
+        h, w = ta.dims[l]
+        tiles = (h // 2) * (w // 2)
         ref = np.concatenate([np.nonzero(want[b][l])[0] + b * tiles for b in range(batch)])
         tm = ta.mask_bool(l).numpy().reshape(batch, -1)
         for b in range(batch):
             assert np.array_equal(tm[b], want[b][l]), (l, b)
         assert nl[l] == len(ref)
         assert np.array_equal(tl[l, :nl[l]], ref)     # ascending (image, tile): deterministic order
-    assert 0.05 < nl[0] / (batch * tiles) < 0.6 and nl[0] < nl[1] < nl[2]
+    assert 0.05 < nl[0] / (batch * (H // 2) * (W // 2)) < 0.6 and nl[0] < nl[1] < nl[2]
+    if ta.n_slots == 5:
+        assert ta.dims[3] == (H // 2, W // 2) and nl[3] < nl[4] <= batch * (H // 4) * (W // 4)
 
 
 def _layer(seed, c):
@@ -130,6 +149,52 @@ def test_active_chain_equals_the_dense_layers(dev, batch, shape, min_rounds):
     # the workspace counters are left zero (the next launch relies on it)
     units = batch * ((H // 2) * (W // 2) + 31) // 32 * (C // (128 if shape == 0 else 64))
     assert int(ws[:units * 4].view(torch.int32).abs().sum()) == 0
+
+
+def test_active_chain_through_the_stride_2_layer(dev):
+    """rpn_v1.py:135-160 as the engine runs it: three active layers at 200 x 176, the stride-2 layer over the whole map, two active
+    layers of 256 channels at 100 x 88 -- against the dense kernels, 2e-5 of each layer's largest value."""
+    batch, C0, C1 = 1, 128, 256
+    idx = _sites(21, batch, 400)
+    x = torch.zeros(batch, C0, H, W)
+    x[idx[:, 0], :, idx[:, 2], idx[:, 3]] = torch.randn(len(idx), C0, generator=torch.Generator().manual_seed(5))
+    x = x.to(dev)
+    g = torch.Generator().manual_seed(11)
+    def mk(ci, co):
+        return (torch.randn(co, ci, 3, 3, generator=g) / (3.0 * ci ** 0.5), 0.5 + torch.rand(co, generator=g), torch.randn(co, generator=g) * 0.3)
+    layers = [mk(C0, C0), mk(C0, C0), mk(C0, C0), mk(C0, C1), mk(C1, C1), mk(C1, C1)]
+    steps = [0, 0, 0, 1, 0, 0]
+    c = torch.zeros(C0, dtype=torch.float64)
+    consts = []
+    for w_, sc_, sh_ in layers:
+        c = torch.relu(sc_.double() * (w_.double().sum((2, 3)) @ c) + sh_.double())
+        consts.append(c.float().to(dev))
+    ta = ops.TileActivity(batch, H, W, steps, dev)
+    ta.run(torch.from_numpy(idx).to(dev), torch.tensor([len(idx)], dtype=torch.int32, device=dev), len(idx))
+    outs = [torch.full((batch, C0, H, W), float("nan"), device=dev) for _ in range(3)] + \
+           [torch.full((batch, C1, H // 2, W // 2), float("nan"), device=dev) for _ in range(2)]
+    ta.fill(outs, [consts[0], consts[1], consts[2], consts[4], consts[5]])
+    ws = torch.zeros(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(batch, H, W, C1, 1, 0)), dtype=torch.uint8, device=dev)
+    cur_a = cur_d = x
+    slot = 0
+    for li, (w_, sc_, sh_) in enumerate(layers):
+        sc, sh = sc_.to(dev), sh_.to(dev)
+        if li == 3:   # the stride-2 layer: dense on both sides
+            pc = ops.pack_conv2d(w_.to(dev), 2)
+            cur_a, cur_d = ops.conv2d(cur_a, pc, sc, sh, True), ops.conv2d(cur_d, pc, sc, sh, True)
+            continue
+        pc = ops.pack_conv2d(w_.to(dev))
+        dense = ops.conv2d(cur_d, pc, sc, sh, True, None, None, 23)
+        ops.conv2d_winograd_sk_active(cur_a, pc.upk_sk(1), pc.cout, sc, sh, True, outs[slot], 1, ws, ta.tile_list[slot], ta.n_list[slot:slot + 1])
+        got = outs[slot]
+        assert torch.isfinite(got).all(), "layer %d: a tile neither filled nor computed" % li
+        ref, err = float(dense.abs().max()), float((got - dense).abs().max())
+        assert err <= 2e-5 * ref, (li, err, ref)
+        cur_a, cur_d = got, dense
+        slot += 1
+    frac = [float(ta.n_list[s]) / (batch * (ta.dims[s][0] // 2) * (ta.dims[s][1] // 2)) for s in range(5)]
+    print("computed tile fractions", [round(f, 3) for f in frac])
+    assert frac[0] < frac[1] < frac[2] and frac[3] < frac[4] < 1.0
 
 
 def test_active_layer_is_repeatable(dev):
