@@ -507,10 +507,11 @@ int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int ci
  * whose 4x4 input patch holds no non-constant pixel (82 % / 71 % / 61 % of the tiles on a 20 k-point scan):
  *   sessd_bev_tile_activity     tile masks + ordered tile lists (entry image * tiles + tile) + device counts of a chain of 3x3 layers
  *                               given as HOST steps (0 = stride-1 layer taking the next of <= 6 slots, 1 = stride-2 layer computed
- *                               everywhere: rpn_v1.py:135-160 is {0, 0, 0, 1, 0, 0}), from the (image, z, y, x) rows of the last
- *                               sparse level
+ *                               everywhere, 2 = stride-2 layer that takes a slot itself -- the 2x2 tiles of ITS output with a
+ *                               non-constant pixel: rpn_v1.py:135-160 is {0, 0, 0, 2, 0, 0}), from the (image, z, y, x) rows of
+ *                               the last sparse level
  *   sessd_fill_inactive_tiles   out[b][co][tile] = value[co] (the layer's constant, computed by the host from the folded weights)
- *                               in the tiles nobody computes, up to 6 layers per launch
+ *                               in the tiles nobody computes, up to 8 layers per launch
  *   sessd_conv3x3_winograd_sk_active   sessd_conv3x3_winograd_sk over the listed tiles only (same packed U, same workspace; the
  *                               shares of the round list are sized on the device, workgroups beyond rounds / min_rounds exit)
  * Results equal the dense layer's to float32 rounding (tests/test_dense_active_gpu.py); replaces nothing in the reference -- it is
@@ -542,6 +543,18 @@ int sessd_conv2d_sk(const float* in, int batch, int cin, int hin, int win, int n
                     int cout, int hout, int wout, int out_mul, const int* out_py, const int* out_px, const float* scale,
                     const float* shift, int relu, const float* residual, void* workspace, size_t workspace_bytes, int workgroups,
                     sessd_stream_t stream);
+/* ACTIVE-TILE mode of that launch (the stride-2 conv that opens bottom_up_block_1 and the 1x1 trans_0 / trans_1 of the SSFA neck,
+ * rpn_v1.py:150-152,163-172, whose inputs are a per-channel constant away from the sparse sites): only the 2x2 tiles of the TILE
+ * SPACE listed in tile_list[0 .. min(*n_list, list_cap)) (entries image * (tile_h/2 * tile_w/2) + tile, count on the device:
+ * sessd_bev_tile_activity; a 1x1 layer takes the list of the layer that produced its input) are computed, the other output
+ * pixels are left alone (sessd_fill_inactive_tiles). Even tile_h, tile_w; the whole batch tensor is addressed through 32-bit
+ * offsets. Shares of the round list are at least min_rounds rounds; same packed weights and workspace as sessd_conv2d_sk. */
+int sessd_conv2d_sk_active(const float* in, int batch, int cin, int hin, int win, int nclass, const float* const* wpk,
+                           const int* ntaps, const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out,
+                           int cout, int hout, int wout, int out_mul, const int* out_py, const int* out_px, const float* scale,
+                           const float* shift, int relu, const float* residual, const int32_t* tile_list, const int32_t* n_list,
+                           int list_cap, int min_rounds, void* workspace, size_t workspace_bytes, int workgroups,
+                           sessd_stream_t stream);
 /* ConvTranspose2d(cin, cout, 3, stride 2, padding 1, output_padding 1) as ONE launch over its four output-parity
  * classes (py,px) = (0,0),(0,1),(1,0),(1,1) with 1,2,2,4 taps: wpk4[c] packed like above, taps_dy4/taps_dx4 are
  * 4 rows of 4 ints. input (B,cin,hin,win) -> output (B,cout,2*hin,2*win); cin % 8 == 0. */

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int NT = 1024;
 constexpr int MAX_H = 256, MAX_W = 192;   // one image's pixel rows as 3 x 64-bit words in LDS; a thread pair per tile row
-constexpr int MAX_SLOTS = 6, MAX_STEPS = 8;
+constexpr int MAX_SLOTS = 6, MAX_STEPS = 8, MAX_FILL_JOBS = 8;
 typedef unsigned long long u64;
 
 struct ActArgs {
@@ -35,7 +35,8 @@ struct ActArgs {
   const int* n_dev;
   int n_cap, batch, h, w;
   int n_steps, n_slots;
-  int kind[MAX_STEPS];        // 0: 3x3 stride-1 layer (takes the next slot), 1: 3x3 stride-2 transition (halves the map)
+  int kind[MAX_STEPS];        // 0: 3x3 stride-1 layer (takes the next slot), 1: 3x3 stride-2 transition (halves the map),
+                              // 2: the same transition, itself computed over a tile list (takes the next slot)
   int slot_th[MAX_SLOTS], slot_tw[MAX_SLOTS];
   int list_cap, mask_th;      // rows of a (slot, image) block of tile_mask = h / 2 (the first resolution's)
   u64* tile_mask;       // [n_slots][batch][mask_th][2]: bit tx of the row's 128-bit word = tile (ty, tx) is computed
@@ -77,6 +78,19 @@ __device__ __forceinline__ void emit_word(u64 m, int first, int at, int* list, i
     m &= m - 1;
     if (at < list_cap) list[at] = first + bit;
     ++at;
+  }
+}
+
+// A slot's tile rows -> its mask words (written by the caller), its ordered list (batch 1) or its per-image count. Every thread of
+// the workgroup calls this (block scan); thread order = (row, word) = ascending tile order.
+__device__ __forceinline__ void emit_slot(const ActArgs& A, int slot, int b, int row, int half, int TH, int TW, u64 mine, int* s_scan) {
+  int total;
+  const int at = sessd_block_exscan<NT>(__popcll(mine), s_scan, &total);
+  if (A.batch == 1) {
+    if (row < TH) emit_word(mine, row * TW + 64 * half, at, A.tile_list + (size_t)slot * A.list_cap, A.list_cap);
+    if (threadIdx.x == 0) A.n_list[slot] = total;
+  } else if (threadIdx.x == 0) {
+    A.counts[slot * A.batch + b] = total;
   }
 }
 
@@ -132,14 +146,7 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
         mine = half ? t1 : t0;
         A.tile_mask[(((size_t)slot * A.batch + b) * A.mask_th + row) * 2 + half] = mine;
       }
-      int total;   // (the scan's barriers also separate this step's reads of nc from the writes below)
-      const int at = sessd_block_exscan<NT>(__popcll(mine), s_scan, &total);   // thread order = (row, word) = ascending tile order
-      if (A.batch == 1) {
-        if (row < TH) emit_word(mine, row * TW + 64 * half, at, A.tile_list + (size_t)slot * A.list_cap, A.list_cap);
-        if (threadIdx.x == 0) A.n_list[slot] = total;
-      } else if (threadIdx.x == 0) {
-        A.counts[slot * A.batch + b] = total;
-      }
+      emit_slot(A, slot, b, row, half, TH, TW, mine, s_scan);   // (its barriers also separate this step's reads of nc from the writes below)
       // the layer's output is non-constant exactly in its computed tiles: pixel rows 2 ty, 2 ty + 1 = the tile row, every bit twice
       // (each thread of the pair writes the words that come from its own half)
       if (row < TH) {
@@ -176,9 +183,27 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
         tmb[row][0] = t0 & v0; tmb[row][1] = t1 & v1;
       }
       __syncthreads();
+      if (A.kind[st] == 2) {
+        // the transition itself over a tile list: its 2x2-output tile (ty, tx) is computed iff one of its four output pixels is
+        // not constant (W2 <= 96: the tile row is one word). The NEXT layer still sees the pixel rows: a pixel that is computed
+        // inside such a tile although its window is constant holds the constant to float32 rounding, as it does when the whole
+        // map is computed.
+        const int TH = H2 >> 1, TW = W2 >> 1;
+        u64 mine = 0ull;
+        if (row < TH) {
+          if (half == 0) {
+            const u64 p0 = tmb[2 * row][0] | tmb[2 * row + 1][0], p1 = tmb[2 * row][1] | tmb[2 * row + 1][1];
+            mine = (u64)even_bits(p0 | (p0 >> 1)) | ((u64)even_bits(p1 | (p1 >> 1)) << 32);
+          }
+          A.tile_mask[(((size_t)slot * A.batch + b) * A.mask_th + row) * 2 + half] = mine;
+        }
+        emit_slot(A, slot, b, row, half, TH, TW, mine, s_scan);
+        ++slot;
+      }
       if (row < H2 && half == 0) { nc[row][0] = tmb[row][0]; nc[row][1] = tmb[row][1]; nc[row][2] = 0ull; }
       __syncthreads();
       H = H2; W = W2;
+      zero_input = false;   // (conv + BatchNorm + ReLU of a zero map is relu(shift))
     }
   }
 }
@@ -199,8 +224,8 @@ __global__ __launch_bounds__(NT) void bev_tile_list_kernel(ActArgs A) {
 
 struct FillJobs {
   int njobs;
-  int blk_off[MAX_SLOTS + 1];   // first block of every job (a job = tile-pair chunks of 256 x cout x batch blocks)
-  sessd_fill_tiles_job_t J[MAX_SLOTS];
+  int blk_off[MAX_FILL_JOBS + 1];   // first block of every job (a job = tile-pair chunks of 256 x cout x batch blocks)
+  sessd_fill_tiles_job_t J[MAX_FILL_JOBS];
 };
 
 // One block = 256 threads = 256 pairs of adjacent tiles (2 tx, 2 tx + 1) of one (job, image, channel): a thread writes up to two
@@ -208,13 +233,13 @@ struct FillJobs {
 __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, int batch) {
   int j = 0;
 #pragma unroll
-  for (int q = 1; q < MAX_SLOTS; ++q)
+  for (int q = 1; q < MAX_FILL_JOBS; ++q)
     if (q < Q.njobs && (int)blockIdx.x >= Q.blk_off[q]) j = q;
   // static-index copies (a dynamically indexed kernel-argument array goes to scratch)
   sessd_fill_tiles_job_t J = Q.J[0];
   int off = Q.blk_off[0];
 #pragma unroll
-  for (int q = 1; q < MAX_SLOTS; ++q)
+  for (int q = 1; q < MAX_FILL_JOBS; ++q)
     if (q == j) { J = Q.J[q]; off = Q.blk_off[q]; }
   const int h = J.h, w = J.w, th = h >> 1, tw = w >> 1, pairs = th * (tw >> 1);
   const int chunks = sessd_divup(pairs, 256);
@@ -275,8 +300,13 @@ int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_
       if (A.n_slots == MAX_SLOTS) return SESSD_EINVAL;
       A.slot_th[A.n_slots] = ch / 2; A.slot_tw[A.n_slots] = cw / 2;
       ++A.n_slots;
-    } else if (steps[s] == 1) {
+    } else if (steps[s] == 1 || steps[s] == 2) {
       ch /= 2; cw /= 2;
+      if (steps[s] == 2) {   // the transition takes a slot of 2x2 tiles of ITS output
+        if (A.n_slots == MAX_SLOTS || (ch & 1) || (cw & 1) || cw / 2 > 64) return SESSD_EINVAL;
+        A.slot_th[A.n_slots] = ch / 2; A.slot_tw[A.n_slots] = cw / 2;
+        ++A.n_slots;
+      }
     } else {
       return SESSD_EINVAL;
     }
@@ -293,10 +323,10 @@ int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_
   return SESSD_OK;
 }
 
-// out[b][co][tile pixels] = value[co] for every tile of job j whose bit in tile_mask is 0, for up to 6 jobs (out (batch, cout, h, w),
+// out[b][co][tile pixels] = value[co] for every tile of job j whose bit in tile_mask is 0, for up to 8 jobs (out (batch, cout, h, w),
 // value[cout], tile_mask (batch, mask_th, 2) words, cout, h, w, mask_th) in one launch.
 int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, hipStream_t stream) {
-  if (!jobs || n_jobs < 1 || n_jobs > MAX_SLOTS || batch < 1) return SESSD_EINVAL;
+  if (!jobs || n_jobs < 1 || n_jobs > MAX_FILL_JOBS || batch < 1) return SESSD_EINVAL;
   FillJobs Q;
   Q.njobs = n_jobs;
   int blk = 0;
@@ -310,8 +340,8 @@ int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, in
     Q.blk_off[j] = blk;
     blk += sessd_divup((S.h / 2) * (S.w / 4), 256) * S.cout * batch;
   }
-  for (int j = n_jobs; j < MAX_SLOTS; ++j) { Q.J[j] = jobs[0]; Q.blk_off[j] = blk; }
-  Q.blk_off[MAX_SLOTS] = blk;
+  for (int j = n_jobs; j < MAX_FILL_JOBS; ++j) { Q.J[j] = jobs[0]; Q.blk_off[j] = blk; }
+  Q.blk_off[MAX_FILL_JOBS] = blk;
   SESSD_LAUNCH(fill_inactive_tiles_kernel, dim3(blk), dim3(256), 0, stream, Q, batch);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;

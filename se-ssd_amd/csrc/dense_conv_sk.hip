@@ -63,9 +63,14 @@ struct SkArgs {
   int cin, hin, win, cout, hout, wout, wt, in_mul, out_mul, relu;
   int npix, ptiles, cgroups, ncb, batch, nclass, total_rounds;
   int rpg;                // rounds per group = cin/16 * sum of the classes' taps
+  // active-tile mode (LIST kernel): entries image * (tile_h/2 * tile_w/2) + 2x2 tile of the TILE-SPACE map, count on the device
+  const int* tile_list;
+  const int* n_list;
+  int list_cap, min_rounds, ntiles2, tw2;
   SkClass cls[4];
 };
 
+template <bool LIST>
 __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * CSK_CHUNK_FLOATS];  // [buffer][W image | X image]
   __shared__ unsigned xo_tab[9 * 256];  // this thread's input offset per tap of the unit being loaded (thread-private rows)
@@ -78,11 +83,25 @@ __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
   const int wc = wave & 1, wp = wave >> 1;
   const int hh = wave >> 1;  // loader role: channel half of the chunk (threads 0..127 / 128..255)
   const int lp = tid & 127;  // loader role: pixel of the tile
-  const int G = gridDim.x;
+  int G = gridDim.x;
+  long long R = A.total_rounds;
+  int n_list = 0;
+  if constexpr (LIST) {
+    // ACTIVE-TILE mode (sessd_conv2d_sk_active): the tile-space pixels are the 2x2 tiles of a device list (entry image * ntiles2 +
+    // tile; 32 entries = the 128 pixels of a unit: lanes 0..63 the upper pixel rows of the 32 tiles, 64..127 the lower ones, so
+    // that a run of adjacent tiles is a run of adjacent pixels), their number is on the device: the round list is sized HERE, in
+    // shares of at least `min_rounds` rounds; the workgroups beyond that leave at once. The image is part of every thread's offsets.
+    n_list = uni(min(A.n_list[0], A.list_cap));
+    R = (long long)((n_list + 31) >> 5) * A.cgroups * A.rpg;
+    if (R == 0) return;
+    long long g = R / A.min_rounds;
+    g = g < 1 ? 1 : (g > G ? G : g);
+    G = (int)(g >= 8 ? (g & ~7LL) : g);
+    if ((G & 7) ? ((int)blockIdx.x >= G) : ((int)(blockIdx.x >> 3) >= (G >> 3))) return;
+  }
   // share w of the round list; consecutive shares on one XCD (workgroup b runs on XCD b % 8): neighbouring units share input
   // rows and weights through that XCD's L2
   const int w = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
-  const long long R = A.total_rounds;
   const int ra = (int)((long long)w * R / G), rb = (int)((long long)(w + 1) * R / G);
   if (ra >= rb) return;
   const int in_plane = A.hin * A.win;
@@ -103,10 +122,10 @@ __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
     lt = rr - lcb * lnt;
     lcg = uni(g % A.cgroups);
     const int gb = uni(g / A.cgroups);
-    lpt = uni(gb % A.ptiles);
-    lb = uni(gb / A.ptiles);
+    lpt = LIST ? gb : uni(gb % A.ptiles);
+    lb = LIST ? 0 : uni(gb / A.ptiles);
   }
-  rsrc_t xr = make_rsrc(A.in + (size_t)lb * A.cin * in_plane, xbytes);
+  rsrc_t xr = LIST ? make_rsrc(A.in, (unsigned)A.batch * xbytes) : make_rsrc(A.in + (size_t)lb * A.cin * in_plane, xbytes);
   rsrc_t wr = make_rsrc(Kp->cls[lc].wpk, (unsigned)(A.cgroups * A.ncb * lnt) * (CSK_CHUNK_FLOATS * 4u));
   // this thread's LDS addresses: everything else is an immediate offset
   float* const st_w = lds + tid * 4;
@@ -123,13 +142,23 @@ __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
     asm volatile("" : "+s"(Up));                                                                      \
     const int u_npix = Up->npix, u_wt = Up->wt, u_mul = Up->in_mul, u_hin = Up->hin, u_win = Up->win; \
     const int p_ = lpt * 128 + lp;                                                                    \
-    const bool live_ = p_ < u_npix;                                                                   \
-    const int y_ = live_ ? p_ / u_wt : 0, x_ = live_ ? p_ - (p_ / u_wt) * u_wt : 0;                   \
+    bool live_ = p_ < u_npix;                                                                         \
+    int y_ = live_ ? p_ / u_wt : 0, x_ = live_ ? p_ - (p_ / u_wt) * u_wt : 0;                         \
+    unsigned img_ = 0u;                                                                               \
+    if constexpr (LIST) {                                                                             \
+      const int k_ = lpt * 32 + ((lp & 63) >> 1);                                                     \
+      const int e_ = k_ < n_list ? Up->tile_list[k_] : -1;                                            \
+      live_ = e_ >= 0;                                                                                \
+      const int bl_ = live_ ? e_ / Up->ntiles2 : 0, t_ = live_ ? e_ - bl_ * Up->ntiles2 : 0;          \
+      y_ = 2 * (t_ / Up->tw2) + (lp >> 6);                                                            \
+      x_ = 2 * (t_ - (t_ / Up->tw2) * Up->tw2) + (lp & 1);                                            \
+      img_ = (unsigned)bl_ * xbytes;                                                                  \
+    }                                                                                                 \
     const int y0_ = y_ * u_mul, x0_ = x_ * u_mul;                                                     \
     for (int t_ = 0; t_ < lnt; ++t_) {                                                                \
       const int iy_ = y0_ + Up->cls[lc].dy[t_], ix_ = x0_ + Up->cls[lc].dx[t_];                       \
       const bool ok_ = live_ && iy_ >= 0 && iy_ < u_hin && ix_ >= 0 && ix_ < u_win;                   \
-      xo_tab[t_ * 256 + tid] = ok_ ? (unsigned)((iy_ * u_win + ix_) * 4) : SESSD_OOB;                 \
+      xo_tab[t_ * 256 + tid] = ok_ ? img_ + (unsigned)((iy_ * u_win + ix_) * 4) : SESSD_OOB;          \
     }                                                                                                 \
   }
   // fetch the loader's chunk into register set GS (voff = this thread's input offset for the chunk's tap, read from xo_tab
@@ -168,10 +197,13 @@ __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
           lc = 0;                                                                                     \
           if (++lcg == Vp->cgroups) {                                                                 \
             lcg = 0;                                                                                  \
-            if (++lpt == Vp->ptiles) {                                                                \
-              lpt = 0;                                                                                \
-              ++lb;                                                                                   \
-              xr = make_rsrc(Vp->in + (size_t)lb * Vp->cin * in_plane, xbytes);                       \
+            ++lpt;                                                                                    \
+            if constexpr (!LIST) {                                                                    \
+              if (lpt == Vp->ptiles) {                                                                \
+                lpt = 0;                                                                              \
+                ++lb;                                                                                 \
+                xr = make_rsrc(Vp->in + (size_t)lb * Vp->cin * in_plane, xbytes);                     \
+              }                                                                                       \
             }                                                                                         \
           }                                                                                           \
         }                                                                                             \
@@ -300,7 +332,7 @@ __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
 
     // ---- the segment's result: a whole unit is finished here, a part goes to the scratch slot
     const int cg = uni(g % Fp->cgroups), gb = uni(g / Fp->cgroups);
-    const int pt = uni(gb % Fp->ptiles), b = uni(gb / Fp->ptiles);
+    const int pt = LIST ? gb : uni(gb % Fp->ptiles), b = LIST ? 0 : uni(gb / Fp->ptiles);
     bool fin = (r0 == 0 && n == rpu);
     if (!fin) {
       const long long S = (long long)g * Fp->rpg + Fp->cls[c].r_begin;  // the unit's first round
@@ -370,8 +402,9 @@ __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
       const float* e_shift = Fp->shift;
       const float* e_res = Fp->residual;
       const size_t boff = (size_t)b * e_cout * oplane;
-      const rsrc_t orr = make_rsrc(Fp->out + boff, (unsigned)e_cout * oplane * 4u);
-      const rsrc_t rr = make_rsrc(e_res ? e_res + boff : Fp->out, e_res ? (unsigned)e_cout * oplane * 4u : 0u);
+      const unsigned obytes = (unsigned)e_cout * oplane * 4u * (LIST ? (unsigned)Fp->batch : 1u);
+      const rsrc_t orr = make_rsrc(Fp->out + boff, obytes);
+      const rsrc_t rr = make_rsrc(e_res ? e_res + boff : Fp->out, e_res ? obytes : 0u);
       const rsrc_t scr = make_rsrc(e_scale ? e_scale : Fp->out, e_scale ? (unsigned)e_cout * 4u : 0u);
       const rsrc_t shr = make_rsrc(e_shift ? e_shift : Fp->out, e_shift ? (unsigned)e_cout * 4u : 0u);
       const int co0 = cg * 128 + wc * 64 + 4 * h;  // + a * 32 + (e & 3) + 8 * (e >> 2)
@@ -381,9 +414,19 @@ __global__ __launch_bounds__(256) void conv2d_sk_kernel(SkArgs A) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         const int p = pt * 128 + wp * 64 + q * 32 + j;
-        const bool live = p < e_npix;
-        const int y = live ? p / e_wt : 0, x = live ? p - (p / e_wt) * e_wt : 0;
-        const unsigned vbase = (unsigned)co0 * oplane4 + (unsigned)((y * e_mul + e_py) * e_wout + (x * e_mul + e_px)) * 4u;
+        bool live = p < e_npix;
+        int y = live ? p / e_wt : 0, x = live ? p - (p / e_wt) * e_wt : 0;
+        unsigned oimg = 0u;
+        if constexpr (LIST) {
+          const int k = pt * 32 + ((q * 32 + j) >> 1);
+          const int en = k < n_list ? Fp->tile_list[k] : -1;
+          live = en >= 0;
+          const int bl = live ? en / Fp->ntiles2 : 0, t = live ? en - bl * Fp->ntiles2 : 0;
+          y = 2 * (t / Fp->tw2) + wp;
+          x = 2 * (t - (t / Fp->tw2) * Fp->tw2) + (j & 1);
+          oimg = (unsigned)bl * (unsigned)e_cout * oplane4;
+        }
+        const unsigned vbase = oimg + (unsigned)co0 * oplane4 + (unsigned)((y * e_mul + e_py) * e_wout + (x * e_mul + e_px)) * 4u;
 #pragma unroll
         for (int a = 0; a < 2; ++a) {
           float scv[16], shv[16], rv[16];
@@ -449,6 +492,71 @@ int default_workgroups(int* out) {
   return *out >= 8 ? SESSD_OK : SESSD_EINVAL;
 }
 
+int launch_conv2d_sk(const float* in, int batch, int cin, int hin, int win, int nclass, const float* const* wpk,
+                     const int* ntaps, const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out,
+                     int cout, int hout, int wout, int out_mul, const int* out_py, const int* out_px, const float* scale,
+                     const float* shift, int relu, const float* residual, void* workspace, size_t workspace_bytes, int workgroups,
+                     hipStream_t stream, const int* tile_list, const int* n_list, int list_cap, int min_rounds) {
+  if (batch < 1 || cin < 16 || cin % 16 || cout < 1 || nclass < 1 || nclass > 4 || workgroups < 0 || (workgroups & 7)) return SESSD_EINVAL;
+  // a batch element's input and output are addressed through 32-bit buffer offsets
+  if ((long long)cin * hin * win * 4 >= 0x7fffffffLL || (long long)cout * hout * wout * 4 >= 0x7fffffffLL) return SESSD_EINVAL;
+  // active-tile mode: the image is part of the offsets too, and the tile space is cut into 2x2 tiles
+  if (tile_list && (!n_list || list_cap < 1 || (tile_h & 1) || (tile_w & 1) || (long long)batch * cin * hin * win * 4 >= 0x7fffffffLL ||
+                    (long long)batch * cout * hout * wout * 4 >= 0x7fffffffLL))
+    return SESSD_EINVAL;
+  if (workgroups == 0) {
+    const int rc = default_workgroups(&workgroups);
+    if (rc != SESSD_OK) return rc;
+  }
+  SkArgs A;
+  A.in = in; A.out = out; A.scale = scale; A.shift = shift; A.residual = residual;
+  A.cin = cin; A.hin = hin; A.win = win; A.cout = cout; A.hout = hout; A.wout = wout; A.wt = tile_w;
+  A.in_mul = in_mul; A.out_mul = out_mul; A.relu = relu;
+  A.npix = tile_h * tile_w; A.ptiles = sessd_divup(A.npix, 128); A.cgroups = sessd_divup(cout, 128); A.ncb = cin / 16;
+  A.batch = batch; A.nclass = nclass;
+  A.tile_list = tile_list; A.n_list = n_list; A.list_cap = list_cap; A.min_rounds = min_rounds < 1 ? 1 : min_rounds;
+  A.ntiles2 = (tile_h / 2) * (tile_w / 2); A.tw2 = tile_w / 2;
+  // the round list: for every (batch element, pixel tile, cout group) the units of all classes one after the other (more taps
+  // first) -- the classes of a pixel tile read the same input and write the interleaved pixels of the same output lines, and
+  // consecutive shares run on the same XCD: the input is fetched once and the half-written output lines meet in that L2
+  int order[4] = {0, 1, 2, 3};
+  for (int a = 0; a < nclass; ++a)
+    for (int b = a + 1; b < nclass; ++b)
+      if (ntaps[order[b]] > ntaps[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+  const long long groups = (long long)batch * A.ptiles * A.cgroups;  // (batch element, pixel tile, cout group)
+  int rpg = 0;
+  for (int k = 0; k < nclass; ++k) {
+    const int c = order[k];
+    if (ntaps[c] < 1 || ntaps[c] > 9) return SESSD_EINVAL;
+    SkClass& C = A.cls[k];
+    C.wpk = wpk[c]; C.ntaps = ntaps[c]; C.py = out_py[c]; C.px = out_px[c];
+    C.rpu = ntaps[c] * A.ncb;
+    C.r_begin = rpg; C.u_begin = 0;
+    for (int t = 0; t < 9; ++t) {
+      C.dy[t] = t < ntaps[c] ? taps_dy[9 * c + t] : 0;
+      C.dx[t] = t < ntaps[c] ? taps_dx[9 * c + t] : 0;
+    }
+    rpg += C.rpu;
+  }
+  for (int k = nclass; k < 4; ++k) A.cls[k] = A.cls[0];
+  A.rpg = rpg;
+  const long long rounds = groups * rpg;
+  if (rounds > 0x7fffffffLL || groups * nclass > 0x7fffffffLL) return SESSD_EINVAL;
+  A.total_rounds = (int)rounds;
+  const size_t cbytes = sessd_align((size_t)groups * nclass * 4, 256);
+  if (cbytes + (size_t)2 * workgroups * CSK_SLOT_BYTES > workspace_bytes) return SESSD_EWORKSPACE;
+  // every share must hold at least one round (the part count of a cut unit is a difference of share indices)
+  if (workgroups > A.total_rounds) workgroups = A.total_rounds >= 8 ? (A.total_rounds & ~7) : A.total_rounds;
+  A.counters = (unsigned*)workspace;
+  A.scratch = (float*)((char*)workspace + cbytes);
+  if (tile_list)   // (shares are sized on the device: the workspace and the launch are the dense layer's)
+    SESSD_LAUNCH((conv2d_sk_kernel<true>), dim3(workgroups), dim3(256), 0, stream, A);
+  else
+    SESSD_LAUNCH((conv2d_sk_kernel<false>), dim3(workgroups), dim3(256), 0, stream, A);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -488,55 +596,26 @@ int sessd_conv2d_sk(const float* in, int batch, int cin, int hin, int win, int n
                     int cout, int hout, int wout, int out_mul, const int* out_py, const int* out_px, const float* scale,
                     const float* shift, int relu, const float* residual, void* workspace, size_t workspace_bytes, int workgroups,
                     hipStream_t stream) {
-  if (batch < 1 || cin < 16 || cin % 16 || cout < 1 || nclass < 1 || nclass > 4 || workgroups < 0 || (workgroups & 7)) return SESSD_EINVAL;
-  // a batch element's input and output are addressed through 32-bit buffer offsets
-  if ((long long)cin * hin * win * 4 >= 0x7fffffffLL || (long long)cout * hout * wout * 4 >= 0x7fffffffLL) return SESSD_EINVAL;
-  if (workgroups == 0) {
-    const int rc = default_workgroups(&workgroups);
-    if (rc != SESSD_OK) return rc;
-  }
-  SkArgs A;
-  A.in = in; A.out = out; A.scale = scale; A.shift = shift; A.residual = residual;
-  A.cin = cin; A.hin = hin; A.win = win; A.cout = cout; A.hout = hout; A.wout = wout; A.wt = tile_w;
-  A.in_mul = in_mul; A.out_mul = out_mul; A.relu = relu;
-  A.npix = tile_h * tile_w; A.ptiles = sessd_divup(A.npix, 128); A.cgroups = sessd_divup(cout, 128); A.ncb = cin / 16;
-  A.batch = batch; A.nclass = nclass;
-  // the round list: for every (batch element, pixel tile, cout group) the units of all classes one after the other (more taps
-  // first) -- the classes of a pixel tile read the same input and write the interleaved pixels of the same output lines, and
-  // consecutive shares run on the same XCD: the input is fetched once and the half-written output lines meet in that L2
-  int order[4] = {0, 1, 2, 3};
-  for (int a = 0; a < nclass; ++a)
-    for (int b = a + 1; b < nclass; ++b)
-      if (ntaps[order[b]] > ntaps[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
-  const long long groups = (long long)batch * A.ptiles * A.cgroups;  // (batch element, pixel tile, cout group)
-  int rpg = 0;
-  for (int k = 0; k < nclass; ++k) {
-    const int c = order[k];
-    if (ntaps[c] < 1 || ntaps[c] > 9) return SESSD_EINVAL;
-    SkClass& C = A.cls[k];
-    C.wpk = wpk[c]; C.ntaps = ntaps[c]; C.py = out_py[c]; C.px = out_px[c];
-    C.rpu = ntaps[c] * A.ncb;
-    C.r_begin = rpg; C.u_begin = 0;
-    for (int t = 0; t < 9; ++t) {
-      C.dy[t] = t < ntaps[c] ? taps_dy[9 * c + t] : 0;
-      C.dx[t] = t < ntaps[c] ? taps_dx[9 * c + t] : 0;
-    }
-    rpg += C.rpu;
-  }
-  for (int k = nclass; k < 4; ++k) A.cls[k] = A.cls[0];
-  A.rpg = rpg;
-  const long long rounds = groups * rpg;
-  if (rounds > 0x7fffffffLL || groups * nclass > 0x7fffffffLL) return SESSD_EINVAL;
-  A.total_rounds = (int)rounds;
-  const size_t cbytes = sessd_align((size_t)groups * nclass * 4, 256);
-  if (cbytes + (size_t)2 * workgroups * CSK_SLOT_BYTES > workspace_bytes) return SESSD_EWORKSPACE;
-  // every share must hold at least one round (the part count of a cut unit is a difference of share indices)
-  if (workgroups > A.total_rounds) workgroups = A.total_rounds >= 8 ? (A.total_rounds & ~7) : A.total_rounds;
-  A.counters = (unsigned*)workspace;
-  A.scratch = (float*)((char*)workspace + cbytes);
-  SESSD_LAUNCH(conv2d_sk_kernel, dim3(workgroups), dim3(256), 0, stream, A);
-  SESSD_CHECK_LAUNCH();
-  return SESSD_OK;
+  return launch_conv2d_sk(in, batch, cin, hin, win, nclass, wpk, ntaps, taps_dy, taps_dx, in_mul, tile_h, tile_w, out, cout, hout, wout,
+                          out_mul, out_py, out_px, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream, nullptr,
+                          nullptr, 0, 1);
+}
+
+// The same launch over the listed 2x2 tiles of the TILE SPACE only (active-tile mode, csrc/dense_active.hip: the BEV maps of the
+// SSFA neck are a per-channel constant away from the sparse sites): tile_list[0 .. min(*n_list, list_cap)) entries image *
+// (tile_h/2 * tile_w/2) + tile in any order, count on the device; every class is computed at the four tile-space pixels of a
+// listed tile, the other output pixels are left alone (sessd_fill_inactive_tiles writes the layer's constant there). Even tile_h,
+// tile_w. Shares of the round list are at least min_rounds rounds long; the workgroups beyond rounds / min_rounds leave at once.
+// Same packed weights, same workspace (sized for the dense layer) as sessd_conv2d_sk.
+int sessd_conv2d_sk_active(const float* in, int batch, int cin, int hin, int win, int nclass, const float* const* wpk,
+                           const int* ntaps, const int* taps_dy, const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out,
+                           int cout, int hout, int wout, int out_mul, const int* out_py, const int* out_px, const float* scale,
+                           const float* shift, int relu, const float* residual, const int32_t* tile_list, const int32_t* n_list,
+                           int list_cap, int min_rounds, void* workspace, size_t workspace_bytes, int workgroups, hipStream_t stream) {
+  if (!tile_list || !n_list || list_cap < 1) return SESSD_EINVAL;
+  return launch_conv2d_sk(in, batch, cin, hin, win, nclass, wpk, ntaps, taps_dy, taps_dx, in_mul, tile_h, tile_w, out, cout, hout, wout,
+                          out_mul, out_py, out_px, scale, shift, relu, residual, workspace, workspace_bytes, workgroups, stream, tile_list,
+                          n_list, list_cap, min_rounds);
 }
 
 }  // extern "C"

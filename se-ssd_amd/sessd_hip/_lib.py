@@ -99,6 +99,8 @@ SIGNATURES = {
     "sessd_conv2d_sk_pack": (i32, [vp, i64, i64, vp, i32, i32, i32, vp, vp]),
     "sessd_conv2d_sk": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp,
                               i32, vp, vp, sz, i32, vp]),
+    "sessd_conv2d_sk_active": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp,
+                                     i32, vp, vp, vp, i32, i32, vp, sz, i32, vp]),
     "sessd_deconv2d_s2_mfma_pair": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
     "sessd_deconv2d_s2_mfma": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
     "sessd_ssfa_fuse": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp]),

@@ -77,15 +77,18 @@ class DensePlan:
         # What the first six layers compute where their input is CONSTANT (the BEV map is zero outside the sparse sites):
         # c_0 = 0, c_{l+1}[co] = relu(scale * sum_ci c_l[ci] * sum_k W[co][ci][k] + shift), float64 over the folded weights (the
         # stride-2 layer that opens block 1 included: away from the top / left border its window of a constant map is constant).
-        # The engine writes them into the tiles it does not compute (active-tile mode, csrc/dense_active.hip): slots 0-2 = block 0,
-        # 3-4 = the second and third layer of block 1.
+        # The engine writes them into the tiles it does not compute (active-tile mode, csrc/dense_active.hip): entries 0-2 = block 0,
+        # 3-5 = block 1, 6 / 7 = trans_0 / trans_1 (1x1 layers over the constants of block 0 / block 1: rpn_v1.py:163-172).
+        def step(seq, ci, bi, c):
+            s_, t_ = fold_bn(seq[bi])
+            return torch.relu(s_.double().cpu() * (seq[ci].weight.detach().double().cpu().sum((2, 3)) @ c) + t_.double().cpu())
         c = torch.zeros(b0[1].weight.shape[1], dtype=torch.float64)
         chain = []
         for seq, ci, bi in ((b0, 1, 2), (b0, 4, 5), (b0, 7, 8), (b1, 0, 1), (b1, 3, 4), (b1, 6, 7)):
-            s_, t_ = fold_bn(seq[bi])
-            c = torch.relu(s_.double().cpu() * (seq[ci].weight.detach().double().cpu().sum((2, 3)) @ c) + t_.double().cpu())
-            chain.append(c.float().to(device).contiguous())
-        self.act_const = [chain[0], chain[1], chain[2], chain[4], chain[5]]
+            c = step(seq, ci, bi, c)
+            chain.append(c)
+        chain += [step(neck.trans_0, 0, 1, chain[2]), step(neck.trans_1, 0, 1, chain[5])]
+        self.act_const = [v.float().to(device).contiguous() for v in chain]
         self.b1 = [cbr(b1, 0, 1), cbr(b1, 3, 4), cbr(b1, 6, 7)]
         self.trans_0 = cbr(neck.trans_0, 0, 1)
         self.trans_1 = cbr(neck.trans_1, 0, 1)
@@ -264,17 +267,23 @@ class InferenceEngine:
         # critical path, and with two engines the four streams serialise against each other.
         self.fork_front = False
         self.side_stream = torch.cuda.Stream(device=dev)
-        # Active-tile mode of bottom_up_block_0 and of the stride-1 layers of bottom_up_block_1 (round 4): the BEV map is zero
+        # Active-tile mode of bottom_up_block_0, bottom_up_block_1 and the two 1x1 trans layers (round 4): the BEV map is zero
         # outside the last sparse level's sites, so these layers are computed only in the 2x2-output tiles whose input patch is
-        # not constant (14 / 26 / 36 % of the tiles of block 0, 54 / 68 % of block 1's on a 20 k-point scan) and the rest is filled
-        # with the layer's constant. ACTIVE_SLOTS: slot -> (layer name, layer, input buffer, output buffer).
+        # not constant (14 / 26 / 36 % of the tiles of block 0, 46 / 54 / 68 % of block 1's on a 20 k-point scan; a 1x1 layer is
+        # computed where its input was) and the rest is filled with the layer's constant.
+        # ACTIVE_SLOTS: layer id -> (layer name, layer, input buffer, output buffer); ACTIVE_MASK: id -> slot of the tile mask / list
+        # (sessd_bev_tile_activity steps {0, 0, 0, 2, 0, 0}); ACTIVE_SK: ids on the LDS-tiled stream-K kernel (the others: Winograd).
         self.active_tiles = bool(active_tiles)
-        self.active_cfg = {}   # slot -> (stream-K shape, min_rounds), chosen by autotune(); empty = dense launches
-        ok = self.active_tiles and H <= 256 and W <= 192 and H % 4 == 0 and W % 4 == 0
-        self.ta = ops.TileActivity(B, H, W, [0, 0, 0, 1, 0, 0], dev) if ok else None
+        self.active_cfg = {}   # id -> (stream-K shape, min_rounds) / (30, min_rounds), chosen by autotune(); empty = dense launches
+        ok = self.active_tiles and H <= 256 and W <= 192 and H % 4 == 0 and W % 8 == 0
+        self.ta = ops.TileActivity(B, H, W, [0, 0, 0, 2, 0, 0], dev) if ok else None
         self.ACTIVE_SLOTS = {0: ("b0.0", self.dn.b0[0], self.bev, self.t["a"]), 1: ("b0.1", self.dn.b0[1], self.t["a"], self.t["b"]),
-                             2: ("b0.2", self.dn.b0[2], self.t["b"], self.t["x0"]), 3: ("b1.1", self.dn.b1[1], self.h["a"], self.h["b"]),
-                             4: ("b1.2", self.dn.b1[2], self.h["b"], self.h["x1"])}
+                             2: ("b0.2", self.dn.b0[2], self.t["b"], self.t["x0"]), 3: ("b1.0", self.dn.b1[0], self.t["x0"], self.h["a"]),
+                             4: ("b1.1", self.dn.b1[1], self.h["a"], self.h["b"]), 5: ("b1.2", self.dn.b1[2], self.h["b"], self.h["x1"]),
+                             6: ("trans_0", self.dn.trans_0, self.t["x0"], self.t["tr0"]),
+                             7: ("trans_1", self.dn.trans_1, self.h["x1"], self.h["tr1"])}
+        self.ACTIVE_MASK = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 2, 7: 5}
+        self.ACTIVE_SK = (3, 6, 7)
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -371,9 +380,15 @@ class InferenceEngine:
         if active is not None:
             # active-tile mode: the listed tiles only (the others were filled with the layer's constant at the head of the stage)
             shape, min_rounds = self.active_cfg[active]
-            call = lambda: ops.conv2d_winograd_sk_active(x, pc.upk_sk(shape), pc.cout, scale, shift, relu, out, shape, self.sk_ws,
-                                                         self.ta.tile_list[active], self.ta.n_list[active:active + 1],
-                                                         workgroups=self.sk_workgroups, residual=residual, min_rounds=min_rounds)
+            m = self.ACTIVE_MASK[active]
+            if active in self.ACTIVE_SK:
+                call = lambda: ops.conv2d_sk_active(x, pc, scale, shift, relu, out, self.sk_ws, self.ta.tile_list[m],
+                                                    self.ta.n_list[m:m + 1], workgroups=self.sk_workgroups, residual=residual,
+                                                    min_rounds=min_rounds)
+            else:
+                call = lambda: ops.conv2d_winograd_sk_active(x, pc.upk_sk(shape), pc.cout, scale, shift, relu, out, shape, self.sk_ws,
+                                                             self.ta.tile_list[m], self.ta.n_list[m:m + 1],
+                                                             workgroups=self.sk_workgroups, residual=residual, min_rounds=min_rounds)
             if self._kmarks is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -519,25 +534,39 @@ class InferenceEngine:
         pick, gain = {}, 0.0
         for l, (name, (pc, scale, shift), x_in, x_out) in self.ACTIVE_SLOTS.items():
             best = (None, 1e30)
-            for shape in (0, 1):
-                if pc.upk_sk(shape) is None:
+            m = self.ACTIVE_MASK[l]
+            if l in self.ACTIVE_SK:
+                if pc.sk_args() is None:
                     continue
-                need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(self.B, x_in.shape[2], x_in.shape[3], pc.cout, shape, 0))
+                need = int(lib.sessd_conv2d_sk_workspace_bytes(self.B, x_out.shape[2], x_out.shape[3], pc.cout, len(pc.launches), 0))
                 if self.sk_ws is None or self.sk_ws.numel() < need:
                     self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
-                for mr in (1, 2, 4):
-                    tt = timed(lambda: ops.conv2d_winograd_sk_active(x_in, pc.upk_sk(shape), pc.cout, scale, shift, True, x_out, shape,
-                                                                     self.sk_ws, self.ta.tile_list[l], self.ta.n_list[l:l + 1],
-                                                                     workgroups=self.sk_workgroups, min_rounds=mr))
+                for mr in (1, 2, 4, 8):
+                    tt = timed(lambda: ops.conv2d_sk_active(x_in, pc, scale, shift, True, x_out, self.sk_ws, self.ta.tile_list[m],
+                                                            self.ta.n_list[m:m + 1], workgroups=self.sk_workgroups, min_rounds=mr))
                     if tt < best[1]:
-                        best = ((shape, mr), tt)
+                        best = ((30, mr), tt)
+            else:
+                for shape in (0, 1):
+                    if pc.upk_sk(shape) is None:
+                        continue
+                    need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(self.B, x_in.shape[2], x_in.shape[3], pc.cout, shape, 0))
+                    if self.sk_ws is None or self.sk_ws.numel() < need:
+                        self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+                    for mr in (1, 2, 4):
+                        tt = timed(lambda: ops.conv2d_winograd_sk_active(x_in, pc.upk_sk(shape), pc.cout, scale, shift, True, x_out, shape,
+                                                                         self.sk_ws, self.ta.tile_list[m], self.ta.n_list[m:m + 1],
+                                                                         workgroups=self.sk_workgroups, min_rounds=mr))
+                        if tt < best[1]:
+                            best = ((shape, mr), tt)
             dense_t = self.tune_report.get(name, (None, 0.0))[1]
             if best[0] is not None and best[1] < dense_t:
                 pick[l] = best
                 gain += dense_t - best[1]
         sl = sorted(pick)
         over = timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]),
-                              self.ta.fill([self.ACTIVE_SLOTS[l][3] for l in sl], [d.act_const[l] for l in sl], layers=sl))) if pick else 0.0
+                              self.ta.fill([self.ACTIVE_SLOTS[l][3] for l in sl], [d.act_const[l] for l in sl],
+                                           layers=[self.ACTIVE_MASK[l] for l in sl]))) if pick else 0.0
         if pick and gain > over:
             self.active_cfg = {l: pick[l][0] for l in pick}
         # (choice, gain ms per frame over the dense launches, ms of the activity + fill launches, per-layer ms): a tuple like the others
@@ -550,7 +579,8 @@ class InferenceEngine:
         if not act:
             return {}
         n = self.ta.n_list.cpu().numpy()
-        return {self.ACTIVE_SLOTS[l][0]: float(n[l]) / (self.B * (self.ta.dims[l][0] // 2) * (self.ta.dims[l][1] // 2)) for l in act}
+        M = self.ACTIVE_MASK
+        return {self.ACTIVE_SLOTS[l][0]: float(n[M[l]]) / (self.B * (self.ta.dims[M[l]][0] // 2) * (self.ta.dims[M[l]][1] // 2)) for l in act}
 
     # ------------------------------------------------------------------ the frame
     def enqueue(self):
@@ -648,18 +678,18 @@ class InferenceEngine:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             self.ta.run(L4["indices"], L4["n"], L4["cap"])
-            self.ta.fill([self.ACTIVE_SLOTS[l][3] for l in act], [d.act_const[l] for l in act], layers=act)
+            self.ta.fill([self.ACTIVE_SLOTS[l][3] for l in act], [d.act_const[l] for l in act], layers=[self.ACTIVE_MASK[l] for l in act])
             if self._kmarks is not None:
                 e1.record()
                 self._kmarks.append(("tile_activity+fill", e0, e1))
         x = self._conv(self.bev, d.b0[0], t["a"], name="b0.0", active=0 if 0 in act else None)
         x = self._conv(x, d.b0[1], t["b"], name="b0.1", active=1 if 1 in act else None)
         x0 = self._conv(x, d.b0[2], t["x0"], name="b0.2", active=2 if 2 in act else None)
-        y = self._conv(x0, d.b1[0], h["a"], name="b1.0")
-        y = self._conv(y, d.b1[1], h["b"], name="b1.1", active=3 if 3 in act else None)
-        x1 = self._conv(y, d.b1[2], h["x1"], name="b1.2", active=4 if 4 in act else None)
-        tr0 = self._conv(x0, d.trans_0, t["tr0"], name="trans_0")
-        tr1 = self._conv(x1, d.trans_1, h["tr1"], name="trans_1")
+        y = self._conv(x0, d.b1[0], h["a"], name="b1.0", active=3 if 3 in act else None)
+        y = self._conv(y, d.b1[1], h["b"], name="b1.1", active=4 if 4 in act else None)
+        x1 = self._conv(y, d.b1[2], h["x1"], name="b1.2", active=5 if 5 in act else None)
+        tr0 = self._conv(x0, d.trans_0, t["tr0"], name="trans_0", active=6 if 6 in act else None)
+        tr1 = self._conv(x1, d.trans_1, h["tr1"], name="trans_1", active=7 if 7 in act else None)
         cd = self.tile_cfg.get("deconv_0")
         if self.merge_branch_convs and cd in (3, 4, 11, 12) and self.tile_cfg.get("deconv_1") in (3, 4, 11, 12) and self._tuning is None:
             # both transposed convs read tr1: one launch over their 2 x 4 parity classes (same bits as two launches)

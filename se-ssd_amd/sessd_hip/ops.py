@@ -1381,9 +1381,36 @@ def conv2d_winograd_sk_active(x, upk, cout, scale, shift, relu, out, shape, work
     return out
 
 
+def conv2d_sk_active(x, pc, scale, shift, relu, out, workspace, tile_list, n_list, workgroups=0, residual=None, min_rounds=4):
+    """sessd_conv2d_sk_active: the LDS-tiled stream-K layer (tile_cfg 30: stride-2 / 1x1 conv, or the four classes of a transposed
+    conv) over the listed 2x2 tiles of its tile space only (entries image * (th/2 * tw/2) + tile, count on the device); the other
+    output pixels of `out` are left alone."""
+    import ctypes
+    _req(x, torch.float32, "x"); _req(tile_list, torch.int32, "tile_list"); _req(n_list, torch.int32, "n_list")
+    B, ci, H, W = x.shape
+    sk = pc.sk_args()
+    if sk is None:
+        raise ValueError("conv2d_sk_active needs cin % 16 == 0")
+    if pc.kind == "conv":
+        Ho, Wo = (H + pc.stride - 1) // pc.stride, (W + pc.stride - 1) // pc.stride
+        th, tw = Ho, Wo
+    else:
+        Ho, Wo, th, tw = 2 * H, 2 * W, H, W
+    la = pc.launches[0]
+    check(lib.sessd_conv2d_sk_active(x.data_ptr(), B, ci, H, W, sk["n"], ctypes.cast(sk["wptr"], ctypes.c_void_p).value,
+                                     ctypes.cast(sk["ntaps"], ctypes.c_void_p).value, ctypes.cast(sk["dy"], ctypes.c_void_p).value,
+                                     ctypes.cast(sk["dx"], ctypes.c_void_p).value, la["in_mul"], th, tw, out.data_ptr(), pc.cout,
+                                     Ho, Wo, la["out_mul"], ctypes.cast(sk["py"], ctypes.c_void_p).value,
+                                     ctypes.cast(sk["px"], ctypes.c_void_p).value, _p(scale), _p(shift), 1 if relu else 0,
+                                     _p(residual), tile_list.data_ptr(), n_list.data_ptr(), tile_list.numel(), int(min_rounds),
+                                     workspace.data_ptr(), workspace.numel(), int(workgroups), _stream()), "conv2d_sk_active")
+    return out
+
+
 class TileActivity:
     """Buffers + launches of sessd_bev_tile_activity / sessd_fill_inactive_tiles for a chain of 3x3 layers over (batch, ., H, W) maps.
-    steps: 0 = a 3x3 stride-1 layer (takes the next slot), 1 = a 3x3 stride-2 layer computed everywhere (the map halves);
+    steps: 0 = a 3x3 stride-1 layer (takes the next slot), 1 = a 3x3 stride-2 layer computed everywhere (the map halves), 2 = a
+    stride-2 layer that takes a slot itself (the 2x2 tiles of its OUTPUT that hold a non-constant pixel);
     an int n means n stride-1 layers. Per slot s: dims[s] = (h, w) of the layer, tile_mask[s] (batch, H/2, 2) int64 -- bit tx of a
     row's 128 bits = tile (ty, tx) is computed; rows beyond h/2 unused --, tile_list[s] (batch * H/2 * W/2,) int32, n_list[s]."""
 
@@ -1397,6 +1424,8 @@ class TileActivity:
                 self.dims.append((h, w))
             else:
                 h, w = h // 2, w // 2
+                if k == 2:
+                    self.dims.append((h, w))
         self.n_slots = self.n_layers = len(self.dims)
         self._steps = (ctypes.c_int32 * len(steps))(*steps)
         tiles = (H // 2) * (W // 2)
@@ -1421,7 +1450,8 @@ class TileActivity:
         return torch.from_numpy(((m[:, :, tx >> 6] >> (tx & 63).astype("uint64")) & np.uint64(1)).astype(bool))
 
     def fill(self, outs, values, layers=None):
-        """outs[i] (batch, cout, h, w) <- values[i][cout] in the tiles slot layers[i] (default i) does not compute (one launch)."""
+        """outs[i] (batch, cout, h, w) <- values[i][cout] in the tiles slot layers[i] (default i) does not compute (one launch of up
+        to 8 jobs; several outputs may share a slot: a 1x1 layer is computed where its input was)."""
         from ._lib import FillTilesJob
         layers = list(range(len(outs))) if layers is None else list(layers)
         key = tuple((o.data_ptr(), v.data_ptr(), l) for o, v, l in zip(outs, values, layers))

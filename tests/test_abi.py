@@ -54,6 +54,19 @@ def test_dense_entry_points_reject_bad_shapes_before_touching_the_device():
     # explicit workgroup count: pure arithmetic (counters of nclass * batch * pixel tiles * cout groups + two 64 KB slots per workgroup)
     assert lib.sessd_conv2d_sk_workspace_bytes(2, 100, 88, 256, 1, 256) == 256 * ((2 * 69 * 2 * 4 + 255) // 256) + 2 * 256 * 65536
     assert lib.sessd_conv2d_sk_pack(None, 1, 1, None, 1, 32, 24, None, None) == -1
+    # its active-tile mode: a tile list with its device count, even tile space, the WHOLE batch inside 32-bit offsets
+    import ctypes
+    one = ctypes.c_int32(1)
+    ska = lambda tl, nl, cap, hw=16, batch=1, cin=32: lib.sessd_conv2d_sk_active(None, batch, cin, hw, hw, 1, None, None, None, None, 1, hw, hw, None, 32,
+                                                                                 hw, hw, 1, None, None, None, None, 1, None, tl, nl, cap, 1, None, 0, 8, None)
+    ptr = ctypes.addressof(one)
+    assert ska(None, ptr, 4) == -1 and ska(ptr, None, 4) == -1 and ska(ptr, ptr, 0) == -1 and ska(ptr, ptr, 4, hw=15) == -1
+    assert ska(ptr, ptr, 4, hw=1024, batch=32, cin=16) == -1
+    # tile activity: a stride-2 step that takes a slot needs an output of even size; at most six slots
+    steps = lambda *v: (ctypes.c_int32 * len(v))(*v)
+    act = lambda st, h=200, w=176: lib.sessd_bev_tile_activity(ptr, ptr, 1, 1, h, w, st, len(st), ptr, ptr, ptr, 1, None, 0, None)
+    assert act(steps(2), h=202) == -1 and act(steps(0, 0, 0, 2, 0, 0, 0)) == -1 and act(steps(3)) == -1
+    assert lib.sessd_fill_inactive_tiles(None, 9, 1, None) == -1
     # Winograd stream-K over weight sets: the batch must split evenly
     assert lib.sessd_conv3x3_winograd_sk_sets(None, 3, 2, 128, 8, 8, None, None, 128, None, None, 1, None, None, 0, 0, 8, None) == -1
     assert lib.sessd_conv3x3_winograd_sk_sets(None, 2, 2, 128, 7, 8, None, None, 128, None, None, 1, None, None, 0, 0, 8, None) == -1

@@ -31,8 +31,9 @@ def _masks_numpy(idx, batch, steps):
     """The rule of csrc/dense_active.hip restated. Step 0 (3x3 stride-1 layer): tile computed iff its 4x4 input patch touches a
     non-constant pixel (+ the border ring once the input constant is not zero, i.e. from the second layer on); the layer's output
     is non-constant exactly in its computed tiles. Step 1 (3x3 stride-2 layer, padding 1, computed everywhere): output pixel
-    non-constant iff its 3x3 window is (+ the top row / left column, where the padding enters). Returns per image the list of the
-    layers' tile masks (flattened)."""
+    non-constant iff its 3x3 window is (+ the top row / left column, where the padding enters). Step 2: the same layer, taking a
+    slot of its own -- the 2x2 tiles of its output that hold a non-constant pixel (the next layer still sees the pixels). Returns
+    per image the list of the slots' tile masks (flattened)."""
     steps = [0] * steps if isinstance(steps, int) else steps
     out = []
     for b in range(batch):
@@ -62,12 +63,16 @@ def _masks_numpy(idx, batch, steps):
                 if not zero_input:
                     o[0, :] = True
                     o[:, 0] = True
+                if k == 2:
+                    per.append(o.reshape(h // 4, 2, w // 4, 2).any((1, 3)).reshape(-1).copy())
                 nc = o
+                zero_input = False
         out.append(per)
     return out
 
 
-@pytest.mark.parametrize("batch,steps", [(1, 3), (3, 3), (1, [0, 0, 0, 1, 0, 0]), (2, [0, 0, 0, 1, 0, 0])])
+@pytest.mark.parametrize("batch,steps", [(1, 3), (3, 3), (1, [0, 0, 0, 1, 0, 0]), (2, [0, 0, 0, 1, 0, 0]), (1, [0, 0, 0, 2, 0, 0]),
+                                         (3, [0, 0, 0, 2, 0, 0]), (2, [2, 0])])
 def test_tile_masks_and_lists(dev, batch, steps):
     idx = _sites(1, batch, 1600 if isinstance(steps, int) else 500)
     ta = ops.TileActivity(batch, H, W, steps, dev)
@@ -87,9 +92,12 @@ def test_tile_masks_and_lists(dev, batch, steps):
             assert np.array_equal(tm[b], want[b][l]), (l, b)
         assert nl[l] == len(ref)
         assert np.array_equal(tl[l, :nl[l]], ref)     # ascending (image, tile): deterministic order
-    assert 0.05 < nl[0] / (batch * (H // 2) * (W // 2)) < 0.6 and nl[0] < nl[1] < nl[2]
+    if ta.n_slots >= 3:
+        assert 0.05 < nl[0] / (batch * (H // 2) * (W // 2)) < 0.6 and nl[0] < nl[1] < nl[2]
     if ta.n_slots == 5:
         assert ta.dims[3] == (H // 2, W // 2) and nl[3] < nl[4] <= batch * (H // 4) * (W // 4)
+    if ta.n_slots == 6:   # the stride-2 layer's own slot: fewer tiles than the layer after it computes
+        assert ta.dims[3] == ta.dims[4] == (H // 2, W // 2) and nl[3] < nl[4] < nl[5] <= batch * (H // 4) * (W // 4)
 
 
 def _layer(seed, c):
@@ -195,6 +203,96 @@ def test_active_chain_through_the_stride_2_layer(dev):
     frac = [float(ta.n_list[s]) / (batch * (ta.dims[s][0] // 2) * (ta.dims[s][1] // 2)) for s in range(5)]
     print("computed tile fractions", [round(f, 3) for f in frac])
     assert frac[0] < frac[1] < frac[2] and frac[3] < frac[4] < 1.0
+
+
+@pytest.mark.parametrize("batch,min_rounds", [(1, 1), (1, 4), (2, 2), (3, 8)])
+def test_stride_2_and_1x1_layers_over_tile_lists(dev, batch, min_rounds):
+    """rpn_v1.py:150-152,163-172 in active-tile mode (conv2d_sk_kernel<LIST>, sessd_conv2d_sk_active): the stride-2 conv that opens
+    block 1 over ITS tile list (step 2 of the activity program), the 1x1 trans layers over the list of the layer that produced
+    their input -- against the dense stream-K launches on the same inputs. A computed pixel is the dense kernel's arithmetic in
+    another summation split (stream-K shares differ): 1e-5 of the layer's largest value; filled pixels: the constants' chain."""
+    C0, C1 = 128, 256
+    idx = _sites(31 + batch, batch, 500)
+    x = torch.zeros(batch, C0, H, W)
+    x[idx[:, 0], :, idx[:, 2], idx[:, 3]] = torch.randn(len(idx), C0, generator=torch.Generator().manual_seed(5))
+    x = x.to(dev)
+    g = torch.Generator().manual_seed(13)
+    def mk(ci, co, k):
+        return (torch.randn(co, ci, k, k, generator=g) / (k * ci ** 0.5), 0.5 + torch.rand(co, generator=g), torch.randn(co, generator=g) * 0.3)
+    l0, l1, l2, tr0, tr1 = mk(C0, C0, 3), mk(C0, C1, 3), mk(C1, C1, 3), mk(C0, C0, 1), mk(C1, C1, 1)
+    def const(layer, c):
+        w_, sc_, sh_ = layer
+        return torch.relu(sc_.double() * (w_.double().sum((2, 3)) @ c) + sh_.double())
+    c0 = const(l0, torch.zeros(C0, dtype=torch.float64)); c1 = const(l1, c0); c2 = const(l2, c1)
+    ct0, ct1 = const(tr0, c0), const(tr1, c2)
+    f32 = lambda v: v.float().to(dev)
+    ta = ops.TileActivity(batch, H, W, [0, 2, 0], dev)
+    ta.run(torch.from_numpy(idx).to(dev), torch.tensor([len(idx)], dtype=torch.int32, device=dev), len(idx))
+    nan = lambda c, h, w: torch.full((batch, c, h, w), float("nan"), device=dev)
+    o0, o1, o2, ot0, ot1 = nan(C0, H, W), nan(C1, H // 2, W // 2), nan(C1, H // 2, W // 2), nan(C0, H, W), nan(C1, H // 2, W // 2)
+    ta.fill([o0, o1, o2, ot0, ot1], [f32(c0), f32(c1), f32(c2), f32(ct0), f32(ct1)], layers=[0, 1, 2, 0, 2])
+    ws = torch.zeros(max(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(batch, H, W, C1, 1, 0)),
+                         int(ops.lib.sessd_conv2d_sk_workspace_bytes(batch, H, W, C1, 1, 0))), dtype=torch.uint8, device=dev)
+    dv = lambda layer: (layer[1].to(dev), layer[2].to(dev))
+    def check(got, dense, what, tol=1e-5):
+        assert torch.isfinite(got).all(), "%s: a pixel neither filled nor computed" % what
+        ref, err = float(dense.abs().max()), float((got - dense).abs().max())
+        assert err <= tol * ref, (what, err, ref)
+    # layer 0 (3x3 stride 1, Winograd list kernel) gives the input of the stride-2 layer and of trans_0
+    p0 = ops.pack_conv2d(l0[0].to(dev))
+    d0 = ops.conv2d(x, p0, *dv(l0), True, None, None, 23)
+    ops.conv2d_winograd_sk_active(x, p0.upk_sk(1), C0, *dv(l0), True, o0, 1, ws, ta.tile_list[0], ta.n_list[0:1])
+    check(o0, d0, "layer 0")
+    # the stride-2 layer over its own list
+    p1 = ops.pack_conv2d(l1[0].to(dev), 2)
+    d1 = ops.conv2d(d0, p1, *dv(l1), True, None, None, 30, workspace=ws)
+    ops.conv2d_sk_active(o0, p1, *dv(l1), True, o1, ws, ta.tile_list[1], ta.n_list[1:2], min_rounds=min_rounds)
+    check(o1, d1, "stride-2 layer", 2e-5)
+    # the layer after it (Winograd list kernel) sees the pixel-level rows of the transition
+    p2 = ops.pack_conv2d(l2[0].to(dev))
+    d2 = ops.conv2d(d1, p2, *dv(l2), True, None, None, 23)
+    ops.conv2d_winograd_sk_active(o1, p2.upk_sk(1), C1, *dv(l2), True, o2, 1, ws, ta.tile_list[2], ta.n_list[2:3])
+    check(o2, d2, "layer 2", 2e-5)
+    # the 1x1 layers: computed where their input was
+    pt0, pt1 = ops.pack_conv2d(tr0[0].to(dev)), ops.pack_conv2d(tr1[0].to(dev))
+    dt0 = ops.conv2d(d0, pt0, *dv(tr0), True, None, None, 30, workspace=ws)
+    dt1 = ops.conv2d(d2, pt1, *dv(tr1), True, None, None, 30, workspace=ws)
+    ops.conv2d_sk_active(o0, pt0, *dv(tr0), True, ot0, ws, ta.tile_list[0], ta.n_list[0:1], min_rounds=min_rounds)
+    ops.conv2d_sk_active(o2, pt1, *dv(tr1), True, ot1, ws, ta.tile_list[2], ta.n_list[2:3], min_rounds=min_rounds)
+    check(ot0, dt0, "trans_0", 2e-5)
+    check(ot1, dt1, "trans_1", 2e-5)
+    # a residual rides along in the listed pixels only (the engine does not use one here; the entry point takes it)
+    res = torch.randn(batch, C0, H, W, device=dev)
+    keep = ot0.clone()
+    ops.conv2d_sk_active(o0, pt0, *dv(tr0), True, ot0, ws, ta.tile_list[0], ta.n_list[0:1], residual=res, min_rounds=min_rounds)
+    tm = ta.mask_bool(0).to(dev).view(batch, 1, H // 2, W // 2).repeat_interleave(2, 2).repeat_interleave(2, 3).expand(-1, C0, -1, -1)
+    assert torch.equal(ot0[~tm], keep[~tm]) and torch.allclose(ot0[tm], (keep + res)[tm], rtol=0, atol=1e-6 * float(keep.abs().max()) + 1e-6)
+    # same list, same launch configuration -> same bits; the counters are left zero
+    again = nan(C1, H // 2, W // 2)
+    ta.fill([again], [f32(c1)], layers=[1])
+    ops.conv2d_sk_active(o0, p1, *dv(l1), True, again, ws, ta.tile_list[1], ta.n_list[1:2], min_rounds=min_rounds)
+    assert torch.equal(again, o1)
+    units = batch * ((H * W + 127) // 128) * 2
+    assert int(ws[:units * 4].view(torch.int32).abs().sum()) == 0
+    frac = [float(ta.n_list[s]) / (batch * (ta.dims[s][0] // 2) * (ta.dims[s][1] // 2)) for s in range(3)]
+    print("computed tile fractions", [round(f, 3) for f in frac])
+    assert frac[0] < 0.6 and frac[1] < frac[2] < 1.0
+
+
+def test_an_empty_list_computes_nothing(dev):
+    """no site -> no tile: the launch returns at once and leaves the output alone"""
+    C = 128
+    ta = ops.TileActivity(1, H, W, [2], dev)
+    idx = torch.zeros((4, 4), dtype=torch.int32, device=dev)
+    ta.run(idx, torch.zeros(1, dtype=torch.int32, device=dev), 4)
+    assert int(ta.n_list[0]) == 0
+    w, scale, shift = _layer(3, C)
+    pc = ops.pack_conv2d(w.to(dev), 2)
+    ws = torch.zeros(int(ops.lib.sessd_conv2d_sk_workspace_bytes(1, H // 2, W // 2, C, 1, 0)), dtype=torch.uint8, device=dev)
+    out = torch.full((1, C, H // 2, W // 2), 3.0, device=dev)
+    ops.conv2d_sk_active(torch.randn(1, C, H, W, device=dev), pc, scale.to(dev), shift.to(dev), True, out, ws, ta.tile_list[0], ta.n_list[0:1])
+    torch.cuda.synchronize()
+    assert bool((out == 3.0).all())
 
 
 def test_active_layer_is_repeatable(dev):

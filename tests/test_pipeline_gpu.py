@@ -335,25 +335,28 @@ def test_active_tiles_do_not_change_the_frame(dev, model):
         for act in (True, False):
             eng = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, B, 20480, dev, active_tiles=act)
             eng.set_points(frames)
-            eng.tile_cfg.update({"b0.0": 22, "b0.1": 22, "b0.2": 23, "b1.1": 23, "b1.2": 22})
-            need = max(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(2 * B, eng.H, eng.W, 256, sh, 0)) for sh in (0, 1))
+            eng.tile_cfg.update({"b0.0": 22, "b0.1": 22, "b0.2": 23, "b1.0": 30, "b1.1": 23, "b1.2": 22, "trans_0": 30, "trans_1": 30})
+            need = max([int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(2 * B, eng.H, eng.W, 256, sh, 0)) for sh in (0, 1)] +
+                       [int(ops.lib.sessd_conv2d_sk_workspace_bytes(B, eng.H, eng.W, 256, 1, 0))])
             eng.sk_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
             if act:
-                eng.active_cfg = {0: (1, 4), 1: (0, 1), 2: (1, 2), 3: (1, 2), 4: (0, 1)}
+                eng.active_cfg = {0: (1, 4), 1: (0, 1), 2: (1, 2), 3: (30, 4), 4: (1, 2), 5: (0, 1), 6: (30, 2), 7: (30, 8)}
             eng.enqueue()
             out = eng.results()
-            x0 = torch.cat([eng.t["x0"].reshape(-1), eng.h["x1"].reshape(-1)])
+            x0 = torch.cat([eng.t["x0"].reshape(-1), eng.h["x1"].reshape(-1), eng.t["tr0"].reshape(-1), eng.h["tr1"].reshape(-1)])
             frac = eng.active_tile_fractions()
             if act:
                 eng.capture()
                 eng.replay()
                 out_g = eng.results()
-                assert torch.equal(torch.cat([eng.t["x0"].reshape(-1), eng.h["x1"].reshape(-1)]), x0)   # same lists, same shares: same bits
+                assert torch.equal(torch.cat([eng.t["x0"].reshape(-1), eng.h["x1"].reshape(-1), eng.t["tr0"].reshape(-1),
+                                              eng.h["tr1"].reshape(-1)]), x0)   # same lists, same shares: same bits
                 for a, b in zip(out, out_g):
                     assert np.array_equal(a["box3d_lidar"], b["box3d_lidar"]) and np.array_equal(a["scores"], b["scores"])
             res.append((x0, out, frac))
-        assert set(res[0][2]) == {"b0.0", "b0.1", "b0.2", "b1.1", "b1.2"} and res[1][2] == {}
+        assert set(res[0][2]) == {"b0.0", "b0.1", "b0.2", "b1.0", "b1.1", "b1.2", "trans_0", "trans_1"} and res[1][2] == {}
         assert 0.05 < res[0][2]["b0.0"] < res[0][2]["b0.1"] < res[0][2]["b0.2"] < 0.6 and res[0][2]["b1.1"] < res[0][2]["b1.2"] < 0.9, res[0][2]
+        assert res[0][2]["b1.0"] < res[0][2]["b1.1"] and res[0][2]["trans_0"] == res[0][2]["b0.2"] and res[0][2]["trans_1"] == res[0][2]["b1.2"]
         ref = float(res[1][0].abs().max())
         assert float((res[0][0] - res[1][0]).abs().max()) <= 2e-6 * ref
         for a, b in zip(res[0][1], res[1][1]):
