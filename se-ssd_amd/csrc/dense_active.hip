@@ -71,23 +71,69 @@ __device__ __forceinline__ void valid_bits(int n, u64& v0, u64& v1) {
   v1 = n > 64 ? (n >= 128 ? ~0ull : ((1ull << (n - 64)) - 1ull)) : 0ull;
 }
 
-// entries of one 64-bit word of a tile row, ascending, starting at list[at]
-__device__ __forceinline__ void emit_word(u64 m, int first, int at, int* list, int list_cap) {
-  while (m) {
-    const int bit = __ffsll((long long)m) - 1;
-    m &= m - 1;
-    if (at < list_cap) list[at] = first + bit;
-    ++at;
+// __syncthreads() is a workgroup-scope FENCE as well: it waits until every global store the wave has issued is acknowledged
+// (~0.7 us each time; the masks / lists / counts this kernel writes are read by nobody before it ends). Four of them per step
+// were two thirds of a step's 3 us. The LDS traffic of the workgroup only needs its own counter drained.
+#define ACT_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// sessd_block_exscan (common.hpp) with LDS-only barriers
+__device__ __forceinline__ int act_exscan(int v, int* smem, int* total) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  int incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) smem[wid] = incl;
+  ACT_LDS_BARRIER();
+  int wbase = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < NT / 64; ++w) {
+    const int sv = smem[w];
+    if (w < wid) wbase += sv;
+    tot += sv;
+  }
+  ACT_LDS_BARRIER();
+  *total = tot;
+  return wbase + incl - v;
+}
+
+// The set bits of the mask words s_m[0 .. n_words) (word wd = tile row wd / 2, half wd % 2; s_pre[wd] = entries before the word) as
+// list entries first + row * TW + 64 * half + bit, ascending from list[0]: a wave per word, a lane per bit -- the entries of a word
+// are consecutive addresses (first version: every thread walked its own word bit by bit, up to 64 dependent iterations and
+// scattered 4-byte stores; that loop was a third of this kernel's 34 us).
+__device__ __forceinline__ void emit_words(const u64* s_m, const int* s_pre, int n_words, int TW, int first, int* list, int list_cap) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // n_words <= MAX_H = 16 words per wave: all of a wave's LDS reads are issued before the first is used
+  u64 m[MAX_H / (NT / 64)];
+  int pre[MAX_H / (NT / 64)];
+#pragma unroll
+  for (int k = 0; k < MAX_H / (NT / 64); ++k) {
+    const int wd = wave + k * (NT / 64);
+    m[k] = wd < n_words ? s_m[wd] : 0ull;
+    pre[k] = wd < n_words ? s_pre[wd] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < MAX_H / (NT / 64); ++k) {
+    const int wd = wave + k * (NT / 64);
+    if ((m[k] >> lane) & 1ull) {
+      const int at = pre[k] + __popcll(m[k] & ((1ull << lane) - 1ull));
+      if (at < list_cap) list[at] = first + (wd >> 1) * TW + 64 * (wd & 1) + lane;
+    }
   }
 }
 
 // A slot's tile rows -> its mask words (written by the caller), its ordered list (batch 1) or its per-image count. Every thread of
-// the workgroup calls this (block scan); thread order = (row, word) = ascending tile order.
-__device__ __forceinline__ void emit_slot(const ActArgs& A, int slot, int b, int row, int half, int TH, int TW, u64 mine, int* s_scan) {
+// the workgroup calls this (block scan + barriers); thread order = (row, word) = ascending tile order.
+__device__ __forceinline__ void emit_slot(const ActArgs& A, int slot, int b, int row, int half, int TH, int TW, u64 mine, int* s_scan,
+                                          u64* s_m, int* s_pre) {
   int total;
-  const int at = sessd_block_exscan<NT>(__popcll(mine), s_scan, &total);
+  const int at = act_exscan(__popcll(mine), s_scan, &total);
   if (A.batch == 1) {
-    if (row < TH) emit_word(mine, row * TW + 64 * half, at, A.tile_list + (size_t)slot * A.list_cap, A.list_cap);
+    if (row < TH) { s_m[threadIdx.x] = mine; s_pre[threadIdx.x] = at; }
+    ACT_LDS_BARRIER();
+    emit_words(s_m, s_pre, 2 * TH, TW, 0, A.tile_list + (size_t)slot * A.list_cap, A.list_cap);
     if (threadIdx.x == 0) A.n_list[slot] = total;
   } else if (threadIdx.x == 0) {
     A.counts[slot * A.batch + b] = total;
@@ -100,24 +146,35 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
   __shared__ u64 nc[MAX_H][3];            // non-constant pixels of the current step's input
   __shared__ u64 tmb[MAX_H / 2][2];       // computed tiles of the current layer / rows of a transition
   __shared__ int s_scan[NT / 64];
+  __shared__ u64 s_m[MAX_H];              // a slot's mask words / entries before each word (emit_slot)
+  __shared__ int s_pre[MAX_H];
   const int b = blockIdx.x;
   int H = A.h, W = A.w;
-  for (int i = threadIdx.x; i < H * 3; i += NT) (&nc[0][0])[i] = 0ull;
-  __syncthreads();
-  const int n = min(A.n_dev[0], A.n_cap);
-  // the site rows of ALL images are walked by every workgroup (they are few); eight independent loads per thread and round
-  for (int base = 0; base < n; base += NT * 8) {
-    int4 c[8];
+  // the site rows of ALL images are walked by every workgroup (they are few); eight independent loads per thread and round. The
+  // first round is fetched up to the CAPACITY, together with the count (one memory latency instead of two), and masked afterwards.
+  int4 c[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int i = base + k * NT + (int)threadIdx.x;
-      c[k] = i < n ? *reinterpret_cast<const int4*>(A.indices + (size_t)i * 4) : make_int4(-1, 0, 0, 0);
+  for (int k = 0; k < 8; ++k) {
+    const int i = k * NT + (int)threadIdx.x;
+    c[k] = i < A.n_cap ? *reinterpret_cast<const int4*>(A.indices + (size_t)i * 4) : make_int4(-1, 0, 0, 0);
+  }
+  const int n = min(A.n_dev[0], A.n_cap);
+  for (int i = threadIdx.x; i < H * 3; i += NT) (&nc[0][0])[i] = 0ull;
+  ACT_LDS_BARRIER();
+  for (int base = 0; base < n; base += NT * 8) {
+    if (base > 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int i = base + k * NT + (int)threadIdx.x;
+        c[k] = i < n ? *reinterpret_cast<const int4*>(A.indices + (size_t)i * 4) : make_int4(-1, 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k)
-      if (c[k].x == b && c[k].z >= 0 && c[k].z < H && c[k].w >= 0 && c[k].w < W) atomicOr(&nc[c[k].z][c[k].w >> 6], 1ull << (c[k].w & 63));
+      if (base + k * NT + (int)threadIdx.x < n && c[k].x == b && c[k].z >= 0 && c[k].z < H && c[k].w >= 0 && c[k].w < W)
+        atomicOr(&nc[c[k].z][c[k].w >> 6], 1ull << (c[k].w & 63));
   }
-  __syncthreads();
+  ACT_LDS_BARRIER();
   bool zero_input = true;   // the map's constant is zero: zero padding does not show at the border
   int slot = 0;
   const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
@@ -146,7 +203,7 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
         mine = half ? t1 : t0;
         A.tile_mask[(((size_t)slot * A.batch + b) * A.mask_th + row) * 2 + half] = mine;
       }
-      emit_slot(A, slot, b, row, half, TH, TW, mine, s_scan);   // (its barriers also separate this step's reads of nc from the writes below)
+      emit_slot(A, slot, b, row, half, TH, TW, mine, s_scan, s_m, s_pre);   // (its barriers also separate this step's reads of nc from the writes below)
       // the layer's output is non-constant exactly in its computed tiles: pixel rows 2 ty, 2 ty + 1 = the tile row, every bit twice
       // (each thread of the pair writes the words that come from its own half)
       if (row < TH) {
@@ -160,7 +217,7 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
           nc[2 * row + 1][2] = p2;
         }
       }
-      __syncthreads();
+      ACT_LDS_BARRIER();
       zero_input = false;   // (a layer's own constant relu(shift) is not zero in general)
       ++slot;
     } else {
@@ -182,7 +239,7 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
         }
         tmb[row][0] = t0 & v0; tmb[row][1] = t1 & v1;
       }
-      __syncthreads();
+      ACT_LDS_BARRIER();
       if (A.kind[st] == 2) {
         // the transition itself over a tile list: its 2x2-output tile (ty, tx) is computed iff one of its four output pixels is
         // not constant (W2 <= 96: the tile row is one word). The NEXT layer still sees the pixel rows: a pixel that is computed
@@ -197,11 +254,11 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
           }
           A.tile_mask[(((size_t)slot * A.batch + b) * A.mask_th + row) * 2 + half] = mine;
         }
-        emit_slot(A, slot, b, row, half, TH, TW, mine, s_scan);
+        emit_slot(A, slot, b, row, half, TH, TW, mine, s_scan, s_m, s_pre);
         ++slot;
       }
       if (row < H2 && half == 0) { nc[row][0] = tmb[row][0]; nc[row][1] = tmb[row][1]; nc[row][2] = 0ull; }
-      __syncthreads();
+      ACT_LDS_BARRIER();
       H = H2; W = W2;
       zero_input = false;   // (conv + BatchNorm + ReLU of a zero map is relu(shift))
     }
@@ -211,6 +268,8 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
 // batch > 1: number the lists (grid = (batch, n_slots)); an image's entries follow those of the earlier images
 __global__ __launch_bounds__(NT) void bev_tile_list_kernel(ActArgs A) {
   __shared__ int s_scan[NT / 64];
+  __shared__ u64 s_m[MAX_H];
+  __shared__ int s_pre[MAX_H];
   const int b = blockIdx.x, l = blockIdx.y, TH = A.slot_th[l < MAX_SLOTS ? l : 0], TW = A.slot_tw[l < MAX_SLOTS ? l : 0], tiles = TH * TW;
   int base = 0;
   for (int q = 0; q < b; ++q) base += A.counts[l * A.batch + q];
@@ -218,7 +277,9 @@ __global__ __launch_bounds__(NT) void bev_tile_list_kernel(ActArgs A) {
   const u64 mine = row < TH ? A.tile_mask[(((size_t)l * A.batch + b) * A.mask_th + row) * 2 + half] : 0ull;
   int total;
   const int at = base + sessd_block_exscan<NT>(__popcll(mine), s_scan, &total);
-  if (row < TH) emit_word(mine, b * tiles + row * TW + 64 * half, at, A.tile_list + (size_t)l * A.list_cap, A.list_cap);
+  if (row < TH) { s_m[threadIdx.x] = mine; s_pre[threadIdx.x] = at; }
+  __syncthreads();
+  emit_words(s_m, s_pre, 2 * TH, TW, b * tiles, A.tile_list + (size_t)l * A.list_cap, A.list_cap);
   if (b == A.batch - 1 && threadIdx.x == 0) A.n_list[l] = base + total;
 }
 

@@ -541,7 +541,7 @@ class InferenceEngine:
                 need = int(lib.sessd_conv2d_sk_workspace_bytes(self.B, x_out.shape[2], x_out.shape[3], pc.cout, len(pc.launches), 0))
                 if self.sk_ws is None or self.sk_ws.numel() < need:
                     self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
-                for mr in (1, 2, 4, 8):
+                for mr in (1, 4, 8, 16):
                     tt = timed(lambda: ops.conv2d_sk_active(x_in, pc, scale, shift, True, x_out, self.sk_ws, self.ta.tile_list[m],
                                                             self.ta.n_list[m:m + 1], workgroups=self.sk_workgroups, min_rounds=mr))
                     if tt < best[1]:
@@ -553,7 +553,7 @@ class InferenceEngine:
                     need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(self.B, x_in.shape[2], x_in.shape[3], pc.cout, shape, 0))
                     if self.sk_ws is None or self.sk_ws.numel() < need:
                         self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
-                    for mr in (1, 2, 4):
+                    for mr in (1, 4, 8, 16):
                         tt = timed(lambda: ops.conv2d_winograd_sk_active(x_in, pc.upk_sk(shape), pc.cout, scale, shift, True, x_out, shape,
                                                                          self.sk_ws, self.ta.tile_list[m], self.ta.n_list[m:m + 1],
                                                                          workgroups=self.sk_workgroups, min_rounds=mr))
