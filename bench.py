@@ -482,6 +482,8 @@ def roofline_legs(args, out, eng, batch_of):
     # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
     # under profiles/; it cannot be collected inside this process
     cands = ["r4_wino_sk_traffic.json", "r3_wino_sk_traffic.json", "r2_wino_sk_traffic.json"] if streamk else ["r1_winograd_traffic.json"]
+    if streamk and act:
+        cands.insert(0, "r4s2_wino_traffic.json")  # counter passes of the frame with the list launches (average over its six launches)
     cands = cands if wino else ["r1_conv_traffic.json"]
     for nm in cands:
         tpath = os.path.join(ROOT, "profiles", nm)
