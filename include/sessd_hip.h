@@ -506,12 +506,13 @@ int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int ci
  * the first three layers of bottom_up_block_0 (rpn_v1.py:135-148) compute the same per-channel constant in every 2x2-output tile
  * whose 4x4 input patch holds no non-constant pixel (82 % / 71 % / 61 % of the tiles on a 20 k-point scan):
  *   sessd_bev_tile_activity     tile masks + ordered tile lists (entry image * tiles + tile) + device counts of a chain of 3x3 layers
- *                               given as HOST steps (0 = stride-1 layer taking the next of <= 6 slots, 1 = stride-2 layer computed
+ *                               given as HOST steps (0 = stride-1 layer taking the next slot, 1 = stride-2 layer computed
  *                               everywhere, 2 = stride-2 layer that takes a slot itself -- the 2x2 tiles of ITS output with a
- *                               non-constant pixel: rpn_v1.py:135-160 is {0, 0, 0, 2, 0, 0}), from the (image, z, y, x) rows of
- *                               the last sparse level
+ *                               non-constant pixel, 3 = stride-2 transposed conv on the current map with a residual of the
+ *                               resolution before the halving, a slot of 2x2 tiles of its INPUT: rpn_v1.py:135-160 + 224 is
+ *                               {0, 0, 0, 2, 0, 0, 3}; <= 7 slots), from the (image, z, y, x) rows of the last sparse level
  *   sessd_fill_inactive_tiles   out[b][co][tile] = value[co] (the layer's constant, computed by the host from the folded weights)
- *                               in the tiles nobody computes, up to 8 layers per launch
+ *                               in the tiles nobody computes, up to 10 layers per launch
  *   sessd_conv3x3_winograd_sk_active   sessd_conv3x3_winograd_sk over the listed tiles only (same packed U, same workspace; the
  *                               shares of the round list are sized on the device, workgroups beyond rounds / min_rounds exit)
  * Results equal the dense layer's to float32 rounding (tests/test_dense_active_gpu.py); replaces nothing in the reference -- it is
@@ -570,6 +571,26 @@ int sessd_deconv2d_s2_mfma_pair(const float* in, int batch, int cin, int hin, in
                                 float* out_a, float* out_b, int cout, const float* scale_a, const float* shift_a,
                                 const float* scale_b, const float* shift_b, int relu, const float* residual_a,
                                 const float* residual_b, int tile_cfg, sessd_stream_t stream);
+/* ACTIVE-TILE mode of sessd_conv2d_mfma (1x1 layers: trans_0 / trans_1, rpn_v1.py:163-172) and of sessd_deconv2d_s2_mfma_pair
+ * (rpn_v1.py:175-199, 224-226) on maps that are a per-channel constant away from the sparse sites (csrc/dense_active.hip): only the
+ * 2x2 tiles of the TILE SPACE listed in tile_list[0 .. min(*n_list, list_cap)) (entries image * (tile_h/2 * tile_w/2) + tile, count
+ * on the device: sessd_bev_tile_activity) are computed -- for the transposed convs the tile space is the INPUT map (step 3 of the
+ * activity program), a listed tile gives a 4x4 block of both outputs --, the other output pixels are left alone
+ * (sessd_fill_inactive_tiles, tile = 4 with one constant per output parity class for the transposed convs). The launch is sized
+ * for the whole map, workgroups beyond the device count leave at once. Four effective taps (a 1x1 layer with cin % 8 == 0 or a
+ * class of the transposed conv), tile_cfg 3 / 4 / 11 / 12, even tile_h / tile_w, the whole batch inside 32-bit buffer offsets.
+ * Per computed pixel the code of the plain launch: the same bits. */
+int sessd_conv2d_mfma_active(const float* in, int batch, int cin, int hin, int win, const float* wpk, int ntaps, const int* taps_dy,
+                             const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out, int cout, int hout, int wout,
+                             int out_mul, int out_py, int out_px, const float* scale, const float* shift, int relu,
+                             const float* residual, const int32_t* tile_list, const int32_t* n_list, int list_cap, int tile_cfg,
+                             sessd_stream_t stream);
+int sessd_deconv2d_s2_mfma_pair_active(const float* in, int batch, int cin, int hin, int win, const float* const* wpk4_a,
+                                       const float* const* wpk4_b, const int* ntaps4, const int* taps_dy4, const int* taps_dx4,
+                                       float* out_a, float* out_b, int cout, const float* scale_a, const float* shift_a,
+                                       const float* scale_b, const float* shift_b, int relu, const float* residual_a,
+                                       const float* residual_b, const int32_t* tile_list, const int32_t* n_list, int list_cap,
+                                       int tile_cfg, sessd_stream_t stream);
 /* rpn_v1.py:227-233: softmax over the two 1-channel weight maps and the weighted sum of x0, x1 */
 int sessd_ssfa_fuse(const float* x0, const float* x1, const float* w0, const float* w1, float bn_scale0,
                     float bn_shift0, float bn_scale1, float bn_shift1, int batch, int channels, int num_pixels,

@@ -50,6 +50,9 @@ typedef struct {
   const float* value;
   const uint64_t* tile_mask;
   int32_t cout, h, w, mask_th;
+  int32_t tile;   /* 0 / 2: 2x2-pixel tiles, value[cout]; 4: 4x4-pixel tiles (a transposed conv over 2x2 tiles of its input),
+                     value[4][cout] = the constant of each output parity class (py * 2 + px) */
+  int32_t reserved;
 } sessd_fill_tiles_job_t;
 
 /* One sparse-conv weight packing of sessd_sparse_pack_batch: sessd_sparse_pack_weight (adjoint 0) or

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int NT = 1024;
 constexpr int MAX_H = 256, MAX_W = 192;   // one image's pixel rows as 3 x 64-bit words in LDS; a thread pair per tile row
-constexpr int MAX_SLOTS = 6, MAX_STEPS = 8, MAX_FILL_JOBS = 8;
+constexpr int MAX_SLOTS = 7, MAX_STEPS = 8, MAX_FILL_JOBS = 10;
 typedef unsigned long long u64;
 
 struct ActArgs {
@@ -36,7 +36,9 @@ struct ActArgs {
   int n_cap, batch, h, w;
   int n_steps, n_slots;
   int kind[MAX_STEPS];        // 0: 3x3 stride-1 layer (takes the next slot), 1: 3x3 stride-2 transition (halves the map),
-                              // 2: the same transition, itself computed over a tile list (takes the next slot)
+                              // 2: the same transition, itself computed over a tile list (takes the next slot),
+                              // 3: a stride-2 TRANSPOSED conv on the current map, its 2x2 INPUT tiles (takes the next slot; the map
+                              //    and the resolution stay)
   int slot_th[MAX_SLOTS], slot_tw[MAX_SLOTS];
   int list_cap, mask_th;      // rows of a (slot, image) block of tile_mask = h / 2 (the first resolution's)
   u64* tile_mask;       // [n_slots][batch][mask_th][2]: bit tx of the row's 128-bit word = tile (ty, tx) is computed
@@ -130,8 +132,8 @@ __device__ __forceinline__ void emit_slot(const ActArgs& A, int slot, int b, int
                                           u64* s_m, int* s_pre) {
   int total;
   const int at = act_exscan(__popcll(mine), s_scan, &total);
+  if (row < TH) { s_m[threadIdx.x] = mine; s_pre[threadIdx.x] = at; }   // (s_m is also what a later transition keeps)
   if (A.batch == 1) {
-    if (row < TH) { s_m[threadIdx.x] = mine; s_pre[threadIdx.x] = at; }
     ACT_LDS_BARRIER();
     emit_words(s_m, s_pre, 2 * TH, TW, 0, A.tile_list + (size_t)slot * A.list_cap, A.list_cap);
     if (threadIdx.x == 0) A.n_list[slot] = total;
@@ -148,6 +150,7 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
   __shared__ int s_scan[NT / 64];
   __shared__ u64 s_m[MAX_H];              // a slot's mask words / entries before each word (emit_slot)
   __shared__ int s_pre[MAX_H];
+  __shared__ u64 s_keep[MAX_H];           // mask words of the last LAYER slot before the most recent transition (step 3's residual input)
   const int b = blockIdx.x;
   int H = A.h, W = A.w;
   // the site rows of ALL images are walked by every workgroup (they are few); eight independent loads per thread and round. The
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
   }
   ACT_LDS_BARRIER();
   bool zero_input = true;   // the map's constant is zero: zero padding does not show at the border
+  bool have_layer = false, have_keep = false;   // s_m holds a layer slot of the current resolution / s_keep one of twice the resolution
   int slot = 0;
   const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
   for (int st = 0; st < A.n_steps; ++st) {
@@ -219,8 +223,45 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
       }
       ACT_LDS_BARRIER();
       zero_input = false;   // (a layer's own constant relu(shift) is not zero in general)
+      have_layer = true;
+      ++slot;
+    } else if (A.kind[st] == 3) {
+      // ---- ConvTranspose2d(3, stride 2, padding 1, output_padding 1) on the current map, computed over 2x2 tiles of its INPUT
+      // (= 4x4 blocks of its output): out(2y+py, 2x+px) reads in(y .. y+py, x .. x+px), so tile (ty, tx) has something to compute
+      // iff rows 2ty .. 2ty+2, cols 2tx .. 2tx+2 hold a non-constant pixel; the last tile row / column always (beyond the map the
+      // sum loses terms: not the constant); and wherever the RESIDUAL added to the output is not constant -- the kept layer slot
+      // of twice the resolution, 2x2 of its tiles per tile of this one (rpn_v1.py:224: deconv_block_0(x_trans_1) + x_trans_0).
+      const int TH = H >> 1, TW = W >> 1;   // TW <= 64 (checked by the host)
+      u64 v0, v1;
+      valid_bits(TW, v0, v1);
+      u64 mine = 0ull;
+      if (row < TH) {
+        if (half == 0) {
+          u64 r0 = 0ull, r1 = 0ull;
+          for (int y = 2 * row; y <= min(2 * row + 2, H - 1); ++y) { r0 |= nc[y][0]; r1 |= nc[y][1]; }
+          const u64 h0 = r0 | (r0 >> 1) | (r1 << 63) | (r0 >> 2) | (r1 << 62);
+          const u64 h1 = r1 | (r1 >> 1) | (r1 >> 2);
+          u64 t0 = (u64)even_bits(h0) | ((u64)even_bits(h1) << 32);
+          if (!zero_input) {
+            if (row == TH - 1) t0 = ~0ull;
+            t0 |= 1ull << (TW - 1);
+          }
+          if (have_keep) {
+            const u64 k0 = s_keep[4 * row] | s_keep[4 * row + 2], k1 = s_keep[4 * row + 1] | s_keep[4 * row + 3];
+            t0 |= (u64)even_bits(k0 | (k0 >> 1)) | ((u64)even_bits(k1 | (k1 >> 1)) << 32);
+          }
+          mine = t0 & v0;
+        }
+        A.tile_mask[(((size_t)slot * A.batch + b) * A.mask_th + row) * 2 + half] = mine;
+      }
+      emit_slot(A, slot, b, row, half, TH, TW, mine, s_scan, s_m, s_pre);
+      ACT_LDS_BARRIER();
+      have_layer = false;   // (s_m no longer holds a layer slot)
       ++slot;
     } else {
+      if (have_layer && threadIdx.x < 2 * (H >> 1)) s_keep[threadIdx.x] = s_m[threadIdx.x];   // (the thread's own words)
+      have_keep = have_layer;
+      have_layer = false;
       // ---- 3x3 stride-2 conv, padding 1, computed everywhere: output pixel (Y, X) is constant iff rows 2Y-1 .. 2Y+1, cols 2X-1 ..
       // 2X+1 are; the padding enters at Y = 0 / X = 0 only (2Y+1 <= H-1 for even H)
       const int H2 = H >> 1, W2 = W >> 1;
@@ -302,7 +343,30 @@ __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, in
 #pragma unroll
   for (int q = 1; q < MAX_FILL_JOBS; ++q)
     if (q == j) { J = Q.J[q]; off = Q.blk_off[q]; }
-  const int h = J.h, w = J.w, th = h >> 1, tw = w >> 1, pairs = th * (tw >> 1);
+  const int h = J.h, w = J.w;
+  if (J.tile == 4) {
+    // 4x4-pixel tiles (the output of a transposed conv over 2x2 tiles of its input): a thread per tile, four 16-byte rows; the
+    // constant depends on the output parity class: value[(py * 2 + px) * cout + co]
+    const int th = h >> 2, tw = w >> 2, tiles = th * tw;
+    const int chunks = sessd_divup(tiles, 256);
+    int r = (int)blockIdx.x - off;
+    const int chunk = r % chunks; r /= chunks;
+    const int co = r % J.cout, b = r / J.cout;
+    const int t = chunk * 256 + threadIdx.x;
+    if (t >= tiles) return;
+    const int ty = t / tw, tx = t - ty * tw;
+    const u64 word = J.tile_mask[((size_t)b * J.mask_th + ty) * 2 + (tx >> 6)];
+    if ((word >> (tx & 63)) & 1ull) return;
+    const float c00 = J.value[co], c01 = J.value[J.cout + co], c10 = J.value[2 * J.cout + co], c11 = J.value[3 * J.cout + co];
+    float* o = J.out + (((size_t)b * J.cout + co) * h + 4 * ty) * w + 4 * tx;
+    const float4 e = make_float4(c00, c01, c00, c01), d = make_float4(c10, c11, c10, c11);
+    *reinterpret_cast<float4*>(o) = e;
+    *reinterpret_cast<float4*>(o + w) = d;
+    *reinterpret_cast<float4*>(o + 2 * w) = e;
+    *reinterpret_cast<float4*>(o + 3 * w) = d;
+    return;
+  }
+  const int th = h >> 1, tw = w >> 1, pairs = th * (tw >> 1);
   const int chunks = sessd_divup(pairs, 256);
   int r = (int)blockIdx.x - off;
   const int chunk = r % chunks; r /= chunks;
@@ -361,6 +425,10 @@ int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_
       if (A.n_slots == MAX_SLOTS) return SESSD_EINVAL;
       A.slot_th[A.n_slots] = ch / 2; A.slot_tw[A.n_slots] = cw / 2;
       ++A.n_slots;
+    } else if (steps[s] == 3) {   // 2x2 tiles of the current map, one word per tile row
+      if (A.n_slots == MAX_SLOTS || cw / 2 > 64) return SESSD_EINVAL;
+      A.slot_th[A.n_slots] = ch / 2; A.slot_tw[A.n_slots] = cw / 2;
+      ++A.n_slots;
     } else if (steps[s] == 1 || steps[s] == 2) {
       ch /= 2; cw /= 2;
       if (steps[s] == 2) {   // the transition takes a slot of 2x2 tiles of ITS output
@@ -384,7 +452,8 @@ int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_
   return SESSD_OK;
 }
 
-// out[b][co][tile pixels] = value[co] for every tile of job j whose bit in tile_mask is 0, for up to 8 jobs (out (batch, cout, h, w),
+// out[b][co][tile pixels] = value[co] for every tile of job j whose bit in tile_mask is 0, for up to 10 jobs (tile = 4: 4x4-pixel
+// tiles with one value per output parity class, value[(py * 2 + px) * cout + co]) (out (batch, cout, h, w),
 // value[cout], tile_mask (batch, mask_th, 2) words, cout, h, w, mask_th) in one launch.
 int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, hipStream_t stream) {
   if (!jobs || n_jobs < 1 || n_jobs > MAX_FILL_JOBS || batch < 1) return SESSD_EINVAL;
@@ -393,13 +462,15 @@ int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, in
   int blk = 0;
   for (int j = 0; j < n_jobs; ++j) {
     const sessd_fill_tiles_job_t& S = jobs[j];
-    // (w % 4 == 0: a thread owns two adjacent tiles = 16-byte aligned rows of four pixels)
-    if (!S.out || !S.value || !S.tile_mask || S.cout < 1 || S.h < 2 || S.w < 4 || (S.h & 1) || (S.w & 3) || S.mask_th < S.h / 2 ||
-        S.w / 2 > 128)
+    // (w % 4 == 0: a thread owns two adjacent 2x2 tiles, or one 4x4 tile = 16-byte aligned rows of four pixels)
+    const int tile = S.tile == 4 ? 4 : 2;
+    if (!S.out || !S.value || !S.tile_mask || S.cout < 1 || S.h < tile || S.w < 4 || (S.h % tile) || (S.w & 3) || S.mask_th < S.h / tile ||
+        S.w / tile > 128 || (S.tile != 0 && S.tile != 2 && S.tile != 4))
       return SESSD_EINVAL;
     Q.J[j] = S;
+    Q.J[j].tile = tile;
     Q.blk_off[j] = blk;
-    blk += sessd_divup((S.h / 2) * (S.w / 4), 256) * S.cout * batch;
+    blk += (tile == 4 ? sessd_divup((S.h / 4) * (S.w / 4), 256) : sessd_divup((S.h / 2) * (S.w / 4), 256)) * S.cout * batch;
   }
   for (int j = n_jobs; j < MAX_FILL_JOBS; ++j) { Q.J[j] = jobs[0]; Q.blk_off[j] = blk; }
   Q.blk_off[MAX_FILL_JOBS] = blk;

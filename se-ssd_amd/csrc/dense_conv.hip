@@ -40,6 +40,11 @@ struct ConvArgs {
   int cgroup;          // cin pairs consumed per k-step (1 for 3x3; >1 batches 1x1 / few-tap convs into "virtual taps")
   int dy[9], dx[9];
   int dc[9];           // cin-pair displacement of a tap inside its k-step group
+  // active-tile mode (LIST kernels; csrc/dense_active.hip): the tile-space pixels are the 2x2 tiles of a device list, entries
+  // image * ntiles2 + tile, their count on the device; lbatch = images the buffers hold (the image is part of the lane offsets)
+  const int* tile_list;
+  const int* n_list;
+  int list_cap, ntiles2, tw2, lbatch;
 };
 
 struct ConvArgs4 {
@@ -60,13 +65,32 @@ __device__ __forceinline__ float bufload(rsrc_t rsrc, unsigned voff, unsigned so
 }
 #define SESSD_OOB 0x80000000u  // a lane offset beyond any buffer: the load returns 0 (out-of-image tap)
 
-template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
+// LIST: slot p of the launch's pixel axis -> (image, y, x) through the tile list. 128 consecutive slots = 32 list entries: slots
+// 0..63 the upper pixel rows of the 32 tiles, 64..127 the lower ones, so that a run of adjacent tiles is a run of adjacent pixels.
+__device__ __forceinline__ bool list_pixel(const ConvArgs& A, int n_list, int p, int& y, int& x, int& img) {
+  const int k = (p >> 7) * 32 + ((p & 63) >> 1);
+  const int e = k < n_list ? A.tile_list[k] : -1;
+  const bool live = e >= 0;
+  img = live ? e / A.ntiles2 : 0;
+  const int t = live ? e - img * A.ntiles2 : 0;
+  y = 2 * (t / A.tw2) + ((p >> 6) & 1);
+  x = 2 * (t - (t / A.tw2) * A.tw2) + (p & 1);
+  return live;
+}
+
+template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false, bool LIST = false>
 __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   static_assert(WC * WP == 4, "four waves per workgroup");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = lane & 31, h = lane >> 5;
   const int wc = wave % WC, wp = wave / WC;
-  const int npix = A.ht * A.wt;
+  int npix = A.ht * A.wt;
+  int n_list = 0;
+  if constexpr (LIST) {
+    // ACTIVE-TILE mode: the launch is sized for the whole map, the workgroups beyond the device count leave at once
+    n_list = __builtin_amdgcn_readfirstlane(min(A.n_list[0], A.list_cap));
+    npix = ((n_list + 31) >> 5) * 128;
+  }
   // XCD-aware workgroup order: the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs (private
   // L2 each). Remap so that each XCD owns one contiguous run of pixel tiles (with all their cout groups): the
   // 3-row halo that neighbouring tiles share then hits in that XCD's L2 instead of being fetched once per XCD
@@ -74,7 +98,8 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   const int ny = sessd_divup(A.cout_pad, WC * CT * 32);
   int bx, by;
   {
-    const int total = gridDim.x, bid = blockIdx.x;
+    const int total = LIST ? sessd_divup(npix, WP * PT * 32) * ny : (int)gridDim.x, bid = blockIdx.x;
+    if (LIST && bid >= total) return;
     const int q = total >> 3, r = total & 7, xcd = bid & 7, loc = bid >> 3;
     const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     bx = wgid / ny;
@@ -90,19 +115,21 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   // ALU work for addressing -- on gfx950 the f32 MFMA shares the SIMD's f32 lanes with the VALU, so every VALU
   // instruction in the loop is MFMA time lost (a 64-bit pointer add per load halved the rate of this kernel).
   // Out-of-image taps get the offset SESSD_OOB: the hardware range check returns 0, no select needed.
-  const rsrc_t xr = make_rsrc(A.in + (size_t)b * A.cin * in_plane, (unsigned)A.cin * in_plane * 4u);
+  const unsigned xbytes = (unsigned)A.cin * in_plane * 4u;
+  const rsrc_t xr = LIST ? make_rsrc(A.in, (unsigned)A.lbatch * xbytes) : make_rsrc(A.in + (size_t)b * A.cin * in_plane, xbytes);
   const rsrc_t wr = make_rsrc(A.wpk, (unsigned)(A.cin >> 1) * NTAPS / A.cgroup * 2u * A.cout_pad * 4u);
   unsigned xo[PT][NTAPS];
 #pragma unroll
   for (int q = 0; q < PT; ++q) {
     const int p = p_base + q * 32 + j;
-    const bool live = p < npix;
-    const int y = live ? p / A.wt : 0, x = live ? p - (p / A.wt) * A.wt : 0;
+    bool live = p < npix;
+    int y = live ? p / A.wt : 0, x = live ? p - (p / A.wt) * A.wt : 0, img = 0;
+    if constexpr (LIST) live = list_pixel(A, n_list, p, y, x, img);
 #pragma unroll
     for (int t = 0; t < NTAPS; ++t) {
       const int iy = y * A.in_mul + A.dy[t], ix = x * A.in_mul + A.dx[t];
       const bool ok = live && iy >= 0 && iy < A.hin && ix >= 0 && ix < A.win;
-      xo[q][t] = ok ? (unsigned)(((h + A.dc[t] * 2) * in_plane + iy * A.win + ix) * 4) : SESSD_OOB;
+      xo[q][t] = ok ? (unsigned)img * xbytes + (unsigned)(((h + A.dc[t] * 2) * in_plane + iy * A.win + ix) * 4) : SESSD_OOB;
     }
   }
   const unsigned wo = (unsigned)((h * A.cout_pad + m_base + j) * 4);
@@ -186,8 +213,9 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
   // (With `if (co < cout)` / `if (residual)` around each element hipcc emitted load, s_waitcnt vmcnt(0), load, s_waitcnt vmcnt(0),
   // store per element: 32 serialised memory round trips per tile, each also waiting for the previous store.)
   const unsigned oplane4 = (unsigned)(A.hout * A.wout) * 4u;
-  const size_t boff = (size_t)b * A.cout * (size_t)(A.hout * A.wout);
-  const unsigned obytes = (unsigned)A.cout * oplane4;
+  const size_t boff = LIST ? (size_t)0 : (size_t)b * A.cout * (size_t)(A.hout * A.wout);
+  const unsigned obytes1 = (unsigned)A.cout * oplane4;   // one image's output
+  const unsigned obytes = LIST ? (unsigned)A.lbatch * obytes1 : obytes1;
   const rsrc_t orr = make_rsrc(A.out + boff, obytes);
   const rsrc_t rr = make_rsrc(A.residual ? A.residual + boff : A.out, A.residual ? obytes : 0u);
   const rsrc_t scr = make_rsrc(A.scale ? A.scale : A.out, A.scale ? (unsigned)A.cout * 4u : 0u);
@@ -195,9 +223,10 @@ __device__ __forceinline__ void conv_body(const ConvArgs& A, const int b) {
 #pragma unroll
   for (int q = 0; q < PT; ++q) {
     const int p = p_base + q * 32 + j;
-    const bool live = p < npix;
-    const int y = live ? p / A.wt : 0, x = live ? p - (p / A.wt) * A.wt : 0;
-    const unsigned pix4 = (unsigned)((y * A.out_mul + A.out_py) * A.wout + (x * A.out_mul + A.out_px)) * 4u;
+    bool live = p < npix;
+    int y = live ? p / A.wt : 0, x = live ? p - (p / A.wt) * A.wt : 0, img = 0;
+    if constexpr (LIST) live = list_pixel(A, n_list, p, y, x, img);
+    const unsigned pix4 = (unsigned)img * obytes1 + (unsigned)((y * A.out_mul + A.out_py) * A.wout + (x * A.out_mul + A.out_px)) * 4u;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       const int co0 = m_base + c * 32 + 4 * h;
@@ -559,9 +588,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3s1_winograd_kernel(ConvArgs A) 
   }
 }
 
-template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
+template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false, bool LIST = false>
 __global__ __launch_bounds__(256) void conv2d_mfma_kernel(ConvArgs A) {
-  conv_body<NTAPS, CT, PT, WC, WP, DEEP>(A, blockIdx.z);
+  conv_body<NTAPS, CT, PT, WC, WP, DEEP, LIST>(A, LIST ? 0 : blockIdx.z);
 }
 
 // Up to four convolutions that share shapes but not weights / taps / output phase in ONE launch
@@ -575,9 +604,9 @@ __global__ __launch_bounds__(256) void conv2d_mfma4_kernel(ConvArgs4 A4) {
 
 // Two transposed convs that read the SAME input (deconv_block_0 / deconv_block_1 of the SSFA neck, rpn_v1.py:224-226) in one
 // launch: eight classes, c[2k] / c[2k+1] = class k of the first / second layer; blockIdx.z = batch*8 + (7 - index), heaviest first.
-template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false>
+template <int NTAPS, int CT, int PT, int WC, int WP, bool DEEP = false, bool LIST = false>
 __global__ __launch_bounds__(256) void conv2d_mfma8_kernel(ConvArgs8 A8) {
-  conv_body<NTAPS, CT, PT, WC, WP, DEEP>(A8.c[7 - (blockIdx.z & 7)], blockIdx.z >> 3);
+  conv_body<NTAPS, CT, PT, WC, WP, DEEP, LIST>(A8.c[7 - (blockIdx.z & 7)], LIST ? 0 : blockIdx.z >> 3);
 }
 
 // SSFA tail (rpn_v1.py:227-233): w0 = BN(conv1x1(x0)), w1 = BN(conv1x1(x1)) (C -> 1 channel, no ReLU),
@@ -746,10 +775,24 @@ int launch_conv(const ConvArgs* A, int nconv, int batch, hipStream_t stream) {
 template <int CT, int PT, int WC, int WP, bool DEEP>
 int launch_conv8(const ConvArgs* A, int batch, hipStream_t stream) {
   const int npix = A[0].ht * A[0].wt;
-  dim3 grid(sessd_divup(npix, WP * PT * 32) * sessd_divup(A[0].cout_pad, WC * CT * 32), 1, batch * 8);
+  const bool list = A[0].tile_list != nullptr;   // the images of a list launch share the pixel axis
+  dim3 grid(sessd_divup(npix * (list ? batch : 1), WP * PT * 32) * sessd_divup(A[0].cout_pad, WC * CT * 32), 1, (list ? 1 : batch) * 8);
   ConvArgs8 A8;
   for (int i = 0; i < 8; ++i) A8.c[i] = A[i];
-  SESSD_LAUNCH((conv2d_mfma8_kernel<4, CT, PT, WC, WP, DEEP>), grid, dim3(256), 0, stream, A8);
+  if (list)
+    SESSD_LAUNCH((conv2d_mfma8_kernel<4, CT, PT, WC, WP, DEEP, true>), grid, dim3(256), 0, stream, A8);
+  else
+    SESSD_LAUNCH((conv2d_mfma8_kernel<4, CT, PT, WC, WP, DEEP>), grid, dim3(256), 0, stream, A8);
+  SESSD_CHECK_LAUNCH();
+  return SESSD_OK;
+}
+
+// one conv over a tile list (four effective taps: a 1x1 layer with its cin pairs grouped, or one class of a transposed conv)
+template <int CT, int PT, int WC, int WP, bool DEEP>
+int launch_conv_list(const ConvArgs& A, int batch, hipStream_t stream) {
+  const int npix = A.ht * A.wt;
+  dim3 grid(sessd_divup(npix * batch, WP * PT * 32) * sessd_divup(A.cout_pad, WC * CT * 32), 1, 1);
+  SESSD_LAUNCH((conv2d_mfma_kernel<4, CT, PT, WC, WP, DEEP, true>), grid, dim3(256), 0, stream, A);
   SESSD_CHECK_LAUNCH();
   return SESSD_OK;
 }
@@ -787,6 +830,7 @@ int fill_args(ConvArgs& A, const float* in, int cin, int hin, int win, const flo
   A.ht = tile_h; A.wt = tile_w;
   A.in_mul = in_mul; A.out_mul = out_mul; A.out_py = py; A.out_px = px;
   A.relu = relu;
+  A.tile_list = nullptr; A.n_list = nullptr; A.list_cap = 0; A.ntiles2 = 1; A.tw2 = 1; A.lbatch = 1;
   int group = 1;
   const int pairs = cin / 2;
   if (ntaps == 1 && pairs % 4 == 0) group = 4;
@@ -1050,6 +1094,63 @@ int sessd_deconv2d_s2_mfma_pair(const float* in, int batch, int cin, int hin, in
                                 1, hin, win, l ? out_b : out_a, cout, 2 * hin, 2 * win, 2, c >> 1, c & 1, l ? scale_b : scale_a,
                                 l ? shift_b : shift_a, relu, l ? residual_b : residual_a);
       if (eff != 4) return SESSD_EINVAL;
+    }
+  switch (tile_cfg) {
+    case 3: return launch_conv8<1, 1, 4, 1, false>(A, batch, stream);
+    case 4: return launch_conv8<1, 1, 1, 4, false>(A, batch, stream);
+    case 11: return launch_conv8<1, 1, 1, 4, true>(A, batch, stream);
+    case 12: return launch_conv8<1, 1, 4, 1, true>(A, batch, stream);
+    default: return SESSD_EINVAL;
+  }
+}
+
+// ACTIVE-TILE mode of the two launches above (csrc/dense_active.hip; rpn_v1.py:163-199 on maps that are a per-channel constant
+// away from the sparse sites): only the 2x2 tiles of the TILE SPACE listed in tile_list[0 .. min(*n_list, list_cap)) (entries
+// image * (tile_h/2 * tile_w/2) + tile; count on the device) are computed -- for the transposed convs the tile space is the INPUT
+// map, a listed tile gives a 4x4 block of output pixels --, the other output pixels are left alone. The launch is sized for the
+// whole map; workgroups beyond the count leave at once. Even tile_h / tile_w, the whole batch inside 32-bit buffer offsets.
+// Per computed pixel the code of the plain launch: the same bits.
+int sessd_conv2d_mfma_active(const float* in, int batch, int cin, int hin, int win, const float* wpk, int ntaps, const int* taps_dy,
+                             const int* taps_dx, int in_mul, int tile_h, int tile_w, float* out, int cout, int hout, int wout,
+                             int out_mul, int out_py, int out_px, const float* scale, const float* shift, int relu,
+                             const float* residual, const int32_t* tile_list, const int32_t* n_list, int list_cap, int tile_cfg,
+                             hipStream_t stream) {
+  if (cin % 2 || ntaps < 1 || ntaps > 9 || batch < 1 || cout < 1 || !tile_list || !n_list || list_cap < 1 || (tile_h & 1) || (tile_w & 1))
+    return SESSD_EINVAL;
+  if ((long long)batch * cout * hout * wout * 4 >= 0x7fffffffLL || (long long)batch * cin * hin * win * 4 >= 0x7fffffffLL) return SESSD_EINVAL;
+  ConvArgs A;
+  const int eff = fill_args(A, in, cin, hin, win, wpk, ntaps, taps_dy, taps_dx, in_mul, tile_h, tile_w, out, cout, hout, wout, out_mul,
+                            out_py, out_px, scale, shift, relu, residual);
+  if (eff != 4) return SESSD_EINVAL;   // 1x1 layers with cin % 8 == 0 (four cin pairs per k-step) and 4-tap classes
+  A.tile_list = tile_list; A.n_list = n_list; A.list_cap = list_cap; A.ntiles2 = (tile_h / 2) * (tile_w / 2); A.tw2 = tile_w / 2;
+  A.lbatch = batch;
+  switch (tile_cfg) {
+    case 3: return launch_conv_list<1, 1, 4, 1, false>(A, batch, stream);
+    case 4: return launch_conv_list<1, 1, 1, 4, false>(A, batch, stream);
+    case 11: return launch_conv_list<1, 1, 1, 4, true>(A, batch, stream);
+    case 12: return launch_conv_list<1, 1, 4, 1, true>(A, batch, stream);
+    default: return SESSD_EINVAL;
+  }
+}
+
+int sessd_deconv2d_s2_mfma_pair_active(const float* in, int batch, int cin, int hin, int win, const float* const* wpk4_a,
+                                       const float* const* wpk4_b, const int* ntaps4, const int* taps_dy4, const int* taps_dx4,
+                                       float* out_a, float* out_b, int cout, const float* scale_a, const float* shift_a,
+                                       const float* scale_b, const float* shift_b, int relu, const float* residual_a,
+                                       const float* residual_b, const int32_t* tile_list, const int32_t* n_list, int list_cap,
+                                       int tile_cfg, hipStream_t stream) {
+  if (cin % 8 || batch < 1 || cout < 1 || !tile_list || !n_list || list_cap < 1 || (hin & 1) || (win & 1)) return SESSD_EINVAL;
+  if ((long long)batch * cout * 4 * hin * win * 4 >= 0x7fffffffLL || (long long)batch * cin * hin * win * 4 >= 0x7fffffffLL) return SESSD_EINVAL;
+  ConvArgs A[8];
+  for (int c = 0; c < 4; ++c)
+    for (int l = 0; l < 2; ++l) {
+      ConvArgs& C = A[2 * c + l];
+      const int eff = fill_args(C, in, cin, hin, win, (l ? wpk4_b : wpk4_a)[c], ntaps4[c], taps_dy4 + 4 * c, taps_dx4 + 4 * c, 1, hin, win,
+                                l ? out_b : out_a, cout, 2 * hin, 2 * win, 2, c >> 1, c & 1, l ? scale_b : scale_a,
+                                l ? shift_b : shift_a, relu, l ? residual_b : residual_a);
+      if (eff != 4) return SESSD_EINVAL;
+      C.tile_list = tile_list; C.n_list = n_list; C.list_cap = list_cap; C.ntiles2 = (hin / 2) * (win / 2); C.tw2 = win / 2;
+      C.lbatch = batch;
     }
   switch (tile_cfg) {
     case 3: return launch_conv8<1, 1, 4, 1, false>(A, batch, stream);

@@ -32,7 +32,8 @@ class RulebookJob(C.Structure):
 
 class FillTilesJob(C.Structure):
     """sessd_fill_tiles_job_t (include/sessd_hip_types.h)"""
-    _fields_ = [("out", vp), ("value", vp), ("tile_mask", vp), ("cout", i32), ("h", i32), ("w", i32), ("mask_th", i32)]
+    _fields_ = [("out", vp), ("value", vp), ("tile_mask", vp), ("cout", i32), ("h", i32), ("w", i32), ("mask_th", i32), ("tile", i32),
+                ("reserved", i32)]
 
 
 class HeadLossNet(C.Structure):
@@ -101,6 +102,10 @@ SIGNATURES = {
                               i32, vp, vp, sz, i32, vp]),
     "sessd_conv2d_sk_active": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, vp, vp, vp, vp,
                                      i32, vp, vp, vp, i32, i32, vp, sz, i32, vp]),
+    "sessd_conv2d_mfma_active": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, vp, i32, i32, i32, vp, i32, i32, i32, i32, i32, i32, vp, vp, i32, vp,
+                                       vp, vp, i32, i32, vp]),
+    "sessd_deconv2d_s2_mfma_pair_active": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, vp,
+                                                 i32, i32, vp]),
     "sessd_deconv2d_s2_mfma_pair": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, i32, vp, vp, i32, vp]),
     "sessd_deconv2d_s2_mfma": (i32, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]),
     "sessd_ssfa_fuse": (i32, [vp, vp, vp, vp, f32, f32, f32, f32, i32, i32, i32, vp, vp]),

@@ -88,7 +88,22 @@ class DensePlan:
             c = step(seq, ci, bi, c)
             chain.append(c)
         chain += [step(neck.trans_0, 0, 1, chain[2]), step(neck.trans_1, 0, 1, chain[5])]
+        # entry 8 = the two transposed convs on a constant trans_1 map (rpn_v1.py:175-199): one constant per output parity class
+        # (py, px) -- out(2y+py, 2x+px) sums the taps ky in K(py), kx in K(px), K(0) = {1}, K(1) = {0, 2} --, (4, cout) each; the
+        # first one plus the constant of the residual trans_0 map (rpn_v1.py:224)
+        def dstep(seq, c):
+            s_, t_ = fold_bn(seq[1])
+            w = seq[0].weight.detach().double().cpu()   # (cin, cout, 3, 3)
+            K = {0: [1], 1: [0, 2]}
+            rows = []
+            for py in (0, 1):
+                for px in (0, 1):
+                    ws = sum(w[:, :, ky, kx] for ky in K[py] for kx in K[px])   # (cin, cout)
+                    rows.append(torch.relu(s_.double().cpu() * (c @ ws) + t_.double().cpu()))
+            return torch.stack(rows)
         self.act_const = [v.float().to(device).contiguous() for v in chain]
+        self.act_const.append(((dstep(neck.deconv_block_0, chain[7]) + chain[6][None]).float().to(device).contiguous(),
+                               dstep(neck.deconv_block_1, chain[7]).float().to(device).contiguous()))
         self.b1 = [cbr(b1, 0, 1), cbr(b1, 3, 4), cbr(b1, 6, 7)]
         self.trans_0 = cbr(neck.trans_0, 0, 1)
         self.trans_1 = cbr(neck.trans_1, 0, 1)
@@ -272,18 +287,22 @@ class InferenceEngine:
         # not constant (14 / 26 / 36 % of the tiles of block 0, 46 / 54 / 68 % of block 1's on a 20 k-point scan; a 1x1 layer is
         # computed where its input was) and the rest is filled with the layer's constant.
         # ACTIVE_SLOTS: layer id -> (layer name, layer, input buffer, output buffer); ACTIVE_MASK: id -> slot of the tile mask / list
-        # (sessd_bev_tile_activity steps {0, 0, 0, 2, 0, 0}); ACTIVE_SK: ids on the LDS-tiled stream-K kernel (the others: Winograd).
+        # (sessd_bev_tile_activity steps {0, 0, 0, 2, 0, 0, 3}); ACTIVE_SK: ids on the LDS-tiled stream-K kernel (30, min_rounds) or,
+        # for the 1x1 layers, on the direct kernel over the list (tile_cfg, 0); the others: Winograd. Id 8 = the two transposed
+        # convs as one launch over 2x2 tiles of their input (direct kernel, (tile_cfg, 0); buffers: trans_1 in, mid0 / mid1 out).
         self.active_tiles = bool(active_tiles)
         self.active_cfg = {}   # id -> (stream-K shape, min_rounds) / (30, min_rounds), chosen by autotune(); empty = dense launches
         ok = self.active_tiles and H <= 256 and W <= 192 and H % 4 == 0 and W % 8 == 0
-        self.ta = ops.TileActivity(B, H, W, [0, 0, 0, 2, 0, 0], dev) if ok else None
+        self.ta = ops.TileActivity(B, H, W, [0, 0, 0, 2, 0, 0, 3], dev) if ok else None
         self.ACTIVE_SLOTS = {0: ("b0.0", self.dn.b0[0], self.bev, self.t["a"]), 1: ("b0.1", self.dn.b0[1], self.t["a"], self.t["b"]),
                              2: ("b0.2", self.dn.b0[2], self.t["b"], self.t["x0"]), 3: ("b1.0", self.dn.b1[0], self.t["x0"], self.h["a"]),
                              4: ("b1.1", self.dn.b1[1], self.h["a"], self.h["b"]), 5: ("b1.2", self.dn.b1[2], self.h["b"], self.h["x1"]),
                              6: ("trans_0", self.dn.trans_0, self.t["x0"], self.t["tr0"]),
-                             7: ("trans_1", self.dn.trans_1, self.h["x1"], self.h["tr1"])}
-        self.ACTIVE_MASK = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 2, 7: 5}
+                             7: ("trans_1", self.dn.trans_1, self.h["x1"], self.h["tr1"]),
+                             8: ("deconv_0+deconv_1", (self.dn.deconv_0, self.dn.deconv_1), self.h["tr1"], (self.t["mid0"], self.t["mid1"]))}
+        self.ACTIVE_MASK = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 2, 7: 5, 8: 6}
         self.ACTIVE_SK = (3, 6, 7)
+        self.ACTIVE_PAIR = 8
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -369,6 +388,17 @@ class InferenceEngine:
                                     shift=torch.stack([t0, t1]).contiguous()) if ok else None)
         return getattr(self, key)
 
+    def _fill_jobs(self, ids):
+        """(outs, values, mask slots, tile sizes) of sessd_fill_inactive_tiles for the active layer ids"""
+        outs, vals, slots, tiles = [], [], [], []
+        for l in ids:
+            if l == self.ACTIVE_PAIR:
+                for o, v in zip(self.ACTIVE_SLOTS[l][3], self.dn.act_const[l]):
+                    outs.append(o); vals.append(v); slots.append(self.ACTIVE_MASK[l]); tiles.append(4)
+            else:
+                outs.append(self.ACTIVE_SLOTS[l][3]); vals.append(self.dn.act_const[l]); slots.append(self.ACTIVE_MASK[l]); tiles.append(2)
+        return outs, vals, slots, tiles
+
     def _active_layers(self):
         """slots (ACTIVE_SLOTS) of the layers that run in active-tile mode in this configuration"""
         if self.ta is None or self._tuning is not None or self.sk_ws is None:
@@ -381,7 +411,10 @@ class InferenceEngine:
             # active-tile mode: the listed tiles only (the others were filled with the layer's constant at the head of the stage)
             shape, min_rounds = self.active_cfg[active]
             m = self.ACTIVE_MASK[active]
-            if active in self.ACTIVE_SK:
+            if active in self.ACTIVE_SK and shape != 30:   # a 1x1 layer on the direct kernel over the list
+                call = lambda: ops.conv2d_mfma_active(x, pc, scale, shift, relu, out, self.ta.tile_list[m], self.ta.n_list[m:m + 1],
+                                                      tile_cfg=shape, residual=residual)
+            elif active in self.ACTIVE_SK:
                 call = lambda: ops.conv2d_sk_active(x, pc, scale, shift, relu, out, self.sk_ws, self.ta.tile_list[m],
                                                     self.ta.n_list[m:m + 1], workgroups=self.sk_workgroups, residual=residual,
                                                     min_rounds=min_rounds)
@@ -532,20 +565,47 @@ class InferenceEngine:
         L4, d = self.levels[-1], self.dn
         self.ta.run(L4["indices"], L4["n"], L4["cap"])
         pick, gain = {}, 0.0
-        for l, (name, (pc, scale, shift), x_in, x_out) in self.ACTIVE_SLOTS.items():
+        t = self.t
+        for l, (name, layer, x_in, x_out) in self.ACTIVE_SLOTS.items():
             best = (None, 1e30)
             m = self.ACTIVE_MASK[l]
-            if l in self.ACTIVE_SK:
-                if pc.sk_args() is None:
-                    continue
-                need = int(lib.sessd_conv2d_sk_workspace_bytes(self.B, x_out.shape[2], x_out.shape[3], pc.cout, len(pc.launches), 0))
-                if self.sk_ws is None or self.sk_ws.numel() < need:
-                    self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
-                for mr in (1, 4, 8, 16):
-                    tt = timed(lambda: ops.conv2d_sk_active(x_in, pc, scale, shift, True, x_out, self.sk_ws, self.ta.tile_list[m],
-                                                            self.ta.n_list[m:m + 1], workgroups=self.sk_workgroups, min_rounds=mr))
+            if l == self.ACTIVE_PAIR:
+                # the two transposed convs as one launch: over the list against the whole map, both on the direct kernel
+                (pa, sa, ta_), (pb, sb, tb_) = layer
+                tr0 = t["tr0"]
+                cd0, cd1 = self.tile_cfg.get("deconv_0"), self.tile_cfg.get("deconv_1")
+                if self.merge_branch_convs and cd0 in (3, 4, 11, 12) and cd1 in (3, 4, 11, 12):   # what enqueue() runs otherwise
+                    dense_t = timed(lambda: ops.deconv2d_s2_pair(x_in, pa, pb, sa, ta_, sb, tb_, True, x_out[0], x_out[1], residual_a=tr0,
+                                                                 tile_cfg=cd0))
+                else:
+                    dense_t = self.tune_report.get("deconv_0", (None, 0.0))[1] + self.tune_report.get("deconv_1", (None, 0.0))[1]
+                for cfg in (3, 4, 11, 12):
+                    tt = timed(lambda: ops.deconv2d_s2_pair_active(x_in, pa, pb, sa, ta_, sb, tb_, True, x_out[0], x_out[1],
+                                                                   self.ta.tile_list[m], self.ta.n_list[m:m + 1], residual_a=tr0,
+                                                                   tile_cfg=cfg))
                     if tt < best[1]:
-                        best = ((30, mr), tt)
+                        best = ((cfg, 0), tt)
+                if best[1] < dense_t:
+                    pick[l] = best
+                    gain += dense_t - best[1]
+                continue
+            pc, scale, shift = layer
+            if l in self.ACTIVE_SK:
+                if pc.launches[0]["ntaps"] == 1 and pc.cin % 8 == 0:
+                    for cfg in (3, 4, 11, 12):
+                        tt = timed(lambda: ops.conv2d_mfma_active(x_in, pc, scale, shift, True, x_out, self.ta.tile_list[m],
+                                                                  self.ta.n_list[m:m + 1], tile_cfg=cfg))
+                        if tt < best[1]:
+                            best = ((cfg, 0), tt)
+                if pc.sk_args() is not None:
+                    need = int(lib.sessd_conv2d_sk_workspace_bytes(self.B, x_out.shape[2], x_out.shape[3], pc.cout, len(pc.launches), 0))
+                    if self.sk_ws is None or self.sk_ws.numel() < need:
+                        self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+                    for mr in (1, 4, 8, 16):
+                        tt = timed(lambda: ops.conv2d_sk_active(x_in, pc, scale, shift, True, x_out, self.sk_ws, self.ta.tile_list[m],
+                                                                self.ta.n_list[m:m + 1], workgroups=self.sk_workgroups, min_rounds=mr))
+                        if tt < best[1]:
+                            best = ((30, mr), tt)
             else:
                 for shape in (0, 1):
                     if pc.upk_sk(shape) is None:
@@ -564,9 +624,9 @@ class InferenceEngine:
                 pick[l] = best
                 gain += dense_t - best[1]
         sl = sorted(pick)
+        fj = self._fill_jobs(sl)
         over = timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]),
-                              self.ta.fill([self.ACTIVE_SLOTS[l][3] for l in sl], [d.act_const[l] for l in sl],
-                                           layers=[self.ACTIVE_MASK[l] for l in sl]))) if pick else 0.0
+                              self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3]))) if pick else 0.0
         if pick and gain > over:
             self.active_cfg = {l: pick[l][0] for l in pick}
         # (choice, gain ms per frame over the dense launches, ms of the activity + fill launches, per-layer ms): a tuple like the others
@@ -678,7 +738,8 @@ class InferenceEngine:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             self.ta.run(L4["indices"], L4["n"], L4["cap"])
-            self.ta.fill([self.ACTIVE_SLOTS[l][3] for l in act], [d.act_const[l] for l in act], layers=[self.ACTIVE_MASK[l] for l in act])
+            fj = self._fill_jobs(act)
+            self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3])
             if self._kmarks is not None:
                 e1.record()
                 self._kmarks.append(("tile_activity+fill", e0, e1))
@@ -691,7 +752,20 @@ class InferenceEngine:
         tr0 = self._conv(x0, d.trans_0, t["tr0"], name="trans_0", active=6 if 6 in act else None)
         tr1 = self._conv(x1, d.trans_1, h["tr1"], name="trans_1", active=7 if 7 in act else None)
         cd = self.tile_cfg.get("deconv_0")
-        if self.merge_branch_convs and cd in (3, 4, 11, 12) and self.tile_cfg.get("deconv_1") in (3, 4, 11, 12) and self._tuning is None:
+        if self.ACTIVE_PAIR in act:
+            # both transposed convs over the 2x2 tiles of trans_1's map that can differ from the constant (or carry a residual that does)
+            (pa, sa, ta), (pb, sb, tb) = d.deconv_0, d.deconv_1
+            mp = self.ACTIVE_MASK[self.ACTIVE_PAIR]
+            if self._kmarks is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            ops.deconv2d_s2_pair_active(tr1, pa, pb, sa, ta, sb, tb, True, t["mid0"], t["mid1"], self.ta.tile_list[mp],
+                                        self.ta.n_list[mp:mp + 1], residual_a=tr0, tile_cfg=self.active_cfg[self.ACTIVE_PAIR][0])
+            if self._kmarks is not None:
+                e1.record()
+                self._kmarks.append(("deconv_0+deconv_1", e0, e1))
+            mid0, mid1 = t["mid0"], t["mid1"]
+        elif self.merge_branch_convs and cd in (3, 4, 11, 12) and self.tile_cfg.get("deconv_1") in (3, 4, 11, 12) and self._tuning is None:
             # both transposed convs read tr1: one launch over their 2 x 4 parity classes (same bits as two launches)
             (pa, sa, ta), (pb, sb, tb) = d.deconv_0, d.deconv_1
             if self._kmarks is not None:

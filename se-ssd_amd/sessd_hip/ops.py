@@ -1407,10 +1407,43 @@ def conv2d_sk_active(x, pc, scale, shift, relu, out, workspace, tile_list, n_lis
     return out
 
 
+def conv2d_mfma_active(x, pc, scale, shift, relu, out, tile_list, n_list, tile_cfg=11, residual=None):
+    """sessd_conv2d_mfma_active: a 1x1 layer on the direct kernel (tile_cfg 3 / 4 / 11 / 12) over the listed 2x2 tiles only; the
+    computed pixels carry the bits of the plain launch."""
+    _req(x, torch.float32, "x"); _req(tile_list, torch.int32, "tile_list"); _req(n_list, torch.int32, "n_list")
+    B, ci, H, W = x.shape
+    assert pc.kind == "conv" and pc.stride == 1 and len(pc.launches) == 1 and pc.launches[0]["ntaps"] == 1 and ci % 8 == 0
+    la = pc.launches[0]
+    check(lib.sessd_conv2d_mfma_active(x.data_ptr(), B, ci, H, W, la["wpk"].data_ptr(), 1, la["dy"].data_ptr(), la["dx"].data_ptr(), 1, H, W,
+                                       out.data_ptr(), pc.cout, H, W, 1, 0, 0, _p(scale), _p(shift), 1 if relu else 0, _p(residual),
+                                       tile_list.data_ptr(), n_list.data_ptr(), tile_list.numel(), int(tile_cfg), _stream()),
+          "conv2d_mfma_active")
+    return out
+
+
+def deconv2d_s2_pair_active(x, pc_a, pc_b, scale_a, shift_a, scale_b, shift_b, relu, out_a, out_b, tile_list, n_list, residual_a=None,
+                            residual_b=None, tile_cfg=11):
+    """sessd_deconv2d_s2_mfma_pair_active: deconv2d_s2_pair over the listed 2x2 tiles of the INPUT map only (a listed tile = a 4x4
+    block of both outputs); the other output pixels are left alone."""
+    import ctypes
+    _req(x, torch.float32, "x"); _req(tile_list, torch.int32, "tile_list"); _req(n_list, torch.int32, "n_list")
+    B, ci, H, W = x.shape
+    assert pc_a.kind == pc_b.kind == "deconv" and pc_a.cin == pc_b.cin == ci and pc_a.cout == pc_b.cout
+    check(lib.sessd_deconv2d_s2_mfma_pair_active(x.data_ptr(), B, ci, H, W, ctypes.cast(pc_a.wpk4, ctypes.c_void_p).value,
+                                                 ctypes.cast(pc_b.wpk4, ctypes.c_void_p).value, pc_a.ntaps4.data_ptr(),
+                                                 pc_a.dy4.data_ptr(), pc_a.dx4.data_ptr(), out_a.data_ptr(), out_b.data_ptr(), pc_a.cout,
+                                                 _p(scale_a), _p(shift_a), _p(scale_b), _p(shift_b), 1 if relu else 0, _p(residual_a),
+                                                 _p(residual_b), tile_list.data_ptr(), n_list.data_ptr(), tile_list.numel(),
+                                                 int(tile_cfg), _stream()), "deconv2d_s2_mfma_pair_active")
+    return out_a, out_b
+
+
 class TileActivity:
     """Buffers + launches of sessd_bev_tile_activity / sessd_fill_inactive_tiles for a chain of 3x3 layers over (batch, ., H, W) maps.
     steps: 0 = a 3x3 stride-1 layer (takes the next slot), 1 = a 3x3 stride-2 layer computed everywhere (the map halves), 2 = a
-    stride-2 layer that takes a slot itself (the 2x2 tiles of its OUTPUT that hold a non-constant pixel);
+    stride-2 layer that takes a slot itself (the 2x2 tiles of its OUTPUT that hold a non-constant pixel), 3 = a stride-2 transposed
+    conv on the current map whose output also receives, as a residual, a map of the last layer slot before the halving (takes a
+    slot of 2x2 tiles of its INPUT = 4x4 blocks of its output; dims = the input map);
     an int n means n stride-1 layers. Per slot s: dims[s] = (h, w) of the layer, tile_mask[s] (batch, H/2, 2) int64 -- bit tx of a
     row's 128 bits = tile (ty, tx) is computed; rows beyond h/2 unused --, tile_list[s] (batch * H/2 * W/2,) int32, n_list[s]."""
 
@@ -1420,7 +1453,7 @@ class TileActivity:
         self.batch, self.H, self.W, self.steps = int(batch), int(H), int(W), steps
         self.dims, h, w = [], H, W
         for k in steps:
-            if k == 0:
+            if k in (0, 3):
                 self.dims.append((h, w))
             else:
                 h, w = h // 2, w // 2
@@ -1449,19 +1482,23 @@ class TileActivity:
         tx = np.arange(w // 2)
         return torch.from_numpy(((m[:, :, tx >> 6] >> (tx & 63).astype("uint64")) & np.uint64(1)).astype(bool))
 
-    def fill(self, outs, values, layers=None):
+    def fill(self, outs, values, layers=None, tiles=None):
         """outs[i] (batch, cout, h, w) <- values[i][cout] in the tiles slot layers[i] (default i) does not compute (one launch of up
-        to 8 jobs; several outputs may share a slot: a 1x1 layer is computed where its input was)."""
+        to 10 jobs; several outputs may share a slot: a 1x1 layer is computed where its input was). tiles[i] = 4: the output of a
+        transposed conv over the slot's 2x2 INPUT tiles -- 4x4-pixel tiles, values[i] (4, cout) per output parity class."""
         from ._lib import FillTilesJob
         layers = list(range(len(outs))) if layers is None else list(layers)
-        key = tuple((o.data_ptr(), v.data_ptr(), l) for o, v, l in zip(outs, values, layers))
+        tiles = [2] * len(outs) if tiles is None else list(tiles)
+        key = tuple((o.data_ptr(), v.data_ptr(), l, t) for o, v, l, t in zip(outs, values, layers, tiles))
         if self._jobs is None or self._jobs[0] != key:
             arr = (FillTilesJob * len(outs))()
-            for i, (o, v, l) in enumerate(zip(outs, values, layers)):
+            for i, (o, v, l, t) in enumerate(zip(outs, values, layers, tiles)):
                 _req(o, torch.float32, "out"); _req(v, torch.float32, "value")
-                assert tuple(o.shape[2:]) == tuple(self.dims[l]) and o.shape[0] == self.batch
+                up = 2 if t == 4 else 1
+                assert tuple(o.shape[2:]) == (up * self.dims[l][0], up * self.dims[l][1]) and o.shape[0] == self.batch
+                assert v.numel() == (4 if t == 4 else 1) * o.shape[1]
                 arr[i].out, arr[i].value, arr[i].tile_mask, arr[i].cout = o.data_ptr(), v.data_ptr(), self.tile_mask[l].data_ptr(), o.shape[1]
-                arr[i].h, arr[i].w, arr[i].mask_th = o.shape[2], o.shape[3], self.H // 2
+                arr[i].h, arr[i].w, arr[i].mask_th, arr[i].tile = o.shape[2], o.shape[3], self.H // 2, t
             self._jobs = (key, arr)
         arr = self._jobs[1]
         check(lib.sessd_fill_inactive_tiles(arr, len(outs), self.batch, _stream()), "fill_inactive_tiles")

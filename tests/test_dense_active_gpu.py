@@ -32,8 +32,11 @@ def _masks_numpy(idx, batch, steps):
     non-constant pixel (+ the border ring once the input constant is not zero, i.e. from the second layer on); the layer's output
     is non-constant exactly in its computed tiles. Step 1 (3x3 stride-2 layer, padding 1, computed everywhere): output pixel
     non-constant iff its 3x3 window is (+ the top row / left column, where the padding enters). Step 2: the same layer, taking a
-    slot of its own -- the 2x2 tiles of its output that hold a non-constant pixel (the next layer still sees the pixels). Returns
-    per image the list of the slots' tile masks (flattened)."""
+    slot of its own -- the 2x2 tiles of its output that hold a non-constant pixel (the next layer still sees the pixels). Step 3
+    (stride-2 transposed conv on the current map, residual = a map of the last layer slot before the halving): 2x2 tile of its
+    INPUT computed iff input rows 2ty .. 2ty+2, cols 2tx .. 2tx+2 hold a non-constant pixel, or it is in the last tile row /
+    column (once the constant is not zero), or one of the 2x2 kept tiles it covers was computed. Returns per image the list of
+    the slots' tile masks (flattened)."""
     steps = [0] * steps if isinstance(steps, int) else steps
     out = []
     for b in range(batch):
@@ -41,9 +44,26 @@ def _masks_numpy(idx, batch, steps):
         s = idx[idx[:, 0] == b]
         nc[s[:, 2], s[:, 3]] = True
         per, zero_input = [], True
+        last_layer, keep = None, None
         for k in steps:
             h, w = nc.shape
             p = np.pad(nc, 1)
+            if k == 3:
+                q = np.pad(nc, ((0, 2), (0, 2)))
+                tm = np.zeros((h // 2, w // 2), bool)
+                for dy in range(3):
+                    for dx in range(3):
+                        tm |= q[dy:dy + h:2, dx:dx + w:2][:h // 2, :w // 2]
+                if not zero_input:
+                    tm[-1, :] = True
+                    tm[:, -1] = True
+                if keep is not None:
+                    tm |= keep.reshape(h // 2, 2, w // 2, 2).any((1, 3))
+                per.append(tm.reshape(-1).copy())
+                last_layer = None
+                continue
+            if k != 0:
+                keep, last_layer = last_layer, None
             if k == 0:
                 tm = np.zeros((h // 2, w // 2), bool)
                 for dy in range(4):
@@ -53,6 +73,7 @@ def _masks_numpy(idx, batch, steps):
                     tm[0, :] = tm[-1, :] = True
                     tm[:, 0] = tm[:, -1] = True
                 per.append(tm.reshape(-1).copy())
+                last_layer = tm.copy()
                 nc = tm.repeat(2, 0).repeat(2, 1)
                 zero_input = False
             else:
@@ -72,7 +93,8 @@ def _masks_numpy(idx, batch, steps):
 
 
 @pytest.mark.parametrize("batch,steps", [(1, 3), (3, 3), (1, [0, 0, 0, 1, 0, 0]), (2, [0, 0, 0, 1, 0, 0]), (1, [0, 0, 0, 2, 0, 0]),
-                                         (3, [0, 0, 0, 2, 0, 0]), (2, [2, 0])])
+                                         (3, [0, 0, 0, 2, 0, 0]), (2, [2, 0]), (1, [0, 0, 0, 2, 0, 0, 3]), (3, [0, 0, 0, 2, 0, 0, 3]),
+                                         (2, [0, 1, 3]), (1, [2, 3])])
 def test_tile_masks_and_lists(dev, batch, steps):
     idx = _sites(1, batch, 1600 if isinstance(steps, int) else 500)
     ta = ops.TileActivity(batch, H, W, steps, dev)
@@ -96,7 +118,9 @@ def test_tile_masks_and_lists(dev, batch, steps):
         assert 0.05 < nl[0] / (batch * (H // 2) * (W // 2)) < 0.6 and nl[0] < nl[1] < nl[2]
     if ta.n_slots == 5:
         assert ta.dims[3] == (H // 2, W // 2) and nl[3] < nl[4] <= batch * (H // 4) * (W // 4)
-    if ta.n_slots == 6:   # the stride-2 layer's own slot: fewer tiles than the layer after it computes
+    if ta.n_slots == 7:   # the transposed convs' slot: at least what the layer before them computed
+        assert ta.dims[6] == (H // 2, W // 2) and nl[5] <= nl[6] <= batch * (H // 4) * (W // 4)
+    if ta.n_slots >= 6:   # the stride-2 layer's own slot: fewer tiles than the layer after it computes
         assert ta.dims[3] == ta.dims[4] == (H // 2, W // 2) and nl[3] < nl[4] < nl[5] <= batch * (H // 4) * (W // 4)
 
 
@@ -277,6 +301,73 @@ def test_stride_2_and_1x1_layers_over_tile_lists(dev, batch, min_rounds):
     frac = [float(ta.n_list[s]) / (batch * (ta.dims[s][0] // 2) * (ta.dims[s][1] // 2)) for s in range(3)]
     print("computed tile fractions", [round(f, 3) for f in frac])
     assert frac[0] < 0.6 and frac[1] < frac[2] < 1.0
+
+
+@pytest.mark.parametrize("batch,cfg", [(1, 11), (2, 4), (3, 12), (1, 3)])
+def test_direct_kernels_over_tile_lists(dev, batch, cfg):
+    """rpn_v1.py:163-199, 224 on the direct kernel over lists (conv_body<.., LIST>: sessd_conv2d_mfma_active,
+    sessd_deconv2d_s2_mfma_pair_active): trans_0 over the list of the layer that produced its input, the two transposed convs
+    over the step-3 slot (2x2 tiles of their input = 4x4 output blocks; residual from the full-resolution layer). A computed pixel
+    is the plain launch's code: BIT-EQUAL to it on the same input; a filled pixel: the constants' chain (one value per output
+    parity class for the transposed convs), 1e-5 of the layer's largest value."""
+    C0, C1 = 128, 256
+    idx = _sites(41 + batch, batch, 500)
+    x = torch.zeros(batch, C0, H, W)
+    x[idx[:, 0], :, idx[:, 2], idx[:, 3]] = torch.randn(len(idx), C0, generator=torch.Generator().manual_seed(5))
+    x = x.to(dev)
+    g = torch.Generator().manual_seed(17)
+    def mk(ci, co, k):
+        return (torch.randn(co, ci, k, k, generator=g) / (k * ci ** 0.5), 0.5 + torch.rand(co, generator=g), torch.randn(co, generator=g) * 0.3)
+    l0, l1, tr0, tr1 = mk(C0, C0, 3), mk(C0, C1, 3), mk(C0, C0, 1), mk(C1, C1, 1)
+    dwa = (torch.randn(C1, C0, 3, 3, generator=g) / (3 * C1 ** 0.5), 0.5 + torch.rand(C0, generator=g), torch.randn(C0, generator=g) * 0.3)
+    dwb = (torch.randn(C1, C0, 3, 3, generator=g) / (3 * C1 ** 0.5), 0.5 + torch.rand(C0, generator=g), torch.randn(C0, generator=g) * 0.3)
+    def const(layer, c):
+        w_, sc_, sh_ = layer
+        return torch.relu(sc_.double() * (w_.double().sum((2, 3)) @ c) + sh_.double())
+    def dconst(layer, c):
+        w_, sc_, sh_ = layer
+        K = {0: [1], 1: [0, 2]}
+        return torch.stack([torch.relu(sc_.double() * (c @ sum(w_.double()[:, :, ky, kx] for ky in K[py] for kx in K[px])) + sh_.double())
+                            for py in (0, 1) for px in (0, 1)])
+    c0 = const(l0, torch.zeros(C0, dtype=torch.float64)); c1 = const(l1, c0)
+    ct0, ct1 = const(tr0, c0), const(tr1, c1)
+    cda, cdb = dconst(dwa, ct1) + ct0[None], dconst(dwb, ct1)
+    f32 = lambda v: v.float().to(dev).contiguous()
+    dv = lambda layer: (layer[1].to(dev), layer[2].to(dev))
+    ta = ops.TileActivity(batch, H, W, [0, 2, 3], dev)
+    ta.run(torch.from_numpy(idx).to(dev), torch.tensor([len(idx)], dtype=torch.int32, device=dev), len(idx))
+    # the inputs through the dense kernels (the list kernels of the layers before are tested above)
+    p0, p1 = ops.pack_conv2d(l0[0].to(dev)), ops.pack_conv2d(l1[0].to(dev), 2)
+    x0 = ops.conv2d(x, p0, *dv(l0), True, None, None, 20)
+    x1 = ops.conv2d(x0, p1, *dv(l1), True)
+    pt0, pt1 = ops.pack_conv2d(tr0[0].to(dev)), ops.pack_conv2d(tr1[0].to(dev))
+    d_t0 = ops.conv2d(x0, pt0, *dv(tr0), True, None, None, cfg)
+    d_t1 = ops.conv2d(x1, pt1, *dv(tr1), True, None, None, cfg)
+    pa, pb = ops.pack_deconv2d_s2(dwa[0].to(dev)), ops.pack_deconv2d_s2(dwb[0].to(dev))
+    d_a, d_b = torch.empty(batch, C0, H, W, device=dev), torch.empty(batch, C0, H, W, device=dev)
+    ops.deconv2d_s2_pair(d_t1, pa, pb, *dv(dwa), *dv(dwb), True, d_a, d_b, residual_a=d_t0, tile_cfg=cfg)
+    nan = lambda c, h, w: torch.full((batch, c, h, w), float("nan"), device=dev)
+    o_t0, o_t1, o_a, o_b = nan(C0, H, W), nan(C1, H // 2, W // 2), nan(C0, H, W), nan(C0, H, W)
+    # slot 0 = layer 0's tiles (trans_0's list), slot 1 = the stride-2 layer's own tiles (trans_1's list here), slot 2 = the
+    # transposed convs' input tiles
+    ta.fill([o_t0, o_t1, o_a, o_b], [f32(ct0), f32(ct1), f32(cda), f32(cdb)], layers=[0, 1, 2, 2], tiles=[2, 2, 4, 4])
+    ops.conv2d_mfma_active(x0, pt0, *dv(tr0), True, o_t0, ta.tile_list[0], ta.n_list[0:1], tile_cfg=cfg)
+    ops.conv2d_mfma_active(x1, pt1, *dv(tr1), True, o_t1, ta.tile_list[1], ta.n_list[1:2], tile_cfg=cfg)
+    ops.deconv2d_s2_pair_active(d_t1, pa, pb, *dv(dwa), *dv(dwb), True, o_a, o_b, ta.tile_list[2], ta.n_list[2:3], residual_a=d_t0, tile_cfg=cfg)
+    torch.cuda.synchronize()
+    def tmask(slot, up):
+        h, w = ta.dims[slot]
+        return ta.mask_bool(slot).to(dev).view(batch, 1, h // 2, w // 2).repeat_interleave(2 * up, 2).repeat_interleave(2 * up, 3)
+    for got, dense, slot, up, what in ((o_t0, d_t0, 0, 1, "trans_0"), (o_t1, d_t1, 1, 1, "trans_1"), (o_a, d_a, 2, 2, "deconv_0 + residual"),
+                                       (o_b, d_b, 2, 2, "deconv_1")):
+        assert torch.isfinite(got).all(), "%s: a pixel neither filled nor computed" % what
+        tm = tmask(slot, up).expand_as(got)
+        assert torch.equal(got[tm], dense[tm]), "%s: a computed pixel differs from the plain launch" % what
+        ref, err = float(dense.abs().max()), float((got - dense).abs().max())
+        assert err <= 1e-5 * ref, (what, err, ref)
+    frac = [float(ta.n_list[s]) / (batch * (ta.dims[s][0] // 2) * (ta.dims[s][1] // 2)) for s in range(3)]
+    print("computed tile fractions", [round(f, 3) for f in frac])
+    assert frac[0] < 0.6 and frac[2] < 1.0
 
 
 def test_an_empty_list_computes_nothing(dev):

@@ -340,21 +340,25 @@ def test_active_tiles_do_not_change_the_frame(dev, model):
                        [int(ops.lib.sessd_conv2d_sk_workspace_bytes(B, eng.H, eng.W, 256, 1, 0))])
             eng.sk_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
             if act:
-                eng.active_cfg = {0: (1, 4), 1: (0, 1), 2: (1, 2), 3: (30, 4), 4: (1, 2), 5: (0, 1), 6: (30, 2), 7: (30, 8)}
+                # (stream-K shape, minimum share) for the Winograd layers, (30, minimum share) = LDS-tiled stream-K kernel,
+                # (direct-kernel tile_cfg, 0) for a 1x1 layer / the pair of transposed convs over their lists
+                eng.active_cfg = {0: (1, 4), 1: (0, 1), 2: (1, 2), 3: (30, 4), 4: (1, 2), 5: (0, 1), 6: (11, 0), 7: (30, 8), 8: (4, 0)}
             eng.enqueue()
             out = eng.results()
-            x0 = torch.cat([eng.t["x0"].reshape(-1), eng.h["x1"].reshape(-1), eng.t["tr0"].reshape(-1), eng.h["tr1"].reshape(-1)])
+            x0 = torch.cat([eng.t["x0"].reshape(-1), eng.h["x1"].reshape(-1), eng.t["tr0"].reshape(-1), eng.h["tr1"].reshape(-1),
+                            eng.t["mid"].reshape(-1)])
             frac = eng.active_tile_fractions()
             if act:
                 eng.capture()
                 eng.replay()
                 out_g = eng.results()
                 assert torch.equal(torch.cat([eng.t["x0"].reshape(-1), eng.h["x1"].reshape(-1), eng.t["tr0"].reshape(-1),
-                                              eng.h["tr1"].reshape(-1)]), x0)   # same lists, same shares: same bits
+                                              eng.h["tr1"].reshape(-1), eng.t["mid"].reshape(-1)]), x0)   # same lists, same shares: same bits
                 for a, b in zip(out, out_g):
                     assert np.array_equal(a["box3d_lidar"], b["box3d_lidar"]) and np.array_equal(a["scores"], b["scores"])
             res.append((x0, out, frac))
-        assert set(res[0][2]) == {"b0.0", "b0.1", "b0.2", "b1.0", "b1.1", "b1.2", "trans_0", "trans_1"} and res[1][2] == {}
+        assert set(res[0][2]) == {"b0.0", "b0.1", "b0.2", "b1.0", "b1.1", "b1.2", "trans_0", "trans_1", "deconv_0+deconv_1"} and res[1][2] == {}
+        assert res[0][2]["b1.2"] <= res[0][2]["deconv_0+deconv_1"] < 0.95
         assert 0.05 < res[0][2]["b0.0"] < res[0][2]["b0.1"] < res[0][2]["b0.2"] < 0.6 and res[0][2]["b1.1"] < res[0][2]["b1.2"] < 0.9, res[0][2]
         assert res[0][2]["b1.0"] < res[0][2]["b1.1"] and res[0][2]["trans_0"] == res[0][2]["b0.2"] and res[0][2]["trans_1"] == res[0][2]["b1.2"]
         ref = float(res[1][0].abs().max())
