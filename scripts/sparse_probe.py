@@ -41,7 +41,7 @@ if a.force_active and e.ta is not None:
                int(ops.lib.sessd_conv2d_sk_workspace_bytes(B, e.H, e.W, 256, 1, 0)))
     if e.sk_ws is None or e.sk_ws.numel() < need:
         e.sk_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
-    e.active_cfg = {0: (1, 4), 1: (1, 8), 2: (1, 16), 3: (30, 4), 4: (1, 4), 5: (1, 8)}
+    e.active_cfg = {0: (1, 4), 1: (1, 8), 2: (1, 16), 3: (30, 4), 4: (1, 4), 5: (1, 8), 6: (4, 0), 8: (3, 0)}
     print("active_tiles forced:", e.active_cfg)
 if a.graph:
     e.capture()

@@ -552,19 +552,19 @@ class InferenceEngine:
         self.active_cfg = {}
         if self.ta is None or not self.allow_streamk or not self.allow_winograd:
             return
-        def timed(fn):
+        def timed(fn, n=reps):
             for _ in range(2):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(reps):
+            for _ in range(n):
                 fn()
             e1.record()
             torch.cuda.synchronize()
-            return e0.elapsed_time(e1) / reps
+            return e0.elapsed_time(e1) / n
         L4, d = self.levels[-1], self.dn
         self.ta.run(L4["indices"], L4["n"], L4["cap"])
-        pick, gain = {}, 0.0
+        pick, gain, pair_dense_t = {}, 0.0, 0.0
         t = self.t
         for l, (name, layer, x_in, x_out) in self.ACTIVE_SLOTS.items():
             best = (None, 1e30)
@@ -585,6 +585,7 @@ class InferenceEngine:
                                                                    tile_cfg=cfg))
                     if tt < best[1]:
                         best = ((cfg, 0), tt)
+                pair_dense_t = dense_t
                 if best[1] < dense_t:
                     pick[l] = best
                     gain += dense_t - best[1]
@@ -623,10 +624,22 @@ class InferenceEngine:
             if best[0] is not None and best[1] < dense_t:
                 pick[l] = best
                 gain += dense_t - best[1]
+        def overhead(ids):
+            fj = self._fill_jobs(ids)
+            return timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]), self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3])),
+                         4 * reps)   # (differences of a few microseconds are decided on these)
         sl = sorted(pick)
-        fj = self._fill_jobs(sl)
-        over = timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]),
-                              self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3]))) if pick else 0.0
+        over = overhead(sl) if pick else 0.0
+        # the layers whose outputs are read by full-map launches need the constant EVERYWHERE outside their lists (trans_0 / trans_1:
+        # 0.4 - 0.7 of an 18 / 9 MB map, the transposed pair: two 18 MB maps): each must pay for its own share of the fill launch
+        for l in (self.ACTIVE_PAIR, 7, 6):
+            if l in pick and len(pick) > 1:
+                rest = [q for q in sl if q != l]
+                over_wo = overhead(rest)
+                g = (self.tune_report.get(self.ACTIVE_SLOTS[l][0], (None, 0.0))[1] if l != self.ACTIVE_PAIR else pair_dense_t) - pick[l][1]
+                if over - over_wo >= g:
+                    del pick[l]
+                    sl, over, gain = rest, over_wo, gain - g
         if pick and gain > over:
             self.active_cfg = {l: pick[l][0] for l in pick}
         # (choice, gain ms per frame over the dense launches, ms of the activity + fill launches, per-layer ms): a tuple like the others
