@@ -61,6 +61,38 @@ class SparsePlan:
                                     wpk=ops.sparse_pack_weight(w), scale=scale.to(device), shift=shift.to(device)))
 
 
+def active_tile_constants(neck):
+    """What the SSFA layers in front of conv_0 / conv_1 (rpn_v1.py:135-199, 224) compute where their input is CONSTANT, float64 on
+    the host over the folded weights: c_0 = 0 (the BEV map away from the sparse sites), c_{l+1}[co] = relu(scale * sum_ci c_l[ci] *
+    sum_k W[co][ci][k] + shift) -- the stride-2 layer that opens block 1 included: away from the top / left border its window of a
+    constant map is constant. Entries 0-2 = bottom_up_block_0, 3-5 = bottom_up_block_1, 6 / 7 = trans_0 / trans_1 (1x1 layers over
+    the constants of block 0 / block 1), 8 = (deconv_block_0 + the residual trans_0 map, deconv_block_1): (4, cout) each, one
+    constant per output parity class (py, px) -- out(2y+py, 2x+px) sums the taps ky in K(py), kx in K(px), K(0) = {1},
+    K(1) = {0, 2}. tests/test_active_rule_cpu.py holds them to the modules applied to constant maps."""
+    b0, b1 = neck.bottom_up_block_0, neck.bottom_up_block_1
+    def step(seq, ci, bi, c):
+        s_, t_ = fold_bn(seq[bi])
+        return torch.relu(s_.double().cpu() * (seq[ci].weight.detach().double().cpu().sum((2, 3)) @ c) + t_.double().cpu())
+    def dstep(seq, c):
+        s_, t_ = fold_bn(seq[1])
+        w = seq[0].weight.detach().double().cpu()   # (cin, cout, 3, 3)
+        K = {0: [1], 1: [0, 2]}
+        rows = []
+        for py in (0, 1):
+            for px in (0, 1):
+                ws = sum(w[:, :, ky, kx] for ky in K[py] for kx in K[px])   # (cin, cout)
+                rows.append(torch.relu(s_.double().cpu() * (c @ ws) + t_.double().cpu()))
+        return torch.stack(rows)
+    c = torch.zeros(b0[1].weight.shape[1], dtype=torch.float64)
+    chain = []
+    for seq, ci, bi in ((b0, 1, 2), (b0, 4, 5), (b0, 7, 8), (b1, 0, 1), (b1, 3, 4), (b1, 6, 7)):
+        c = step(seq, ci, bi, c)
+        chain.append(c)
+    chain += [step(neck.trans_0, 0, 1, chain[2]), step(neck.trans_1, 0, 1, chain[5])]
+    chain.append((dstep(neck.deconv_block_0, chain[7]) + chain[6][None], dstep(neck.deconv_block_1, chain[7])))
+    return chain
+
+
 class DensePlan:
     """SSFA neck + head lowered to conv launches (det3d/models/necks/rpn_v1.py:135-235, mg_head_sessd.py:202-230)."""
 
@@ -74,36 +106,11 @@ class DensePlan:
 
         b0, b1 = neck.bottom_up_block_0, neck.bottom_up_block_1
         self.b0 = [cbr(b0, 1, 2), cbr(b0, 4, 5), cbr(b0, 7, 8)]  # index 0 is ZeroPad2d(1) + unpadded conv == pad 1
-        # What the first six layers compute where their input is CONSTANT (the BEV map is zero outside the sparse sites):
-        # c_0 = 0, c_{l+1}[co] = relu(scale * sum_ci c_l[ci] * sum_k W[co][ci][k] + shift), float64 over the folded weights (the
-        # stride-2 layer that opens block 1 included: away from the top / left border its window of a constant map is constant).
-        # The engine writes them into the tiles it does not compute (active-tile mode, csrc/dense_active.hip): entries 0-2 = block 0,
-        # 3-5 = block 1, 6 / 7 = trans_0 / trans_1 (1x1 layers over the constants of block 0 / block 1: rpn_v1.py:163-172).
-        def step(seq, ci, bi, c):
-            s_, t_ = fold_bn(seq[bi])
-            return torch.relu(s_.double().cpu() * (seq[ci].weight.detach().double().cpu().sum((2, 3)) @ c) + t_.double().cpu())
-        c = torch.zeros(b0[1].weight.shape[1], dtype=torch.float64)
-        chain = []
-        for seq, ci, bi in ((b0, 1, 2), (b0, 4, 5), (b0, 7, 8), (b1, 0, 1), (b1, 3, 4), (b1, 6, 7)):
-            c = step(seq, ci, bi, c)
-            chain.append(c)
-        chain += [step(neck.trans_0, 0, 1, chain[2]), step(neck.trans_1, 0, 1, chain[5])]
-        # entry 8 = the two transposed convs on a constant trans_1 map (rpn_v1.py:175-199): one constant per output parity class
-        # (py, px) -- out(2y+py, 2x+px) sums the taps ky in K(py), kx in K(px), K(0) = {1}, K(1) = {0, 2} --, (4, cout) each; the
-        # first one plus the constant of the residual trans_0 map (rpn_v1.py:224)
-        def dstep(seq, c):
-            s_, t_ = fold_bn(seq[1])
-            w = seq[0].weight.detach().double().cpu()   # (cin, cout, 3, 3)
-            K = {0: [1], 1: [0, 2]}
-            rows = []
-            for py in (0, 1):
-                for px in (0, 1):
-                    ws = sum(w[:, :, ky, kx] for ky in K[py] for kx in K[px])   # (cin, cout)
-                    rows.append(torch.relu(s_.double().cpu() * (c @ ws) + t_.double().cpu()))
-            return torch.stack(rows)
-        self.act_const = [v.float().to(device).contiguous() for v in chain]
-        self.act_const.append(((dstep(neck.deconv_block_0, chain[7]) + chain[6][None]).float().to(device).contiguous(),
-                               dstep(neck.deconv_block_1, chain[7]).float().to(device).contiguous()))
+        # What the layers in front of conv_0 / conv_1 compute where their input is CONSTANT (the BEV map is zero outside the sparse
+        # sites): active_tile_constants() above; the engine writes them into the tiles it does not compute (csrc/dense_active.hip).
+        chain = active_tile_constants(neck)
+        self.act_const = [v.float().to(device).contiguous() for v in chain[:8]]
+        self.act_const.append((chain[8][0].float().to(device).contiguous(), chain[8][1].float().to(device).contiguous()))
         self.b1 = [cbr(b1, 0, 1), cbr(b1, 3, 4), cbr(b1, 6, 7)]
         self.trans_0 = cbr(neck.trans_0, 0, 1)
         self.trans_1 = cbr(neck.trans_1, 0, 1)
