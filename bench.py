@@ -373,7 +373,11 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
                        "tuning": {"dense_tile_cfg": dict(getattr(eng, "tile_cfg", {})),
                                   "sparse": {str(k): v for k, v in getattr(eng, "sparse_split", {}).items()},
                                   "sparse_offset_pattern_tiles": {str(k): bool(v) for k, v in getattr(eng, "sparse_sorted", {}).items()},
-                                  "active_tiles": {eng.ACTIVE_SLOTS[l][0]: {"streamk_shape": v[0], "min_rounds": v[1]}
+                                  # layers that run over tile lists: Winograd stream-K (shape, minimum share), the LDS-tiled
+                                  # stream-K kernel (tile_cfg 30, minimum share), or a direct kernel (its tile_cfg)
+                                  "active_tiles": {eng.ACTIVE_SLOTS[l][0]: ({"direct_tile_cfg": v[0]} if v[1] == 0 else
+                                                                            {"lds_tiled_streamk": True, "min_rounds": v[1]} if v[0] == 30 else
+                                                                            {"streamk_shape": v[0], "min_rounds": v[1]})
                                                    for l, v in getattr(eng, "active_cfg", {}).items()}}},
         }
         if parity is not None:
