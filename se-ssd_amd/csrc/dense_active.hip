@@ -1,25 +1,35 @@
-// Which 2x2-output tiles of the first SSFA layers have anything to compute (gfx950; round 4).
+// Which tiles of the SSFA layers in front of conv_0 / conv_1 have anything to compute (gfx950; round 4).
 //
 // The BEV map that enters the neck (det3d/models/backbones/scn.py:179-183: `.dense()` of the last sparse level, 64 channels x 2
 // z-slices per pixel) is ZERO outside the sparse backbone's sites -- 7 % of the 200 x 176 pixels of a KITTI-shaped scan hold one.
-// rpn_v1.py:135-160 then runs three 3x3 stride-1 conv + BatchNorm + ReLU layers over the whole map. Away from the sites that is
-// arithmetic on constants: conv(0) = 0 -> BatchNorm -> ReLU gives the same value c1[co] in every pixel whose 3x3 window holds no
-// site, the next layer maps a window of c1 to c2[co], and so on (the image border, where zero padding enters the window, is not
-// constant from the second layer on). A 2x2-output Winograd tile has something to compute iff its 4x4 input patch touches a
-// non-constant pixel of the layer's input; on 20 k-point scans that is 18 % / 29 % / 39 % of the tiles of b0.0 / b0.1 / b0.2.
-//   bev_tile_activity   per image: site pixels -> bit rows in LDS; per layer: tile bits (4x4 patch test = OR of four pixel rows,
-//                       shifted-OR over the patch columns, every second bit; + the border ring from the second layer on), ordered
-//                       list of the active tiles (entry image * tiles + tile; ascending: deterministic, no atomics), the next layer's
-//                       non-constant rows = the tile rows with every bit doubled. One thread per tile row: a few microseconds. One
-//                       launch at batch 1; with more images a second launch numbers the lists (an image's base is the sum of the
-//                       earlier images' counts). (First version: byte maps walked by one workgroup -- 104 us.)
-//   fill_inactive_tiles the layers' constants into the tiles nobody computes (<= 4 layers per launch).
-//   The walk continues THROUGH the stride-2 conv that opens bottom_up_block_1 (rpn_v1.py:150-152: computed over the whole map; an
-//   output pixel is constant iff its 3x3 stride-2 window is, zero padding enters at the top / left border only) into that block's
-//   two 3x3 stride-1 layers at half resolution: a "step program" of conv layers (each with a mask / list slot) and transitions.
-// The convolutions themselves: conv3x3s1_winograd_sk_kernel<.., LIST = true> (dense_wino_sk.hip) over the list.
-// The constants come from the host (float64 over the folded weights: sessd_hip.engine); a computed tile and a filled tile agree
-// to float32 rounding of that chain (1e-7 relative), bit-exactly for the first layer (0 * U = 0).
+// rpn_v1.py:135-160 then runs 3x3 conv + BatchNorm + ReLU layers over the whole map. Away from the sites that is arithmetic on
+// constants: conv(0) = 0 -> BatchNorm -> ReLU gives the same value c1[co] in every pixel whose 3x3 window holds no site, the next
+// layer maps a window of c1 to c2[co], and so on (the image border, where zero padding enters the window, is not constant from
+// the second layer on). A 2x2-output Winograd tile has something to compute iff its 4x4 input patch touches a non-constant pixel of
+// the layer's input; on 20 k-point scans that is 12 - 14 % / 23 - 25 % / 32 - 36 % of the tiles of b0.0 / b0.1 / b0.2.
+//   bev_tile_activity   per image: site pixels -> bit rows in LDS; then a STEP PROGRAM, one slot (tile mask + ordered tile list +
+//                       device count) per step that takes one:
+//                         0  3x3 stride-1 layer: tile bits = 4x4 patch test (OR of four pixel rows, shifted-OR over the patch
+//                            columns, every second bit; + the border ring once the input constant is not zero); the next step's
+//                            non-constant rows = the tile rows with every bit doubled
+//                         1  3x3 stride-2 layer computed over the whole map (rpn_v1.py:150-152): an output pixel is constant iff
+//                            its 3x3 stride-2 window is, zero padding enters at the top / left border only; the map halves
+//                         2  the same layer over a list of its own: the 2x2 tiles of its OUTPUT that hold a non-constant pixel
+//                         3  stride-2 transposed conv on the current map (rpn_v1.py:175-199) whose output also receives a map of
+//                            the resolution before the halving as a residual (:224): 2x2 tiles of its INPUT = 4x4 output blocks
+//                       rpn_v1.py:135-160 + 224 is {0, 0, 0, 2, 0, 0, 3}; the 1x1 trans layers take the list of the layer that
+//                       produced their input. Lists are ascending in (image, tile): deterministic, no atomics. One launch at batch
+//                       1; with more images a second launch numbers the lists (an image's base is the sum of the earlier images'
+//                       counts). (First version: byte maps walked by one workgroup -- 104 us; now 25 - 28 us, issue-bound.)
+//   fill_inactive_tiles the layers' constants into the tiles nobody computes, all layers in one launch (2x2-pixel tiles with one
+//                       constant per channel; 4x4-pixel tiles with one constant per channel and output parity class behind the
+//                       transposed convs).
+// The convolutions themselves: conv3x3s1_winograd_sk_kernel<.., LIST = true> (dense_wino_sk.hip), conv2d_sk_kernel<LIST = true>
+// (dense_conv_sk.hip) and conv_body<.., LIST = true> (dense_conv.hip) over the lists.
+// The constants come from the host (float64 over the folded weights: sessd_hip.engine.active_tile_constants); a computed tile and
+// a filled tile agree to float32 rounding of that chain (1e-7 relative), bit-exactly for the first layer (0 * U = 0). The rule and
+// the constants are held to torch's own convolutions in tests/test_active_rule_cpu.py, the kernels to the rule and to the dense
+// kernels in tests/test_dense_active_gpu.py.
 #include "common.hpp"
 #include "sessd_hip_types.h"
 
