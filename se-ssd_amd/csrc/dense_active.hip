@@ -385,8 +385,33 @@ __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, in
   if (p >= pairs) return;
   const int ty = p / (tw >> 1), tx = 2 * (p - ty * (tw >> 1));
   const u64 word = J.tile_mask[((size_t)b * J.mask_th + ty) * 2 + (tx >> 6)];   // tx even: both bits in one word
-  const bool on0 = (word >> (tx & 63)) & 1ull, on1 = (word >> ((tx & 63) + 1)) & 1ull;
+  bool on0 = (word >> (tx & 63)) & 1ull, on1 = (word >> ((tx & 63) + 1)) & 1ull;
   if (on0 && on1) return;
+  if (J.near_mask) {
+    // the only reader of this map is a 3x3 layer that runs over ITS tile list (near_mask): a tile it cannot reach -- none of the
+    // 3x3 tiles around it is on that list -- is never read and keeps whatever it holds
+    bool n0 = false, n1 = false;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int y = ty + dy;
+      if (y < 0 || y >= th) continue;
+      const uint64_t* rowp = J.near_mask + ((size_t)b * J.mask_th + y) * 2;
+      const u64 w0 = rowp[0], w1 = rowp[1];
+      // bits tx - 1 .. tx + 2 of the 128-bit row (beyond the row: zero)
+      unsigned win = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int x = tx - 1 + k;
+        const u64 wd = x < 64 ? w0 : w1;
+        if (x >= 0 && x < tw) win |= (unsigned)((wd >> (x & 63)) & 1ull) << k;
+      }
+      n0 |= (win & 7u) != 0;
+      n1 |= (win & 14u) != 0;
+    }
+    on0 |= !n0;   // (as good as computed: nobody fills it)
+    on1 |= !n1;
+    if (on0 && on1) return;
+  }
   const float c = J.value[co];
   float* o = J.out + (((size_t)b * J.cout + co) * h + 2 * ty) * w + 2 * tx;
   if (!on0 && !on1) {
@@ -475,7 +500,7 @@ int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, in
     // (w % 4 == 0: a thread owns two adjacent 2x2 tiles, or one 4x4 tile = 16-byte aligned rows of four pixels)
     const int tile = S.tile == 4 ? 4 : 2;
     if (!S.out || !S.value || !S.tile_mask || S.cout < 1 || S.h < tile || S.w < 4 || (S.h % tile) || (S.w & 3) || S.mask_th < S.h / tile ||
-        S.w / tile > 128 || (S.tile != 0 && S.tile != 2 && S.tile != 4))
+        S.w / tile > 128 || (S.tile != 0 && S.tile != 2 && S.tile != 4) || (S.near_mask && tile != 2))
       return SESSD_EINVAL;
     Q.J[j] = S;
     Q.J[j].tile = tile;

@@ -310,6 +310,7 @@ class InferenceEngine:
         self.ACTIVE_MASK = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 2, 7: 5, 8: 6}
         self.ACTIVE_SK = (3, 6, 7)
         self.ACTIVE_PAIR = 8
+        self.near_fill = True   # fill only the tiles a list-driven reader can reach where that reader is the map's only one
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -395,16 +396,22 @@ class InferenceEngine:
                                     shift=torch.stack([t0, t1]).contiguous()) if ok else None)
         return getattr(self, key)
 
+    # a map with ONE reader, a 3x3 stride-1 layer on the same tile grid: id -> id of that reader. When the reader runs over its
+    # list, only the tiles it can reach need the constant (sessd_fill_tiles_job_t.near_mask)
+    NEAR_READER = {0: 1, 1: 2, 3: 4, 4: 5}
+
     def _fill_jobs(self, ids):
-        """(outs, values, mask slots, tile sizes) of sessd_fill_inactive_tiles for the active layer ids"""
-        outs, vals, slots, tiles = [], [], [], []
+        """(outs, values, mask slots, tile sizes, near slots) of sessd_fill_inactive_tiles for the active layer ids"""
+        outs, vals, slots, tiles, near = [], [], [], [], []
         for l in ids:
             if l == self.ACTIVE_PAIR:
                 for o, v in zip(self.ACTIVE_SLOTS[l][3], self.dn.act_const[l]):
-                    outs.append(o); vals.append(v); slots.append(self.ACTIVE_MASK[l]); tiles.append(4)
+                    outs.append(o); vals.append(v); slots.append(self.ACTIVE_MASK[l]); tiles.append(4); near.append(None)
             else:
                 outs.append(self.ACTIVE_SLOTS[l][3]); vals.append(self.dn.act_const[l]); slots.append(self.ACTIVE_MASK[l]); tiles.append(2)
-        return outs, vals, slots, tiles
+                rd = self.NEAR_READER.get(l)
+                near.append(self.ACTIVE_MASK[rd] if self.near_fill and rd is not None and rd in ids and rd not in self.ACTIVE_SK else None)
+        return outs, vals, slots, tiles, near
 
     def _active_layers(self):
         """slots (ACTIVE_SLOTS) of the layers that run in active-tile mode in this configuration"""
@@ -633,7 +640,7 @@ class InferenceEngine:
                 gain += dense_t - best[1]
         def overhead(ids):
             fj = self._fill_jobs(ids)
-            return timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]), self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3])),
+            return timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]), self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4])),
                          4 * reps)   # (differences of a few microseconds are decided on these)
         sl = sorted(pick)
         over = overhead(sl) if pick else 0.0
@@ -759,7 +766,7 @@ class InferenceEngine:
                 e0.record()
             self.ta.run(L4["indices"], L4["n"], L4["cap"])
             fj = self._fill_jobs(act)
-            self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3])
+            self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4])
             if self._kmarks is not None:
                 e1.record()
                 self._kmarks.append(("tile_activity+fill", e0, e1))

@@ -1482,14 +1482,17 @@ class TileActivity:
         tx = np.arange(w // 2)
         return torch.from_numpy(((m[:, :, tx >> 6] >> (tx & 63).astype("uint64")) & np.uint64(1)).astype(bool))
 
-    def fill(self, outs, values, layers=None, tiles=None):
+    def fill(self, outs, values, layers=None, tiles=None, near=None):
         """outs[i] (batch, cout, h, w) <- values[i][cout] in the tiles slot layers[i] (default i) does not compute (one launch of up
         to 10 jobs; several outputs may share a slot: a 1x1 layer is computed where its input was). tiles[i] = 4: the output of a
-        transposed conv over the slot's 2x2 INPUT tiles -- 4x4-pixel tiles, values[i] (4, cout) per output parity class."""
+        transposed conv over the slot's 2x2 INPUT tiles -- 4x4-pixel tiles, values[i] (4, cout) per output parity class.
+        near[i] = slot of the ONE reader of outs[i], a 3x3 stride-1 layer over its own list on the same tile grid, or None: only
+        the tiles that reader can reach are filled."""
         from ._lib import FillTilesJob
         layers = list(range(len(outs))) if layers is None else list(layers)
         tiles = [2] * len(outs) if tiles is None else list(tiles)
-        key = tuple((o.data_ptr(), v.data_ptr(), l, t) for o, v, l, t in zip(outs, values, layers, tiles))
+        near = [None] * len(outs) if near is None else list(near)
+        key = tuple((o.data_ptr(), v.data_ptr(), l, t, n) for o, v, l, t, n in zip(outs, values, layers, tiles, near))
         if self._jobs is None or self._jobs[0] != key:
             arr = (FillTilesJob * len(outs))()
             for i, (o, v, l, t) in enumerate(zip(outs, values, layers, tiles)):
@@ -1499,6 +1502,9 @@ class TileActivity:
                 assert v.numel() == (4 if t == 4 else 1) * o.shape[1]
                 arr[i].out, arr[i].value, arr[i].tile_mask, arr[i].cout = o.data_ptr(), v.data_ptr(), self.tile_mask[l].data_ptr(), o.shape[1]
                 arr[i].h, arr[i].w, arr[i].mask_th, arr[i].tile = o.shape[2], o.shape[3], self.H // 2, t
+                if near[i] is not None:
+                    assert t == 2 and self.dims[near[i]] == self.dims[l]
+                    arr[i].near_mask = self.tile_mask[near[i]].data_ptr()
             self._jobs = (key, arr)
         arr = self._jobs[1]
         check(lib.sessd_fill_inactive_tiles(arr, len(outs), self.batch, _stream()), "fill_inactive_tiles")

@@ -370,6 +370,45 @@ def test_direct_kernels_over_tile_lists(dev, batch, cfg):
     assert frac[0] < 0.6 and frac[2] < 1.0
 
 
+@pytest.mark.parametrize("batch", [1, 2])
+def test_fill_only_where_the_reader_can_reach(dev, batch):
+    """sessd_fill_tiles_job_t.near_mask: a map whose only reader is a 3x3 layer over its own list gets the constant only in the
+    tiles that reader can reach. The maps start as NaN: the last layer of a three-layer chain comes out finite and equal to the
+    dense chain (nothing unreachable was read), while the intermediate maps keep NaN somewhere (something WAS left out)."""
+    C = 128
+    idx = _sites(60 + batch, batch, 1200)
+    x = torch.zeros(batch, C, H, W)
+    x[idx[:, 0], :, idx[:, 2], idx[:, 3]] = torch.randn(len(idx), C, generator=torch.Generator().manual_seed(2))
+    x = x.to(dev)
+    layers = [_layer(20 + l, C) for l in range(3)]
+    consts = [c.to(dev) for c in _constants(layers)]
+    ta = ops.TileActivity(batch, H, W, 3, dev)
+    ta.run(torch.from_numpy(idx).to(dev), torch.tensor([len(idx)], dtype=torch.int32, device=dev), len(idx))
+    outs = [torch.full((batch, C, H, W), float("nan"), device=dev) for _ in range(3)]
+    ta.fill(outs, consts, near=[1, 2, None])
+    ws = torch.zeros(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(batch, H, W, C, 1, 0)), dtype=torch.uint8, device=dev)
+    cur_a = cur_d = x
+    for l, (w, scale, shift) in enumerate(layers):
+        pc = ops.pack_conv2d(w.to(dev))
+        sc, sh = scale.to(dev), shift.to(dev)
+        cur_d = ops.conv2d(cur_d, pc, sc, sh, True, None, None, 23)
+        ops.conv2d_winograd_sk_active(cur_a, pc.upk_sk(1), C, sc, sh, True, outs[l], 1, ws, ta.tile_list[l], ta.n_list[l:l + 1])
+        cur_a = outs[l]
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[2]).all()
+    ref, err = float(cur_d.abs().max()), float((outs[2] - cur_d).abs().max())
+    assert err <= 2e-5 * ref, (err, ref)
+    left = [float(torch.isnan(o).float().mean()) for o in outs[:2]]
+    print("share of the maps left alone", [round(v, 3) for v in left])
+    assert left[0] > 0.1 and left[1] > 0.02   # (these clustered-plus-scattered sites are far denser in effect than a scan: there 0.68 / 0.58)
+    # what was filled or computed is exactly the reach of the reader: 3x3 tiles around its list
+    for l in (0, 1):
+        reach = torch.nn.functional.max_pool2d(ta.mask_bool(l + 1).float()[:, None], 3, 1, 1)[:, 0] > 0
+        mine = ta.mask_bool(l)
+        want = (reach | mine).to(dev).view(batch, 1, H // 2, W // 2).repeat_interleave(2, 2).repeat_interleave(2, 3).expand(-1, C, -1, -1)
+        assert torch.equal(~torch.isnan(outs[l]), want), l
+
+
 def test_an_empty_list_computes_nothing(dev):
     """no site -> no tile: the launch returns at once and leaves the output alone"""
     C = 128
