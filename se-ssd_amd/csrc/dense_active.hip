@@ -38,6 +38,7 @@ namespace {
 constexpr int NT = 1024;
 constexpr int MAX_H = 256, MAX_W = 192;   // one image's pixel rows as 3 x 64-bit words in LDS; a thread pair per tile row
 constexpr int MAX_SLOTS = 7, MAX_STEPS = 8, MAX_FILL_JOBS = 10;
+constexpr int FILL_CG = 16;   // channels per fill block
 typedef unsigned long long u64;
 
 struct ActArgs {
@@ -336,12 +337,12 @@ __global__ __launch_bounds__(NT) void bev_tile_list_kernel(ActArgs A) {
 
 struct FillJobs {
   int njobs;
-  int blk_off[MAX_FILL_JOBS + 1];   // first block of every job (a job = tile-pair chunks of 256 x cout x batch blocks)
+  int blk_off[MAX_FILL_JOBS + 1];   // first block of every job (a job = tile-pair chunks of 256 x channel groups of FILL_CG x batch blocks)
   sessd_fill_tiles_job_t J[MAX_FILL_JOBS];
 };
 
-// One block = 256 threads = 256 pairs of adjacent tiles (2 tx, 2 tx + 1) of one (job, image, channel): a thread writes up to two
-// 16-byte rows-of-four-pixels twice. Only blocks that have tiles are launched.
+// One block = 256 threads = 256 pairs of adjacent tiles (2 tx, 2 tx + 1) of one (job, image, group of FILL_CG channels): a thread
+// tests its pair's mask bits once and writes up to two 16-byte rows-of-four-pixels twice per channel.
 __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, int batch) {
   int j = 0;
 #pragma unroll
@@ -354,33 +355,39 @@ __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, in
   for (int q = 1; q < MAX_FILL_JOBS; ++q)
     if (q == j) { J = Q.J[q]; off = Q.blk_off[q]; }
   const int h = J.h, w = J.w;
+  const int cgroups = sessd_divup(J.cout, FILL_CG);
   if (J.tile == 4) {
-    // 4x4-pixel tiles (the output of a transposed conv over 2x2 tiles of its input): a thread per tile, four 16-byte rows; the
-    // constant depends on the output parity class: value[(py * 2 + px) * cout + co]
+    // 4x4-pixel tiles (the output of a transposed conv over 2x2 tiles of its input): a thread per tile, four 16-byte rows per
+    // channel; the constant depends on the output parity class: value[(py * 2 + px) * cout + co]
     const int th = h >> 2, tw = w >> 2, tiles = th * tw;
     const int chunks = sessd_divup(tiles, 256);
     int r = (int)blockIdx.x - off;
     const int chunk = r % chunks; r /= chunks;
-    const int co = r % J.cout, b = r / J.cout;
+    const int cg = r % cgroups, b = r / cgroups;
     const int t = chunk * 256 + threadIdx.x;
     if (t >= tiles) return;
     const int ty = t / tw, tx = t - ty * tw;
     const u64 word = J.tile_mask[((size_t)b * J.mask_th + ty) * 2 + (tx >> 6)];
     if ((word >> (tx & 63)) & 1ull) return;
-    const float c00 = J.value[co], c01 = J.value[J.cout + co], c10 = J.value[2 * J.cout + co], c11 = J.value[3 * J.cout + co];
-    float* o = J.out + (((size_t)b * J.cout + co) * h + 4 * ty) * w + 4 * tx;
-    const float4 e = make_float4(c00, c01, c00, c01), d = make_float4(c10, c11, c10, c11);
-    *reinterpret_cast<float4*>(o) = e;
-    *reinterpret_cast<float4*>(o + w) = d;
-    *reinterpret_cast<float4*>(o + 2 * w) = e;
-    *reinterpret_cast<float4*>(o + 3 * w) = d;
+    const size_t plane = (size_t)h * w;
+    float* o = J.out + ((size_t)b * J.cout + (size_t)cg * FILL_CG) * plane + (size_t)(4 * ty) * w + 4 * tx;
+    const int nco = min(FILL_CG, J.cout - cg * FILL_CG);
+    for (int cc = 0; cc < nco; ++cc, o += plane) {
+      const int co = cg * FILL_CG + cc;
+      const float c00 = J.value[co], c01 = J.value[J.cout + co], c10 = J.value[2 * J.cout + co], c11 = J.value[3 * J.cout + co];
+      const float4 e = make_float4(c00, c01, c00, c01), d = make_float4(c10, c11, c10, c11);
+      *reinterpret_cast<float4*>(o) = e;
+      *reinterpret_cast<float4*>(o + w) = d;
+      *reinterpret_cast<float4*>(o + 2 * w) = e;
+      *reinterpret_cast<float4*>(o + 3 * w) = d;
+    }
     return;
   }
   const int th = h >> 1, tw = w >> 1, pairs = th * (tw >> 1);
   const int chunks = sessd_divup(pairs, 256);
   int r = (int)blockIdx.x - off;
   const int chunk = r % chunks; r /= chunks;
-  const int co = r % J.cout, b = r / J.cout;
+  const int cg = r % cgroups, b = r / cgroups;
   const int p = chunk * 256 + threadIdx.x;
   if (p >= pairs) return;
   const int ty = p / (tw >> 1), tx = 2 * (p - ty * (tw >> 1));
@@ -412,15 +419,24 @@ __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, in
     on1 |= !n1;
     if (on0 && on1) return;
   }
-  const float c = J.value[co];
-  float* o = J.out + (((size_t)b * J.cout + co) * h + 2 * ty) * w + 2 * tx;
+  // one mask test for FILL_CG channels (first version: a block per channel -- ten thousand blocks that mostly tested a word and
+  // left; the launch's time was their scheduling, not its bytes)
+  const size_t plane = (size_t)h * w;
+  float* o = J.out + ((size_t)b * J.cout + (size_t)cg * FILL_CG) * plane + (size_t)(2 * ty) * w + 2 * tx;
+  const int nco = min(FILL_CG, J.cout - cg * FILL_CG);
   if (!on0 && !on1) {
-    *reinterpret_cast<float4*>(o) = make_float4(c, c, c, c);
-    *reinterpret_cast<float4*>(o + w) = make_float4(c, c, c, c);
+    for (int cc = 0; cc < nco; ++cc, o += plane) {
+      const float c = J.value[cg * FILL_CG + cc];
+      *reinterpret_cast<float4*>(o) = make_float4(c, c, c, c);
+      *reinterpret_cast<float4*>(o + w) = make_float4(c, c, c, c);
+    }
   } else {
     float* q = on0 ? o + 2 : o;
-    *reinterpret_cast<float2*>(q) = make_float2(c, c);
-    *reinterpret_cast<float2*>(q + w) = make_float2(c, c);
+    for (int cc = 0; cc < nco; ++cc, q += plane) {
+      const float c = J.value[cg * FILL_CG + cc];
+      *reinterpret_cast<float2*>(q) = make_float2(c, c);
+      *reinterpret_cast<float2*>(q + w) = make_float2(c, c);
+    }
   }
 }
 
@@ -505,7 +521,7 @@ int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, in
     Q.J[j] = S;
     Q.J[j].tile = tile;
     Q.blk_off[j] = blk;
-    blk += (tile == 4 ? sessd_divup((S.h / 4) * (S.w / 4), 256) : sessd_divup((S.h / 2) * (S.w / 4), 256)) * S.cout * batch;
+    blk += (tile == 4 ? sessd_divup((S.h / 4) * (S.w / 4), 256) : sessd_divup((S.h / 2) * (S.w / 4), 256)) * sessd_divup(S.cout, FILL_CG) * batch;
   }
   for (int j = n_jobs; j < MAX_FILL_JOBS; ++j) { Q.J[j] = jobs[0]; Q.blk_off[j] = blk; }
   Q.blk_off[MAX_FILL_JOBS] = blk;
