@@ -450,6 +450,8 @@ def roofline_legs(args, out, eng, batch_of):
     ach = flops / (kms * 1e-3) / 1e12
     full = [p for p in per if p[3] == 1.0]
     ach_full = (CONV_FLOPS * args.batch * sum(p[2] for p in full) / (sum(p[1] for p in full) * 1e-3) / 1e12) if full else 0.0
+    lst = [p for p in per if p[3] != 1.0]
+    ach_list = (CONV_FLOPS * args.batch * sum(p[2] * p[3] for p in lst) / (sum(p[1] for p in lst) * 1e-3) / 1e12) if lst else 0.0
     log("roofline kernel: %.3f ms per launch in sequence" % kms)
     # executed matrix-core FLOPs per algorithmic FLOP: direct 1, Winograd F(2x2,3x3) 16/36, F(4x4,3x3) 36/144
     exe_ratio = sum(ops.winograd_mult_ratio(c if c is not None else (20 if ops.USE_WINOGRAD else 0)) for c in cfgs) / len(cfgs)
@@ -467,11 +469,13 @@ def roofline_legs(args, out, eng, batch_of):
                        "avg_launch_ms": kms,
                        "active_tile_fraction": act,
                        "frac_full_map_launches": ach_full * exe_ratio / F32_MFMA_PEAK_TFLOPS,
+                       "frac_list_launches": (ach_list * exe_ratio / F32_MFMA_PEAK_TFLOPS) if lst else None,
                        "active_tile_note": ("layers listed in active_tile_fraction run over the listed 2x2-output tiles only (the BEV map is "
                                             "zero outside the sparse sites: the other tiles hold a per-channel constant, written by one fill "
                                             "launch); their FLOPs count with that share, the activity + fill launches are in "
                                             "dense_launch_ms['tile_activity+fill']; frac_full_map_launches = the same figure over the "
-                                            "launches that cover the whole map (comparable with earlier rounds)") if act else None,
+                                            "launches that cover the whole map (comparable with earlier rounds), frac_list_launches "
+                                            "over the list launches alone (short stream-K shares: DESIGN.md section 3)") if act else None,
                        "avg_launch_source": "HIP events before / after each of the kernel's %d launches inside 20 whole frames " % len(times) +
                                             "(eager enqueue; same stream as the kernels; one frame in flight, the same "
                                             "launch configuration as the timed region unless --sk-workgroups says otherwise)",
