@@ -561,8 +561,10 @@ class InferenceEngine:
         return self.tune_report
 
     def _autotune_active_tiles(self, reps):
-        """Block 0 in active-tile mode (csrc/dense_active.hip) where that is faster on the staged frame: per layer the stream-K
-        shape and the minimum share length, then the whole set against the cost of the activity + fill launches."""
+        """The SSFA layers in front of conv_0 / conv_1 in active-tile mode (csrc/dense_active.hip) where that is faster on the staged
+        frame: per layer the kernel (Winograd stream-K shape / LDS-tiled stream-K / direct tile_cfg) and the minimum share length
+        against its full-map launch; then each layer whose output needs the constant over the whole map against its own share of
+        the fill launch; then the whole set against the cost of the activity + fill launches."""
         self.active_cfg = {}
         if self.ta is None or not self.allow_streamk or not self.allow_winograd:
             return
