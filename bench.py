@@ -80,6 +80,7 @@ def parse(argv=None):
                          "kernel then runs 14 % longer per launch -- the default keeps the timed kernel the one the roofline describes")
     ap.add_argument("--spinup-seconds", type=float, default=0.5,
                     help="untimed frames run for this long before the warm-up steps (the CPU oracle sample leaves the GPU idle at low clocks)")
+    ap.add_argument("--fork-active", action="store_true", help="EXPERIMENT: the tile-list + fill launches as a side branch of the graph beside the sparse convs")
     ap.add_argument("--fork", action="store_true", help="engines with the parallel front branch (level-0 table + first two sparse convs beside the site chain; measured slower)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
     ap.add_argument("--no-offset-split", action="store_true", help="autotune without the offset-split sparse conv variants")
@@ -120,6 +121,7 @@ def default_engine_factory(args, dev):
                for _ in range(max(1, args.streams))]
     for e in engines:
         e.fork_front = bool(args.fork)
+        e.fork_active = bool(getattr(args, "fork_active", False))
     return model, engines
 
 

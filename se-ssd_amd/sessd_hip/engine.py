@@ -311,6 +311,7 @@ class InferenceEngine:
         self.ACTIVE_SK = (3, 6, 7)
         self.ACTIVE_PAIR = 8
         self.near_fill = True   # fill only the tiles a list-driven reader can reach where that reader is the map's only one
+        self.fork_active = False   # EXPERIMENT: the activity + fill launches as a side branch beside the sparse convs (see enqueue)
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -720,6 +721,7 @@ class InferenceEngine:
             lead += 1
         lead_jobs = 1 + max([self._job_of[i] for i in range(lead)] + [-1])
         fork = self.fork_front and lead > 0 and self._tuning_sparse is None and self._marks is None
+        forked_active = False
 
         def run_layers(lo, hi, feat, li, st):
             for idx in range(lo, hi):
@@ -756,12 +758,25 @@ class InferenceEngine:
             feat, li = run_layers(lead, n_layers, feat, li, s)
         else:
             self.chain.run(L0["indices"], self._n(0), L0["cap"], L0["hash"], self.err, clear=False, stream=s)
+            # EXPERIMENT (off): the tile lists and the fill depend on the last level's SITES only -- as a side branch beside the 14
+            # sparse convs (which leave most of the chip idle) instead of in front of the dense stage
+            forked_active = self.fork_active and self._marks is None and self._kmarks is None and bool(self._active_layers())
+            if forked_active:
+                main, side = torch.cuda.current_stream(), self.side_stream
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    L4 = self.levels[-1]
+                    self.ta.run(L4["indices"], L4["n"], L4["cap"])
+                    fj = self._fill_jobs(self._active_layers())
+                    self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4])
             feat, li = run_layers(0, n_layers, feat, 0, s)
+            if forked_active:
+                main.wait_stream(side)
         self._mark("spmiddle")
         # ---- SSFA (a9) rpn_v1.py:220-235
         t, h, d = self.t, self.h, self.dn
         act = self._active_layers()
-        if act:
+        if act and not forked_active:
             L4 = self.levels[-1]
             if self._kmarks is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
