@@ -311,7 +311,9 @@ class InferenceEngine:
         self.ACTIVE_SK = (3, 6, 7)
         self.ACTIVE_PAIR = 8
         self.near_fill = True   # fill only the tiles a list-driven reader can reach where that reader is the map's only one
-        self.fork_active = False   # EXPERIMENT: the activity + fill launches as a side branch beside the sparse convs (see enqueue)
+        # EXPERIMENT, measured slower on MI355X / ROCm 7.2 and therefore off (1154 against 1163 frames/s one frame at a time, 1132
+        # against ~1550 with two frames in flight): the activity + fill launches as a side branch beside the sparse convs (see enqueue)
+        self.fork_active = False
         self.sort_sites = bool(sort_sites)
         if self.sort_sites:
             self.coors_s, self.vfeat_s = E(cap0, 4, dt=i32), E(cap0, 4)
@@ -758,8 +760,8 @@ class InferenceEngine:
             feat, li = run_layers(lead, n_layers, feat, li, s)
         else:
             self.chain.run(L0["indices"], self._n(0), L0["cap"], L0["hash"], self.err, clear=False, stream=s)
-            # EXPERIMENT (off): the tile lists and the fill depend on the last level's SITES only -- as a side branch beside the 14
-            # sparse convs (which leave most of the chip idle) instead of in front of the dense stage
+            # EXPERIMENT (off, measured slower): the tile lists and the fill depend on the last level's SITES only -- as a side branch
+            # beside the 14 sparse convs (which leave most of the chip idle) instead of in front of the dense stage
             forked_active = self.fork_active and self._marks is None and self._kmarks is None and bool(self._active_layers())
             if forked_active:
                 main, side = torch.cuda.current_stream(), self.side_stream
