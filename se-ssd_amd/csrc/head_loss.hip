@@ -91,13 +91,22 @@ __device__ __forceinline__ float sl1(float diff, float s2, float* d) {
 }
 
 // the consistency filter of one anchor (mg_head_sessd.py:653-661): score >= thresh and the decoded centre inside the range;
-// ONE function for the counting and the compacting launch (their decisions must be the same bits)
+// ONE function for the counting and the compacting launch: their decisions must be the same bits (a disagreement would make
+// two candidates share a slot). NOT inlined -- both kernels call the one compiled body, so the expf lowering and the
+// contractions cannot differ between them -- and no multiply-add is contracted (round-4 advisor finding).
+__device__ __noinline__ bool cons_candidate(float cls_logit, float c0, float c1, float c2, float a0, float a1, float a2, float a3,
+                                            float a4, float a5, float thresh, float lo0, float lo1, float lo2, float hi0, float hi1,
+                                            float hi2) {
+  if (!(sigmoid_f(cls_logit) >= thresh)) return false;
+  // every product and sum rounded on its own, as the torch ops of box_torch_ops.second_box_decode round them
+  const float diag = sqrtf(__fadd_rn(__fmul_rn(a4, a4), __fmul_rn(a3, a3)));
+  const float x = __fadd_rn(__fmul_rn(c0, diag), a0), y = __fadd_rn(__fmul_rn(c1, diag), a1), z = __fadd_rn(__fmul_rn(c2, a5), a2);
+  return x >= lo0 && y >= lo1 && z >= lo2 && x <= hi0 && y <= hi1 && z <= hi2;
+}
 __device__ __forceinline__ bool cons_candidate(float cls_logit, const float* code, const float* an0, const sessd_head_loss_cfg_t& P) {
-  if (!(sigmoid_f(cls_logit) >= P.score_thresh)) return false;
-  const float diag = sqrtf(an0[4] * an0[4] + an0[3] * an0[3]);
-  const float x = code[0] * diag + an0[0], y = code[1] * diag + an0[1], z = code[2] * an0[5] + an0[2];
-  return x >= P.center_range[0] && y >= P.center_range[1] && z >= P.center_range[2] && x <= P.center_range[3] &&
-         y <= P.center_range[4] && z <= P.center_range[5];
+  return cons_candidate(cls_logit, code[0], code[1], code[2], an0[0], an0[1], an0[2], an0[3], an0[4], an0[5], P.score_thresh,
+                        P.center_range[0], P.center_range[1], P.center_range[2], P.center_range[3], P.center_range[4],
+                        P.center_range[5]);
 }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -348,7 +357,7 @@ __global__ __launch_bounds__(64) void hl_pos_kernel(sessd_head_loss_net_t S, ses
     const float o3 = ov * oh;
     const float iou3d = o3 / fmaxf(q[3] * q[4] * q[5] + g[3] * g[4] * g[5] - o3, 1e-7f);
     const float target = 2.f * iou3d - 1.f;
-    const float s2 = P.smooth_l1_sigma * P.smooth_l1_sigma;
+    const float s2 = 9.0f;  // loss_iou_pred is built with sigma = 3 whatever the config says (mg_head_sessd.py:431,767)
     float d;
     const float v = sl1(N.iou[i] - target, s2, &d);
     terms[0] = v * reg_w;
@@ -434,7 +443,9 @@ __global__ __launch_bounds__(NTC) void hl_cons_kernel(sessd_head_loss_cfg_t P, c
   }
   const float cw = cons_weight[0];
   const float scale = cw / ((float)n1 * (float)B);
-  const float s2 = 9.0f;  // the consistency losses are built with sigma = 3 whatever the config says (mg_head_sessd.py:488-491)
+  // the score / IoU consistency losses are built with sigma = 3 whatever the config says (mg_head_sessd.py:488-491); the box
+  // term goes through self.loss_reg, i.e. the config's loss_bbox.sigma (nn_distance :594-597)
+  const float s2 = 9.0f, s2_box = P.smooth_l1_sigma * P.smooth_l1_sigma;
   double l_box = 0.0, l_cls = 0.0, l_iou = 0.0;
   for (int r = threadIdx.x; r < ns; r += NTC) {
     if (!(W.row_max[(size_t)b * K + r] > P.match_iou_thresh)) continue;
@@ -452,11 +463,11 @@ __global__ __launch_bounds__(NTC) void hl_cons_kernel(sessd_head_loss_cfg_t P, c
     float lb = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-      lb += sl1(sb[k] - tb[k], s2, &d);
+      lb += sl1(sb[k] - tb[k], s2_box, &d);
       gb[k] = d / 7.0f;
     }
     const float sa = sinf(sb[6]), ca = cosf(sb[6]), st = sinf(tb[6]), ct = cosf(tb[6]);
-    lb += sl1(sa * ct - ca * st, s2, &d);
+    lb += sl1(sa * ct - ca * st, s2_box, &d);
     gb[6] = d * (ca * ct + sa * st) / 7.0f;
     l_box += (double)(lb / 7.0f);
 #pragma unroll

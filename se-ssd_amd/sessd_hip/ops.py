@@ -843,9 +843,28 @@ def bn_relu_train(x, n_dev, bn, relu=True):
 _SYNC_BN = {"on": False, "group": None, "reduce": None}
 
 
-def set_sync_bn(on=True, group=None, reduce_fn=None):
-    """reduce_fn(tensor) (tests): replaces dist.all_reduce on the float64 totals."""
-    _SYNC_BN.update(on=bool(on), group=group, reduce=reduce_fn)
+_KEEP = object()
+
+
+def set_sync_bn(on=True, group=_KEEP, reduce_fn=_KEEP):
+    """Switch the split (statistics | all-reduce | apply) BatchNorm passes on or off. group: the process group of the all-reduce
+    (None = WORLD); reduce_fn(tensor) (tests): replaces dist.all_reduce on the float64 totals. An argument that is not passed
+    keeps its current value, so that toggling the switch (TrainStep does, around every iteration) does not forget a configured
+    group (round-4 advisor finding)."""
+    _SYNC_BN["on"] = bool(on)
+    if group is not _KEEP:
+        _SYNC_BN["group"] = group
+    if reduce_fn is not _KEEP:
+        _SYNC_BN["reduce"] = reduce_fn
+
+
+def sync_bn_state():
+    """(on, group, reduce_fn): hand the tuple back to restore_sync_bn()."""
+    return (_SYNC_BN["on"], _SYNC_BN["group"], _SYNC_BN["reduce"])
+
+
+def restore_sync_bn(state):
+    _SYNC_BN.update(on=bool(state[0]), group=state[1], reduce=state[2])
 
 
 def sync_bn_active():

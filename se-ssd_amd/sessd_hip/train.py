@@ -238,6 +238,8 @@ class TrainStep:
         # SyncBN (apis/train_sessd.py:286-294): None = like the reference, on exactly when the process group has more than one
         # rank; True / False force it (True with one rank runs the split passes without a collective: same bits as the fused ones)
         self.sync_bn = None
+        self.sync_bn_group = None   # process group of the SyncBN all-reduces (None: whatever ops.set_sync_bn was given, else WORLD)
+        self.loss_overflow = None  # sticky device flag: bit 0 positives / bit 1 consistency candidates beyond their capacity
         self.cw_dev = None        # consistency weight as a device scalar (a captured iteration reads it from here)
         self._cw_host = None
         self.last_record = None
@@ -251,12 +253,16 @@ class TrainStep:
         self.student.train()
         self.teacher.train()  # trainer_sessd.py:321-322: both nets in train mode
         # SyncBN like the reference's distributed path (apis/train_sessd.py:286-294): statistics over the batches of all ranks
-        prev_sync = ops.sync_bn_active()
-        ops.set_sync_bn(self.sync_bn if self.sync_bn is not None else self._world() > 1)
+        prev_sync = ops.sync_bn_state()   # the whole state: a configured process group / reduce hook survives the iteration
+        on = self.sync_bn if self.sync_bn is not None else self._world() > 1
+        if self.sync_bn_group is not None:
+            ops.set_sync_bn(on, group=self.sync_bn_group)
+        else:
+            ops.set_sync_bn(on)
         try:
             return self._fwd_bwd_body(example, consistency_weight)
         finally:
-            ops.set_sync_bn(prev_sync)
+            ops.restore_sync_bn(prev_sync)
 
     def _fwd_bwd_body(self, example, consistency_weight):
         # packed weights of both networks are kept and re-packed together at the first use after an update (two launches instead
@@ -295,6 +301,13 @@ class TrainStep:
                 loss, self.last_record = head.loss_device(example, student_preds, teacher_preds, self.cw_dev, unit_grad=True,
                                                           pos_capacity=self.pos_capacity, cons_capacity=self.cons_capacity)
                 self.last_losses = None
+                # capacity overflow of the loss (positives beyond pos_capacity / candidates beyond cons_capacity are dropped):
+                # STICKY on the device, like the engine's flag -- one elementwise launch, also inside a captured iteration; read
+                # and raised by check_overflow() / record() whenever the log is read (round-4 advisor finding: nothing looked)
+                if self.loss_overflow is None:
+                    self.loss_overflow = torch.zeros(1, dtype=torch.float32, device=self.last_record.device)
+                o = ops.HEAD_LOSS_RECORD["overflow"]
+                torch.maximum(self.loss_overflow, self.last_record.detach()[o:o + 1], out=self.loss_overflow)
             elif self.loss_fn is None:   # VoxelNet.forward(example, is_ema=[False, teacher_preds], return_loss=True) after its forward
                 losses = head.loss(example, student_preds, teacher_preds)
                 loss = losses["loss"][0] + losses["consistency_loss"][0][0] * consistency_weight
@@ -331,6 +344,23 @@ class TrainStep:
             self.cw_dev.fill_(float(consistency_weight))
             self._cw_host = float(consistency_weight)
 
+    def check_overflow(self):
+        """Synchronising: raise if ANY iteration since the last check dropped positives (bit 0) or consistency candidates (bit 1)
+        beyond the loss capacities -- such an iteration trained on a truncated loss. Re-arms the flag."""
+        if self.loss_overflow is None:
+            return
+        v = int(self.loss_overflow.item())
+        if v:
+            self.loss_overflow.zero_()
+            raise RuntimeError("sessd_head_loss capacity overflow (flags %d: 1 = positives beyond pos_capacity, 2 = consistency "
+                               "candidates beyond cons_capacity): raise TrainStep.pos_capacity / cons_capacity" % v)
+
+    def record(self):
+        """The last iteration's log terms as the dict MultiGroupHead.loss returns (one host read); raises on a capacity overflow
+        of any iteration since the last call."""
+        self.check_overflow()
+        return None if self.last_record is None else self.student.bbox_head.record_to_dict(self.last_record)
+
     def __call__(self, example, consistency_weight=1.0, device_schedule=False):
         """One eager iteration. device_schedule=True evaluates the OneCycle schedule and the Adam constants on the device from
         the device iteration counter (the arithmetic a captured iteration replays) instead of passing host scalars."""
@@ -352,6 +382,11 @@ class TrainStep:
         the example's tensors before replay(); replay(consistency_weight=...) refills the device scalar the graph reads."""
         if "num_voxels_dev" not in example:
             raise ValueError("capture() needs a capacity-form example (sessd_hip.train.capacity_example)")
+        if self.loss_fn is None and self.device_loss and "transformation_dev" not in example:
+            # without it loss_device() builds the (B, 5) augmentation tensor from host floats INSIDE the capture: a pageable
+            # host-to-device copy that either aborts the capture or bakes this batch's flip / rotation / scale into every replay
+            raise ValueError("capture() with the device loss needs example['transformation_dev'] (capacity_example adds it from "
+                             "example['transformation']); refill it with each new batch before replay()")
         if self._world() > 1 and (self.sync_bn if self.sync_bn is not None else True):
             raise RuntimeError("TrainStep.capture() at world size %d with SyncBN: the BatchNorm all-reduces sit inside the forward and "
                                "backward passes and cannot be captured; run the iteration eagerly (step(example)) or set "
@@ -370,6 +405,8 @@ class TrainStep:
         # copy): a tensor inside the pool read back only after other work had run on the device was once seen overwritten
         # (tests/test_train_gpu.py, three trainers in one process; not reproduced with the output outside the pool)
         self.static_loss = torch.zeros((), dtype=torch.float32, device=self.flat_s.data.device)
+        if self.loss_overflow is None:   # (warmup=0: allocated outside the graph's pool as well)
+            self.loss_overflow = torch.zeros(1, dtype=torch.float32, device=self.flat_s.data.device)
         ops.new_capture_epoch()   # scratch caches: nothing allocated by an earlier capture is reused in this one
         if self.repack is not None:
             self.repack.prepare()  # job tables of everything the warm-up iterations packed: uploaded before the capture

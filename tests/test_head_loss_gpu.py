@@ -184,3 +184,36 @@ def test_device_head_loss_reports_capacity_overflow(dev, golden_dir):
     assert r[ops_record("num_pos")] == 0 and r[ops_record("cls_loss_reduced")] > 0
     total.backward()
     assert float(stu["box"].grad.abs().max()) == 0 and float(stu["cls"].grad.abs().max()) > 0
+
+
+def test_device_head_loss_with_another_box_sigma(dev):
+    """config loss_bbox.sigma != 3 (round-4 advisor finding: the kernel had the two sigmas swapped, which only a sigma other than
+    3 can show): the IoU-prediction term and the score / IoU consistency terms keep the FIXED sigma 3 of mg_head_sessd.py:431,
+    488-491, the logged localisation terms and the box-consistency term take the config's (self.loss_reg, :594-597,737). Device op
+    against the torch restatement MultiGroupHead.loss built from the same config, 2 x 70400 anchors."""
+    import copy
+    from det3d.models import build_detector
+    cfg = copy.deepcopy(configs.kitti_car_model())
+    cfg["bbox_head"]["loss_bbox"]["sigma"] = 1.5
+    head = build_detector(cfg, train_cfg=None, test_cfg=configs.TEST_CFG).bbox_head.to(dev)
+    assert head.loss_reg._sigma == 1.5 and head.loss_iou_pred._sigma == 3.0
+    g = _big_case(5, 2, 70400)
+    example, stu, preds, ema = _example_from(g, dev)
+    cw = 1.0
+    total, rec = head.loss_device(example, preds, ema, consistency_weight=cw)
+    rec1 = rec.clone()
+    total.backward()
+    got = {k: stu[k].grad.clone() for k in stu}
+    dev_ret = head.record_to_dict(rec1)
+    for k in stu:
+        stu[k].grad = None
+    ref = head.loss(example, preds, ema)
+    (ref["loss"][0] + cw * ref["consistency_loss"][0].sum()).backward()
+    val = lambda d, k: float(d[k][0].detach().sum()) if torch.is_tensor(d[k][0]) else float(d[k][0])
+    assert val(ref, "consistency_loss") > 0 and float(rec1[ops_record("matched_boxes")]) > 10
+    for k in ("loss", "loc_loss_reduced", "iou_pred_loss", "ious_loss", "consistency_loss", "loss_ema", "iou_pred_loss_ema"):
+        a, b = val(dev_ret, k), val(ref, k)
+        assert abs(a - b) <= 2e-4 * max(1e-3, abs(b)), (k, a, b)
+    for k in stu:
+        w, gk = stu[k].grad, got[k]
+        assert float((gk - w).abs().max()) <= 2e-3 * float(w.abs().max()), (k, float((gk - w).abs().max()), float(w.abs().max()))

@@ -100,3 +100,22 @@ def test_flat_allreduce_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok and alias for _, ok, alias in res), res
+
+
+def test_sync_bn_switch_keeps_group_and_reduce_hook():
+    """Round-4 advisor finding: toggling SyncBN (TrainStep does, around every iteration) forgot a configured process group /
+    reduce hook. set_sync_bn keeps what it is not given; sync_bn_state / restore_sync_bn carry the whole state."""
+    from sessd_hip import ops
+    before = ops.sync_bn_state()
+    try:
+        f = lambda t: t
+        ops.set_sync_bn(True, group="G", reduce_fn=f)
+        ops.set_sync_bn(False)
+        assert ops.sync_bn_state() == (False, "G", f)
+        st = ops.sync_bn_state()
+        ops.set_sync_bn(True, group=None)
+        assert ops.sync_bn_state() == (True, None, f)
+        ops.restore_sync_bn(st)
+        assert ops.sync_bn_state() == (False, "G", f)
+    finally:
+        ops.restore_sync_bn(before)

@@ -633,6 +633,35 @@ def test_captured_iteration_with_the_reference_loss(dev):
     assert graph.global_step == eager.global_step == 4 and int(graph.opt.global_step_dev.item()) == 4
 
 
+def test_loss_capacity_overflow_is_sticky_and_raised(dev):
+    """Round-4 advisor findings on TrainStep: (1) positives beyond pos_capacity are dropped by sessd_head_loss and only flagged in
+    that iteration's record -- the flag is now STICKY on the device (also through graph replays) and check_overflow() / record()
+    raise and re-arm it; (2) capture() with the device loss refuses an example without `transformation_dev` (it would copy host
+    floats inside the capture)."""
+    step = strain.TrainStep(configs.build_synthetic_detector(dev, seed=0), None, total_steps=20)
+    ex = _labelled(_example(dev, (61, 62), 9000, 8000)[1], dev, 100, 2)
+    cap = strain.capacity_example(ex, 16384)
+    step.pos_capacity = 8          # the batch has 40 positives
+    step(cap, device_schedule=True)
+    step.pos_capacity = None       # the next iteration has room: its own record is clean, the sticky flag is not
+    step(cap, device_schedule=True)
+    assert step.student.bbox_head.record_to_dict(step.last_record)["overflow"] == 0
+    with pytest.raises(RuntimeError, match="capacity overflow"):
+        step.record()
+    assert step.record()["overflow"] == 0      # re-armed
+    bad = {k: v for k, v in cap.items() if k != "transformation_dev"}
+    with pytest.raises(ValueError, match="transformation_dev"):
+        step.capture(bad, warmup=0)
+    # through a capture: the flag accumulates inside the graph
+    step2 = strain.TrainStep(configs.build_synthetic_detector(dev, seed=0), None, total_steps=20)
+    step2.pos_capacity = 8
+    step2.capture(cap, warmup=1)
+    step2.loss_overflow.zero_()
+    step2.replay()
+    with pytest.raises(RuntimeError, match="capacity overflow"):
+        step2.check_overflow()
+
+
 def test_graph_safe_reductions(dev):
     """ops.sum_all / mean_all (sessd_sum_f32): value and gradient against torch in eager mode, and -- the reason they exist --
     correct on EVERY replay of a captured graph on changing inputs (torch's own mean of a tensor this size returns its first
