@@ -469,6 +469,25 @@ class InferenceEngine:
         self.merge_branch_convs = other.merge_branch_convs
         self.sk_ws = torch.zeros_like(other.sk_ws) if other.sk_ws is not None else None
 
+    DEFAULT_ACTIVE_CFG = {0: (1, 4), 1: (0, 1), 2: (1, 2), 3: (30, 4), 4: (1, 2), 5: (0, 1), 6: (11, 0), 7: (30, 8), 8: (4, 0)}
+
+    def force_active_tiles(self, active_cfg=None):
+        """The configuration autotune() ends in on MI355X, WITHOUT timing anything: the neck's 3x3 stride-1 layers on the stream-K
+        Winograd kernels, the stride-2 / 1x1 layers on the LDS-tiled stream-K kernel, and every layer of ACTIVE_SLOTS over its
+        tile list with the given (kernel, minimum share) choices (default: all nine). Allocates the stream-K workspace. Used by
+        __graft_entry__.smoke() and the tests, so that what the driver smokes is the kind of configuration bench.py times."""
+        if self.ta is None:
+            raise RuntimeError("this engine has no tile-activity program (active_tiles=False or an unsupported BEV size)")
+        self.tile_cfg.update({"b0.0": 22, "b0.1": 22, "b0.2": 23, "b1.0": 30, "b1.1": 23, "b1.2": 22, "trans_0": 30, "trans_1": 30,
+                              "conv_0": 22, "conv_1": 22})
+        B = self.B
+        need = max([int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(2 * B, self.H, self.W, 256, sh, 0)) for sh in (0, 1)] +
+                   [int(lib.sessd_conv2d_sk_workspace_bytes(B, self.H, self.W, 256, 1, 0))])
+        if self.sk_ws is None or self.sk_ws.numel() < need:
+            self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+        self.active_cfg = dict(self.DEFAULT_ACTIVE_CFG if active_cfg is None else active_cfg)
+        return self.active_cfg
+
     def autotune(self, candidates=(1, 2, 3, 4, 6, 11, 12), reps=5):
         """Pick the wave/workgroup tiling of every dense conv launch by timing it on this device (one-off, ~0.1 s).
         Needs one representative frame already staged with set_points()."""

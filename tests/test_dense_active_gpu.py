@@ -132,6 +132,29 @@ def _layer(seed, c):
     return w, scale, shift
 
 
+def _torch_cbr(x, w, scale, shift, stride=1, residual=None, transposed=False):
+    """FIRST-HAND reference of one neck layer (round-4 review item: the list kernels were only held to the repo's own dense
+    kernels): torch on the CPU in float64 -- conv (rpn_v1.py:135-160: 3x3 pad 1 / 1x1 pad 0) or ConvTranspose2d(3, stride 2,
+    padding 1, output_padding 1) (:176-199), folded BatchNorm, ReLU, then the residual (:224) -- rounded once to float32."""
+    import torch.nn.functional as F
+    xd, wd = x.detach().cpu().double(), w.detach().cpu().double()
+    if transposed:
+        y = F.conv_transpose2d(xd, wd, stride=2, padding=1, output_padding=1)
+    else:
+        y = F.conv2d(xd, wd, stride=stride, padding=wd.shape[-1] // 2)
+    y = torch.relu(y * scale.detach().cpu().double().view(1, -1, 1, 1) + shift.detach().cpu().double().view(1, -1, 1, 1))
+    if residual is not None:
+        y = y + residual.detach().cpu().double()
+    return y.float()
+
+
+def _check_first_hand(got, ref, what, tol=2e-5):
+    """device output against the float64 torch reference of THE SAME input: computed tiles (the list kernel's arithmetic) and
+    filled tiles (the host's float64 constants) alike, tol * the layer's largest value"""
+    r, e = float(ref.abs().max()), float((got.cpu() - ref).abs().max())
+    assert e <= tol * r, (what, e, r)
+
+
 def _constants(layers):
     """value of a layer's output where its input is the previous layer's constant (float64, then float32)"""
     c = torch.zeros(layers[0][0].shape[1], dtype=torch.float64)
@@ -170,6 +193,8 @@ def test_active_chain_equals_the_dense_layers(dev, batch, shape, min_rounds):
         torch.cuda.synchronize()
         got = outs[l]
         assert torch.isfinite(got).all(), "layer %d: a tile neither filled nor computed" % l
+        # first hand: torch float64 on the very input the list launch read (its computed tiles AND the filled constants)
+        _check_first_hand(got, _torch_cbr(cur_a, w, scale, shift), "Winograd list layer %d vs torch" % l)
         ref = float(dense.abs().max())
         err = float((got - dense).abs().max())
         assert err <= 1e-5 * ref, (l, err, ref)
@@ -272,6 +297,7 @@ def test_stride_2_and_1x1_layers_over_tile_lists(dev, batch, min_rounds):
     d1 = ops.conv2d(d0, p1, *dv(l1), True, None, None, 30, workspace=ws)
     ops.conv2d_sk_active(o0, p1, *dv(l1), True, o1, ws, ta.tile_list[1], ta.n_list[1:2], min_rounds=min_rounds)
     check(o1, d1, "stride-2 layer", 2e-5)
+    _check_first_hand(o1, _torch_cbr(o0, l1[0], l1[1], l1[2], stride=2), "stride-2 list layer (conv2d_sk LIST) vs torch")
     # the layer after it (Winograd list kernel) sees the pixel-level rows of the transition
     p2 = ops.pack_conv2d(l2[0].to(dev))
     d2 = ops.conv2d(d1, p2, *dv(l2), True, None, None, 23)
@@ -285,6 +311,8 @@ def test_stride_2_and_1x1_layers_over_tile_lists(dev, batch, min_rounds):
     ops.conv2d_sk_active(o2, pt1, *dv(tr1), True, ot1, ws, ta.tile_list[2], ta.n_list[2:3], min_rounds=min_rounds)
     check(ot0, dt0, "trans_0", 2e-5)
     check(ot1, dt1, "trans_1", 2e-5)
+    _check_first_hand(ot0, _torch_cbr(o0, *tr0), "trans_0 (conv2d_sk LIST, 1x1) vs torch")
+    _check_first_hand(ot1, _torch_cbr(o2, *tr1), "trans_1 (conv2d_sk LIST, 1x1) vs torch")
     # a residual rides along in the listed pixels only (the engine does not use one here; the entry point takes it)
     res = torch.randn(batch, C0, H, W, device=dev)
     keep = ot0.clone()
@@ -365,6 +393,11 @@ def test_direct_kernels_over_tile_lists(dev, batch, cfg):
         assert torch.equal(got[tm], dense[tm]), "%s: a computed pixel differs from the plain launch" % what
         ref, err = float(dense.abs().max()), float((got - dense).abs().max())
         assert err <= 1e-5 * ref, (what, err, ref)
+    # first hand: torch float64 on the inputs the list launches read
+    _check_first_hand(o_t0, _torch_cbr(x0, *tr0), "trans_0 (direct 1x1 over a list) vs torch")
+    _check_first_hand(o_t1, _torch_cbr(x1, *tr1), "trans_1 (direct 1x1 over a list) vs torch")
+    _check_first_hand(o_a, _torch_cbr(d_t1, *dwa, residual=d_t0, transposed=True), "deconv_0 + residual (pair over a list) vs torch")
+    _check_first_hand(o_b, _torch_cbr(d_t1, *dwb, transposed=True), "deconv_1 (pair over a list) vs torch")
     frac = [float(ta.n_list[s]) / (batch * (ta.dims[s][0] // 2) * (ta.dims[s][1] // 2)) for s in range(3)]
     print("computed tile fractions", [round(f, 3) for f in frac])
     assert frac[0] < 0.6 and frac[2] < 1.0

@@ -323,17 +323,23 @@ def test_offset_pattern_tiles_do_not_change_the_frame(dev, model):
         assert res[0][2] > res[1][2] + 0.08
 
 
-def test_active_tiles_do_not_change_the_frame(dev, model):
+def test_active_tiles_do_not_change_the_frame(dev, model, state):
     """Blocks 0 and 1 of the neck in active-tile mode (csrc/dense_active.hip: only the 2x2-output tiles whose input patch is not
     constant are computed, the others are filled with the layer's constant) against the same engine with the whole map computed: the
     blocks' outputs within 2e-6 of their largest value (float32 rounding of the constants' chain; a computed tile is the same
     arithmetic as before), the same detections under the tolerance of the oracle comparison, at batch 1 and 2, eagerly and as a
     captured graph; and the share of computed tiles is what the occupancy of a 20 k-point scan gives (well under half)."""
+    anchors = pp.create_anchors_3d_range().reshape(-1, 7)
     for B, seeds in ((1, (51,)), (2, (52, 53))):
-        frames = [torch.from_numpy(synth.make_frame(s, 20000)).to(dev) for s in seeds]
+        frames_np = [synth.make_frame(s, 20000) for s in seeds]
+        frames = [torch.from_numpy(f).to(dev) for f in frames_np]
+        # FIRST HAND (round-4 review item): the forced-active engine against the CPU oracle pipeline itself, not only against
+        # the full-map engine
+        want, inter = pipeline.run_frames(frames_np, state, VG["range"], VG["voxel_size"], 5, 16000, anchors, None, return_intermediate=True)
         res = []
         for act in (True, False):
             eng = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, B, 20480, dev, active_tiles=act)
+            eng.keep_ssfa = True
             eng.set_points(frames)
             eng.tile_cfg.update({"b0.0": 22, "b0.1": 22, "b0.2": 23, "b1.0": 30, "b1.1": 23, "b1.2": 22, "trans_0": 30, "trans_1": 30})
             need = max([int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(2 * B, eng.H, eng.W, 256, sh, 0)) for sh in (0, 1)] +
@@ -349,6 +355,11 @@ def test_active_tiles_do_not_change_the_frame(dev, model):
                             eng.t["mid"].reshape(-1)])
             frac = eng.active_tile_fractions()
             if act:
+                assert sorted(eng._active_layers()) == list(range(9))   # every layer really ran over its list
+                ssfa = eng.t["out"].cpu()
+                assert float((ssfa - inter["ssfa"]).abs().max()) < 5e-4 * max(1.0, float(inter["ssfa"].abs().max()))
+                cmp = [_compare_dets(g, w, d) for g, w, d in zip(out, want, inter["debug"])]
+                assert all(r["matched"] == r["n"] for r in cmp)
                 eng.capture()
                 eng.replay()
                 out_g = eng.results()
