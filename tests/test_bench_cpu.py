@@ -101,7 +101,7 @@ def test_rank_function_two_gloo_ranks_on_a_stub_engine(capfd):
     assert out["config"]["rccl_ranks_seen"] == world
     assert out["config"]["frames_in_flight"] == 2
     assert out["value"] > 0 and abs(out["value"] - world * steps / (out["ms_per_step"] * 1e-3 * steps)) < 1e-6 * out["value"]
-    assert out["parity"] is None  # the oracle sample belongs to the N = 1 line
+    assert "parity" not in out  # off the GPU (stub engines) there is no gate; on GPUs every rank runs a short one (bench.py)
     json.dumps(out)
 
 
