@@ -83,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--fork-active", action="store_true", help="EXPERIMENT: the tile-list + fill launches as a side branch of the graph beside the sparse convs")
     ap.add_argument("--fork", action="store_true", help="engines with the parallel front branch (level-0 table + first two sparse convs beside the site chain; measured slower)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
+    ap.add_argument("--weights", default=None,
+                    help="state_dict file (torch.save) loaded into the detector instead of the seeded random weights, e.g. the student "
+                         "trained by tests/trained_parity.py --save; the parity gate then uses oracle/compare.py's STRICT rule")
     ap.add_argument("--no-offset-split", action="store_true", help="autotune without the offset-split sparse conv variants")
     ap.add_argument("--no-streamk", action="store_true", help="autotune without the stream-K Winograd variants")
     ap.add_argument("--wino-cfg", type=int, default=0, help="force this tile_cfg (20-25) on the seven 3x3 stride-1 SSFA layers after autotune")
@@ -115,6 +118,9 @@ def default_engine_factory(args, dev):
     from sessd_hip.engine import InferenceEngine
     VG = configs.VOXEL_GENERATOR
     model = configs.build_synthetic_detector(dev, seed=0, max_voxels=args.max_voxels, num_points=args.points, supersample=args.supersample)
+    if getattr(args, "weights", None):
+        model.load_state_dict(torch.load(args.weights, map_location=dev))
+        model.eval()
     engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], args.max_voxels,
                                configs.TEST_CFG, batch_size=args.batch, max_points_per_frame=args.points, device=dev,
                                active_tiles=not getattr(args, "no_active_tiles", False))
@@ -167,13 +173,14 @@ def parity_gate(args, engines, streams, frames, sample):
     unit is cut depends on the slot) -- and every frame of every batch is compared."""
     from oracle.compare import compare_detections
     B = args.batch
+    rule = "strict" if getattr(args, "weights", None) else "synthetic"
     rep = {"frames": 0, "identical": 0, "flipped_near_threshold": 0, "mismatch": [], "bev_rel_err": None, "engines": len(engines),
            "batch": B, "launch": "eager" if args.eager else "hipGraph replay",
-           "rule_set": "synthetic",
-           "rule": "oracle/compare.py rule='synthetic' (seeded random weights: sizes relative beyond 1 m, <= 10 listed decisions; the "
-                   "strict default -- absolute sizes, <= 6 -- is for real KITTI weights): same count / order, boxes 2e-3, scores 1e-3 "
+           "rule_set": rule,
+           "rule": "oracle/compare.py rule='%s' (synthetic = seeded random weights: sizes relative beyond 1 m, <= 10 listed decisions; "
+                   "strict = trained weights (--weights): absolute sizes, <= 6): same count / order, boxes 2e-3, scores 1e-3 "
                    "relative; a frame with oracle-LISTED NMS decisions within 1e-4 of the 0.01 IoU threshold may equal the oracle under "
-                   "one assignment of those decisions (counted as flipped)"}
+                   "one assignment of those decisions (counted as flipped)" % rule}
     if B == 1:
         batches = [[s] for s in sample]
     else:
@@ -202,7 +209,7 @@ def parity_gate(args, engines, streams, frames, sample):
             for slot, ((fi, want, dbg, bev), got) in enumerate(zip(grp, res)):
                 rep["frames"] += 1
                 try:
-                    r = compare_detections(got, want, dbg, rule="synthetic")
+                    r = compare_detections(got, want, dbg, rule=rule)
                     rep["identical" if not r["flipped"] else "flipped_near_threshold"] += 1
                 except AssertionError as ex:
                     rep["mismatch"].append({"engine": ei, "frame": fi, "slot": slot, "why": str(ex)[:300]})
@@ -383,8 +390,10 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "SE-SSD KITTI-car inference, %d frame(s)/step: %d-point synthetic HDL-64E front-FOV scans, "
                                    "voxel grid [1408,1600,40], max_voxels %d, batch %d (BASELINE.json configs[%d]); "
-                                   "seeded random weights, BatchNorm calibrated"
-                                   % (args.batch, args.points, args.max_voxels, args.batch, 4 if args.stress else 1),
+                                   "%s"
+                                   % (args.batch, args.points, args.max_voxels, args.batch, 4 if args.stress else 1,
+                                      ("TRAINED weights from %s (tests/trained_parity.py)" % os.path.basename(args.weights))
+                                      if getattr(args, "weights", None) else "seeded random weights, BatchNorm calibrated"),
                        "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps * args.batch,
                        "frames_in_flight": len(engines), "streamk_workgroups": args.sk_workgroups,
                        "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,

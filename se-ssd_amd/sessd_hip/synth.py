@@ -2,7 +2,7 @@
 
 There is no KITTI data and no released checkpoint in this environment, so the benchmark and the
 parity tests run on ray-cast point clouds of the KITTI front-camera field of view and on seeded
-random weights. numpy only; nothing here touches the device.
+random weights. numpy only (frame_labels: the numpy box helpers of the det3d mirror); nothing here touches the device.
 """
 import math
 
@@ -77,15 +77,31 @@ def make_frame(seed=0, num_points=20000, supersample=1):
 
 def frame_cars(seed=0):
     """The 15 car-sized boxes make_frame(seed) places in its scene, as KITTI lidar boxes (15, 7) [x, y, z, w, l, h, r] (the same
-    random draws in the same order as make_frame: six walls first). Ground-truth stand-ins of the training benchmark."""
+    random draws in the same order as make_frame: six walls first). The ray caster turns a car's LONG side (3.9 m) to
+    (cos yaw, sin yaw); a det3d lidar box turns its length axis to (sin r, cos r) (box_np_ops.rotation_3d_in_axis, axis 2), so
+    r = pi/2 - yaw, folded into [-pi, pi). (Rounds 1 - 4 returned r = yaw: boxes a quarter turn off the points they label -- it
+    did not matter to a timing benchmark on random weights, it does to training.) Ground truth of the synthetic training set."""
     rng = np.random.RandomState(seed)
     for _ in range(6):
         rng.uniform(15, 65); rng.uniform(-0.7, 0.7); rng.uniform(6, 25); rng.uniform(-math.pi, math.pi)
     out = np.zeros((15, 7), np.float32)
     for i in range(15):
         x, y = rng.uniform(5, 60), rng.uniform(-25, 25)
-        out[i] = [x, y, -1.73 + 0.78, 1.6, 3.9, 1.56, rng.uniform(-math.pi, math.pi)]
+        r = math.pi / 2 - rng.uniform(-math.pi, math.pi)
+        out[i] = [x, y, -1.73 + 0.78, 1.6, 3.9, 1.56, (r + math.pi) % (2 * math.pi) - math.pi]
     return out
+
+
+def frame_labels(seed, points, margin=0.1):
+    """(boxes (15, 7), point counts (15,)) of make_frame(seed)'s cars for the cloud `points` (the subsampled scan): how many of
+    its points lie inside each car's box grown by `margin` (the rays end ON the surfaces, with 1 cm of range noise). A car behind
+    a wall or outside the +-45 degree field of view has none: what a labeller could not see is not ground truth."""
+    from det3d.core.bbox import box_np_ops
+    cars = frame_cars(seed)
+    grown = cars.copy()
+    grown[:, 3:6] += margin
+    counts = box_np_ops.points_in_rbbox(points[:, :3], grown, z_axis=2, origin=(0.5, 0.5, 0.5)).sum(0)
+    return cars, counts.astype(np.int64)
 
 
 def kitti_calib():
