@@ -83,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--fork-active", action="store_true", help="EXPERIMENT: the tile-list + fill launches as a side branch of the graph beside the sparse convs")
     ap.add_argument("--fork", action="store_true", help="engines with the parallel front branch (level-0 table + first two sparse convs beside the site chain; measured slower)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
+    ap.add_argument("--list-shares", default="auto", choices=["auto", "whole", "cut"],
+                    help="A/B of the Winograd list launches: whole-unit shares for every layer / stream-K shares only / the autotune's "
+                         "per-launch choice")
     ap.add_argument("--weights", default=None,
                     help="state_dict file (torch.save) loaded into the detector instead of the seeded random weights, e.g. the student "
                          "trained by tests/trained_parity.py --save; the parity gate then uses oracle/compare.py's STRICT rule")
@@ -276,7 +279,11 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
     if not args.no_autotune:
         eng.allow_offset_split = not args.no_offset_split
         eng.allow_streamk = not args.no_streamk
+        if getattr(args, "list_shares", "auto") == "cut":
+            eng.list_share_candidates = (1, 4, 8, 16)
         rep = eng.autotune()
+        if getattr(args, "list_shares", "auto") != "auto" and hasattr(eng, "set_list_shares"):
+            eng.set_list_shares(args.list_shares)
         log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
     if args.wino_cfg:
         for nm in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):

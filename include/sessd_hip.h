@@ -514,7 +514,8 @@ int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int ci
  *   sessd_fill_inactive_tiles   out[b][co][tile] = value[co] (the layer's constant, computed by the host from the folded weights)
  *                               in the tiles nobody computes, up to 10 layers per launch
  *   sessd_conv3x3_winograd_sk_active   sessd_conv3x3_winograd_sk over the listed tiles only (same packed U, same workspace; the
- *                               shares of the round list are sized on the device, workgroups beyond rounds / min_rounds exit)
+ *                               shares of the round list are sized on the device, workgroups beyond rounds / min_rounds exit;
+ *                               min_rounds = -k: whole-unit shares of at least k units, no unit cut, no partial sums in memory)
  * Results equal the dense layer's to float32 rounding (tests/test_dense_active_gpu.py); replaces nothing in the reference -- it is
  * how this path avoids arithmetic on constants that ATen's dense conv performs. */
 size_t sessd_bev_tile_activity_workspace_bytes(int batch, int n_layers);

@@ -35,7 +35,11 @@
 
 namespace {
 
-constexpr int NT = 1024;
+// 256 threads = a thread pair per tile row (MAX_H / 2 rows). Round 4 ran 1024: every step's ~400 instructions were issued by
+// sixteen waves of which twelve had no row to work on, and every barrier / block scan ran over sixteen waves -- the kernel was
+// issue-bound at ~3.2 us per step (scripts/activity_probe.py). Four waves, one per SIMD.
+constexpr int NT = 256;
+constexpr int LPT = 16;   // site rows a thread fetches per round (all in flight together)
 constexpr int MAX_H = 256, MAX_W = 192;   // one image's pixel rows as 3 x 64-bit words in LDS; a thread pair per tile row
 constexpr int MAX_SLOTS = 7, MAX_STEPS = 8, MAX_FILL_JOBS = 10;
 constexpr int FILL_CG = 16;   // channels per fill block
@@ -166,25 +170,25 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
   int H = A.h, W = A.w;
   // the site rows of ALL images are walked by every workgroup (they are few); eight independent loads per thread and round. The
   // first round is fetched up to the CAPACITY, together with the count (one memory latency instead of two), and masked afterwards.
-  int4 c[8];
+  int4 c[LPT];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) {
+  for (int k = 0; k < LPT; ++k) {
     const int i = k * NT + (int)threadIdx.x;
     c[k] = i < A.n_cap ? *reinterpret_cast<const int4*>(A.indices + (size_t)i * 4) : make_int4(-1, 0, 0, 0);
   }
   const int n = min(A.n_dev[0], A.n_cap);
   for (int i = threadIdx.x; i < H * 3; i += NT) (&nc[0][0])[i] = 0ull;
   ACT_LDS_BARRIER();
-  for (int base = 0; base < n; base += NT * 8) {
+  for (int base = 0; base < n; base += NT * LPT) {
     if (base > 0) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < LPT; ++k) {
         const int i = base + k * NT + (int)threadIdx.x;
         c[k] = i < n ? *reinterpret_cast<const int4*>(A.indices + (size_t)i * 4) : make_int4(-1, 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
+    for (int k = 0; k < LPT; ++k)
       if (base + k * NT + (int)threadIdx.x < n && c[k].x == b && c[k].z >= 0 && c[k].z < H && c[k].w >= 0 && c[k].w < W)
         atomicOr(&nc[c[k].z][c[k].w >> 6], 1ull << (c[k].w & 63));
   }

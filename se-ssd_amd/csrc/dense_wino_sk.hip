@@ -100,16 +100,29 @@ __global__ __launch_bounds__(NW * 64, 8 / NW) void conv3x3s1_winograd_sk_kernel(
     n_list = __builtin_amdgcn_readfirstlane(min(A.n_list[0], A.list_cap));
     R = (long long)((n_list + 31) >> 5) * A.ngroups * A.rpu;
     if (R == 0) return;
-    long long g = R / A.min_rounds;
-    g = g < 1 ? 1 : (g > G ? G : g);
-    G = (int)(g >= 8 ? (g & ~7LL) : g);
-    if ((G & 7) ? ((int)blockIdx.x >= G) : ((int)(blockIdx.x >> 3) >= (G >> 3))) return;
+    if (A.min_rounds < 0) {
+      // WHOLE-UNIT shares (round 5; min_rounds = -k: at least k units per workgroup): no unit is ever cut, so no partial sum
+      // crosses memory (the cut-unit exchange of short shares was 4 of the 5x algorithmic traffic of a list launch,
+      // profiles/r4s2_wino_traffic.json) and a layer with few listed tiles occupies as many workgroups as it has units -- the
+      // other CUs stay free for the other frame in flight. One workgroup per unit while the launch has enough of them.
+      const long long U = R / A.rpu;
+      long long g = U / (-A.min_rounds);
+      g = g < 1 ? 1 : (g > G ? G : g);
+      G = (int)g;
+      if ((int)blockIdx.x >= G) return;
+    } else {
+      long long g = R / A.min_rounds;
+      g = g < 1 ? 1 : (g > G ? G : g);
+      G = (int)(g >= 8 ? (g & ~7LL) : g);
+      if ((G & 7) ? ((int)blockIdx.x >= G) : ((int)(blockIdx.x >> 3) >= (G >> 3))) return;
+    }
   }
+  const bool whole_units = LIST && A.min_rounds < 0;
   // share w of the round list; consecutive shares on one XCD (workgroup b runs on XCD b % 8): neighbouring units share
   // input rows through that XCD's L2
-  const int w = (G & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
-  int r = (int)((long long)w * R / G);
-  const int r_stop = (int)((long long)(w + 1) * R / G);
+  const int w = (whole_units || (G & 7)) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (G >> 3) + (blockIdx.x >> 3));
+  int r = whole_units ? (int)((long long)w * (R / A.rpu) / G) * A.rpu : (int)((long long)w * R / G);
+  const int r_stop = whole_units ? (int)((long long)(w + 1) * (R / A.rpu) / G) * A.rpu : (int)((long long)(w + 1) * R / G);
   const int in_plane = A.hin * A.win;
   const size_t out_plane = (size_t)in_plane;
   const unsigned xstep = 2u * (unsigned)in_plane * 4u;  // bytes per k-step (2 channels)
@@ -885,7 +898,8 @@ int launch_sk(const float* in, int batch, int nsets, int cin, int h, int w, cons
   A.rpu = cin / (2 * NW);
   A.bper = batch / nsets; A.ss_stride = nsets > 1 ? cout : 0;
   A.upk_stride = nsets > 1 ? (long long)sessd_divup(cout, CBN * 32) * (cin >> 1) * (NW * 2 * 32 * 32 / 4) : 0;
-  A.tile_list = tile_list; A.n_list = n_list; A.list_cap = list_cap; A.min_rounds = min_rounds < 1 ? 1 : min_rounds; A.batch = batch;
+  // min_rounds < 0 (list launches only): whole-unit shares, at least -min_rounds units per workgroup
+  A.tile_list = tile_list; A.n_list = n_list; A.list_cap = list_cap; A.min_rounds = (min_rounds < 0 && tile_list) ? min_rounds : (min_rounds < 1 ? 1 : min_rounds); A.batch = batch;
   const long long units = (long long)batch * A.tblocks * A.ngroups;
   if (units * A.rpu > 0x7fffffffLL) return SESSD_EINVAL;
   A.total_rounds = (int)(units * A.rpu);
@@ -962,7 +976,8 @@ int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int ci
 // outside the sparse backbone's sites): only the 2x2-output tiles listed in tile_list[0 .. min(*n_list, list_cap)) are computed
 // and written -- entries image * (h/2 * w/2) + tile in any fixed order, count on the device (sessd_bev_tile_activity builds both).
 // The other tiles of `out` are the caller's (sessd_fill_inactive_tiles writes the layer's constant there). Workgroups beyond
-// rounds / min_rounds leave at once. Same packed U, same workspace (sized for the dense layer) as sessd_conv3x3_winograd_sk.
+// rounds / min_rounds leave at once. min_rounds = -k (round 5): WHOLE-UNIT shares -- every workgroup takes at least k whole
+// units (32 tiles x the shape's couts x all input channels), nothing is cut, the scratch slots stay untouched. Same packed U, same workspace (sized for the dense layer) as sessd_conv3x3_winograd_sk.
 int sessd_conv3x3_winograd_sk_active(const float* in, int batch, int cin, int h, int w, const float* upk, float* out, int cout,
                                      const float* scale, const float* shift, int relu, const float* residual,
                                      const int32_t* tile_list, const int32_t* n_list, int list_cap, int min_rounds, void* workspace,

@@ -311,6 +311,10 @@ class InferenceEngine:
         self.ACTIVE_SK = (3, 6, 7)
         self.ACTIVE_PAIR = 8
         self.near_fill = True   # fill only the tiles a list-driven reader can reach where that reader is the map's only one
+        # minimum share lengths autotune() tries for a Winograd list launch: > 0 rounds of a stream-K share (units may be cut, partial
+        # sums through memory), < 0 WHOLE units per workgroup (round 5: nothing cut, as many workgroups as units -- slower alone on
+        # a short list, but it leaves the other CUs to the second frame in flight)
+        self.list_share_candidates = (1, 4, 8, 16, -1, -2)
         # EXPERIMENT, measured slower on MI355X / ROCm 7.2 and therefore off (1154 against 1163 frames/s one frame at a time, 1132
         # against ~1550 with two frames in flight): the activity + fill launches as a side branch beside the sparse convs (see enqueue)
         self.fork_active = False
@@ -652,7 +656,7 @@ class InferenceEngine:
                     need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(self.B, x_in.shape[2], x_in.shape[3], pc.cout, shape, 0))
                     if self.sk_ws is None or self.sk_ws.numel() < need:
                         self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
-                    for mr in (1, 4, 8, 16):
+                    for mr in self.list_share_candidates:
                         tt = timed(lambda: ops.conv2d_winograd_sk_active(x_in, pc.upk_sk(shape), pc.cout, scale, shift, True, x_out, shape,
                                                                          self.sk_ws, self.ta.tile_list[m], self.ta.n_list[m:m + 1],
                                                                          workgroups=self.sk_workgroups, min_rounds=mr))
@@ -683,6 +687,18 @@ class InferenceEngine:
         # (choice, gain ms per frame over the dense launches, ms of the activity + fill launches, per-layer ms): a tuple like the others
         self.tune_report["active_tiles"] = ({self.ACTIVE_SLOTS[l][0]: v for l, v in self.active_cfg.items()}, gain - over, over,
                                             {self.ACTIVE_SLOTS[l][0]: pick[l][1] for l in pick})
+
+    def set_list_shares(self, mode):
+        """After autotune(): 'whole' = every Winograd list layer on whole-unit shares (min_rounds -1), 'cut' = on stream-K shares
+        (the best positive candidate is not re-timed: 4 rounds), anything else leaves the autotune's choice. For A/B runs of
+        the two-frames-in-flight rate, which autotune()'s per-launch timing cannot see."""
+        for l, (shape, mr) in list(self.active_cfg.items()):
+            if l in self.ACTIVE_SK or l == self.ACTIVE_PAIR:
+                continue
+            if mode == "whole":
+                self.active_cfg[l] = (shape, -1)
+            elif mode == "cut" and mr < 0:
+                self.active_cfg[l] = (shape, 4)
 
     def active_tile_fractions(self):
         """name -> share of the 2x2-output tiles the layer computed in the LAST enqueued batch (layers in active-tile mode only)"""

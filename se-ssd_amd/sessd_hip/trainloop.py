@@ -193,7 +193,7 @@ def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50
     ema_ref = step.flat_t.data.clone() if ema_check else None
     R = ops.HEAD_LOSS_RECORD
     keys = ("total", "loss", "cls_loss_reduced", "ious_loss", "dir_loss_reduced", "iou_pred_loss", "consistency_loss", "loss_ema",
-            "num_pos", "matched_boxes", "candidates", "candidates_ema", "overflow")
+            "num_pos", "positives", "matched_boxes", "candidates", "candidates_ema", "overflow")
     log, flags = [], 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()

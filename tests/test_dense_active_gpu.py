@@ -165,8 +165,9 @@ def _constants(layers):
     return out
 
 
-@pytest.mark.parametrize("batch,shape,min_rounds", [(1, 0, 2), (1, 1, 2), (2, 0, 1), (2, 1, 4), (1, 0, 8)])
+@pytest.mark.parametrize("batch,shape,min_rounds", [(1, 0, 2), (1, 1, 2), (2, 0, 1), (2, 1, 4), (1, 0, 8), (1, 1, -1), (2, 0, -1), (3, 1, -3)])
 def test_active_chain_equals_the_dense_layers(dev, batch, shape, min_rounds):
+    """min_rounds < 0 (round 5): whole-unit shares -- no unit is cut, so the partial-sum scratch of the workspace is never written"""
     C = 128
     idx = _sites(2 + batch, batch, 1600)
     x = torch.zeros(batch, C, H, W)
@@ -183,14 +184,17 @@ def test_active_chain_equals_the_dense_layers(dev, batch, shape, min_rounds):
     outs = [torch.full((batch, C, H, W), float("nan"), device=dev) for _ in range(3)]
     ta.fill(outs, consts)
     ws = torch.zeros(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(batch, H, W, C, shape, 0)), dtype=torch.uint8, device=dev)
+    ws_list = torch.zeros_like(ws)   # the list launches' own workspace: whole-unit shares must leave ALL of it untouched
     cur_a, cur_d = x, x
     for l, (w, scale, shift) in enumerate(layers):
         pc = ops.pack_conv2d(w.to(dev))
         sc, sh = scale.to(dev), shift.to(dev)
-        dense = ops.conv2d(cur_d, pc, sc, sh, True, None, None, 22 + shape)
-        ops.conv2d_winograd_sk_active(cur_a, pc.upk_sk(shape), C, sc, sh, True, outs[l], shape, ws, ta.tile_list[l], ta.n_list[l:l + 1],
+        dense = ops.conv2d(cur_d, pc, sc, sh, True, None, None, 22 + shape, workspace=ws)
+        ops.conv2d_winograd_sk_active(cur_a, pc.upk_sk(shape), C, sc, sh, True, outs[l], shape, ws_list, ta.tile_list[l], ta.n_list[l:l + 1],
                                       min_rounds=min_rounds)
         torch.cuda.synchronize()
+        if min_rounds < 0:
+            assert int(ws_list.view(torch.int32).abs().sum()) == 0, "a whole-unit launch wrote a partial sum"
         got = outs[l]
         assert torch.isfinite(got).all(), "layer %d: a tile neither filled nor computed" % l
         # first hand: torch float64 on the very input the list launch read (its computed tiles AND the filled constants)
@@ -205,7 +209,7 @@ def test_active_chain_equals_the_dense_layers(dev, batch, shape, min_rounds):
         cur_a, cur_d = got, dense
     # the workspace counters are left zero (the next launch relies on it)
     units = batch * ((H // 2) * (W // 2) + 31) // 32 * (C // (128 if shape == 0 else 64))
-    assert int(ws[:units * 4].view(torch.int32).abs().sum()) == 0
+    assert int(ws[:units * 4].view(torch.int32).abs().sum()) == 0 and int(ws_list[:units * 4].view(torch.int32).abs().sum()) == 0
 
 
 def test_active_chain_through_the_stride_2_layer(dev):
