@@ -20,6 +20,8 @@ ap.add_argument("--graph", action="store_true")
 ap.add_argument("--force-active", action="store_true",
                 help="blocks 0 / 1 of the neck in active-tile mode whatever the autotune timed (under a counter pass every launch "
                      "carries the profiler's overhead and the autotune declines the two extra launches)")
+ap.add_argument("--list-shares", default="auto", choices=["auto", "whole", "cut"],
+                help="with --force-active: the Winograd list layers on whole-unit shares (round 5) / stream-K shares")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 VG = configs.VOXEL_GENERATOR
@@ -42,6 +44,7 @@ if a.force_active and e.ta is not None:
     if e.sk_ws is None or e.sk_ws.numel() < need:
         e.sk_ws = torch.zeros(need, dtype=torch.uint8, device=dev)
     e.active_cfg = {0: (1, 4), 1: (1, 8), 2: (1, 16), 3: (30, 4), 4: (1, 4), 5: (1, 8), 6: (4, 0), 8: (3, 0)}
+    e.set_list_shares(a.list_shares)
     print("active_tiles forced:", e.active_cfg)
 if a.graph:
     e.capture()
