@@ -35,11 +35,12 @@
 
 namespace {
 
-// 256 threads = a thread pair per tile row (MAX_H / 2 rows). Round 4 ran 1024: every step's ~400 instructions were issued by
-// sixteen waves of which twelve had no row to work on, and every barrier / block scan ran over sixteen waves -- the kernel was
-// issue-bound at ~3.2 us per step (scripts/activity_probe.py). Four waves, one per SIMD.
-constexpr int NT = 256;
-constexpr int LPT = 16;   // site rows a thread fetches per round (all in flight together)
+// 1024 threads: a thread pair per tile row needs 256 of them, but the list emission (a wave per mask word, a lane per bit) and the
+// site walk use all sixteen waves. MEASURED in round 5 (review item "four waves instead of sixteen"): with NT = 256 / LPT = 16
+// the kernel took 46.8 us instead of 29 (profiles/r5_dense_pmc_whole_unit_shares.txt was taken with that build): the steps'
+// arithmetic is not what the kernel waits for, its ~200 mask words per slot emitted four at a time are.
+constexpr int NT = 1024;
+constexpr int LPT = 8;    // site rows a thread fetches per round (all in flight together)
 constexpr int MAX_H = 256, MAX_W = 192;   // one image's pixel rows as 3 x 64-bit words in LDS; a thread pair per tile row
 constexpr int MAX_SLOTS = 7, MAX_STEPS = 8, MAX_FILL_JOBS = 10;
 constexpr int FILL_CG = 16;   // channels per fill block

@@ -73,15 +73,36 @@ def labelled_batch(dev, batch=4, seed0=50, npts=20000, max_voxels=16000, aug_see
     return ex, cap
 
 
-def measure(dev, batch=4, steps=20, warmup=3, real_loss=True, standin_loss_fn=None, seed=0):
+def measure(dev, batch=4, steps=20, warmup=3, real_loss=True, standin_loss_fn=None, seed=0, pretrain=300, scenes=24):
     """Capture the whole iteration as ONE hipGraph (teacher forward, student forward, loss, backward, flat all-reduce hook,
     fused clip + Adam + EMA) on a labelled synthetic batch and time `steps` replays. real_loss=True: the reference loss
     (MultiGroupHead.loss + consistency loss through sessd_head_loss) -- BASELINE configs[2]; False: `standin_loss_fn`
-    (round 3's slice). Returns a dict."""
+    (round 3's slice). Returns a dict.
+    pretrain (round 5, real loss only): the timed replays come AFTER `pretrain` captured iterations on fresh batches of a small
+    scene pool (sessd_hip.trainloop: device data path), so that the timed iteration exercises what a training run exercises --
+    teacher and student agree on boxes (matched pairs, consistency loss > 0; the round-4 figure was taken at iteration 3 of a
+    random network: `matched_boxes` 0). `ms_per_iter` stays the replay of one resident batch (comparable with earlier rounds);
+    `ms_per_iter_fresh_batches` has the data path inside the clock."""
     model = configs.build_synthetic_detector(dev, seed=seed)
-    step = strain.TrainStep(model, None if real_loss else standin_loss_fn, total_steps=1000)
-    ex, cap = labelled_batch(dev, batch)
-    step.capture(cap, consistency_weight=1.0, warmup=max(1, warmup))
+    fresh = None
+    if real_loss and pretrain > 0:
+        from . import trainloop
+        pool = trainloop.ScenePool(range(50, 50 + scenes), 20000)
+        step = strain.TrainStep(model, None, total_steps=2 * pretrain + 100)
+        data = trainloop.DeviceBatcher(pool, dev, batch, pretrain + 2, seed=seed)
+        cap = ex = data.load(0)
+        step.capture(cap, consistency_weight=1.0, warmup=max(1, warmup))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for it in range(1, pretrain + 1):
+            data.load(it)
+            step.replay()
+        torch.cuda.synchronize()
+        fresh = (time.perf_counter() - t0) / pretrain * 1e3
+    else:
+        step = strain.TrainStep(model, None if real_loss else standin_loss_fn, total_steps=1000)
+        ex, cap = labelled_batch(dev, batch)
+        step.capture(cap, consistency_weight=1.0, warmup=max(1, warmup))
     for _ in range(3):
         step.replay()
     torch.cuda.synchronize()
@@ -91,14 +112,21 @@ def measure(dev, batch=4, steps=20, warmup=3, real_loss=True, standin_loss_fn=No
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
     out = {"what": "SE-SSD training iteration as ONE captured hipGraph: teacher forward (raw cloud) + student forward (augmented "
-                   "cloud) + %s + backward + fused clip / Adam / EMA update; batch %d x 20 k-point synthetic scans with their 15 car "
-                   "boxes as ground truth, targets by sessd_assign_targets, random-init weights"
+                   "cloud) + %s + backward + fused clip / Adam / EMA update; batch %d x 20 k-point synthetic scans with their cars as "
+                   "ground truth, targets by sessd_assign_targets, random-init weights"
                    % ("MultiGroupHead.loss (focal + ODIoU + direction + IoU-prediction) + teacher-student consistency loss as the "
                       "capacity-form device op sessd_head_loss" if real_loss else "a stand-in loss on the head outputs", batch),
            "config": "BASELINE.json configs[2]" if real_loss else "slice (stand-in loss)", "batch": batch, "replays": steps,
-           "ms_per_iter": ms, "samples_per_s": batch / ms * 1e3, "voxels_student": int(ex["voxels"].shape[0]),
-           "voxels_teacher": int(ex["voxels_raw"].shape[0]), "sparse_overflow_flag": int(step.student.backbone.last_err.item()),
+           "ms_per_iter": ms, "samples_per_s": batch / ms * 1e3,
+           "voxels_student": int(ex["num_voxels_dev"].item()) if "num_voxels_dev" in ex else int(ex["voxels"].shape[0]),
+           "voxels_teacher": int(ex["num_voxels_dev_raw"].item()) if "num_voxels_dev_raw" in ex else int(ex["voxels_raw"].shape[0]),
+           "sparse_overflow_flag": int(step.student.backbone.last_err.item()),
            "loss": float(step.static_loss)}
+    if fresh is not None:
+        out["pretrain_iterations"] = pretrain
+        out["ms_per_iter_fresh_batches"] = fresh
+        out["samples_per_s_fresh_batches"] = batch / fresh * 1e3
+        out["what"] += "; timed after %d captured iterations on fresh batches of %d scenes (visible cars as ground truth)" % (pretrain, scenes)
     if real_loss:
         L = step.student.bbox_head.record_to_dict(step.last_record)
         R = ops.HEAD_LOSS_RECORD
