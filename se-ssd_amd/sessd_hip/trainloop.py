@@ -142,13 +142,33 @@ class DeviceBatcher:
         far[:, 0] = FAR
         return torch.where(keep[:, None], b, far)
 
-    def load(self, it=None):
-        """Fill the static example with batch `it` (default: the next one). No host synchronisation."""
+    _MOVING = ("voxels", "coordinates", "num_points", "num_voxels_dev", "voxels_raw", "coordinates_raw", "num_points_raw",
+               "num_voxels_dev_raw", "transformation_dev")
+    _LISTED = ("labels", "reg_targets", "labels_raw", "reg_targets_raw")
+
+    def staging(self):
+        """A second set of the tensors load() writes (made on first use): load(it, into=staging()) on a side stream prepares the
+        next batch while the captured iteration runs on the static example, commit() then copies it over (fit(overlap=True))."""
+        if getattr(self, "_staging", None) is None:
+            st = {k: torch.empty_like(self.example[k]) for k in self._MOVING}
+            st.update({k: [torch.empty_like(self.example[k][0])] for k in self._LISTED})
+            self._staging = st
+            self._pairs = ([self.example[k] for k in self._MOVING] + [self.example[k][0] for k in self._LISTED],
+                           [st[k] for k in self._MOVING] + [st[k][0] for k in self._LISTED])
+        return self._staging
+
+    def commit(self):
+        """staging -> the static example (one multi-tensor copy on the current stream, ~20 MB)"""
+        self.staging()
+        torch._foreach_copy_(self._pairs[0], self._pairs[1])
+
+    def load(self, it=None, into=None):
+        """Fill the static example (or `into`: staging()) with batch `it` (default: the next one). No host synchronisation."""
         it = self.cursor if it is None else int(it)
         if it >= self.T:
             raise IndexError("DeviceBatcher was built for %d iterations" % self.T)
         self.cursor = it + 1
-        ex, B = self.example, self.B
+        ex, B = (self.example if into is None else into), self.B
         idx = self.choice[it]
         raw = [self.frames[i] for i in idx]
         stu = [self._student_cloud(self.frames[i], self.par[it, b]) for b, i in enumerate(idx)]
@@ -176,16 +196,21 @@ def consistency_weight(it, total):
     return strain.consistency_rampup(int(it * 60 // max(1, total)), 60)
 
 
-def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50, capture=True, on_log=None, ema_check=False):
+def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50, capture=True, on_log=None, ema_check=False,
+        overlap=True):
     """Train `model` (student; the teacher is its EMA copy) for `iterations` captured iterations on fresh batches from `pool`.
     Returns (TrainStep, report). report: log rows (iteration, the record's terms averaged over the window's LAST iteration -- one
     host read per `log_every` iterations), sustained samples/s with the data path inside the clock, overflow flags seen.
     ema_check: also carry teacher_ref = alpha * teacher_ref + (1 - alpha) * student (trainer_sessd.py:315-318) in torch on the
-    device after every iteration and report its largest difference from the fused update's teacher."""
+    device after every iteration and report its largest difference from the fused update's teacher.
+    overlap: batch i + 1 is assembled on a SIDE stream into staging tensors while iteration i runs, then copied into the static
+    example (the reference overlaps its DataLoader workers with the iteration the same way); False: load, then iterate, on one
+    stream. Same batches, same arithmetic: the trained parameters are bit-identical either way (tests/test_trainloop_gpu.py)."""
     dev = next(model.parameters()).device
     step = strain.TrainStep(model, None, total_steps=iterations, lr_max=lr_max)
     data = DeviceBatcher(pool, dev, batch, iterations, seed=seed)
     ex = data.load(0)
+    side = torch.cuda.Stream(device=dev) if overlap else None
     warm = 1
     if capture:
         step.capture(ex, consistency_weight=consistency_weight(0, iterations), warmup=warm)   # `warm` real iterations on batch 0
@@ -197,13 +222,24 @@ def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50
     log, flags = [], 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if overlap and done < iterations:
+        data.load(done)
     for it in range(done, iterations):
-        data.load(it)
+        main = torch.cuda.current_stream()
+        if not overlap:
+            data.load(it)
+        elif it + 1 < iterations:
+            side.wait_stream(main)   # the staging set is free: the copy out of it (previous commit) is older than this point
+            with torch.cuda.stream(side):
+                data.load(it + 1, into=data.staging())
         w = consistency_weight(it, iterations)
         if capture:
             step.replay(consistency_weight=w)
         else:
             step(ex, consistency_weight=w, device_schedule=True)
+        if overlap and it + 1 < iterations:
+            main.wait_stream(side)
+            data.commit()
         if ema_ref is not None:
             a = strain.ema_alpha(step.global_step - 1)
             ema_ref.mul_(a).add_(step.flat_s.data, alpha=1.0 - a)
@@ -224,7 +260,7 @@ def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50
     n = iterations - done
     rep = {"iterations": iterations, "batch": batch, "timed_iterations": n, "seconds": dt, "ms_per_iteration": dt / max(1, n) * 1e3,
            "samples_per_s": n * batch / dt if n else 0.0, "log": log, "overflow_flags": flags, "scenes": len(pool),
-           "sparse_overflow_flag": int(step.student.backbone.last_err.item()),
+           "sparse_overflow_flag": int(step.student.backbone.last_err.item()), "data_path_overlapped": bool(overlap),
            "what": "captured SE-SSD iterations (teacher + student forward, reference loss, backward, clip / Adam / EMA) on FRESH "
                    "batches: scene choice + global augmentation + voxelization of both clouds + target assignment on the device "
                    "inside the clock, one host read of the loss record per %d iterations" % log_every}

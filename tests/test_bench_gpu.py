@@ -1,0 +1,53 @@
+"""bench.py at N > 1 on real engines (round-4 review: "no N > 1 result is ever held to the oracle; every rank autotunes on its
+own"): two ranks -- two processes on the one GPU of the test box, collectives over gloo, as the two-rank training tests do -- each
+with its own autotuned, captured engines. Every rank holds its engines to the CPU oracle on a short sample of ITS frames before
+the clock starts; the verdicts are summed over the ranks and rank 0's line carries them (`parity.ranks`, also inside `config`)."""
+import json
+import os
+import socket
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, argv, q):
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "se-ssd_amd")]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        import bench
+        args = bench.parse(argv)
+        out = bench.run_rank(args, rank, world, 0, backend="gloo")   # both ranks on cuda:0
+        q.put((rank, out))
+    except SystemExit as ex:
+        q.put((rank, {"exit": str(ex)}))
+    except Exception:
+        import traceback
+        q.put((rank, {"error": traceback.format_exc()[-1500:]}))
+
+
+def test_two_ranks_each_hold_their_engines_to_the_oracle():
+    world, steps = 2, 8
+    argv = ["--gpus", str(world), "--steps", str(steps), "--warmup", "2", "--streams", "1", "--cpu-frames", "3", "--no-roofline",
+            "--no-host-io", "--no-sequential", "--no-train-step", "--pool", "4", "--spinup-seconds", "0.1"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, argv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+    assert res[1] is None, res[1]
+    out = res[0]
+    assert "error" not in out and "exit" not in out, out
+    par = out["parity"]
+    assert par["ranks"] == 2 and par["frames"] == 2 * 3 and par["matched"] == par["frames"] and par["ok"], par
+    assert out["config"]["parity"]["ok"] and out["config"]["parity"]["frames"] == 6
+    assert out["n_gpus"] == 2 and out["config"]["records_gathered"] == world * steps and out["config"]["rccl_ranks_seen"] == 2
+    assert "cpu_baseline" not in out   # the baseline figure stays on the N = 1 line
+    json.dumps(out)
