@@ -228,16 +228,19 @@ def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50
         main = torch.cuda.current_stream()
         if not overlap:
             data.load(it)
-        elif it + 1 < iterations:
-            side.wait_stream(main)   # the staging set is free: the copy out of it (previous commit) is older than this point
-            with torch.cuda.stream(side):
-                data.load(it + 1, into=data.staging())
+        else:
+            free = main.record_event()   # the staging set is free from here on: the copy out of it (previous commit) is older
         w = consistency_weight(it, iterations)
+        # the iteration is enqueued FIRST (one graph launch): the ~2 ms of host work that assembles the next batch then run while
+        # the device is already busy (loader first: 15.1 ms per iteration; iteration first: see profiles/r5_trainloop_probe.json)
         if capture:
             step.replay(consistency_weight=w)
         else:
             step(ex, consistency_weight=w, device_schedule=True)
         if overlap and it + 1 < iterations:
+            side.wait_event(free)
+            with torch.cuda.stream(side):
+                data.load(it + 1, into=data.staging())
             main.wait_stream(side)
             data.commit()
         if ema_ref is not None:
