@@ -532,7 +532,7 @@ def roofline_legs(args, out, eng, batch_of):
     # under profiles/; it cannot be collected inside this process
     cands = ["r4_wino_sk_traffic.json", "r3_wino_sk_traffic.json", "r2_wino_sk_traffic.json"] if streamk else ["r1_winograd_traffic.json"]
     if streamk and act:
-        cands.insert(0, "r4s2_wino_traffic.json")  # counter passes of the frame with the list launches (average over its six launches)
+        cands[:0] = ["r5_wino_traffic.json", "r4s2_wino_traffic.json"]  # counter passes of the frame with the list launches (average over its six launches)
     cands = cands if wino else ["r1_conv_traffic.json"]
     for nm in cands:
         tpath = os.path.join(ROOT, "profiles", nm)
@@ -554,7 +554,7 @@ def roofline_legs(args, out, eng, batch_of):
                                         "batch 1 the stage is launch/latency-bound, see --stress for the meaningful case. "
                                         "`mfma`: per-layer HIP-event times of the sparse convs alone and their EXECUTED f32 "
                                         "MFMA rate (active 16-site tile x offset steps x 16 x Cin x Cout x 2 FLOP) against the "
-                                        "157.3 TFLOP/s peak; counters and HBM traffic per kernel: profiles/r4_sparse_pmc.txt"}
+                                        "157.3 TFLOP/s peak; counters and HBM traffic per kernel: profiles/r4_sparse_pmc.txt, r5_sparse_pmc_stress.txt"}
 
 
 def train_step_leg(args, out, engines, dev):

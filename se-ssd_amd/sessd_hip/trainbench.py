@@ -92,11 +92,18 @@ def measure(dev, batch=4, steps=20, warmup=3, real_loss=True, standin_loss_fn=No
         data = trainloop.DeviceBatcher(pool, dev, batch, pretrain + 2, seed=seed)
         cap = ex = data.load(0)
         step.capture(cap, consistency_weight=1.0, warmup=max(1, warmup))
+        side, main = torch.cuda.Stream(device=dev), torch.cuda.current_stream()
+        data.load(1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for it in range(1, pretrain + 1):
-            data.load(it)
+        for it in range(1, pretrain + 1):   # trainloop.fit's loop: the next batch is assembled on a side stream while this one trains
+            free = main.record_event()
             step.replay()
+            side.wait_event(free)
+            with torch.cuda.stream(side):
+                data.load(it + 1, into=data.staging())
+            main.wait_stream(side)
+            data.commit()
         torch.cuda.synchronize()
         fresh = (time.perf_counter() - t0) / pretrain * 1e3
     else:
