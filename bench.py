@@ -83,6 +83,9 @@ def parse(argv=None):
     ap.add_argument("--fork-active", action="store_true", help="EXPERIMENT: the tile-list + fill launches as a side branch of the graph beside the sparse convs")
     ap.add_argument("--fork", action="store_true", help="engines with the parallel front branch (level-0 table + first two sparse convs beside the site chain; measured slower)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
+    ap.add_argument("--cu-split", default="", choices=["", "contiguous", "interleaved"],
+                    help="EXPERIMENT (round 5): every frame in flight on a stream of its own CU set (256 / --streams compute units each, "
+                         "hipExtStreamCreateWithCUMask), persistent launches sized for that set")
     ap.add_argument("--list-shares", default="auto", choices=["auto", "whole", "cut"],
                     help="A/B of the Winograd list launches: whole-unit shares for every layer / stream-K shares only / the autotune's "
                          "per-launch choice")
@@ -247,7 +250,14 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
     from sessd_hip import synth
     from sessd_hip import dist as sdist
     model, engines = (engine_factory or default_engine_factory)(args, dev)
-    if on_gpu:
+    if on_gpu and getattr(args, "cu_split", "") and len(engines) > 1:
+        from sessd_hip import ops as _ops
+        streams = []
+        for k, e in enumerate(engines):
+            st, ncu = _ops.cu_masked_stream(k, len(engines), dev, layout=args.cu_split)
+            streams.append(st)
+            e.cu_budget = ncu
+    elif on_gpu:
         streams = [torch.cuda.Stream() for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream()]
     else:
         streams = [None for _ in engines]
@@ -281,7 +291,9 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
         eng.allow_streamk = not args.no_streamk
         if getattr(args, "list_shares", "auto") == "cut":
             eng.list_share_candidates = (1, 4, 8, 16)
-        rep = eng.autotune()
+        with _on(streams[0] if getattr(args, "cu_split", "") else None):   # (a CU-masked engine is tuned on its own CU set)
+            rep = eng.autotune()
+            sync()
         if getattr(args, "list_shares", "auto") != "auto" and hasattr(eng, "set_list_shares"):
             eng.set_list_shares(args.list_shares)
         log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
@@ -403,6 +415,7 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
                                       if getattr(args, "weights", None) else "seeded random weights, BatchNorm calibrated"),
                        "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps * args.batch,
                        "frames_in_flight": len(engines), "streamk_workgroups": args.sk_workgroups,
+                       "cu_split": getattr(args, "cu_split", "") or None, "cus_per_frame_in_flight": getattr(eng, "cu_budget", 0) or None,
                        "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                        "rccl_ranks_seen": ranks_seen,
                        "detections_last_frame": dets, "detections_first_frame": int(len(first["scores"])),

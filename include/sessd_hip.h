@@ -38,6 +38,10 @@ int sessd_fill_u32_multi(int n_segments, void* const* ptrs, const uint32_t* valu
  * downsample workspace) -- the caller fills them with 0x7F7F7F7F itself, e.g. one fill over a contiguous arena.
  * The switch is per calling host thread (thread-local) and is read when an entry point is CALLED, not when its kernels run. */
 void sessd_set_external_clear(int on);
+/* A stream confined to a subset of the compute units (hipExtStreamCreateWithCUMask): mask[n_words], bit i = CU i. Several frames
+ * in flight on disjoint CU sets do not hold each other's kernels back (bench.py --cu-split). */
+int sessd_stream_create_cu_mask(int n_words, const uint32_t* mask, sessd_stream_t* stream);
+int sessd_stream_destroy(sessd_stream_t stream);
 
 /* ------------------------------------------------------------------ voxelizer (a1-a3)
  * replaces det3d/ops/point_cloud/point_cloud_ops_v2.py:120-194 points_to_voxel (numba, CPU),

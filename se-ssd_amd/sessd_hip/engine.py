@@ -337,6 +337,9 @@ class InferenceEngine:
         self.allow_streamk = True  # autotune may choose the stream-K kernels (Winograd: tile_cfg 22 / 23; LDS-tiled direct: 30)
         self.allow_offset_split = True  # autotune may choose the offset-split sparse conv (see sessd_sparse_conv)
         self.sk_workgroups = 0  # persistent workgroups of those launches (0 = one or two per CU; fewer leaves CUs to a second stream)
+        # compute units this engine's stream may use (0 = the whole chip): with several frames in flight on CU-masked streams
+        # (ops.cu_masked_stream, bench.py --cu-split) the persistent launches are sized for the engine's own CUs
+        self.cu_budget = 0
         self.tune_report = {}
         self._tuning = None
         self._kmarks = None
@@ -352,6 +355,18 @@ class InferenceEngine:
             t = torch.tensor(key, dtype=torch.int32)
             self._ks[key] = t
         return t
+
+    def _wgs(self, shape):
+        """persistent workgroups of a stream-K launch: shape 0 / 1 = the Winograd shapes (one / two workgroups per CU), 2 = the
+        LDS-tiled kernel (one per CU); 0 = the library's default for the whole chip"""
+        if self.sk_workgroups:
+            return self.sk_workgroups
+        if not self.cu_budget:
+            return 0
+        return max(8, ((2 if shape == 1 else 1) * int(self.cu_budget)) & ~7)
+
+    def _wgs_cfg(self, cfg):
+        return self._wgs(1 if cfg == 23 else (2 if cfg == 30 else 0))
 
     def set_points(self, points_list, frustum=None):
         """Copy a batch of (P,4) float32 DEVICE point clouds into the static input buffer (async D2D)."""
@@ -437,12 +452,12 @@ class InferenceEngine:
                                                       tile_cfg=shape, residual=residual)
             elif active in self.ACTIVE_SK:
                 call = lambda: ops.conv2d_sk_active(x, pc, scale, shift, relu, out, self.sk_ws, self.ta.tile_list[m],
-                                                    self.ta.n_list[m:m + 1], workgroups=self.sk_workgroups, residual=residual,
+                                                    self.ta.n_list[m:m + 1], workgroups=self._wgs(2), residual=residual,
                                                     min_rounds=min_rounds)
             else:
                 call = lambda: ops.conv2d_winograd_sk_active(x, pc.upk_sk(shape), pc.cout, scale, shift, relu, out, shape, self.sk_ws,
                                                              self.ta.tile_list[m], self.ta.n_list[m:m + 1],
-                                                             workgroups=self.sk_workgroups, residual=residual, min_rounds=min_rounds)
+                                                             workgroups=self._wgs(shape), residual=residual, min_rounds=min_rounds)
             if self._kmarks is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -456,11 +471,11 @@ class InferenceEngine:
         if self._kmarks is not None:  # per-launch HIP events inside a whole eager frame (dense_layer_times)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            r = ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name), workspace=self.sk_ws, workgroups=self.sk_workgroups)
+            r = ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name), workspace=self.sk_ws, workgroups=self._wgs_cfg(self.tile_cfg.get(name)))
             e1.record()
             self._kmarks.append((name, e0, e1))
             return r
-        return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name), workspace=self.sk_ws, workgroups=self.sk_workgroups)
+        return ops.conv2d(x, pc, scale, shift, relu, residual, out, self.tile_cfg.get(name), workspace=self.sk_ws, workgroups=self._wgs_cfg(self.tile_cfg.get(name)))
 
     def adopt_tuning(self, other):
         """Take another engine's tuned configuration (per-layer tilings, sparse variants, stream-K workgroup count) with a
@@ -470,6 +485,7 @@ class InferenceEngine:
         self.sparse_split = dict(other.sparse_split)
         self.sparse_sorted = dict(other.sparse_sorted)
         self.sk_workgroups = other.sk_workgroups
+        self.cu_budget = other.cu_budget
         self.merge_branch_convs = other.merge_branch_convs
         self.sk_ws = torch.zeros_like(other.sk_ws) if other.sk_ws is not None else None
 
@@ -569,11 +585,11 @@ class InferenceEngine:
                 if cfg == 13 and pc.kind != "conv":
                     continue
                 for _ in range(2):
-                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg, workspace=self.sk_ws, workgroups=self.sk_workgroups)
+                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg, workspace=self.sk_ws, workgroups=self._wgs_cfg(cfg))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(reps):
-                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg, workspace=self.sk_ws, workgroups=self.sk_workgroups)
+                    ops.conv2d(x, pc, scale, shift, relu, residual, out, cfg, workspace=self.sk_ws, workgroups=self._wgs_cfg(cfg))
                 e1.record()
                 torch.cuda.synchronize()
                 t = e0.elapsed_time(e1) / reps
@@ -646,7 +662,7 @@ class InferenceEngine:
                         self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
                     for mr in (1, 4, 8, 16):
                         tt = timed(lambda: ops.conv2d_sk_active(x_in, pc, scale, shift, True, x_out, self.sk_ws, self.ta.tile_list[m],
-                                                                self.ta.n_list[m:m + 1], workgroups=self.sk_workgroups, min_rounds=mr))
+                                                                self.ta.n_list[m:m + 1], workgroups=self._wgs(2), min_rounds=mr))
                         if tt < best[1]:
                             best = ((30, mr), tt)
             else:
@@ -659,7 +675,7 @@ class InferenceEngine:
                     for mr in self.list_share_candidates:
                         tt = timed(lambda: ops.conv2d_winograd_sk_active(x_in, pc.upk_sk(shape), pc.cout, scale, shift, True, x_out, shape,
                                                                          self.sk_ws, self.ta.tile_list[m], self.ta.n_list[m:m + 1],
-                                                                         workgroups=self.sk_workgroups, min_rounds=mr))
+                                                                         workgroups=self._wgs(shape), min_rounds=mr))
                         if tt < best[1]:
                             best = ((shape, mr), tt)
             dense_t = self.tune_report.get(name, (None, 0.0))[1]
@@ -868,7 +884,7 @@ class InferenceEngine:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             ops.conv2d_winograd_sk_sets(t["mid"], sets["upk"], 2, 128, sets["scale"], sets["shift"], True, t["o"], c01 - 22,
-                                        self.sk_ws, self.sk_workgroups)
+                                        self.sk_ws, self._wgs(c01 - 22))
             if self._kmarks is not None:
                 e1.record()
                 self._kmarks.append(("conv_0+conv_1", e0, e1))

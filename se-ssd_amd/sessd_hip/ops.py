@@ -53,6 +53,29 @@ def _cache_scope():
     return (st, _CAPTURE_EPOCH[0] if torch.cuda.is_current_stream_capturing() else 0)
 
 
+_MASKED_STREAMS = []   # (torch ExternalStream, raw handle): kept alive for the life of the process
+
+
+def cu_masked_stream(part, parts, device=None, layout="contiguous"):
+    """A torch stream (ExternalStream over hipExtStreamCreateWithCUMask) whose kernels run on the `part`-th of `parts` equal,
+    disjoint sets of the device's compute units. layout: 'contiguous' = CU numbers [part * n, (part + 1) * n), 'interleaved' = every
+    parts-th CU. Returns (stream, CUs in the set). Several frames in flight on such streams never wait for each other's CUs."""
+    import ctypes
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    n = total // parts
+    words = (ctypes.c_uint32 * ((total + 31) // 32))()
+    cus = range(part * n, (part + 1) * n) if layout == "contiguous" else range(part, n * parts, parts)
+    for c in cus:
+        words[c >> 5] |= 1 << (c & 31)
+    h = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        check(lib.sessd_stream_create_cu_mask(len(words), ctypes.cast(words, ctypes.c_void_p), ctypes.byref(h)), "stream_create_cu_mask")
+    st = torch.cuda.ExternalStream(h.value, device=dev)
+    _MASKED_STREAMS.append((st, h))
+    return st, n
+
+
 def workspace(nbytes, device, tag="default"):
     """A cached per-(device, stream, capture, tag) byte workspace, grown on demand (never shrinks)."""
     key = (device.index, _cache_scope(), tag)
