@@ -9,9 +9,12 @@
 A "step" is ONE frame of BASELINE.json configs[1] ("Single MI355X inference, KITTI car voxel grid [1600,1408,40],
 max 16000 voxels, batch=1") through the whole path, input points already resident in HBM, detections left on the
 device (<= 100 boxes). Frames shard across ranks with no data-path collective (weak scaling: every rank runs K
-frames); value = total frames / max-over-ranks wall time. By default TWO frames are in flight per GPU (two independent
-batch-1 engines on two HIP streams, `--streams 1` for strictly sequential frames): a batch-1 layer is 4.3 wave tiles per
-SIMD, so the tail of one frame's kernels overlaps the other's. One JSON line on rank 0, with
+frames); value = total frames / max-over-ranks wall time. By default FOUR frames are in flight per GPU: four independent
+batch-1 engines, two on each HALF of the chip (CU-masked streams, hipExtStreamCreateWithCUMask: every engine owns a hardware
+queue, its kernels are confined to its half, its persistent stream-K launches are sized for 128 CUs) -- a batch-1 frame is 44
+dependent launches of which most cannot fill 256 CUs, and a frame on half the chip pays the per-launch latency chains once while
+its arithmetic takes twice as long: 1925 frames/s against 1563 for rounds 1 - 4's two plain streams sharing the whole chip
+(`--streams 2 --cu-split none`; `--streams 1` = strictly sequential frames on the whole chip). One JSON line on rank 0, with
   parity        THE TIMED CONFIGURATION held to the oracle before the clock starts: the frames of the cpu_baseline sample go
                 through the very engines that are timed (autotuned tilings, stream-K workgroup counts, captured graphs) and
                 every detection is compared with the oracle's (oracle/compare.py: identical, or identical under the oracle's
@@ -63,8 +66,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-frames", type=int, default=40, help="frames of the CPU baseline / parity sample (0 = skip both)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads of the baseline (capped by affinity)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="time budget of the CPU baseline sample")
-    ap.add_argument("--streams", type=int, default=2,
-                    help="frames in flight: independent batch-1 engines on separate HIP streams (1 = strictly one frame at a time)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="frames in flight: independent batch-1 engines on separate HIP streams (1 = strictly one frame at a time). "
+                         "Round 5 default: 4, on two CU sets (--cu-split / --cu-parts); rounds 1 - 4 ran `--streams 2 --cu-split none`")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-host-io", action="store_true", help="skip the informational host-buffer legs (kernel traces of the timed region)")
     ap.add_argument("--no-sequential", action="store_true", help="skip the informational one-frame-at-a-time leg")
@@ -83,9 +87,14 @@ def parse(argv=None):
     ap.add_argument("--fork-active", action="store_true", help="EXPERIMENT: the tile-list + fill launches as a side branch of the graph beside the sparse convs")
     ap.add_argument("--fork", action="store_true", help="engines with the parallel front branch (level-0 table + first two sparse convs beside the site chain; measured slower)")
     ap.add_argument("--no-autotune", action="store_true", help="keep the default conv tilings")
-    ap.add_argument("--cu-split", default="", choices=["", "contiguous", "interleaved"],
-                    help="EXPERIMENT (round 5): every frame in flight on a stream of its own CU set (256 / --streams compute units each, "
-                         "hipExtStreamCreateWithCUMask), persistent launches sized for that set")
+    ap.add_argument("--cu-parts", type=int, default=0,
+                    help="with --cu-split: number of disjoint CU sets (default 2: the two halves of the chip); engine i runs on set i %% parts")
+    ap.add_argument("--cu-budget", type=int, default=0,
+                    help="size every engine's persistent launches for this many compute units (default: the CUs of its set)")
+    ap.add_argument("--cu-split", default="contiguous", choices=["none", "contiguous", "interleaved"],
+                    help="frames in flight on CU-masked streams (hipExtStreamCreateWithCUMask: a hardware queue of its own per engine, "
+                         "confined to its CU set; persistent launches sized for the set). contiguous: set k = CU numbers [k n, (k+1) n); "
+                         "none: plain torch streams sharing the whole chip (rounds 1 - 4)")
     ap.add_argument("--list-shares", default="auto", choices=["auto", "whole", "cut"],
                     help="A/B of the Winograd list launches: whole-unit shares for every layer / stream-K shares only / the autotune's "
                          "per-launch choice")
@@ -118,19 +127,20 @@ def free_port():
     return p
 
 
-def default_engine_factory(args, dev):
+def default_engine_factory(args, dev, model=None, count=None):
     """(model, [engines]) of the timed configuration: `--streams` independent batch-`--batch` engines on one detector."""
     from sessd_hip import configs
     from sessd_hip.engine import InferenceEngine
     VG = configs.VOXEL_GENERATOR
-    model = configs.build_synthetic_detector(dev, seed=0, max_voxels=args.max_voxels, num_points=args.points, supersample=args.supersample)
-    if getattr(args, "weights", None):
-        model.load_state_dict(torch.load(args.weights, map_location=dev))
-        model.eval()
+    if model is None:
+        model = configs.build_synthetic_detector(dev, seed=0, max_voxels=args.max_voxels, num_points=args.points, supersample=args.supersample)
+        if getattr(args, "weights", None):
+            model.load_state_dict(torch.load(args.weights, map_location=dev))
+            model.eval()
     engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxel"], args.max_voxels,
                                configs.TEST_CFG, batch_size=args.batch, max_points_per_frame=args.points, device=dev,
                                active_tiles=not getattr(args, "no_active_tiles", False))
-               for _ in range(max(1, args.streams))]
+               for _ in range(max(1, args.streams if count is None else count))]
     for e in engines:
         e.fork_front = bool(args.fork)
         e.fork_active = bool(getattr(args, "fork_active", False))
@@ -250,16 +260,32 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
     from sessd_hip import synth
     from sessd_hip import dist as sdist
     model, engines = (engine_factory or default_engine_factory)(args, dev)
-    if on_gpu and getattr(args, "cu_split", "") and len(engines) > 1:
+    cu_split, cu_note = (getattr(args, "cu_split", "none") or "none"), None
+    masked = on_gpu and cu_split != "none" and len(engines) > 1 and engine_factory is None
+    if masked:
+        # FRAMES IN FLIGHT ON CU SETS (round 5): engine i runs on a stream that is confined to CU set i % parts and owns a hardware
+        # queue (a CU mask is a queue property; plain torch streams share a few queues), its persistent stream-K launches are
+        # sized for the set. Measured on MI355X (profiles/r5_cu_sets_sweep.json): 4 frames on 2 halves 1925 frames/s against 1563
+        # for round 4's two plain streams; 4 quarters 1885; 3 / 5 / 6 sets (uneven over the 8 XCDs) 1327 / 735 / 798; plain
+        # streams with launches merely SIZED for a quarter 1387.
         from sessd_hip import ops as _ops
-        streams = []
-        for k, e in enumerate(engines):
-            st, ncu = _ops.cu_masked_stream(k, len(engines), dev, layout=args.cu_split)
-            streams.append(st)
-            e.cu_budget = ncu
-    elif on_gpu:
+        parts = getattr(args, "cu_parts", 0) or min(2, len(engines))
+        try:
+            streams = []
+            for k, e in enumerate(engines):
+                st, ncu = _ops.cu_masked_stream(k % parts, parts, dev, layout=cu_split)
+                streams.append(st)
+                e.cu_budget = getattr(args, "cu_budget", 0) or ncu
+        except Exception as ex:   # the line must not die with an optimisation: plain streams, and say so
+            masked, cu_note = False, "CU-masked streams unavailable (%s): plain streams" % repr(ex)[:120]
+            for e in engines:
+                e.cu_budget = 0
+    if not masked and on_gpu:
         streams = [torch.cuda.Stream() for _ in engines] if len(engines) > 1 else [torch.cuda.current_stream()]
-    else:
+        for e in engines:
+            if getattr(args, "cu_budget", 0):
+                e.cu_budget = args.cu_budget
+    elif not on_gpu:
         streams = [None for _ in engines]
 
     class _on:  # `with torch.cuda.stream(st)` that is a no-op off the GPU
@@ -291,7 +317,7 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
         eng.allow_streamk = not args.no_streamk
         if getattr(args, "list_shares", "auto") == "cut":
             eng.list_share_candidates = (1, 4, 8, 16)
-        with _on(streams[0] if getattr(args, "cu_split", "") else None):   # (a CU-masked engine is tuned on its own CU set)
+        with _on(streams[0] if masked else None):   # (a CU-masked engine is tuned on its own CU set)
             rep = eng.autotune()
             sync()
         if getattr(args, "list_shares", "auto") != "auto" and hasattr(eng, "set_list_shares"):
@@ -415,7 +441,11 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
                                       if getattr(args, "weights", None) else "seeded random weights, BatchNorm calibrated"),
                        "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps * args.batch,
                        "frames_in_flight": len(engines), "streamk_workgroups": args.sk_workgroups,
-                       "cu_split": getattr(args, "cu_split", "") or None, "cus_per_frame_in_flight": getattr(eng, "cu_budget", 0) or None,
+                       "cu_sets": ({"layout": cu_split, "sets": parts, "cus_per_set": getattr(eng, "cu_budget", 0),
+                                    "what": "engine i on a CU-masked stream (hipExtStreamCreateWithCUMask) confined to CU set i % sets, "
+                                            "persistent launches sized for the set"} if masked else None),
+                       "cu_sets_note": cu_note,
+                       "ms_latency_per_frame_in_flight": len(engines) * dt / args.steps * 1e3 / args.batch,
                        "parallelism": "frames sharded over %d rank(s), no data-path collective" % world,
                        "rccl_ranks_seen": ranks_seen,
                        "detections_last_frame": dets, "detections_first_frame": int(len(first["scores"])),
@@ -439,27 +469,51 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
                                        "identical": parity["identical"], "rule_set": parity["rule_set"], "bev_rel_err": parity["bev_rel_err"]}
     if rank == 0 and on_gpu:
         # ---- the same engines strictly one frame at a time (informational; the driver's record then holds both figures)
+        seq_eng, seq_st = eng, streams[0]
+        if masked and world == 1 and (not args.no_sequential or not args.no_roofline):
+            # one frame at a time is a WHOLE-CHIP figure: an engine of its own on a plain stream, tuned and captured for all CUs
+            seq_eng = default_engine_factory(args, dev, model=model, count=1)[1][0]
+            seq_eng.set_points(batch_of(0))
+            seq_eng.enqueue()
+            sync()
+            if not args.no_autotune:
+                seq_eng.allow_offset_split, seq_eng.allow_streamk = not args.no_offset_split, not args.no_streamk
+                seq_eng.autotune()
+            seq_eng.attach_records(args.batch * 4)
+            seq_st = torch.cuda.current_stream()
+            if not args.eager:
+                seq_eng.capture()
+            sync()
         if not args.no_sequential and len(engines) > 1 and world == 1:
             nseq = max(20, min(args.steps, 200))
-            st0 = streams[0]
             for i in range(5):
-                with _on(st0):
-                    eng.set_points(batch_of(i))
-                    eng.enqueue() if args.eager else eng.replay()
+                with _on(seq_st):
+                    seq_eng.set_points(batch_of(i))
+                    seq_eng.enqueue() if args.eager else seq_eng.replay()
             sync()
             s0 = time.perf_counter()
             for i in range(nseq):
-                with _on(st0):
-                    eng.set_points(batch_of(i))
-                    eng.enqueue() if args.eager else eng.replay()
+                with _on(seq_st):
+                    seq_eng.set_points(batch_of(i))
+                    seq_eng.enqueue() if args.eager else seq_eng.replay()
             sync()
             out["value_sequential"] = {"frames_per_s": nseq * args.batch / (time.perf_counter() - s0), "frames": nseq,
-                                       "what": "one engine, one stream, one frame in flight (--streams 1), inputs resident"}
+                                       "what": "one engine on the whole chip, one stream, one frame in flight (--streams 1), inputs resident"}
             out["config"]["value_sequential_frames_per_s"] = out["value_sequential"]["frames_per_s"]
         if not args.no_roofline:
-            roofline_legs(args, out, eng, batch_of)
+            # the dominant kernel's roofline in THE TIMED CONFIGURATION: on the stream (and CU set) the timed launches run on
+            with _on(streams[0] if masked else None):
+                roofline_legs(args, out, eng, batch_of, cus=(eng.cu_budget if masked else 0))
+            if masked and seq_eng is not eng:
+                # ... and on the whole chip, as rounds 1 - 4 reported it (one frame at a time)
+                whole = {}
+                roofline_legs(args, whole, seq_eng, batch_of)
+                out["roofline_whole_chip_engine"] = {k: whole["roofline"][k] for k in ("achieved", "peak", "frac", "avg_launch_ms", "frac_full_map_launches",
+                                                                                      "frac_list_launches", "dense_launch_ms", "active_tile_fraction")}
+                out["stages_ms_eager_whole_chip_engine"] = whole["stages_ms_eager"]
+                out["roofline_spmiddle_whole_chip_engine"] = {k: whole["roofline_spmiddle"][k] for k in ("achieved", "frac", "ms", "algorithmic_bytes")}
         if not args.eager and args.batch == 1 and not args.no_host_io and world == 1:
-            host_io_legs(args, out, engines, streams, frames_np, dev)
+            host_io_legs(args, out, engines, streams, frames_np, dev, latency_engine=seq_eng)
         if cpu_base is not None:
             out["cpu_baseline"] = cpu_base
         if not args.no_train_step and world == 1 and not args.stress and args.batch == 1 and engine_factory is None:
@@ -474,12 +528,16 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
     return out
 
 
-def roofline_legs(args, out, eng, batch_of):
+def roofline_legs(args, out, eng, batch_of, cus=0):
     """Roofline of the dominant kernel, measured IN THE FRAME: whole frames are enqueued eagerly with a HIP event before and
     after each dense conv launch on the launching stream (engine.dense_layer_times); avg_launch_ms = mean over the launches that
     carry the seven 3x3 stride-1 layers and 20 frames. A loop over ONE layer on a hot input (round 1) is a best case; this is
     what the frame pays, and it agrees with the rocprofv3 kernel trace of the timed region under profiles/."""
     from sessd_hip import ops
+    # cus > 0: the engine's stream is confined to that many compute units (frames in flight on CU sets): the launch's roofline is
+    # the f32 MFMA peak of ITS compute units; the whole-chip figure is carried beside it
+    total_cus = torch.cuda.get_device_properties(eng.dev).multi_processor_count if cus else 0
+    PEAK = F32_MFMA_PEAK_TFLOPS * (float(cus) / total_cus if cus else 1.0)
     names = ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2")
     cfgs = [eng.tile_cfg.get(nm) for nm in names]
     wino = all(c in ops.WINOGRAD_CFGS or (c is None and ops.USE_WINOGRAD) for c in cfgs)
@@ -517,13 +575,21 @@ def roofline_legs(args, out, eng, batch_of):
                        "256->256 @100x88 (2 launches, same FLOPs per layer); the seven layers are 72.6 of the frame's 90.8 "
                        "dense GFLOP" % ("; conv_0 and conv_1 as one launch of two weight sets: %d launches" % len(times)
                                         if "conv_0+conv_1" in lt else ""),
-                       "achieved": exe, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": exe / F32_MFMA_PEAK_TFLOPS,
+                       "achieved": exe, "peak": PEAK, "unit": "TFLOP/s", "frac": exe / PEAK,
+                       "peak_whole_chip": F32_MFMA_PEAK_TFLOPS, "frac_of_whole_chip_peak": exe / F32_MFMA_PEAK_TFLOPS,
+                       "compute_units_of_the_launch": cus or None,
+                       "peak_note": (("the launch runs on a stream confined to %d of the chip's %d compute units (frames in flight on CU sets): "
+                                      "`peak` = %.1f TFLOP/s x %d / %d, the dense f32 MFMA peak of ITS compute units -- the other set runs other "
+                                      "frames' kernels at the same time; `frac_of_whole_chip_peak` prices the same launch against all %d CUs, "
+                                      "`roofline_whole_chip_engine` is the same kernel tuned for and measured on the whole chip (one frame at a "
+                                      "time), as rounds 1 - 4 reported it") % (cus, total_cus, F32_MFMA_PEAK_TFLOPS, cus, total_cus, total_cus))
+                                     if cus else None,
                        "frac_definition": "EXECUTED matrix-core FLOPs (what SQ_INSTS_MFMA counts: 16/36 of the direct-"
                                           "convolution count for Winograd F(2x2,3x3)) / launch time / dense f32 MFMA peak",
                        "avg_launch_ms": kms,
                        "active_tile_fraction": act,
-                       "frac_full_map_launches": ach_full * exe_ratio / F32_MFMA_PEAK_TFLOPS,
-                       "frac_list_launches": (ach_list * exe_ratio / F32_MFMA_PEAK_TFLOPS) if lst else None,
+                       "frac_full_map_launches": ach_full * exe_ratio / PEAK,
+                       "frac_list_launches": (ach_list * exe_ratio / PEAK) if lst else None,
                        "active_tile_note": ("layers listed in active_tile_fraction run over the listed 2x2-output tiles only (the BEV map is "
                                             "zero outside the sparse sites: the other tiles hold a per-channel constant, written by one fill "
                                             "launch); their FLOPs count with that share, the activity + fill launches are in "
@@ -537,7 +603,7 @@ def roofline_legs(args, out, eng, batch_of):
                        "dense_tile_cfg": {k: eng.tile_cfg.get(k) for k in lt},
                        "flops_per_launch_executed": flops * exe_ratio,
                        "flops_per_launch_algorithmic": flops,
-                       "achieved_algorithmic": ach, "frac_algorithmic": ach / F32_MFMA_PEAK_TFLOPS,
+                       "achieved_algorithmic": ach, "frac_algorithmic": ach / PEAK,
                        "frac_algorithmic_note": "direct-convolution FLOPs 2*H*W*Cin*Cout*9 / time: a speed-up figure, not a "
                                                 "utilisation -- it exceeds 1 at batch >= 4",
                        "traffic": None}
@@ -561,6 +627,7 @@ def roofline_legs(args, out, eng, batch_of):
     out["stages_ms_eager"] = {k: round(v, 4) for k, v in st.items()}
     gbs = sp_bytes / (st["spmiddle"] * 1e-3) / 1e9
     out["roofline_spmiddle"] = {"bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0,
+                                "compute_units_of_the_stage": cus or None,
                                 "algorithmic_bytes": sp_bytes, "sites_per_level": sites, "ms": st["spmiddle"],
                                 "mfma": eng.spmiddle_mfma_report(),
                                 "note": "all 14 sparse layers + the site / rulebook chain of one batch, eager launches; at "
@@ -586,12 +653,12 @@ def train_step_leg(args, out, engines, dev):
         out["train_step"] = {"error": repr(ex)[:300]}
 
 
-def host_io_legs(args, out, engines, streams, frames_np, dev):
+def host_io_legs(args, out, engines, streams, frames_np, dev, latency_engine=None):
     """PCIe-inclusive rates (never `value`): (a) pipelined -- pinned host points in, host detections out, H2D one frame ahead on
     a copy stream, the timed engines and graphs, detections fetched from the device record rings every `fetch_every` frames
     (sessd_hip/runner.py); (b) latency mode -- one frame at a time with a host synchronisation per frame."""
     from sessd_hip.runner import HostFedPipeline
-    eng = engines[0]
+    eng = latency_engine if latency_engine is not None else engines[0]   # (latency mode: the whole-chip engine on the current stream)
     pinned = [torch.from_numpy(f).pin_memory() for f in frames_np[:8]]
     nio = 100
     stage = torch.empty((args.points, 4), dtype=torch.float32, device=dev)

@@ -426,3 +426,50 @@ def test_detection_records_follow_the_frames(dev, model):
         assert np.array_equal(g["box3d_lidar"], w["box3d_lidar"]) and np.array_equal(g["scores"], w["scores"])
         assert np.array_equal(g["label_preds"], w["label_preds"])
     assert sum(len(w["scores"]) for w in want) > 20
+
+
+def test_frames_in_flight_on_cu_sets_equal_the_oracle(dev, model, state):
+    """The configuration bench.py times since round 5: four batch-1 engines, two on each half of the chip -- CU-masked streams
+    (ops.cu_masked_stream -> hipExtStreamCreateWithCUMask), persistent stream-K launches sized for the half (engine.cu_budget = 128),
+    every active-tile layer over its list, captured graphs replayed round-robin with all four in flight. Every frame of every
+    engine against the CPU oracle pipeline; replays reproduce the eager bits (fixed launch sizes => fixed summation order)."""
+    anchors = pp.create_anchors_3d_range().reshape(-1, 7)
+    frames_np = [synth.make_frame(s, 20000) for s in (71, 72, 73, 74, 75, 76, 77, 78)]
+    frames = [torch.from_numpy(f).to(dev) for f in frames_np]
+    want, inter = pipeline.run_frames(frames_np, state, VG["range"], VG["voxel_size"], 5, 16000, anchors, None, return_intermediate=True)
+    engines, streams = [], []
+    for k in range(4):
+        st, ncu = ops.cu_masked_stream(k % 2, 2, dev)
+        assert ncu == torch.cuda.get_device_properties(dev).multi_processor_count // 2
+        e = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 1, 20480, dev)
+        e.cu_budget = ncu
+        e.force_active_tiles()
+        assert e._wgs(0) == ncu and e._wgs(1) == 2 * ncu and e._wgs(2) == ncu
+        engines.append(e)
+        streams.append(st)
+    eager = []
+    for i, f in enumerate(frames[:4]):
+        with torch.cuda.stream(streams[i]):
+            engines[i].set_points([f])
+            engines[i].enqueue()
+        streams[i].synchronize()
+        eager.append((engines[i].results()[0], engines[i].bev.clone()))
+    for e, st in zip(engines, streams):
+        with torch.cuda.stream(st):
+            e.capture()
+    torch.cuda.synchronize()
+    got = [None] * 8
+    for rnd in range(2):
+        for k in range(4):                      # all four in flight before the first is read back
+            with torch.cuda.stream(streams[k]):
+                engines[k].set_points([frames[rnd * 4 + k]])
+                engines[k].replay()
+        for k in range(4):
+            streams[k].synchronize()
+            got[rnd * 4 + k] = engines[k].results()[0]
+            if rnd == 0:
+                assert torch.equal(engines[k].bev, eager[k][1])
+                assert np.array_equal(got[k]["box3d_lidar"], eager[k][0]["box3d_lidar"]) and np.array_equal(got[k]["scores"], eager[k][0]["scores"])
+    res = [_compare_dets(g, w, d) for g, w, d in zip(got, want, inter["debug"])]
+    assert all(r["matched"] == r["n"] for r in res)
+    assert sum(len(g["scores"]) for g in got) > 100
