@@ -673,7 +673,7 @@ def host_io_legs(args, out, engines, streams, frames_np, dev, latency_engine=Non
         last = eng.results()
     lat = nio / (time.perf_counter() - h0)
     # pipelined: needs rings of 2 * fetch_every records -> re-attach + re-capture (the ring address is part of the graph)
-    fetch_every, ring = 16, 4
+    fetch_every, ring = [int(v) for v in os.environ.get("SESSD_HOSTIO", "16,4").split(",")]   # (probe knob; the defaults ship)
     for e, st in zip(engines, streams):
         e.graph = None
         e.attach_records(2 * fetch_every)
@@ -686,8 +686,11 @@ def host_io_legs(args, out, engines, streams, frames_np, dev, latency_engine=Non
         pipe.reset()
         n_out = 0
         p0 = time.perf_counter()
+        t_sub = 0.0
         for i in range(64 if warm else npipe):
+            ts = time.perf_counter()
             pipe.submit(pinned[i % len(pinned)])
+            t_sub += time.perf_counter() - ts
             if (i & 15) == 15:
                 n_out += len(pipe.poll())
         rest = pipe.finish()
@@ -705,6 +708,7 @@ def host_io_legs(args, out, engines, streams, frames_np, dev, latency_engine=Non
     same = bool(np.array_equal(ref["box3d_lidar"], rest[-1]["box3d_lidar"]) and np.array_equal(ref["scores"], rest[-1]["scores"]))
     out["host_io"] = {"frames_per_s": npipe / pdt, "frames": npipe, "engines": len(engines), "staging_ring_depth": ring,
                       "fetch_every": fetch_every, "detections_returned": n_out, "last_frame_equals_latency_mode": same,
+                      "host_ms_in_submit_per_frame": t_sub / npipe * 1e3,
                       "what": "pinned host points -> H2D on a copy stream (up to %d frames ahead per engine) -> stage + graph replay on "
                               "%d engine streams -> the frame appends its record on the device -> D2H of the record ring every %d "
                               "frames into pinned memory; host detections for every frame, no host sync per frame "
