@@ -11,15 +11,16 @@ timeout -k 5 600 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_drive
 timeout -k 5 600 python bench.py --no-train-step > $O/bench_default.json 2>$O/bench_default.err; echo "default rc $?"
 timeout -k 5 600 python bench.py --streams 1 --no-train-step > $O/bench_1stream.json 2>$O/bench_1stream.err; echo "1stream rc $?"
 timeout -k 5 600 python bench.py --stress --no-train-step > $O/bench_stress.json 2>$O/bench_stress.err; echo "stress rc $?"
+timeout -k 5 600 python bench.py --streams 2 --cu-split none --no-train-step > $O/bench_r4config.json 2>$O/bench_r4config.err; echo "r4 config (two plain streams) rc $?"
 if [ -f build/r5_trained_student.pt ]; then
   timeout -k 5 600 python bench.py --weights build/r5_trained_student.pt --no-train-step > $O/bench_trained.json 2>$O/bench_trained.err; echo "trained rc $?"
 fi
 python - <<'PY'
 import json
-for n in ("driver", "default", "1stream", "stress", "trained"):
+for n in ("driver", "default", "1stream", "stress", "r4config", "trained"):
     try:
         d = json.loads(open("gpurun_out/r5f/bench_%s.json" % n).read().strip().splitlines()[-1])
-        print(n, round(d["value"], 1), round(d["ms_per_step"], 4), d["parity"].get("ok"), d["parity"].get("identical"), d["parity"].get("rule_set"), round(d["roofline"]["frac"], 3),
+        print(n, round(d["value"], 1), round(d["ms_per_step"], 4), d["config"]["frames_in_flight"], d["parity"].get("ok"), d["parity"].get("identical"), d["parity"].get("frames"), d["parity"].get("rule_set"), round(d["roofline"]["frac"], 3), d["roofline"].get("frac_of_whole_chip_peak"), (d.get("roofline_whole_chip_engine") or {}).get("frac"),
               d["roofline"].get("frac_full_map_launches"), d["roofline"].get("frac_list_launches"), d.get("stages_ms_eager"), (d.get("value_sequential") or {}).get("frames_per_s"),
               {k: (d.get("train_step") or {}).get(k) for k in ("ms_per_iter", "ms_per_iter_fresh_batches", "matched_boxes")}, {k: (d.get("host_io") or {}).get(k) for k in ("frames_per_s", "latency_mode_frames_per_s")},
               round(d["roofline_spmiddle"]["frac"], 4))
@@ -27,10 +28,11 @@ for n in ("driver", "default", "1stream", "stress", "trained"):
         print(n, "unreadable", ex)
 PY
 cd /tmp && export TMPDIR=/tmp
-for cfg in 1stream 2streams stress; do
+for cfg in 1stream 4inflight 2streams stress; do
   case $cfg in
     1stream)  A="--steps 100 --warmup 10 --streams 1"; F=100;;
-    2streams) A="--steps 200 --warmup 20 --streams 2"; F=200;;
+    4inflight) A="--steps 400 --warmup 40"; F=400;;
+    2streams) A="--steps 200 --warmup 20 --streams 2 --cu-split none"; F=200;;
     stress)   A="--stress --steps 30 --warmup 5"; F=30;;
   esac
   rm -rf $O/p_$cfg
