@@ -56,6 +56,23 @@ def _cache_scope():
 _MASKED_STREAMS = []   # (torch ExternalStream, raw handle): kept alive for the life of the process
 
 
+def _destroy_masked_streams():
+    """At interpreter exit: drain and destroy the CU-masked streams (hipStreamDestroy). Left to the runtime's own teardown they
+    crashed the process in __cxa_finalize under rocprofv3 (round 5: the trace was complete, the exit code was 139)."""
+    try:
+        if _MASKED_STREAMS and torch.cuda.is_available():
+            torch.cuda.synchronize()
+        while _MASKED_STREAMS:
+            _, h = _MASKED_STREAMS.pop()
+            lib.sessd_stream_destroy(h)
+    except Exception:
+        pass
+
+
+import atexit as _atexit
+_atexit.register(_destroy_masked_streams)
+
+
 def cu_masked_stream(part, parts, device=None, layout="contiguous"):
     """A torch stream (ExternalStream over hipExtStreamCreateWithCUMask) whose kernels run on the `part`-th of `parts` equal,
     disjoint sets of the device's compute units. layout: 'contiguous' = CU numbers [part * n, (part + 1) * n), 'interleaved' = every
