@@ -29,9 +29,12 @@ def _worker(rank, world, port, argv, q):
         q.put((rank, {"error": traceback.format_exc()[-1500:]}))
 
 
-def test_two_ranks_each_hold_their_engines_to_the_oracle():
+@pytest.mark.parametrize("streams", [1, 4])
+def test_two_ranks_each_hold_their_engines_to_the_oracle(streams):
+    """streams = 4: bench.py's default since round 5 -- every rank builds four engines on CU-masked streams of its device (two CU
+    sets); here both ranks share the one GPU, so eight engines run on the two halves"""
     world, steps = 2, 8
-    argv = ["--gpus", str(world), "--steps", str(steps), "--warmup", "2", "--streams", "1", "--cpu-frames", "3", "--no-roofline",
+    argv = ["--gpus", str(world), "--steps", str(steps), "--warmup", "2", "--streams", str(streams), "--cpu-frames", "3", "--no-roofline",
             "--no-host-io", "--no-sequential", "--no-train-step", "--pool", "4", "--spinup-seconds", "0.1"]
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
@@ -46,8 +49,9 @@ def test_two_ranks_each_hold_their_engines_to_the_oracle():
     out = res[0]
     assert "error" not in out and "exit" not in out, out
     par = out["parity"]
-    assert par["ranks"] == 2 and par["frames"] == 2 * 3 and par["matched"] == par["frames"] and par["ok"], par
-    assert out["config"]["parity"]["ok"] and out["config"]["parity"]["frames"] == 6
+    assert par["ranks"] == 2 and par["frames"] == 2 * 3 * streams and par["matched"] == par["frames"] and par["ok"], par
+    assert out["config"]["parity"]["ok"] and out["config"]["parity"]["frames"] == 6 * streams
+    assert out["config"]["frames_in_flight"] == streams and (out["config"]["cu_sets"] is not None) == (streams > 1)
     assert out["n_gpus"] == 2 and out["config"]["records_gathered"] == world * steps and out["config"]["rccl_ranks_seen"] == 2
     assert "cpu_baseline" not in out   # the baseline figure stays on the N = 1 line
     json.dumps(out)
