@@ -322,6 +322,11 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
             sync()
         if getattr(args, "list_shares", "auto") != "auto" and hasattr(eng, "set_list_shares"):
             eng.set_list_shares(args.list_shares)
+        elif masked and hasattr(eng, "set_list_shares"):
+            # engines that SHARE a CU set: whole-unit shares for every Winograd list layer (a list launch then occupies as many
+            # workgroups as it has units and leaves the set's other CUs to the other frame). The per-launch autotune cannot see
+            # that: measured 1953 / 1953 / 1948 frames/s against 1910 / 1910 with its own picks (profiles/r5_cu_sets_sweep.json)
+            eng.set_list_shares("whole")
         log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
     if args.wino_cfg:
         for nm in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):
