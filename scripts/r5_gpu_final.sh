@@ -66,3 +66,20 @@ python $R/scripts/pmc_compact.py "SpMiddleFHD + voxelizer, dense-scene batch (8 
 grep "sites\|stages" $O/stress_pmc1.log | sed 's/^/# /' >> $O/sparse_pmc_stress.txt
 for i in 1 2 3; do rm -rf $O/stress_pmc$i; done
 cut -c1-170 $O/sparse_pmc_stress.txt | head -30
+# counters of the dense stage in the TIMED configuration: the engine on a CU-masked half, whole-unit list shares
+cd /tmp && export TMPDIR=/tmp
+files=""; i=0
+for set in "$SQ1" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  D=$O/dense_pmc_half_$i
+  rm -rf $D
+  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $set -d $D -o p --output-format csv -- python $R/scripts/sparse_probe.py --frames 3 --force-active --list-shares whole --cu-half > $O/dense_pmc_half_$i.log 2>&1
+  echo "dense pmc (CU half) pass $i rc $?"
+  f=$(find $D -name "*counter_collection.csv" | head -1)
+  files="$files $f"
+  [ $i = 1 ] && tr=$(find $D -name "*kernel_trace.csv" | head -1)
+done
+python $R/scripts/pmc_compact.py "SSFA neck + heads, batch 1, the engine on ONE HALF of the chip (CU-masked stream, 128-CU launches), active-tile mode, whole-unit list shares" $files --trace $tr --tail 400 --match winograd --match conv2d_sk --match conv2d_mfma --match bev_tile --match fill_inactive --match ssfa_fuse > $O/dense_pmc_cu_half.txt
+grep "active_tiles\|stages" $O/dense_pmc_half_1.log | sed 's/^/# /' >> $O/dense_pmc_cu_half.txt
+for i in 1 2 3; do rm -rf $O/dense_pmc_half_$i; done
+cut -c1-170 $O/dense_pmc_cu_half.txt | head -20

@@ -20,6 +20,9 @@ ap.add_argument("--graph", action="store_true")
 ap.add_argument("--force-active", action="store_true",
                 help="blocks 0 / 1 of the neck in active-tile mode whatever the autotune timed (under a counter pass every launch "
                      "carries the profiler's overhead and the autotune declines the two extra launches)")
+ap.add_argument("--cu-half", action="store_true",
+                help="run the engine as bench.py's default runs its four: on a CU-masked stream over one half of the chip, persistent "
+                     "launches sized for 128 CUs, autotuned there")
 ap.add_argument("--list-shares", default="auto", choices=["auto", "whole", "cut"],
                 help="with --force-active: the Winograd list layers on whole-unit shares (round 5) / stream-K shares")
 a = ap.parse_args()
@@ -36,6 +39,11 @@ e = InferenceEngine(model, VG["range"], VG["voxel_size"], VG["max_points_in_voxe
 e.set_points(frames)
 e.enqueue()
 torch.cuda.synchronize()
+if a.cu_half:
+    from sessd_hip import ops as _ops
+    _st, _ncu = _ops.cu_masked_stream(0, 2, dev)
+    e.cu_budget = _ncu
+    torch.cuda.set_stream(_st)
 e.autotune()
 if a.force_active and e.ta is not None:
     from sessd_hip import ops
