@@ -13,7 +13,7 @@ frames); value = total frames / max-over-ranks wall time. By default FOUR frames
 batch-1 engines, two on each HALF of the chip (CU-masked streams, hipExtStreamCreateWithCUMask: every engine owns a hardware
 queue, its kernels are confined to its half, its persistent stream-K launches are sized for 128 CUs) -- a batch-1 frame is 44
 dependent launches of which most cannot fill 256 CUs, and a frame on half the chip pays the per-launch latency chains once while
-its arithmetic takes twice as long: 1925 frames/s against 1563 for rounds 1 - 4's two plain streams sharing the whole chip
+its arithmetic takes twice as long: 1953 frames/s against 1557 for rounds 1 - 4's two plain streams sharing the whole chip
 (`--streams 2 --cu-split none`; `--streams 1` = strictly sequential frames on the whole chip). One JSON line on rank 0, with
   parity        THE TIMED CONFIGURATION held to the oracle before the clock starts: the frames of the cpu_baseline sample go
                 through the very engines that are timed (autotuned tilings, stream-K workgroup counts, captured graphs) and
