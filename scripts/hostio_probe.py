@@ -1,4 +1,10 @@
-"""Where does HostFedPipeline.submit spend its host time? One MI355X."""
+"""What bounds host-fed inference (pinned host points in, detections on the device ring)? Variants of the per-frame submission on
+the bench's default configuration (four engines on two CU-masked halves) and on two plain streams. One MI355X.
+  resident   : no H2D at all (the timed region of bench.py)
+  copystream : H2D on ONE copy stream, the engine's stream waits for the copy's event (HostFedPipeline)
+  copystreams: one copy stream per engine
+  instream   : H2D enqueued on the engine's own stream, in front of the frame (no cross-stream event)
+  ahead      : like copystream, but the copy of frame i + E is issued right after frame i was submitted (one round ahead)"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "se-ssd_amd")]
@@ -11,41 +17,98 @@ VG = configs.VOXEL_GENERATOR
 model = configs.build_synthetic_detector(dev, seed=0)
 frames_np = [synth.make_frame(i, 20000) for i in range(8)]
 pinned = [torch.from_numpy(f).pin_memory() for f in frames_np]
-engines, streams = [], []
-for k in range(2):
-    st = torch.cuda.Stream()
-    e = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 1, 20480, dev)
-    e.set_points([torch.from_numpy(frames_np[0]).to(dev)])
-    e.attach_records(4096)
-    with torch.cuda.stream(st):
-        e.capture()
-    engines.append(e); streams.append(st)
-copy_stream = torch.cuda.Stream()
-stage = [[torch.empty((20480, 4), dtype=torch.float32, device=dev) for _ in range(4)] for _ in engines]
-torch.cuda.synchronize()
-T = {"copy": 0.0, "event": 0.0, "wait": 0.0, "set_points": 0.0, "replay": 0.0}
-N = 400
-t_all = time.perf_counter()
-for i in range(N):
-    ei = i % 2
-    e, st = engines[ei], streams[ei]
-    src = pinned[i % 8]
-    dst = stage[ei][(i // 2) % 4][:src.shape[0]]
+resident = [torch.from_numpy(f).to(dev) for f in frames_np]
+
+
+def build(masked, n):
+    engines, streams = [], []
+    for k in range(n):
+        if masked:
+            st, ncu = ops.cu_masked_stream(k % 2, 2, dev)
+        else:
+            st, ncu = torch.cuda.Stream(), 0
+        e = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 1, 20480, dev)
+        e.cu_budget = ncu
+        e.set_points([resident[0]])
+        if k == 0:
+            with torch.cuda.stream(st):
+                e.enqueue(); torch.cuda.synchronize(); e.autotune()
+                if masked:
+                    e.set_list_shares("whole")
+        else:
+            e.adopt_tuning(engines[0])
+        e.attach_records(8192)
+        with torch.cuda.stream(st):
+            e.capture()
+        engines.append(e); streams.append(st)
+    torch.cuda.synchronize()
+    return engines, streams
+
+
+def run(engines, streams, mode, N=600):
+    E = len(engines)
+    R = 6
+    stage = [[torch.empty((20480, 4), dtype=torch.float32, device=dev) for _ in range(R)] for _ in engines]
+    consumed = [[None] * R for _ in engines]
+    copy_streams = [torch.cuda.Stream() for _ in range(E if mode == "copystreams" else 1)]
+    for e in engines:
+        e.record_cursor.zero_()
+    torch.cuda.synchronize()
+    pending = {}
+
+    def issue_copy(i):
+        ei, k = i % E, (i // E) % R
+        cs = copy_streams[ei % len(copy_streams)]
+        src = pinned[i % 8]
+        dst = stage[ei][k][:src.shape[0]]
+        with torch.cuda.stream(cs):
+            if consumed[ei][k] is not None:
+                cs.wait_event(consumed[ei][k])
+            dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event(); ev.record(cs)
+        pending[i] = (dst, ev)
+
     t0 = time.perf_counter()
-    with torch.cuda.stream(copy_stream):
-        dst.copy_(src, non_blocking=True)
-        t1 = time.perf_counter()
-        ev = torch.cuda.Event(); ev.record(copy_stream)
-    t2 = time.perf_counter()
-    with torch.cuda.stream(st):
-        st.wait_event(ev)
-        t3 = time.perf_counter()
-        e.set_points([dst])
-        t4 = time.perf_counter()
-        e.replay()
-        t5 = time.perf_counter()
-    T["copy"] += t1 - t0; T["event"] += t2 - t1; T["wait"] += t3 - t2; T["set_points"] += t4 - t3; T["replay"] += t5 - t4
-t_enq = time.perf_counter() - t_all
-torch.cuda.synchronize()
-dt = time.perf_counter() - t_all
-print(json.dumps({"frames_per_s": N / dt, "enqueue_ms_per_frame": t_enq / N * 1e3, "host_us_per_frame": {k: v / N * 1e6 for k, v in T.items()}}, indent=1))
+    if mode == "ahead":
+        for i in range(E):
+            issue_copy(i)
+    for i in range(N):
+        ei, k = i % E, (i // E) % R
+        e, st = engines[ei], streams[ei]
+        if mode == "resident":
+            with torch.cuda.stream(st):
+                e.set_points([resident[i % 8]]); e.replay()
+            continue
+        if mode == "instream":
+            src = pinned[i % 8]
+            dst = stage[ei][k][:src.shape[0]]
+            with torch.cuda.stream(st):
+                dst.copy_(src, non_blocking=True)
+                e.set_points([dst]); e.replay()
+            continue
+        if mode in ("copystream", "copystreams"):
+            issue_copy(i)
+        dst, ev = pending.pop(i)
+        with torch.cuda.stream(st):
+            st.wait_event(ev)
+            e.set_points([dst])
+            done = torch.cuda.Event(); done.record(st)
+            consumed[ei][k] = done
+            e.replay()
+        if mode == "ahead" and i + E < N:
+            issue_copy(i + E)
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"frames_per_s": round(N / dt, 1), "host_enqueue_ms_per_frame": round(t_enq / N * 1e3, 4)}
+
+
+out = {}
+for cfg, masked, n in (("four_engines_two_cu_halves", True, 4), ("two_plain_streams", False, 2)):
+    engines, streams = build(masked, n)
+    out[cfg] = {}
+    for mode in ("resident", "copystream", "copystreams", "instream", "ahead", "resident"):
+        r = run(engines, streams, mode)
+        out[cfg].setdefault(mode, []).append(r)
+    del engines, streams
+print(json.dumps(out, indent=1))

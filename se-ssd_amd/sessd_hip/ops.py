@@ -57,11 +57,23 @@ _MASKED_STREAMS = []   # (torch ExternalStream, raw handle): kept alive for the 
 
 
 def _destroy_masked_streams():
-    """At interpreter exit: drain and destroy the CU-masked streams (hipStreamDestroy). Left to the runtime's own teardown they
-    crashed the process in __cxa_finalize under rocprofv3 (round 5: the trace was complete, the exit code was 139)."""
+    """At interpreter exit, UNDER A PROFILER ONLY (rocprofv3 preloads its tool library: ROCP_TOOL_LIBRARIES is set; or
+    SESSD_DESTROY_MASKED_STREAMS=1): drain and destroy the CU-masked streams. Measured in round 5, both ways: left to the runtime's
+    own teardown the streams crashed the process in __cxa_finalize under rocprofv3 (the trace was complete, the exit code 139);
+    destroyed here they exit cleanly under the profiler -- but a plain process that still holds events recorded on those streams
+    (scripts/hostio_probe.py) crashed when they were destroyed first, and exits cleanly when they are left alone. A plain run
+    therefore leaves them to the runtime."""
+    import os
+    if not (os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("SESSD_DESTROY_MASKED_STREAMS")):
+        return
     try:
         if _MASKED_STREAMS and torch.cuda.is_available():
             torch.cuda.synchronize()
+            # the caching allocator keeps free blocks (and their events) per stream: give them back before the streams go, or its
+            # own teardown touches destroyed streams (a probe that dropped its engines before exit crashed there)
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
         while _MASKED_STREAMS:
             _, h = _MASKED_STREAMS.pop()
             lib.sessd_stream_destroy(h)
