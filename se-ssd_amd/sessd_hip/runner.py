@@ -4,10 +4,16 @@ The reference's evaluation loop (tools/test.py:121-146, det3d/torchie/apis/train
 DataLoader, `example_to_device`s it, runs the model and moves the detections back -- three host round trips per frame. Here the
 same contract (host point clouds in, host detections out, submission order) is a three-stage pipeline:
 
-  copy stream   : pinned host points --H2D--> a device staging ring, one or more frames AHEAD of the frame being computed
-  engine streams: frames alternate between independent batch-1 engines (two frames in flight, like bench.py's timed region);
-                  an engine waits for its frame's H2D event only, stages the points into its static input buffer and replays
-                  its captured graph; the frame appends its detections to the engine's device record ring by itself
+  H2D           : pinned host points --> a device staging ring. Round 5: enqueued ON THE ENGINE'S OWN STREAM, in front of the
+                  frame (copy_mode="instream"); rounds 2 - 4 used one copy stream and an event per frame the engine's stream
+                  waited for (copy_mode="copystream"). Measured (scripts/hostio_probe.py, four engines on two CU-masked halves):
+                  device-resident points 1942 frames/s, in-stream H2D 1909, copy stream + event 1286 (one copy stream per
+                  engine 1259, copies issued a round ahead 1307): the cross-stream wait, not the copy, costs the device a
+                  third of its rate -- with several frames in flight another engine's kernels cover a copy that sits in
+                  stream order anyway
+  engine streams: frames alternate between independent batch-1 engines (like bench.py's timed region); an engine stages the
+                  points into its static input buffer and replays its captured graph; the frame appends its detections to the
+                  engine's device record ring by itself
   fetch         : every `fetch_every` frames of an engine the filled part of its record ring goes D2H into pinned memory
                   (asynchronously, on that engine's stream); the host only ever waits for the fetch BEFORE the newest one,
                   which is also what bounds how far it can run ahead of the device.
@@ -19,7 +25,7 @@ from ._lib import check, lib
 
 
 class HostFedPipeline:
-    def __init__(self, engines, streams=None, ring=4, fetch_every=16, eager=False):
+    def __init__(self, engines, streams=None, ring=4, fetch_every=16, eager=False, copy_mode="instream"):
         """engines: batch-1 InferenceEngines of ONE configuration (captured unless eager=True). ring: staging buffers per
         engine (frames the H2D copies may run ahead). fetch_every: frames of an engine between two D2H record fetches."""
         assert all(e.B == 1 for e in engines), "the pipeline feeds batch-1 engines"
@@ -28,6 +34,8 @@ class HostFedPipeline:
         self.streams = list(streams) if streams is not None else [torch.cuda.Stream(self.dev) for _ in self.engines]
         self.copy_stream = torch.cuda.Stream(self.dev)
         self.ring, self.fetch_every, self.eager = int(ring), int(fetch_every), bool(eager)
+        assert copy_mode in ("instream", "copystream")
+        self.copy_mode = copy_mode
         self.post_max = self.engines[0].post_max
         cap = 2 * self.fetch_every
         self._st = []
@@ -100,16 +108,24 @@ class HostFedPipeline:
         if not src.is_pinned():
             st["pinned"][k][:n].copy_(src)
             src = st["pinned"][k][:n]
-        with torch.cuda.stream(self.copy_stream):
-            if st["consumed"][k] is not None:
-                self.copy_stream.wait_event(st["consumed"][k])
-            dst = st["stage"][k][:n]
-            dst.copy_(src, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(self.copy_stream)
-            st["h2d"][k] = ev
+        dst = st["stage"][k][:n]
+        if self.copy_mode == "copystream":
+            with torch.cuda.stream(self.copy_stream):
+                if st["consumed"][k] is not None:
+                    self.copy_stream.wait_event(st["consumed"][k])
+                dst.copy_(src, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+                st["h2d"][k] = ev
         with torch.cuda.stream(stream):
-            stream.wait_event(ev)
+            if self.copy_mode == "copystream":
+                stream.wait_event(ev)
+            else:
+                # in stream order: the slot's previous reader (set_points of `ring` frames ago) is older than this copy
+                dst.copy_(src, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(stream)
+                st["h2d"][k] = ev
             e.set_points([dst])
             done = torch.cuda.Event()
             done.record(stream)

@@ -19,8 +19,10 @@ def model(dev):
     return configs.build_synthetic_detector(dev, seed=0)
 
 
-@pytest.mark.parametrize("eager", [False, True])
-def test_pipeline_returns_every_frame_in_order(dev, model, eager):
+@pytest.mark.parametrize("eager,copy_mode", [(False, "instream"), (True, "instream"), (False, "copystream")])
+def test_pipeline_returns_every_frame_in_order(dev, model, eager, copy_mode):
+    """copy_mode: the H2D of a frame on its engine's own stream (round 5 default) or on a copy stream with an event the engine waits
+    for (rounds 2 - 4)"""
     engines = [InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 1, 20480, dev) for _ in range(2)]
     frames = [synth.make_frame(70 + i, 20000 - 700 * (i % 5)) for i in range(11)]
     # reference: one frame at a time on engine 0 (both engines share the configuration, so their bits agree)
@@ -29,7 +31,7 @@ def test_pipeline_returns_every_frame_in_order(dev, model, eager):
         engines[0].set_points([torch.from_numpy(f).to(dev)])
         engines[0].enqueue()
         want.append(engines[0].results()[0])
-    pipe = HostFedPipeline(engines, ring=3, fetch_every=4, eager=eager)   # rings of 8 records: 11 + 9 frames wrap them
+    pipe = HostFedPipeline(engines, ring=3, fetch_every=4, eager=eager, copy_mode=copy_mode)   # rings of 8 records: 11 + 9 frames wrap them
     if not eager:
         for e in engines:
             e.capture()
