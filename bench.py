@@ -194,7 +194,8 @@ def parity_gate(args, engines, streams, frames, sample):
            "batch": B, "launch": "eager" if args.eager else "hipGraph replay",
            "rule_set": rule,
            "rule": "oracle/compare.py rule='%s' (synthetic = seeded random weights: sizes relative beyond 1 m, <= 10 listed decisions; "
-                   "strict = trained weights (--weights): absolute sizes, <= 6): same count / order, boxes 2e-3, scores 1e-3 "
+                   "strict = trained weights (--weights): absolute sizes, <= 6): same count / order, boxes 2e-3 (centres 5e-3 under the synthetic "
+                   "rule: the decode multiplies a code's float32 error by the 4.2 m anchor diagonal and random weights give codes of 18), scores 1e-3 "
                    "relative; a frame with oracle-LISTED NMS decisions within 1e-4 of the 0.01 IoU threshold may equal the oracle under "
                    "one assignment of those decisions (counted as flipped)" % rule}
     if B == 1:

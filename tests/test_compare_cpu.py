@@ -138,6 +138,21 @@ def test_box_tolerance_is_absolute_for_the_pose_and_relative_for_large_sizes():
         bad["box3d_lidar"][row, col] += delta
         assert same_detections(bad, want, relative_sizes=True) is not None, (row, col)
         assert same_detections(bad, want) is not None, (row, col)
+    # centres under the synthetic rule (round 5): 5 mm -- a box code's float32 error reaches the centre times the 4.2 m anchor
+    # diagonal, and the random weights give codes of magnitude 18; the strict rule keeps 2 mm, yaw keeps 2e-3 under both
+    from oracle.compare import RULES
+    for col in (0, 1, 2):
+        off = copy.deepcopy(want)
+        off["box3d_lidar"][0, col] += 3e-3
+        assert same_detections(off, want, relative_sizes=True, centre_factor=RULES["synthetic"]["centre_factor"]) is None
+        assert same_detections(off, want, centre_factor=RULES["strict"]["centre_factor"]) is not None
+        off["box3d_lidar"][0, col] += 3e-3   # 6 mm
+        assert same_detections(off, want, relative_sizes=True, centre_factor=RULES["synthetic"]["centre_factor"]) is not None
+    yaw = copy.deepcopy(want)
+    yaw["box3d_lidar"][0, 6] += 3e-3
+    assert same_detections(yaw, want, relative_sizes=True, centre_factor=RULES["synthetic"]["centre_factor"]) is not None
+    with pytest.raises(AssertionError):
+        compare_detections(yaw, want, dbg, rule="synthetic")
     car = copy.deepcopy(want)
     car["box3d_lidar"][0, 4] += 1.5e-3     # a car-sized box 1.5 mm off: fine under both rule sets
     car["box3d_lidar"] = car["box3d_lidar"][:1]
@@ -151,7 +166,7 @@ def test_box_tolerance_is_absolute_for_the_pose_and_relative_for_large_sizes():
 
 def test_strict_rule_allows_fewer_listed_decisions():
     from oracle.compare import RULES
-    assert RULES["strict"] == dict(relative_sizes=False, max_pairs=6) and RULES["synthetic"]["max_pairs"] == 10
+    assert RULES["strict"] == dict(relative_sizes=False, max_pairs=6, centre_factor=1.0) and RULES["synthetic"]["max_pairs"] == 10
     want = dict(box3d_lidar=np.zeros((1, 7), np.float32), scores=np.array([0.5], np.float32))
     got = dict(box3d_lidar=np.zeros((0, 7), np.float32), scores=np.zeros((0,), np.float32))
     dbg = dict(near_pairs=np.stack([np.arange(8), np.arange(8) + 1], 1), rerun=lambda forced: want)
