@@ -80,8 +80,8 @@ def parse(argv=None):
     ap.add_argument("--train-replays", type=int, default=20, help="timed replays of the captured training iteration")
     ap.add_argument("--sk-workgroups", type=int, default=0,
                     help="persistent workgroups of the stream-K Winograd launches (multiple of 8; 0 = the kernel's default, all CUs). "
-                         "224 with two frames in flight leaves 32 CUs to the other stream's small kernels: +2 % frames/s, but the "
-                         "kernel then runs 14 % longer per launch -- the default keeps the timed kernel the one the roofline describes")
+                         "224 with two frames in flight leaves 32 CUs to the other stream's small kernels: +2 %% frames/s, but the "
+                         "kernel then runs 14 %% longer per launch -- the default keeps the timed kernel the one the roofline describes")
     ap.add_argument("--spinup-seconds", type=float, default=0.5,
                     help="untimed frames run for this long before the warm-up steps (the CPU oracle sample leaves the GPU idle at low clocks)")
     ap.add_argument("--fork-active", action="store_true", help="EXPERIMENT: the tile-list + fill launches as a side branch of the graph beside the sparse convs")
