@@ -112,3 +112,13 @@ def test_single_rank_no_process_group():
                         "--points", "300", "--pool", "4", "--streams", "1"])
     out = bench.run_rank(args, 0, 1, 0, backend="gloo", device="cpu", engine_factory=_factory)
     assert out["n_gpus"] == 1 and out["config"]["records_gathered"] == 5 and "parity" not in out
+
+
+def test_help_text_formats(capsys):
+    """argparse %-formats every help string: a bare per-cent sign in one of them broke `bench.py --help` for two rounds"""
+    sys.path[:0] = [ROOT]
+    import bench
+    import pytest
+    with pytest.raises(SystemExit) as ex:
+        bench.parse(["--help"])
+    assert ex.value.code == 0 and "--cu-split" in capsys.readouterr().out
