@@ -52,10 +52,12 @@ typedef struct {
   int32_t cout, h, w, mask_th;
   int32_t tile;   /* 0 / 2: 2x2-pixel tiles, value[cout]; 4: 4x4-pixel tiles (a transposed conv over 2x2 tiles of its input),
                      value[4][cout] = the constant of each output parity class (py * 2 + px) */
-  int32_t reserved;
-  const uint64_t* near_mask;   /* NULL, or (tile 2 only) the tile mask of the ONE layer that reads `out`, a 3x3 stride-1 layer that
-                                  runs over its own tile list on the same tile grid: only the tiles within its reach (one of the
-                                  3x3 tiles around them is on that list) are filled, the others keep what they hold */
+  int32_t near_kind;           /* how near_mask's reader reaches this map: 0 = a 3x3 stride-1 layer on the SAME tile grid (reach:
+                                  the 3x3 tiles around a listed tile); on a grid TWICE AS COARSE: 1 = it touches the map inside its
+                                  listed tiles only (a residual), 2 = a 3x3 stride-2 layer over 2x2 tiles of its output (reach:
+                                  tiles 2Ty-1 .. 2Ty+1, 2Tx-1 .. 2Tx+1 of this map) */
+  const uint64_t* near_mask;   /* NULL, or (tile 2 only) the tile mask of the list-driven reader(s) of `out`: only the tiles within
+                                  its reach are filled, the others keep what they hold */
 } sessd_fill_tiles_job_t;
 
 /* One sparse-conv weight packing of sessd_sparse_pack_batch: sessd_sparse_pack_weight (adjoint 0) or

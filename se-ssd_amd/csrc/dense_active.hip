@@ -399,7 +399,27 @@ __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, in
   const u64 word = J.tile_mask[((size_t)b * J.mask_th + ty) * 2 + (tx >> 6)];   // tx even: both bits in one word
   bool on0 = (word >> (tx & 63)) & 1ull, on1 = (word >> ((tx & 63) + 1)) & 1ull;
   if (on0 && on1) return;
-  if (J.near_mask) {
+  if (J.near_mask && J.near_kind != 0) {
+    // the reader runs over a tile list on a grid TWICE AS COARSE (round 5): near_kind 1 = it touches this map only inside its listed
+    // tiles (the residual of the transposed pair: pair tile (Ty, Tx) = 4x4 output pixels = tiles (2Ty .. 2Ty+1, 2Tx .. 2Tx+1) here);
+    // near_kind 2 = a 3x3 stride-2 layer whose listed 2x2-OUTPUT tile (Ty, Tx) reads input pixel rows 4Ty-1 .. 4Ty+3, i.e. tiles
+    // 2Ty-1 .. 2Ty+1 of this map: tile ty is reached from Ty = ty / 2 and, for odd ty, Ty + 1. tx is even, tx + 1 odd.
+    const int cth = th >> 1, ctw = tw >> 1, Tx = tx >> 1;
+    const int ny = (J.near_kind == 2 && (ty & 1)) ? 2 : 1;
+    bool n0 = false, n1 = false;
+    for (int q = 0; q < ny; ++q) {
+      const int Ty = (ty >> 1) + q;
+      if (Ty >= cth) continue;
+      const uint64_t* rowp = J.near_mask + ((size_t)b * J.mask_th + Ty) * 2;
+      const bool a = Tx < ctw && ((rowp[Tx >> 6] >> (Tx & 63)) & 1ull);
+      const bool c = (J.near_kind == 2) && (Tx + 1 < ctw) && ((rowp[(Tx + 1) >> 6] >> ((Tx + 1) & 63)) & 1ull);
+      n0 |= a;
+      n1 |= a | c;
+    }
+    on0 |= !n0;   // (as good as computed: nobody reads it)
+    on1 |= !n1;
+    if (on0 && on1) return;
+  } else if (J.near_mask) {
     // the only reader of this map is a 3x3 layer that runs over ITS tile list (near_mask): a tile it cannot reach -- none of the
     // 3x3 tiles around it is on that list -- is never read and keeps whatever it holds
     bool n0 = false, n1 = false;

@@ -33,7 +33,7 @@ class RulebookJob(C.Structure):
 class FillTilesJob(C.Structure):
     """sessd_fill_tiles_job_t (include/sessd_hip_types.h)"""
     _fields_ = [("out", vp), ("value", vp), ("tile_mask", vp), ("cout", i32), ("h", i32), ("w", i32), ("mask_th", i32), ("tile", i32),
-                ("reserved", i32), ("near_mask", vp)]
+                ("near_kind", i32), ("near_mask", vp)]
 
 
 class HeadLossNet(C.Structure):

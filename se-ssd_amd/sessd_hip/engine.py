@@ -311,6 +311,7 @@ class InferenceEngine:
         self.ACTIVE_SK = (3, 6, 7)
         self.ACTIVE_PAIR = 8
         self.near_fill = True   # fill only the tiles a list-driven reader can reach where that reader is the map's only one
+        self.coarse_fill = True  # ... also where the readers run on a grid twice as coarse (x0, tr0) or on the map's own list (x1): round 5
         # minimum share lengths autotune() tries for a Winograd list launch: > 0 rounds of a stream-K share (units may be cut, partial
         # sums through memory), < 0 WHOLE units per workgroup (round 5: nothing cut, as many workgroups as units -- slower alone on
         # a short list, but it leaves the other CUs to the second frame in flight)
@@ -423,17 +424,37 @@ class InferenceEngine:
     NEAR_READER = {0: 1, 1: 2, 3: 4, 4: 5}
 
     def _fill_jobs(self, ids):
-        """(outs, values, mask slots, tile sizes, near slots) of sessd_fill_inactive_tiles for the active layer ids"""
-        outs, vals, slots, tiles, near = [], [], [], [], []
+        """(outs, values, mask slots, tile sizes, near slots, near kinds) of sessd_fill_inactive_tiles for the active layer ids.
+        Which tiles of a map need the constant depends on who reads it (near_fill): a map whose readers all run over tile lists
+        gets it only where they can reach --
+          b0.0 / b0.1 / b1.0 / b1.1 outputs: one reader, the next 3x3 stride-1 layer on the same grid (kind 0: 3x3 tiles around its list);
+          x0 (b0.2's output): read by b1.0 (3x3 stride 2, a list on the grid of ITS output: kind 2) and by trans_0 (1x1 over x0's own
+             list: computed tiles only);
+          x1 (b1.2's output): read by trans_1 alone -- when that runs over x1's own list, NOTHING needs the constant (job dropped);
+          tr0 (trans_0's output): read by the transposed pair as a residual inside its listed 4x4-pixel blocks (kind 1);
+        everything a full-map launch reads (trans_1's and the pair's outputs, and any of the above whose reader stayed on the full
+        map) is filled everywhere."""
+        outs, vals, slots, tiles, near, kinds = [], [], [], [], [], []
+        ids = list(ids)
         for l in ids:
             if l == self.ACTIVE_PAIR:
                 for o, v in zip(self.ACTIVE_SLOTS[l][3], self.dn.act_const[l]):
-                    outs.append(o); vals.append(v); slots.append(self.ACTIVE_MASK[l]); tiles.append(4); near.append(None)
-            else:
-                outs.append(self.ACTIVE_SLOTS[l][3]); vals.append(self.dn.act_const[l]); slots.append(self.ACTIVE_MASK[l]); tiles.append(2)
+                    outs.append(o); vals.append(v); slots.append(self.ACTIVE_MASK[l]); tiles.append(4); near.append(None); kinds.append(0)
+                continue
+            nr, kind = None, 0
+            if self.near_fill:
                 rd = self.NEAR_READER.get(l)
-                near.append(self.ACTIVE_MASK[rd] if self.near_fill and rd is not None and rd in ids and rd not in self.ACTIVE_SK else None)
-        return outs, vals, slots, tiles, near
+                if rd is not None and rd in ids and rd not in self.ACTIVE_SK:
+                    nr = self.ACTIVE_MASK[rd]
+                elif self.coarse_fill and l == 2 and 3 in ids and 6 in ids:
+                    nr, kind = self.ACTIVE_MASK[3], 2
+                elif self.coarse_fill and l == 6 and self.ACTIVE_PAIR in ids:
+                    nr, kind = self.ACTIVE_MASK[self.ACTIVE_PAIR], 1
+                elif self.coarse_fill and l == 5 and 7 in ids:
+                    continue   # x1's only reader walks x1's own list
+            outs.append(self.ACTIVE_SLOTS[l][3]); vals.append(self.dn.act_const[l]); slots.append(self.ACTIVE_MASK[l]); tiles.append(2)
+            near.append(nr); kinds.append(kind)
+        return outs, vals, slots, tiles, near, kinds
 
     def _active_layers(self):
         """slots (ACTIVE_SLOTS) of the layers that run in active-tile mode in this configuration"""
@@ -684,7 +705,7 @@ class InferenceEngine:
                 gain += dense_t - best[1]
         def overhead(ids):
             fj = self._fill_jobs(ids)
-            return timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]), self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4])),
+            return timed(lambda: (self.ta.run(L4["indices"], L4["n"], L4["cap"]), self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4], near_kind=fj[5])),
                          4 * reps)   # (differences of a few microseconds are decided on these)
         sl = sorted(pick)
         over = overhead(sl) if pick else 0.0
@@ -821,7 +842,7 @@ class InferenceEngine:
                     L4 = self.levels[-1]
                     self.ta.run(L4["indices"], L4["n"], L4["cap"])
                     fj = self._fill_jobs(self._active_layers())
-                    self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4])
+                    self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4], near_kind=fj[5])
             feat, li = run_layers(0, n_layers, feat, 0, s)
             if forked_active:
                 main.wait_stream(side)
@@ -836,7 +857,7 @@ class InferenceEngine:
                 e0.record()
             self.ta.run(L4["indices"], L4["n"], L4["cap"])
             fj = self._fill_jobs(act)
-            self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4])
+            self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4], near_kind=fj[5])
             if self._kmarks is not None:
                 e1.record()
                 self._kmarks.append(("tile_activity+fill", e0, e1))

@@ -1553,17 +1553,19 @@ class TileActivity:
         tx = np.arange(w // 2)
         return torch.from_numpy(((m[:, :, tx >> 6] >> (tx & 63).astype("uint64")) & np.uint64(1)).astype(bool))
 
-    def fill(self, outs, values, layers=None, tiles=None, near=None):
+    def fill(self, outs, values, layers=None, tiles=None, near=None, near_kind=None):
         """outs[i] (batch, cout, h, w) <- values[i][cout] in the tiles slot layers[i] (default i) does not compute (one launch of up
         to 10 jobs; several outputs may share a slot: a 1x1 layer is computed where its input was). tiles[i] = 4: the output of a
         transposed conv over the slot's 2x2 INPUT tiles -- 4x4-pixel tiles, values[i] (4, cout) per output parity class.
-        near[i] = slot of the ONE reader of outs[i], a 3x3 stride-1 layer over its own list on the same tile grid, or None: only
-        the tiles that reader can reach are filled."""
+        near[i] = slot of the list-driven reader of outs[i], or None: only the tiles that reader can reach are filled.
+        near_kind[i]: 0 (default) a 3x3 stride-1 layer on the same tile grid; on a grid twice as coarse: 1 = the reader touches
+        the map inside its listed tiles only, 2 = a 3x3 stride-2 layer over 2x2 tiles of its output."""
         from ._lib import FillTilesJob
         layers = list(range(len(outs))) if layers is None else list(layers)
         tiles = [2] * len(outs) if tiles is None else list(tiles)
         near = [None] * len(outs) if near is None else list(near)
-        key = tuple((o.data_ptr(), v.data_ptr(), l, t, n) for o, v, l, t, n in zip(outs, values, layers, tiles, near))
+        near_kind = [0] * len(outs) if near_kind is None else list(near_kind)
+        key = tuple((o.data_ptr(), v.data_ptr(), l, t, n, k) for o, v, l, t, n, k in zip(outs, values, layers, tiles, near, near_kind))
         if self._jobs is None or self._jobs[0] != key:
             arr = (FillTilesJob * len(outs))()
             for i, (o, v, l, t) in enumerate(zip(outs, values, layers, tiles)):
@@ -1574,8 +1576,10 @@ class TileActivity:
                 arr[i].out, arr[i].value, arr[i].tile_mask, arr[i].cout = o.data_ptr(), v.data_ptr(), self.tile_mask[l].data_ptr(), o.shape[1]
                 arr[i].h, arr[i].w, arr[i].mask_th, arr[i].tile = o.shape[2], o.shape[3], self.H // 2, t
                 if near[i] is not None:
-                    assert t == 2 and self.dims[near[i]] == self.dims[l]
-                    arr[i].near_mask = self.tile_mask[near[i]].data_ptr()
+                    k = int(near_kind[i])
+                    dn, dl = self.dims[near[i]], self.dims[l]
+                    assert t == 2 and k in (0, 1, 2) and (dn == dl if k == 0 else (2 * dn[0], 2 * dn[1]) == tuple(dl))
+                    arr[i].near_mask, arr[i].near_kind = self.tile_mask[near[i]].data_ptr(), k
             self._jobs = (key, arr)
         arr = self._jobs[1]
         check(lib.sessd_fill_inactive_tiles(arr, len(outs), self.batch, _stream()), "fill_inactive_tiles")

@@ -480,3 +480,38 @@ def test_active_layer_is_repeatable(dev):
         ops.conv2d_winograd_sk_active(x, pc.upk_sk(0), C, scale.to(dev), shift.to(dev), True, o, 0, ws, ta.tile_list[0], ta.n_list[0:1])
         outs.append(o)
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
+@pytest.mark.parametrize("batch", [1, 2])
+def test_fill_reach_of_readers_on_a_coarser_grid(dev, batch):
+    """sessd_fill_tiles_job_t.near_kind (round 5): a map whose list-driven reader works on a tile grid twice as coarse is filled only
+    where that reader can touch it. kind 1 = inside the reader's listed tiles (the transposed pair reads its residual there:
+    reader tile (Ty, Tx) = tiles (2Ty .. 2Ty+1, 2Tx .. 2Tx+1) of the map); kind 2 = a 3x3 stride-2 layer over 2x2 tiles of its
+    OUTPUT (tile (Ty, Tx) reads input pixel rows 4Ty-1 .. 4Ty+3 = tiles 2Ty-1 .. 2Ty+1 of the map). The maps start as NaN; what is
+    finite afterwards must be exactly (reach AND NOT computed) -- the engine's end-to-end check with poisoned maps is
+    tests/test_pipeline_gpu.py::test_active_tiles_do_not_change_the_frame."""
+    C = 32
+    idx = _sites(70 + batch, batch, 700)
+    ta = ops.TileActivity(batch, H, W, [0, 2, 3], dev)   # slot 0: a layer at 200 x 176; slots 1 / 2: readers on the 50 x 44 grid
+    ta.run(torch.from_numpy(idx).to(dev), torch.tensor([len(idx)], dtype=torch.int32, device=dev), len(idx))
+    own = ta.mask_bool(0).numpy()                         # (batch, 100, 88)
+    for kind, slot in ((2, 1), (1, 2)):
+        rd = ta.mask_bool(slot).numpy()                   # (batch, 50, 44)
+        th, tw = own.shape[1:]
+        reach = np.zeros_like(own)
+        for ty in range(th):
+            ys = [ty >> 1] + ([(ty >> 1) + 1] if (kind == 2 and ty & 1 and (ty >> 1) + 1 < rd.shape[1]) else [])
+            for tx in range(tw):
+                xs = [tx >> 1] + ([(tx >> 1) + 1] if (kind == 2 and tx & 1 and (tx >> 1) + 1 < rd.shape[2]) else [])
+                reach[:, ty, tx] = np.any([rd[:, y, x] for y in ys for x in xs], axis=0)
+        out = torch.full((batch, C, H, W), float("nan"), device=dev)
+        val = torch.arange(C, dtype=torch.float32, device=dev) + 1.0
+        ta.fill([out], [val], layers=[0], near=[slot], near_kind=[kind])
+        torch.cuda.synchronize()
+        filled = ~torch.isnan(out)
+        want = torch.from_numpy(reach & ~own).to(dev).view(batch, 1, th, tw).repeat_interleave(2, 2).repeat_interleave(2, 3).expand(-1, C, -1, -1)
+        assert torch.equal(filled, want), (kind, int((filled != want).sum()))
+        assert torch.equal(out[filled], val.view(1, C, 1, 1).expand_as(out)[filled])
+        share = float(want.float().mean())
+        print("kind", kind, "filled share", round(share, 3), "own", round(float(own.mean()), 3), "reach", round(float(reach.mean()), 3))
+        assert 0.02 < share < 0.9

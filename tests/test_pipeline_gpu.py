@@ -349,6 +349,9 @@ def test_active_tiles_do_not_change_the_frame(dev, model, state):
                 # (stream-K shape, minimum share) for the Winograd layers, (30, minimum share) = LDS-tiled stream-K kernel,
                 # (direct-kernel tile_cfg, 0) for a 1x1 layer / the pair of transposed convs over their lists
                 eng.active_cfg = {0: (1, 4), 1: (0, 1), 2: (1, 2), 3: (30, 4), 4: (1, 2), 5: (0, 1), 6: (11, 0), 7: (30, 8), 8: (4, 0)}
+                # (the buffer comparison below looks at WHOLE maps: x0 / x1 / tr0 filled everywhere their lists do not compute. The
+                # round-5 reach limits for those three -- coarse_fill -- leave the tiles nobody reads alone: checked further down)
+                eng.coarse_fill = False
             eng.enqueue()
             out = eng.results()
             x0 = torch.cat([eng.t["x0"].reshape(-1), eng.h["x1"].reshape(-1), eng.t["tr0"].reshape(-1), eng.h["tr1"].reshape(-1),
@@ -367,6 +370,23 @@ def test_active_tiles_do_not_change_the_frame(dev, model, state):
                                               eng.h["tr1"].reshape(-1), eng.t["mid"].reshape(-1)]), x0)   # same lists, same shares: same bits
                 for a, b in zip(out, out_g):
                     assert np.array_equal(a["box3d_lidar"], b["box3d_lidar"]) and np.array_equal(a["scores"], b["scores"])
+                # coarse_fill (round 5): x0 only where b1.0's list can reach, tr0 only inside the pair's listed blocks, x1 not at all
+                # (trans_1 walks x1's own list). Poison the three maps: everything downstream must come out the same BITS, and
+                # something must have been left alone in each of them
+                full = [eng.t["mid"].clone(), eng.h["tr1"].clone(), eng.t["o"].clone(), eng.head.clone()]
+                eng.graph = None
+                eng.coarse_fill = True
+                for m in (eng.t["x0"], eng.h["x1"], eng.t["tr0"]):
+                    m.fill_(float("nan"))
+                eng.enqueue()
+                out_c = eng.results()
+                for a_, b_ in zip(full, [eng.t["mid"], eng.h["tr1"], eng.t["o"], eng.head]):
+                    assert torch.isfinite(b_).all() and torch.equal(a_, b_)
+                for a, b in zip(out, out_c):
+                    assert np.array_equal(a["box3d_lidar"], b["box3d_lidar"]) and np.array_equal(a["scores"], b["scores"])
+                left = [float(torch.isnan(m).float().mean()) for m in (eng.t["x0"], eng.h["x1"], eng.t["tr0"])]
+                print("share of x0 / x1 / tr0 left alone by the reach-limited fill", [round(v, 3) for v in left])
+                assert left[0] > 0.15 and left[1] > 0.15 and left[2] > 0.1, left
             res.append((x0, out, frac))
         assert set(res[0][2]) == {"b0.0", "b0.1", "b0.2", "b1.0", "b1.1", "b1.2", "trans_0", "trans_1", "deconv_0+deconv_1"} and res[1][2] == {}
         assert res[0][2]["b1.2"] <= res[0][2]["deconv_0+deconv_1"] < 0.95
