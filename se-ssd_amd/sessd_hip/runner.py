@@ -24,6 +24,58 @@ import torch
 from ._lib import check, lib
 
 
+def engines_on_cu_sets(model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, n_engines=4, sets=2, device=None,
+                       tune_points=None, layout="contiguous", capture=True, records=0, **engine_kwargs):
+    """The throughput configuration of round 5 as one call: `n_engines` batch-1 InferenceEngines, engine i on a stream of its own
+    that is confined to CU set i % `sets` (ops.cu_masked_stream: hipExtStreamCreateWithCUMask -- a hardware queue per engine, its
+    kernels on its set's compute units only), persistent stream-K launches sized for the set (engine.cu_budget). tune_points: a
+    representative (P, 4) float32 device cloud -- engine 0 is autotuned on it ON ITS CU SET, the others adopt the tuning, and the
+    Winograd list layers run on whole-unit shares (engines that share a set leave each other CUs that way); without it every
+    engine takes engine.force_active_tiles(). capture: capture every engine's graph on its stream; records > 0: attach a device
+    detection ring of that many frames first (HostFedPipeline does that itself). Returns (engines, streams).
+    Measured on MI355X (profiles/r5_cu_sets_sweep.json): 4 engines on 2 sets 1950 frames/s against 1557 for two plain streams; `sets`
+    must divide the chip's 8 XCDs evenly (2 or 4)."""
+    import torch
+    from . import ops
+    from .engine import InferenceEngine
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    engines, streams = [], []
+    for k in range(int(n_engines)):
+        st, ncu = ops.cu_masked_stream(k % int(sets), int(sets), dev, layout=layout)
+        e = InferenceEngine(model, voxel_range, voxel_size, max_points_per_voxel, max_voxels, test_cfg, 1, device=dev, **engine_kwargs)
+        e.cu_budget = ncu
+        engines.append(e)
+        streams.append(st)
+    e0 = engines[0]
+    with torch.cuda.stream(streams[0]):
+        if tune_points is not None:
+            e0.set_points([tune_points])
+            e0.enqueue()
+            streams[0].synchronize()
+            e0.autotune()
+            e0.set_list_shares("whole")
+        else:
+            e0.force_active_tiles()
+            e0.set_list_shares("whole")
+    streams[0].synchronize()
+    for e in engines[1:]:
+        if tune_points is not None:
+            e.adopt_tuning(e0)
+        else:
+            e.force_active_tiles()
+            e.set_list_shares("whole")
+    for e, st in zip(engines, streams):
+        if records:
+            e.attach_records(int(records))
+        if capture:
+            with torch.cuda.stream(st):
+                if tune_points is not None:
+                    e.set_points([tune_points])   # (the capture's warm-up frames run on a real cloud)
+                e.capture()
+    torch.cuda.synchronize(dev)
+    return engines, streams
+
+
 class HostFedPipeline:
     def __init__(self, engines, streams=None, ring=4, fetch_every=16, eager=False, copy_mode="instream"):
         """engines: batch-1 InferenceEngines of ONE configuration (captured unless eager=True). ring: staging buffers per

@@ -457,16 +457,13 @@ def test_frames_in_flight_on_cu_sets_equal_the_oracle(dev, model, state):
     frames_np = [synth.make_frame(s, 20000) for s in (71, 72, 73, 74, 75, 76, 77, 78)]
     frames = [torch.from_numpy(f).to(dev) for f in frames_np]
     want, inter = pipeline.run_frames(frames_np, state, VG["range"], VG["voxel_size"], 5, 16000, anchors, None, return_intermediate=True)
-    engines, streams = [], []
-    for k in range(4):
-        st, ncu = ops.cu_masked_stream(k % 2, 2, dev)
-        assert ncu == torch.cuda.get_device_properties(dev).multi_processor_count // 2
-        e = InferenceEngine(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, 1, 20480, dev)
-        e.cu_budget = ncu
-        e.force_active_tiles()
-        assert e._wgs(0) == ncu and e._wgs(1) == 2 * ncu and e._wgs(2) == ncu
-        engines.append(e)
-        streams.append(st)
+    from sessd_hip.runner import engines_on_cu_sets
+    engines, streams = engines_on_cu_sets(model, VG["range"], VG["voxel_size"], 5, 16000, configs.TEST_CFG, n_engines=4, sets=2, device=dev,
+                                          capture=False, max_points_per_frame=20480)
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count // 2
+    for e in engines:
+        assert e.cu_budget == ncu and e._wgs(0) == ncu and e._wgs(1) == 2 * ncu and e._wgs(2) == ncu
+        assert sorted(e.active_cfg) == list(range(9)) and all(v[1] == -1 for l, v in e.active_cfg.items() if l in (0, 1, 2, 4, 5))
     eager = []
     for i, f in enumerate(frames[:4]):
         with torch.cuda.stream(streams[i]):
