@@ -127,7 +127,7 @@ def predict_frame(box_codes, cls_logits, dir_logits, iou_preds, anchors, frustum
     idx = np.nonzero(keep)[0]
     dbg = dict(num_candidates=len(idx))
     out_empty = dict(box3d_lidar=np.zeros((0, 7), np.float32), scores=np.zeros((0,), np.float32),
-                     label_preds=np.zeros((0,), np.int64))
+                     label_preds=np.zeros((0,), np.int64), box_codes=np.zeros((0, 7), np.float32))
     if len(idx) == 0:
         return (out_empty, dbg) if return_debug else out_empty
     s = scores[idx]
@@ -158,5 +158,8 @@ def predict_frame(box_codes, cls_logits, dir_logits, iou_preds, anchors, frustum
     pr = np.array(post_center_range, np.float32)
     m = (b[:, :3] >= pr[:3]).all(1) & (b[:, :3] <= pr[3:]).all(1)
     dbg["selected_anchor"] = dbg["selected_anchor"][m]
-    out = dict(box3d_lidar=b[m], scores=s[m], label_preds=np.zeros((int(m.sum()),), np.int64))
+    # box_codes (ours, for oracle/compare.py): the network outputs the kept boxes were decoded from -- the decode multiplies a
+    # code's float32 error by the anchor diagonal, so the comparison's centre tolerance is derived per detection from its code
+    out = dict(box3d_lidar=b[m], scores=s[m], label_preds=np.zeros((int(m.sum()),), np.int64),
+               box_codes=np.asarray(box_codes, np.float32)[dbg["selected_anchor"]])
     return (out, dbg) if return_debug else out

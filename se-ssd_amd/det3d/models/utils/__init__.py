@@ -1,65 +1,43 @@
-"""mirrors det3d/models/utils: Sequential (misc.py:22-115), build_norm_layer (norm.py:60-111) -- without the
-import-time dependency on the syncbn CUDA extension."""
-from collections import OrderedDict
+"""Boundary glue of the det3d module API: the container and the norm factory that `rpn_v1.py` / `scn.py` are written against
+(reference interface: det3d/models/utils/misc.py:22 `Sequential`, norm.py:60 `build_norm_layer`). Written on top of
+torch.nn.Sequential; child names are positional ("0", "1", ...) unless given, which is what makes the state_dict keys of the
+mirror equal the reference's (tests/test_det3d_mirror.py holds the key set)."""
+import torch.nn as nn
 
-import torch
-from torch import nn
 
-norm_cfg = {
+class Sequential(nn.Sequential):
+    """nn.Sequential plus the two things the reference's necks use: named children through keyword arguments and `add()`."""
+
+    def __init__(self, *modules, **named):
+        super().__init__(*modules)
+        for key, mod in named.items():
+            self.add_module(key, mod)
+
+    def add(self, module, name=None):
+        self.add_module(name if name is not None else str(len(self)), module)
+
+
+# config `type` -> (attribute prefix, factory(num_features, **kwargs)). SyncBN is torch's own (RCCL all-reduce of the statistics):
+# the reference's apex / det3d.ops.syncbn extension has no importer on this path.
+_NORMS = {
     "BN": ("bn", nn.BatchNorm2d),
     "BN1d": ("bn1d", nn.BatchNorm1d),
-    "GN": ("gn", nn.GroupNorm),
-    "SyncBN": ("bn", nn.SyncBatchNorm),  # RCCL-backed torch SyncBatchNorm replaces apex / det3d.ops.syncbn
+    "SyncBN": ("bn", nn.SyncBatchNorm),
+    "GN": ("gn", lambda c, **kw: nn.GroupNorm(num_channels=c, **kw)),
 }
+norm_cfg = {k: v for k, v in _NORMS.items()}
 
 
 def build_norm_layer(cfg, num_features, postfix=""):
-    assert isinstance(cfg, dict) and "type" in cfg
-    cfg_ = dict(cfg)
-    layer_type = cfg_.pop("type")
-    if layer_type not in norm_cfg:
-        raise KeyError("Unrecognized norm type {}".format(layer_type))
-    abbr, norm_layer = norm_cfg[layer_type]
-    name = abbr + str(postfix)
-    requires_grad = cfg_.pop("requires_grad", True)
-    cfg_.setdefault("eps", 1e-5)
-    if layer_type != "GN":
-        layer = norm_layer(num_features, **cfg_)
-    else:
-        layer = norm_layer(num_channels=num_features, **cfg_)
-    for param in layer.parameters():
-        param.requires_grad = requires_grad
-    return name, layer
-
-
-class Sequential(nn.Module):
-    """torch.nn.Sequential with add() and kwargs (misc.py:22-115); integer keys give the reference's state_dict names."""
-
-    def __init__(self, *args, **kwargs):
-        super().__init__()
-        if len(args) == 1 and isinstance(args[0], OrderedDict):
-            for key, module in args[0].items():
-                self.add_module(key, module)
-        else:
-            for idx, module in enumerate(args):
-                self.add_module(str(idx), module)
-        for name, module in kwargs.items():
-            self.add_module(name, module)
-
-    def __getitem__(self, idx):
-        if not (-len(self) <= idx < len(self)):
-            raise IndexError("index {} is out of range".format(idx))
-        if idx < 0:
-            idx += len(self)
-        return list(self._modules.values())[idx]
-
-    def __len__(self):
-        return len(self._modules)
-
-    def add(self, module, name=None):
-        self.add_module(str(len(self._modules)) if name is None else name, module)
-
-    def forward(self, input):
-        for module in self._modules.values():
-            input = module(input)
-        return input
+    """(name, layer) for a config dict like dict(type="BN", eps=1e-3, momentum=0.01); `requires_grad=False` freezes it."""
+    kw = dict(cfg)
+    kind = kw.pop("type")
+    trainable = kw.pop("requires_grad", True)
+    kw.setdefault("eps", 1e-5)
+    try:
+        prefix, make = _NORMS[kind]
+    except KeyError:
+        raise KeyError("Unrecognized norm type %s" % kind) from None
+    layer = make(num_features, **kw)
+    layer.requires_grad_(trainable)
+    return prefix + str(postfix), layer

@@ -11,6 +11,17 @@ import torch
 import torch.distributed as dist
 
 
+def collectives_enabled(group=None):
+    """True when a collective must really be issued: a process group exists and has more than one rank -- or has ONE rank and
+    SESSD_FORCE_COLLECTIVES=1 is set, which turns every world-1 short-circuit of this package off (gather_records, allreduce_flat,
+    the SyncBN statistics all-reduce, bench.py's barriers): the way the RCCL path is executed on a box with a single GPU
+    (tests/test_rccl_gpu.py; review item: no RCCL call of this project had ever run before an 8-GPU node)."""
+    import os
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("SESSD_FORCE_COLLECTIVES") == "1"
+
+
 def shard_indices(num_frames, rank, world_size):
     """DistributedSampler(shuffle=False) semantics (det3d/datasets/loader/sampler.py:74-96): the index list is padded
     by wrapping to a multiple of world_size, rank r takes indices r, r+world, ... Returns (indices, num_padded)."""
@@ -73,7 +84,7 @@ def gather_records(records, counts, num_frames):
     per = int(math.ceil(num_frames / float(world)))
     assert records.shape[0] >= per and counts.shape[0] >= per
     rec, cnt = records[:per].contiguous(), counts[:per].contiguous()
-    if world == 1:
+    if not collectives_enabled():
         return rec.unsqueeze(0), cnt.unsqueeze(0)
     # concatenated along dim 0 (the layout both the RCCL and the gloo backend accept), viewed as (world, per, ...)
     all_rec = torch.empty((world * per,) + tuple(rec.shape[1:]), dtype=rec.dtype, device=rec.device)

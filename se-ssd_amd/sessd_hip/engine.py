@@ -547,7 +547,7 @@ class InferenceEngine:
             cands += [(a, 2, 2) for a in (1, 2, 4)]  # mode 2: W[k] shared through LDS by the four tiles of a workgroup (same bits)
             # modes 16 / 32: two / four tiles per wave, the next tile's neighbour rows fetched under the current tile's MFMAs (same
             # bits); only where a level has several tiles per wave slot (the dense-scene batch)
-            if self.levels[out_li]["cap"] >= 65536:
+            if self.levels[out_li]["cap"] >= 65536 or getattr(self, "sparse_mt_candidates", False):
                 cands += [(a, b, c) for c in (16, 32) for a in (1, 2, 4) for b in (2, 3)]
             for split, depth, ks in cands:
                 if (lay["cout"] // 16) % split or (ks == 1 and depth == 4):
@@ -569,6 +569,13 @@ class InferenceEngine:
             self.sparse_split[idx] = best[0] & 0xFFFFFF
             self.sparse_sorted[idx] = bool(best[0] >> 24)
             self.tune_report["sparse%d" % idx] = best
+        # A/B hook (round 6: levers that lose a per-launch timing are re-measured in the THROUGHPUT regime, where the partner frame
+        # fills a launch's stalls and frames/s follows executed work): force_sparse = {layer: (tuning or None, sorted or None)}
+        for idx, (tun, srt) in getattr(self, "force_sparse", {}).items():
+            if tun is not None:
+                self.sparse_split[idx] = int(tun)
+            if srt is not None and self.chain.sort_tiles:
+                self.sparse_sorted[idx] = bool(srt)
         for name, x, layer, out, relu, residual in todo:
             pc, scale, shift = layer
             best = (None, 1e30)

@@ -85,6 +85,26 @@ import atexit as _atexit
 _atexit.register(_destroy_masked_streams)
 
 
+def close_masked_streams():
+    """Deterministic end of life of every CU-masked stream of this process (round 6; bench.py calls it last): device idle, the
+    caching allocator's free blocks (which carry events of the streams they were used on) returned, then hipStreamDestroy on each
+    handle. The caller drops what was recorded ON those streams first -- captured graphs, engines, its torch.cuda.Event objects,
+    a process group whose collectives ran on them (dist.destroy_process_group) -- and must not use the ExternalStream objects
+    afterwards. After this the exit hook above finds nothing to do, with or without a profiler attached. Returns the number of
+    streams destroyed."""
+    import gc
+    n = 0
+    if _MASKED_STREAMS and torch.cuda.is_available():
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+    while _MASKED_STREAMS:
+        _, h = _MASKED_STREAMS.pop()
+        check(lib.sessd_stream_destroy(h), "stream_destroy")
+        n += 1
+    return n
+
+
 def cu_masked_stream(part, parts, device=None, layout="contiguous"):
     """A torch stream (ExternalStream over hipExtStreamCreateWithCUMask) whose kernels run on the `part`-th of `parts` equal,
     disjoint sets of the device's compute units. layout: 'contiguous' = CU numbers [part * n, (part + 1) * n), 'interleaved' = every
@@ -927,8 +947,9 @@ def _sync_reduce(t):
     if _SYNC_BN["reduce"] is not None:
         _SYNC_BN["reduce"](t)
         return
+    from .dist import collectives_enabled
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_BN["group"]) > 1:
+    if collectives_enabled(_SYNC_BN["group"]):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("SyncBN all-reduces cannot be captured in a hipGraph here: run the iteration eagerly at world size > 1 "
                                "(TrainStep.capture refuses it), or switch SyncBN off (rank-local statistics)")

@@ -188,11 +188,10 @@ def capacity_example(example, voxel_capacity, device=None):
 def allreduce_flat(flat_grad, group=None):
     """Average the flat gradient buffer over the ranks with ONE collective (dist_utils.py:38-42 divides before the
     all-reduce; kept so the summation order matches)."""
-    if not (dist.is_available() and dist.is_initialized()):
+    from .dist import collectives_enabled
+    if not collectives_enabled(group):
         return flat_grad
     world = dist.get_world_size(group)
-    if world == 1:
-        return flat_grad
     flat_grad.div_(world)
     dist.all_reduce(flat_grad, group=group)
     return flat_grad
@@ -239,13 +238,22 @@ class TrainStep:
         # rank; True / False force it (True with one rank runs the split passes without a collective: same bits as the fused ones)
         self.sync_bn = None
         self.sync_bn_group = None   # process group of the SyncBN all-reduces (None: whatever ops.set_sync_bn was given, else WORLD)
-        self.loss_overflow = None  # sticky device flag: bit 0 positives / bit 1 consistency candidates beyond their capacity
+        self.loss_overflow = None  # sticky device int32 bit mask: bit 0 positives / bit 1 consistency candidates beyond their capacity
+        # sticky device int32 bit mask OR-ed from BOTH networks' SparseConvTensor.err after every pass (bit 0 student, bit 1 teacher):
+        # SpMiddleFHD clears its own flag at the start of each pass, so without this only the last pass of the student was ever
+        # visible and a run could train on truncated sparse tensors unnoticed (round-5 review item)
+        self.sparse_overflow = None
         self.cw_dev = None        # consistency weight as a device scalar (a captured iteration reads it from here)
         self._cw_host = None
         self.last_record = None
 
     def _world(self):
         return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+    def _collective(self):
+        """the iteration talks to other ranks (or to itself: sessd_hip.dist.collectives_enabled, SESSD_FORCE_COLLECTIVES=1)"""
+        from .dist import collectives_enabled
+        return collectives_enabled()
 
     def _fwd_bwd(self, example, consistency_weight):
         """Teacher forward, student forward, loss, backward, gradients packed into the flat buffer -- everything of an iteration
@@ -254,7 +262,7 @@ class TrainStep:
         self.teacher.train()  # trainer_sessd.py:321-322: both nets in train mode
         # SyncBN like the reference's distributed path (apis/train_sessd.py:286-294): statistics over the batches of all ranks
         prev_sync = ops.sync_bn_state()   # the whole state: a configured process group / reduce hook survives the iteration
-        on = self.sync_bn if self.sync_bn is not None else self._world() > 1
+        on = self.sync_bn if self.sync_bn is not None else self._collective()
         if self.sync_bn_group is not None:
             ops.set_sync_bn(on, group=self.sync_bn_group)
         else:
@@ -270,7 +278,7 @@ class TrainStep:
         with ops.batched_repack(self.repack), ops.deferred_batch_counts():
             # with SyncBN both networks issue collectives: they stay on one stream, in one order on every rank
             main = torch.cuda.current_stream() if (self.overlap_teacher and self.flat_s.data.is_cuda
-                                                   and not (ops.sync_bn_active() and self._world() > 1)) else None
+                                                   and not (ops.sync_bn_active() and self._collective())) else None
             if main is not None:
                 # The two forward passes are independent until the loss: the teacher's runs on a second stream (a parallel branch
                 # of the captured graph), so that the launch-bound sparse half of one network fills the gaps of the other's dense
@@ -292,6 +300,7 @@ class TrainStep:
             student_preds = self.student.forward_preds(example)
             if main is not None:
                 main.wait_stream(self._side)
+            self._note_sparse_overflow()
             head = self.student.bbox_head
             if self.loss_fn is None and self.device_loss and head.device_loss_covers(example, student_preds):
                 # the reference loss (MultiGroupHead.loss + trainer_sessd.py:267) as one capacity-form device op: six launches,
@@ -305,9 +314,10 @@ class TrainStep:
                 # STICKY on the device, like the engine's flag -- one elementwise launch, also inside a captured iteration; read
                 # and raised by check_overflow() / record() whenever the log is read (round-4 advisor finding: nothing looked)
                 if self.loss_overflow is None:
-                    self.loss_overflow = torch.zeros(1, dtype=torch.float32, device=self.last_record.device)
+                    self.loss_overflow = torch.zeros(1, dtype=torch.int32, device=self.last_record.device)
                 o = ops.HEAD_LOSS_RECORD["overflow"]
-                torch.maximum(self.loss_overflow, self.last_record.detach()[o:o + 1], out=self.loss_overflow)
+                # a BIT mask: OR, not max (an iteration with flag 1 followed by one with flag 2 must leave 3: round-5 advisor finding)
+                self.loss_overflow.bitwise_or_(self.last_record.detach()[o:o + 1].to(torch.int32))
             elif self.loss_fn is None:   # VoxelNet.forward(example, is_ema=[False, teacher_preds], return_loss=True) after its forward
                 losses = head.loss(example, student_preds, teacher_preds)
                 loss = losses["loss"][0] + losses["consistency_loss"][0][0] * consistency_weight
@@ -319,6 +329,19 @@ class TrainStep:
         if self.direct_grads:
             self.flat_s.gather_grads()
         return loss.detach()
+
+    def _note_sparse_overflow(self):
+        """OR both backbones' capacity-overflow flags of the passes just enqueued into the sticky mask (two small launches on the
+        current stream, after the teacher's branch has joined; also inside a captured iteration)."""
+        flags = [getattr(getattr(net, "backbone", None), "last_err", None) for net in (self.student, self.teacher)]
+        if all(f is None for f in flags):
+            return
+        if self.sparse_overflow is None:
+            dev = next(f for f in flags if f is not None).device
+            self.sparse_overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+        for bit, f in enumerate(flags):
+            if f is not None:
+                self.sparse_overflow.bitwise_or_((f.detach().reshape(1) != 0).to(torch.int32) << bit)
 
     def _update(self, device_schedule):
         """Clip + Adam + EMA on the (all-reduced) flat gradient. Returns (lr, momentum) of a host-scheduled step."""
@@ -345,15 +368,22 @@ class TrainStep:
             self._cw_host = float(consistency_weight)
 
     def check_overflow(self):
-        """Synchronising: raise if ANY iteration since the last check dropped positives (bit 0) or consistency candidates (bit 1)
-        beyond the loss capacities -- such an iteration trained on a truncated loss. Re-arms the flag."""
+        """Synchronising: raise if ANY iteration since the last check overflowed a sparse level capacity in either network's
+        SpMiddleFHD pass, or dropped positives (bit 0) or consistency candidates (bit 1) beyond the loss capacities -- such an
+        iteration trained on truncated tensors / a truncated loss. Re-arms the flags."""
+        sp = int(self.sparse_overflow.item()) if self.sparse_overflow is not None else 0
+        if sp:
+            self.sparse_overflow.zero_()
+            raise RuntimeError("sparse level capacity overflow in SpMiddleFHD (mask %d: bit 0 student pass, bit 1 teacher pass) in at "
+                               "least one iteration since the last check: those iterations trained on truncated sparse tensors; "
+                               "raise spconv.CAPACITY_GROWTH / the backbone's capacity_growth or the voxel capacity" % sp)
         if self.loss_overflow is None:
             return
         v = int(self.loss_overflow.item())
         if v:
             self.loss_overflow.zero_()
-            raise RuntimeError("sessd_head_loss capacity overflow (flags %d: 1 = positives beyond pos_capacity, 2 = consistency "
-                               "candidates beyond cons_capacity): raise TrainStep.pos_capacity / cons_capacity" % v)
+            raise RuntimeError("sessd_head_loss capacity overflow (bit mask %d: bit 0 = positives beyond pos_capacity, bit 1 = "
+                               "consistency candidates beyond cons_capacity): raise TrainStep.pos_capacity / cons_capacity" % v)
 
     def record(self):
         """The last iteration's log terms as the dict MultiGroupHead.loss returns (one host read); raises on a capacity overflow
@@ -387,7 +417,7 @@ class TrainStep:
             # host-to-device copy that either aborts the capture or bakes this batch's flip / rotation / scale into every replay
             raise ValueError("capture() with the device loss needs example['transformation_dev'] (capacity_example adds it from "
                              "example['transformation']); refill it with each new batch before replay()")
-        if self._world() > 1 and (self.sync_bn if self.sync_bn is not None else True):
+        if self._collective() and (self.sync_bn if self.sync_bn is not None else True):
             raise RuntimeError("TrainStep.capture() at world size %d with SyncBN: the BatchNorm all-reduces sit inside the forward and "
                                "backward passes and cannot be captured; run the iteration eagerly (step(example)) or set "
                                "step.sync_bn = False (rank-local BatchNorm statistics) to capture it as two graphs around the "
@@ -406,13 +436,14 @@ class TrainStep:
         # (tests/test_train_gpu.py, three trainers in one process; not reproduced with the output outside the pool)
         self.static_loss = torch.zeros((), dtype=torch.float32, device=self.flat_s.data.device)
         if self.loss_overflow is None:   # (warmup=0: allocated outside the graph's pool as well)
-            self.loss_overflow = torch.zeros(1, dtype=torch.float32, device=self.flat_s.data.device)
+            self.loss_overflow = torch.zeros(1, dtype=torch.int32, device=self.flat_s.data.device)
+        if self.sparse_overflow is None:
+            self.sparse_overflow = torch.zeros(1, dtype=torch.int32, device=self.flat_s.data.device)
         ops.new_capture_epoch()   # scratch caches: nothing allocated by an earlier capture is reused in this one
         if self.repack is not None:
             self.repack.prepare()  # job tables of everything the warm-up iterations packed: uploaded before the capture
             self.repack.gen = -1   # the batched re-pack of all weights is the captured iteration's first two launches
-        world = self._world()
-        if world > 1:
+        if self._collective():
             # THE COLLECTIVE OF A CAPTURED ITERATION (review item): an RCCL all-reduce recorded inside a hipGraph is not something
             # this stack lets us validate (one GPU per test box), so it is NOT captured. The iteration is captured as TWO graphs
             # split at the one point where the ranks talk -- [teacher fwd + student fwd + loss + backward + gradient packing] and

@@ -127,7 +127,7 @@ def measure(dev, batch=4, steps=20, warmup=3, real_loss=True, standin_loss_fn=No
            "ms_per_iter": ms, "samples_per_s": batch / ms * 1e3,
            "voxels_student": int(ex["num_voxels_dev"].item()) if "num_voxels_dev" in ex else int(ex["voxels"].shape[0]),
            "voxels_teacher": int(ex["num_voxels_dev_raw"].item()) if "num_voxels_dev_raw" in ex else int(ex["voxels_raw"].shape[0]),
-           "sparse_overflow_flag": int(step.student.backbone.last_err.item()),
+           "sparse_overflow_flag": int(step.sparse_overflow.item()) if step.sparse_overflow is not None else 0,
            "loss": float(step.static_loss)}
     if fresh is not None:
         out["pretrain_iterations"] = pretrain

@@ -135,9 +135,19 @@ class DeviceBatcher:
         return out
 
     def _in_range(self, b):
-        """Voxelization's ground-truth range filter (preprocess.py:205-210) without a host-read shape: a box whose centre left
-        the range is parked where it overlaps no anchor (create_target_np then ignores it: empty_gt_mask, target_ops_v3.py:62-66)"""
-        keep = ((b[:, :2] >= self.lo) & (b[:, :2] <= self.hi)).all(1) & (b[:, 0] > FAR / 2)
+        """Voxelization's ground-truth range filter (preprocess.py:205-210 -> core/sampler/preprocess.py:138-148
+        filter_gt_box_outside_range) without a host-read shape: a box is kept when ANY of its four BEV corners (dims (w, l) about
+        the centre, rotated by box_np_ops.rotation_2d's matrix: x' = x c + y s, y' = -x s + y c) lies STRICTLY inside the range
+        -- the reference's cross-product test fails on the boundary --, not only its centre (that is the reference's OTHER
+        function, filter_gt_box_outside_range_by_center; round-5 advisor finding). A dropped box is parked where it overlaps no
+        anchor (create_target_np then ignores it: empty_gt_mask, target_ops_v3.py:62-66)."""
+        c, s = torch.cos(b[:, 6]), torch.sin(b[:, 6])
+        keep = torch.zeros(b.shape[0], dtype=torch.bool, device=b.device)
+        for fx, fy in ((-0.5, -0.5), (-0.5, 0.5), (0.5, 0.5), (0.5, -0.5)):
+            dx, dy = fx * b[:, 3], fy * b[:, 4]
+            x, y = dx * c + dy * s + b[:, 0], -dx * s + dy * c + b[:, 1]
+            keep |= (x > self.lo[0]) & (x < self.hi[0]) & (y > self.lo[1]) & (y < self.hi[1])
+        keep &= b[:, 0] > FAR / 2
         far = b.clone()
         far[:, 0] = FAR
         return torch.where(keep[:, None], b, far)
@@ -197,7 +207,7 @@ def consistency_weight(it, total):
 
 
 def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50, capture=True, on_log=None, ema_check=False,
-        overlap=True):
+        overlap=True, raise_on_overflow=True):
     """Train `model` (student; the teacher is its EMA copy) for `iterations` captured iterations on fresh batches from `pool`.
     Returns (TrainStep, report). report: log rows (iteration, the record's terms averaged over the window's LAST iteration -- one
     host read per `log_every` iterations), sustained samples/s with the data path inside the clock, overflow flags seen.
@@ -205,7 +215,11 @@ def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50
     device after every iteration and report its largest difference from the fused update's teacher.
     overlap: batch i + 1 is assembled on a SIDE stream into staging tensors while iteration i runs, then copied into the static
     example (the reference overlaps its DataLoader workers with the iteration the same way); False: load, then iterate, on one
-    stream. Same batches, same arithmetic: the trained parameters are bit-identical either way (tests/test_trainloop_gpu.py)."""
+    stream. Same batches, same arithmetic: the trained parameters are bit-identical either way (tests/test_trainloop_gpu.py).
+    raise_on_overflow: with every log record the STICKY device flags are read -- sparse level capacities of both networks' passes
+    (TrainStep.sparse_overflow) and the loss capacities (loss_overflow) -- and a set flag raises: the window trained on truncated
+    tensors. False only records them in the rows / the report (`sparse_overflow_flag` = OR over the whole run, bit 0 student,
+    bit 1 teacher)."""
     dev = next(model.parameters()).device
     step = strain.TrainStep(model, None, total_steps=iterations, lr_max=lr_max)
     data = DeviceBatcher(pool, dev, batch, iterations, seed=seed)
@@ -219,7 +233,7 @@ def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50
     R = ops.HEAD_LOSS_RECORD
     keys = ("total", "loss", "cls_loss_reduced", "ious_loss", "dir_loss_reduced", "iou_pred_loss", "consistency_loss", "loss_ema",
             "num_pos", "positives", "matched_boxes", "candidates", "candidates_ema", "overflow")
-    log, flags = [], 0
+    log, flags, sparse_flags = [], 0, 0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     if overlap and done < iterations:
@@ -255,7 +269,16 @@ def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50
                 flags |= sticky
                 step.loss_overflow.zero_()
             row["overflow_since_last_log"] = sticky
+            sp = int(step.sparse_overflow.item()) if step.sparse_overflow is not None else 0
+            if sp:
+                sparse_flags |= sp
+                step.sparse_overflow.zero_()
+            row["sparse_overflow_since_last_log"] = sp
             log.append(row)
+            if raise_on_overflow and (sp or sticky):
+                raise RuntimeError("capacity overflow in iterations %d .. %d: sparse levels mask %d (bit 0 student, bit 1 teacher pass), "
+                                   "loss capacities mask %d (bit 0 positives, bit 1 consistency candidates)"
+                                   % (it + 2 - log_every, it + 1, sp, sticky))
             if on_log is not None:
                 on_log(row)
     torch.cuda.synchronize()
@@ -263,7 +286,7 @@ def fit(model, pool, iterations=2000, batch=4, lr_max=3e-3, seed=0, log_every=50
     n = iterations - done
     rep = {"iterations": iterations, "batch": batch, "timed_iterations": n, "seconds": dt, "ms_per_iteration": dt / max(1, n) * 1e3,
            "samples_per_s": n * batch / dt if n else 0.0, "log": log, "overflow_flags": flags, "scenes": len(pool),
-           "sparse_overflow_flag": int(step.student.backbone.last_err.item()), "data_path_overlapped": bool(overlap),
+           "sparse_overflow_flag": sparse_flags, "data_path_overlapped": bool(overlap),
            "what": "captured SE-SSD iterations (teacher + student forward, reference loss, backward, clip / Adam / EMA) on FRESH "
                    "batches: scene choice + global augmentation + voxelization of both clouds + target assignment on the device "
                    "inside the clock, one host read of the loss record per %d iterations" % log_every}

@@ -99,7 +99,9 @@ def test_rank_function_two_gloo_ranks_on_a_stub_engine(capfd):
     assert out["n_gpus"] == world and out["steps"] == steps and out["scaling"] == "weak"
     assert out["config"]["records_gathered"] == world * steps     # every timed frame of every rank reached the gather
     assert out["config"]["rccl_ranks_seen"] == world
-    assert out["config"]["frames_in_flight"] == 4 and out["config"]["cu_sets"] is None   # (the default; CU-masked streams exist on the GPU only)
+    assert out["config"]["frames_in_flight"] == 4 and out["config"]["cu_sets"] == 0 and out["cu_sets"] is None   # (the default; CU-masked streams exist on the GPU only)
+    assert all(not isinstance(v, (dict, list)) for v in out["config"].values())   # scalars only: what the driver's record keeps
+    assert out["config"]["collective_backend"] == "gloo" and out["config"]["collectives_in_timed_region"] >= 2 * 4 + 1
     assert out["value"] > 0 and abs(out["value"] - world * steps / (out["ms_per_step"] * 1e-3 * steps)) < 1e-6 * out["value"]
     assert "parity" not in out  # off the GPU (stub engines) there is no gate; on GPUs every rank runs a short one (bench.py)
     json.dumps(out)

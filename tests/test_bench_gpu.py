@@ -45,13 +45,19 @@ def test_two_ranks_each_hold_their_engines_to_the_oracle(streams):
     res = dict(q.get(timeout=600) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
+        # run_rank's ordered teardown (graphs and engines, allocator cache, process group, then the CU-masked streams) must leave
+        # a process that exits cleanly
+        assert p.exitcode == 0, p.exitcode
     assert res[1] is None, res[1]
     out = res[0]
     assert "error" not in out and "exit" not in out, out
     par = out["parity"]
     assert par["ranks"] == 2 and par["frames"] == 2 * 3 * streams and par["matched"] == par["frames"] and par["ok"], par
-    assert out["config"]["parity"]["ok"] and out["config"]["parity"]["frames"] == 6 * streams
-    assert out["config"]["frames_in_flight"] == streams and (out["config"]["cu_sets"] is not None) == (streams > 1)
+    cfg = out["config"]
+    assert all(not isinstance(v, (dict, list)) for v in cfg.values())   # scalars only: what the driver's record keeps
+    assert cfg["parity_ok"] and cfg["parity_frames"] == 6 * streams and cfg["parity_matched"] == 6 * streams and cfg["parity_rule"] == "synthetic"
+    assert cfg["frames_in_flight"] == streams and (cfg["cu_sets"] == 2) == (streams > 1) and (out["cu_sets"] is not None) == (streams > 1)
+    assert cfg["weights"] == "random"   # (--no-train-step: nothing trains, the round-5 line)
     assert out["n_gpus"] == 2 and out["config"]["records_gathered"] == world * steps and out["config"]["rccl_ranks_seen"] == 2
     assert "cpu_baseline" not in out   # the baseline figure stays on the N = 1 line
     json.dumps(out)

@@ -138,19 +138,32 @@ def test_box_tolerance_is_absolute_for_the_pose_and_relative_for_large_sizes():
         bad["box3d_lidar"][row, col] += delta
         assert same_detections(bad, want, relative_sizes=True) is not None, (row, col)
         assert same_detections(bad, want) is not None, (row, col)
-    # centres under the synthetic rule (round 5): 5 mm -- a box code's float32 error reaches the centre times the 4.2 m anchor
-    # diagonal, and the random weights give codes of magnitude 18; the strict rule keeps 2 mm, yaw keeps 2e-3 under both
-    from oracle.compare import RULES
+    # centres under the synthetic rule (round 6): box_tol + code_rtol * |code| * anchor size PER DETECTION, from the oracle's own
+    # code of that box -- a box code's float32 error reaches the centre times the 4.2 m anchor diagonal (z: the 1.56 m anchor
+    # height). A detection decoded from a small code keeps ~2 mm under BOTH rules; the strict rule never takes the code term.
+    from oracle.compare import RULES, ANCHOR_CENTRE_SCALE
+    rt = RULES["synthetic"]["code_rtol"]
+    assert rt == 5e-5 and RULES["strict"]["code_rtol"] == 0.0
+    coded = copy.deepcopy(want)
+    coded["box_codes"] = np.zeros((2, 7), np.float32)
+    coded["box_codes"][0, :3] = 18.5      # detection 0: decoded from codes of 18.5 (the random benchmark weights)
+    coded["box_codes"][1, :3] = 0.4       # detection 1: a car-sized code
     for col in (0, 1, 2):
-        off = copy.deepcopy(want)
-        off["box3d_lidar"][0, col] += 3e-3
-        assert same_detections(off, want, relative_sizes=True, centre_factor=RULES["synthetic"]["centre_factor"]) is None
-        assert same_detections(off, want, centre_factor=RULES["strict"]["centre_factor"]) is not None
-        off["box3d_lidar"][0, col] += 3e-3   # 6 mm
-        assert same_detections(off, want, relative_sizes=True, centre_factor=RULES["synthetic"]["centre_factor"]) is not None
+        big = 2e-3 + rt * 18.5 * ANCHOR_CENTRE_SCALE[col]    # 5.9 mm (x, y) / 3.4 mm (z)
+        off = copy.deepcopy(coded)
+        off["box3d_lidar"][0, col] += 0.9 * big
+        assert same_detections(off, coded, relative_sizes=True, code_rtol=rt) is None, col
+        assert same_detections(off, coded) is not None                      # strict: flat 2 mm
+        assert same_detections(off, want, relative_sizes=True, code_rtol=rt) is not None   # no codes at hand: flat 2 mm as well
+        off["box3d_lidar"][0, col] += 0.3 * big
+        assert same_detections(off, coded, relative_sizes=True, code_rtol=rt) is not None, col
+        small = copy.deepcopy(coded)
+        small["box3d_lidar"][1, col] += 2.5e-3    # the small-code detection: 2.5 mm is a mismatch under every rule
+        assert same_detections(small, coded, relative_sizes=True, code_rtol=rt) is not None, col
+    assert compare_detections(coded, coded, dbg, rule="synthetic")["matched"] == 2
     yaw = copy.deepcopy(want)
     yaw["box3d_lidar"][0, 6] += 3e-3
-    assert same_detections(yaw, want, relative_sizes=True, centre_factor=RULES["synthetic"]["centre_factor"]) is not None
+    assert same_detections(yaw, want, relative_sizes=True, code_rtol=rt) is not None
     with pytest.raises(AssertionError):
         compare_detections(yaw, want, dbg, rule="synthetic")
     car = copy.deepcopy(want)
@@ -166,7 +179,7 @@ def test_box_tolerance_is_absolute_for_the_pose_and_relative_for_large_sizes():
 
 def test_strict_rule_allows_fewer_listed_decisions():
     from oracle.compare import RULES
-    assert RULES["strict"] == dict(relative_sizes=False, max_pairs=6, centre_factor=1.0) and RULES["synthetic"]["max_pairs"] == 10
+    assert RULES["strict"] == dict(relative_sizes=False, max_pairs=6, code_rtol=0.0) and RULES["synthetic"]["max_pairs"] == 10
     want = dict(box3d_lidar=np.zeros((1, 7), np.float32), scores=np.array([0.5], np.float32))
     got = dict(box3d_lidar=np.zeros((0, 7), np.float32), scores=np.zeros((0,), np.float32))
     dbg = dict(near_pairs=np.stack([np.arange(8), np.arange(8) + 1], 1), rerun=lambda forced: want)
