@@ -376,7 +376,7 @@ class TrainStep:
             self.sparse_overflow.zero_()
             raise RuntimeError("sparse level capacity overflow in SpMiddleFHD (mask %d: bit 0 student pass, bit 1 teacher pass) in at "
                                "least one iteration since the last check: those iterations trained on truncated sparse tensors; "
-                               "raise spconv.CAPACITY_GROWTH / the backbone's capacity_growth or the voxel capacity" % sp)
+                               "raise spconv.CAPACITY_GROWTH (level 1 is the one the augmented clouds fill) or the voxel capacity" % sp)
         if self.loss_overflow is None:
             return
         v = int(self.loss_overflow.item())

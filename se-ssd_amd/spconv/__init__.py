@@ -11,9 +11,14 @@ kernel takes the device count (rows beyond it are never read), and nothing synch
 what lets a whole training iteration (sessd_hip.train.TrainStep.capture) be ONE captured graph. Overflow of a capacity is
 reported in `err` (device int, checked by the caller after the step)."""
 
-# capacity of a strided conv's output level relative to its input level, in the order of the strided convs of SpMiddleFHD
-# (observed ratios on KITTI-like scans: ~1.05-1.25, 0.5, 0.4, 0.85; the engine uses the same table)
-CAPACITY_GROWTH = (1.5, 1.0, 0.75, 0.75)
+# capacity of a strided conv's output level relative to its input level, in the order of the strided convs of SpMiddleFHD.
+# Observed ratios on the un-augmented synthetic scans: 0.96 - 1.28, 0.5, 0.4, 0.85 (the inference engine sizes level 1 at 1.5).
+# TRAINING sees the student's AUGMENTED cloud (rotation +-pi/4, scaling): rotated scan lines no longer run along the voxel rows
+# and the first strided conv dilates them into many more output sites -- per frame 1.35 on average, 2.0 at worst, per batch of four
+# up to 1.65 .. 1.9 (scripts/r6_sparse_overflow_scan.py: with 1.5 one student batch in ten overflowed level 1, silently until round
+# 6's sticky flag). Level 1 is therefore sized at 2.5 x the voxel capacity; the deeper factors keep the absolute capacities of
+# rounds 1 - 5 (2.5 x 0.6 = 1.5 x 1.0).
+CAPACITY_GROWTH = (2.5, 0.6, 0.75, 0.75)
 import math
 
 import numpy as np
