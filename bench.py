@@ -399,6 +399,17 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
             # workgroups as it has units and leaves the set's other CUs to the other frame). The per-launch autotune cannot see
             # that: measured 1953 / 1953 / 1948 frames/s against 1910 / 1910 with its own picks (profiles/r5_cu_sets_sweep.json)
             eng.set_list_shares("whole")
+        # A/B hook: SESSD_LIST_SHAPE=0 / 1 forces the stream-K shape (0: 8 waves x 128 couts, 1: 4 waves x 64 couts) of every Winograd
+        # list layer; SESSD_LIST_MIN_ROUNDS its share rule (-1 whole units, -2 two units per workgroup, > 0 stream-K rounds)
+        if os.environ.get("SESSD_LIST_SHAPE") or os.environ.get("SESSD_LIST_MIN_ROUNDS"):
+            only = [int(v) for v in filter(None, os.environ.get("SESSD_LIST_LAYERS", "").split(","))]
+            for l, (shape, mr) in list(eng.active_cfg.items()):
+                if l in eng.ACTIVE_SK or l == eng.ACTIVE_PAIR or (only and l not in only):
+                    continue
+                sh = int(os.environ.get("SESSD_LIST_SHAPE", shape))
+                if eng.ACTIVE_SLOTS[l][1][0].upk_sk(sh) is None:
+                    sh = shape
+                eng.active_cfg[l] = (sh, int(os.environ.get("SESSD_LIST_MIN_ROUNDS", mr)))
         log("autotuned tile configs:", {k: (v[0], round(v[1], 4)) for k, v in rep.items()})
     if args.wino_cfg:
         for nm in ("b0.0", "b0.1", "b0.2", "conv_0", "conv_1", "b1.1", "b1.2"):
@@ -607,6 +618,17 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
                                                                                       "frac_list_launches", "dense_launch_ms", "active_tile_fraction")}
                 out["stages_ms_eager_whole_chip_engine"] = whole["stages_ms_eager"]
                 out["roofline_spmiddle_whole_chip_engine"] = {k: whole["roofline_spmiddle"][k] for k in ("achieved", "frac", "ms", "algorithmic_bytes")}
+        if "roofline" in out and "roofline_spmiddle" in out:
+            # what ALL frames in flight achieve together over the driver-timed region: executed matrix-core FLOPs per step (dense stage
+            # + the sparse convolutions' executed tile steps) / ms_per_step / the whole chip's peak
+            gf = out["roofline"]["dense_stage_executed_gflop"] + out["roofline_spmiddle"]["mfma"]["executed_gflop"]
+            out["roofline"]["executed_gflop_per_step"] = gf
+            out["roofline"]["frac_chip_timed_region"] = gf / out["ms_per_step"] / F32_MFMA_PEAK_TFLOPS
+            out["roofline"]["frac_chip_timed_region_note"] = (
+                "executed MFMA GFLOP per step (analytic: listed layers with their computed shares, Winograd 16/36; the counter-based figure "
+                "of the same frame is in profiles/r6_dense_pmc_cu_half.txt, `mfma` column x FLOPs per instruction) / ms_per_step / 157.3 "
+                "TFLOP/s. The peak is quoted at 2.4 GHz; under this load the chip sustains about 2.0 GHz (profiles/r4_wino_sk_pmc.txt: "
+                "SQ_BUSY_CU_CYCLES / CUs / launch time), so 0.83 is the ceiling of any `frac` here")
         if not args.eager and args.batch == 1 and not args.no_host_io and world == 1:
             host_io_legs(args, out, engines, streams, frames_np, dev, latency_engine=seq_eng)
         if cpu_base is not None:
@@ -723,6 +745,16 @@ def roofline_legs(args, out, eng, batch_of, cus=0):
                        "frac_algorithmic_note": "direct-convolution FLOPs 2*H*W*Cin*Cout*9 / time: a speed-up figure, not a "
                                                 "utilisation -- it exceeds 1 at batch >= 4",
                        "traffic": None}
+    # EXECUTED matrix-core FLOPs of the whole dense stage per batch (what SQ_INSTS_MFMA counts, up to the padding of the last tile block
+    # of a list): Winograd layers 16/36 of the direct count, every listed layer with its computed share; direct kernels in full
+    a_ = lambda nm: act.get(nm, 1.0)
+    HW, HW2 = 200 * 176, 100 * 88
+    dense_exec = (CONV_FLOPS * sum(p[2] * p[3] for p in per) * exe_ratio                       # the seven 3x3 stride-1 layers
+                  + 2.0 * HW2 * 128 * 256 * 9 * a_("b1.0")                                    # 3x3 stride 2, 128 -> 256
+                  + 2.0 * HW * 128 * 128 * a_("trans_0") + 2.0 * HW2 * 256 * 256 * a_("trans_1")  # the 1x1 layers
+                  + 2 * 2.0 * HW2 * 256 * 128 * 9 * a_("deconv_0+deconv_1")                   # two ConvTranspose2d 3x3 stride 2, 256 -> 128
+                  + 2.0 * HW * 128 * 22) * args.batch / 1e9                                    # the four 1x1 heads
+    out["roofline"]["dense_stage_executed_gflop"] = dense_exec
     # HBM traffic of that kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE), committed
     # under profiles/; it cannot be collected inside this process
     cands = ["r4_wino_sk_traffic.json", "r3_wino_sk_traffic.json", "r2_wino_sk_traffic.json"] if streamk else ["r1_winograd_traffic.json"]
