@@ -213,7 +213,7 @@ def parity_gate(args, engines, streams, frames, sample):
            "rule_set": rule,
            "rule": "oracle/compare.py rule='%s' (strict = trained weights, the default line and --weights: same count / order, every box "
                    "component within 2e-3 ABSOLUTE, scores 1e-3 relative, <= 6 listed decisions; synthetic = the seeded random weights of "
-                   "--random-weights: sizes relative beyond 1 m, centres 2e-3 + 5e-5 x |box code| x anchor size PER DETECTION -- the decode "
+                   "--random-weights: sizes relative beyond 1 m, centres 2e-3 + 5e-5 x the frame's largest |box code| x anchor size -- the decode "
                    "multiplies a code's float32 error by the 4.2 m anchor diagonal and random weights give codes of 18 --, <= 10 listed "
                    "decisions); a frame with oracle-LISTED NMS decisions within 1e-4 of the 0.01 IoU threshold may equal the oracle under "
                    "one assignment of those decisions (counted as flipped)" % rule}
@@ -389,6 +389,11 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
         eng.allow_streamk = not args.no_streamk
         if getattr(args, "list_shares", "auto") == "cut":
             eng.list_share_candidates = (1, 4, 8, 16)
+        elif masked and getattr(args, "list_shares", "auto") in ("auto", "whole"):
+            # engines that SHARE a CU set run their Winograd list layers on whole-unit shares (below): the autotune then chooses each
+            # layer's SHAPE among whole-unit launches (round 5 chose the shape with stream-K shares in the race and forced the share rule
+            # afterwards: b1.1 / b1.2 ended on 4-wave units, 132 / 164 of them on 128 CUs, 80 us each; 8-wave units need one round)
+            eng.list_share_candidates = (-1,)
         with _on(streams[0] if masked else None):   # (a CU-masked engine is tuned on its own CU set)
             rep = eng.autotune()
             sync()
@@ -624,9 +629,15 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
             gf = out["roofline"]["dense_stage_executed_gflop"] + out["roofline_spmiddle"]["mfma"]["executed_gflop"]
             out["roofline"]["executed_gflop_per_step"] = gf
             out["roofline"]["frac_chip_timed_region"] = gf / out["ms_per_step"] / F32_MFMA_PEAK_TFLOPS
+            cpath = os.path.join(ROOT, "profiles", "r6_mfma_flops_per_frame.json")
+            if os.path.exists(cpath) and args.batch == 1 and not args.stress:
+                # the same figure with the COUNTED instructions of one frame (SQ_INSTS_MFMA x FLOPs per instruction, committed)
+                cg = json.load(open(cpath))["cu_half" if masked else "whole_chip"]["executed_gflop_per_frame"]
+                out["roofline"]["executed_gflop_per_step_from_counters"] = cg
+                out["roofline"]["frac_chip_timed_region_from_counters"] = cg / out["ms_per_step"] / F32_MFMA_PEAK_TFLOPS
             out["roofline"]["frac_chip_timed_region_note"] = (
-                "executed MFMA GFLOP per step (analytic: listed layers with their computed shares, Winograd 16/36; the counter-based figure "
-                "of the same frame is in profiles/r6_dense_pmc_cu_half.txt, `mfma` column x FLOPs per instruction) / ms_per_step / 157.3 "
+                "executed MFMA GFLOP per step (analytic: listed layers with their computed shares, Winograd 16/36; `_from_counters`: "
+                "SQ_INSTS_MFMA of one frame x FLOPs per instruction, profiles/r6_mfma_flops_per_frame.json) / ms_per_step / 157.3 "
                 "TFLOP/s. The peak is quoted at 2.4 GHz; under this load the chip sustains about 2.0 GHz (profiles/r4_wino_sk_pmc.txt: "
                 "SQ_BUSY_CU_CYCLES / CUs / launch time), so 0.83 is the ceiling of any `frac` here")
         if not args.eager and args.batch == 1 and not args.no_host_io and world == 1:
@@ -759,7 +770,7 @@ def roofline_legs(args, out, eng, batch_of, cus=0):
     # under profiles/; it cannot be collected inside this process
     cands = ["r4_wino_sk_traffic.json", "r3_wino_sk_traffic.json", "r2_wino_sk_traffic.json"] if streamk else ["r1_winograd_traffic.json"]
     if streamk and act:
-        cands[:0] = ["r5_wino_traffic.json", "r4s2_wino_traffic.json"]  # counter passes of the frame with the list launches (average over its six launches)
+        cands[:0] = ["r6_wino_traffic.json", "r5_wino_traffic.json", "r4s2_wino_traffic.json"]  # counter passes of the frame with the list launches (average over its six launches)
     cands = cands if wino else ["r1_conv_traffic.json"]
     for nm in cands:
         tpath = os.path.join(ROOT, "profiles", nm)
@@ -767,6 +778,10 @@ def roofline_legs(args, out, eng, batch_of, cus=0):
             tj = json.load(open(tpath))
             out["roofline"]["traffic"] = tj["traffic_bytes"]
             out["roofline"]["traffic_source"] = tj["source"]
+            if tj.get("algorithmic_bytes_per_launch"):
+                out["roofline"]["traffic_algorithmic_bytes"] = tj["algorithmic_bytes_per_launch"]
+                out["roofline"]["traffic_times_algorithmic"] = round(tj["traffic_bytes"] / float(tj["algorithmic_bytes_per_launch"]), 2)
+                out["roofline"]["traffic_configuration"] = tj.get("traffic_configuration")
             break
     # ---- per-stage time (eager, events) and the HBM roofline of SpMiddleFHD (algorithmic bytes / time)
     eng.set_points(batch_of(0))

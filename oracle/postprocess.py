@@ -125,9 +125,13 @@ def predict_frame(box_codes, cls_logits, dir_logits, iou_preds, anchors, frustum
     scores = sigmoid32(cls_logits)
     keep = scores >= np.float32(score_thresh)
     idx = np.nonzero(keep)[0]
+    # code_scale (ours, for oracle/compare.py): the largest |x / y / z box code| of the frame's head output map -- the scale the
+    # float32 error of ANY code of this frame is proportional to (a code is a 128-term dot product over the same feature maps)
+    code_scale = float(np.abs(np.asarray(box_codes, np.float32)[:, :3]).max()) if len(box_codes) else 0.0
     dbg = dict(num_candidates=len(idx))
+    dbg["code_scale"] = code_scale
     out_empty = dict(box3d_lidar=np.zeros((0, 7), np.float32), scores=np.zeros((0,), np.float32),
-                     label_preds=np.zeros((0,), np.int64), box_codes=np.zeros((0, 7), np.float32))
+                     label_preds=np.zeros((0,), np.int64))
     if len(idx) == 0:
         return (out_empty, dbg) if return_debug else out_empty
     s = scores[idx]
@@ -158,8 +162,5 @@ def predict_frame(box_codes, cls_logits, dir_logits, iou_preds, anchors, frustum
     pr = np.array(post_center_range, np.float32)
     m = (b[:, :3] >= pr[:3]).all(1) & (b[:, :3] <= pr[3:]).all(1)
     dbg["selected_anchor"] = dbg["selected_anchor"][m]
-    # box_codes (ours, for oracle/compare.py): the network outputs the kept boxes were decoded from -- the decode multiplies a
-    # code's float32 error by the anchor diagonal, so the comparison's centre tolerance is derived per detection from its code
-    out = dict(box3d_lidar=b[m], scores=s[m], label_preds=np.zeros((int(m.sum()),), np.int64),
-               box_codes=np.asarray(box_codes, np.float32)[dbg["selected_anchor"]])
+    out = dict(box3d_lidar=b[m], scores=s[m], label_preds=np.zeros((int(m.sum()),), np.int64))
     return (out, dbg) if return_debug else out

@@ -23,6 +23,10 @@ ap.add_argument("--force-active", action="store_true",
 ap.add_argument("--cu-half", action="store_true",
                 help="run the engine as bench.py's default runs its four: on a CU-masked stream over one half of the chip, persistent "
                      "launches sized for 128 CUs, autotuned there")
+ap.add_argument("--fixed", action="store_true",
+                help="NO autotune: engine.force_active_tiles() (the configuration the autotune ends in on MI355X, as smoke() runs it) -- every "
+                     "counter pass of a series then profiles the SAME launches (separate passes of an autotuned probe can pick different "
+                     "tilings: round 6 found FETCH / WRITE columns that belonged to different kernels)")
 ap.add_argument("--list-shares", default="auto", choices=["auto", "whole", "cut"],
                 help="with --force-active: the Winograd list layers on whole-unit shares (round 5) / stream-K shares")
 a = ap.parse_args()
@@ -44,8 +48,13 @@ if a.cu_half:
     _st, _ncu = _ops.cu_masked_stream(0, 2, dev)
     e.cu_budget = _ncu
     torch.cuda.set_stream(_st)
-e.autotune()
-if a.force_active and e.ta is not None:
+if a.fixed:
+    e.force_active_tiles()
+    e.set_list_shares("whole" if a.list_shares == "auto" else a.list_shares)
+    print("fixed configuration:", e.tile_cfg, e.active_cfg)
+else:
+    e.autotune()
+if a.force_active and not a.fixed and e.ta is not None:
     from sessd_hip import ops
     need = max(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(2 * B, e.H, e.W, 256, 1, 0)),
                int(ops.lib.sessd_conv2d_sk_workspace_bytes(B, e.H, e.W, 256, 1, 0)))
@@ -65,4 +74,5 @@ for i in range(a.frames):
 torch.cuda.synchronize()
 print("sites", e.spmiddle_algorithmic_bytes())
 print("stages", e.stage_times(reps=5))
-print("tuning", {k: (v[0] & 255, v[0] >> 8, round(v[1] * 1e3, 1)) for k, v in e.tune_report.items() if k.startswith("sparse")})
+if not a.fixed:
+    print("tuning", {k: (v[0] & 255, v[0] >> 8, round(v[1] * 1e3, 1)) for k, v in e.tune_report.items() if k.startswith("sparse")})

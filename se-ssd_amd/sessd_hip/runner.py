@@ -52,6 +52,7 @@ def engines_on_cu_sets(model, voxel_range, voxel_size, max_points_per_voxel, max
             e0.set_points([tune_points])
             e0.enqueue()
             streams[0].synchronize()
+            e0.list_share_candidates = (-1,)   # shapes are chosen among whole-unit launches: the share rule engines on a shared set run
             e0.autotune()
             e0.set_list_shares("whole")
         else:

@@ -138,29 +138,34 @@ def test_box_tolerance_is_absolute_for_the_pose_and_relative_for_large_sizes():
         bad["box3d_lidar"][row, col] += delta
         assert same_detections(bad, want, relative_sizes=True) is not None, (row, col)
         assert same_detections(bad, want) is not None, (row, col)
-    # centres under the synthetic rule (round 6): box_tol + code_rtol * |code| * anchor size PER DETECTION, from the oracle's own
-    # code of that box -- a box code's float32 error reaches the centre times the 4.2 m anchor diagonal (z: the 1.56 m anchor
-    # height). A detection decoded from a small code keeps ~2 mm under BOTH rules; the strict rule never takes the code term.
+    # centres under the synthetic rule (round 6): box_tol + code_rtol * code_scale * anchor size PER FRAME, code_scale = the largest
+    # |x / y / z code| of the frame's head output as the ORACLE computed it -- a box code's float32 error reaches the centre times
+    # the 4.2 m anchor diagonal (z: the 1.56 m anchor height) and is proportional to the scale of the head output. A frame with
+    # tame codes keeps ~2 mm; the strict rule never takes the code term.
     from oracle.compare import RULES, ANCHOR_CENTRE_SCALE
     rt = RULES["synthetic"]["code_rtol"]
     assert rt == 5e-5 and RULES["strict"]["code_rtol"] == 0.0
-    coded = copy.deepcopy(want)
-    coded["box_codes"] = np.zeros((2, 7), np.float32)
-    coded["box_codes"][0, :3] = 18.5      # detection 0: decoded from codes of 18.5 (the random benchmark weights)
-    coded["box_codes"][1, :3] = 0.4       # detection 1: a car-sized code
+    wild, tame = 18.5, 0.8    # code scale of a frame of the random benchmark weights / of a trained model
     for col in (0, 1, 2):
         big = 2e-3 + rt * 18.5 * ANCHOR_CENTRE_SCALE[col]    # 5.9 mm (x, y) / 3.4 mm (z)
-        off = copy.deepcopy(coded)
+        off = copy.deepcopy(want)
         off["box3d_lidar"][0, col] += 0.9 * big
-        assert same_detections(off, coded, relative_sizes=True, code_rtol=rt) is None, col
-        assert same_detections(off, coded) is not None                      # strict: flat 2 mm
-        assert same_detections(off, want, relative_sizes=True, code_rtol=rt) is not None   # no codes at hand: flat 2 mm as well
+        assert same_detections(off, want, relative_sizes=True, code_rtol=rt, code_scale=wild) is None, col
+        assert same_detections(off, want) is not None                      # strict: flat 2 mm
+        assert same_detections(off, want, relative_sizes=True, code_rtol=rt) is not None   # no code scale at hand: flat 2 mm as well
+        assert same_detections(off, want, relative_sizes=True, code_rtol=rt, code_scale=tame) is not None   # a tame frame: 2.2 mm
         off["box3d_lidar"][0, col] += 0.3 * big
-        assert same_detections(off, coded, relative_sizes=True, code_rtol=rt) is not None, col
-        small = copy.deepcopy(coded)
-        small["box3d_lidar"][1, col] += 2.5e-3    # the small-code detection: 2.5 mm is a mismatch under every rule
-        assert same_detections(small, coded, relative_sizes=True, code_rtol=rt) is not None, col
-    assert compare_detections(coded, coded, dbg, rule="synthetic")["matched"] == 2
+        assert same_detections(off, want, relative_sizes=True, code_rtol=rt, code_scale=wild) is not None, col
+    small = copy.deepcopy(want)
+    small["box3d_lidar"][1, 0] += 2.1e-3
+    assert same_detections(small, want, relative_sizes=True, code_rtol=rt, code_scale=tame) is None and same_detections(small, want) is not None
+    far = copy.deepcopy(want)
+    far["box3d_lidar"][0, 0] += 4e-3
+    assert compare_detections(far, want, dict(dbg, code_scale=wild), rule="synthetic")["matched"] == 2
+    with pytest.raises(AssertionError):
+        compare_detections(far, want, dict(dbg, code_scale=tame), rule="synthetic")
+    with pytest.raises(AssertionError):
+        compare_detections(far, want, dict(dbg, code_scale=wild), rule="strict")
     yaw = copy.deepcopy(want)
     yaw["box3d_lidar"][0, 6] += 3e-3
     assert same_detections(yaw, want, relative_sizes=True, code_rtol=rt) is not None
