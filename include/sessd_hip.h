@@ -42,6 +42,10 @@ void sessd_set_external_clear(int on);
  * in flight on disjoint CU sets do not hold each other's kernels back (bench.py --cu-split). */
 int sessd_stream_create_cu_mask(int n_words, const uint32_t* mask, sessd_stream_t* stream);
 int sessd_stream_destroy(sessd_stream_t stream);
+/* Diagnostics of the CU-masked streams: n_workgroups one-wave workgroups spin ~spin_cycles shader cycles each and record
+ * ids[workgroup] = XCC_ID << 16 | (HW_REG_HW_ID & 0xFFFF) -- bits 11:8 CU, 12 shader array, 15:13 shader engine: the physical CU the
+ * workgroup ran on. tests/test_cu_mask_gpu.py: two streams of different CU sets never share a CU, also under hipGraph replay. */
+int sessd_debug_cu_probe(uint32_t* ids, int n_workgroups, int spin_cycles, sessd_stream_t stream);
 
 /* ------------------------------------------------------------------ voxelizer (a1-a3)
  * replaces det3d/ops/point_cloud/point_cloud_ops_v2.py:120-194 points_to_voxel (numba, CPU),

@@ -68,6 +68,7 @@ SIGNATURES = {
     "sessd_set_external_clear": (None, [i32]),
     "sessd_stream_create_cu_mask": (i32, [i32, vp, vp]),
     "sessd_stream_destroy": (i32, [vp]),
+    "sessd_debug_cu_probe": (i32, [vp, i32, i32, vp]),
     "sessd_hash_capacity": (u32, [i32]),
     "sessd_hash_clear": (i32, [vp, vp, u32, vp]),
     "sessd_voxelize_workspace_bytes": (sz, [u32, i32, i32, i32]),

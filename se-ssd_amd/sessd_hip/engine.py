@@ -758,6 +758,11 @@ class InferenceEngine:
         """Enqueue one batch on the current stream. No host synchronisation, no allocation."""
         s = torch.cuda.current_stream().cuda_stream
         B = self.B
+        if self.cu_budget and (self.fork_front or self.fork_active):
+            # the side branches run on a plain stream of the engine's own: on the whole chip, outside the CU set the engine's stream is
+            # confined to (and its launches are sized for). Both options were measured slower anyway (see __init__).
+            raise RuntimeError("fork_front / fork_active put part of the frame on an unmasked side stream: not available to an engine "
+                               "that runs on a CU set (cu_budget = %d)" % self.cu_budget)
         # ---- voxelize (a1-a3)
         # every clear of the frame in ONE launch: control words + occupancy maps (0), hash tables and per-cell lists (empty marker),
         # the dense BEV map the last sparse layer scatters into (0; round 2 cleared it between two sparse convs, on the critical path)
