@@ -75,6 +75,8 @@ def parse(argv=None):
     ap.add_argument("--no-active-tiles", action="store_true",
                     help="A/B: the first three SSFA layers over the whole BEV map (round 3) instead of only the tiles whose input is not "
                          "constant (csrc/dense_active.hip)")
+    ap.add_argument("--no-active-conv", action="store_true",
+                    help="A/B: conv_0 / conv_1 as the two-set full-map launch (rounds 3 - 5) instead of over their tile list (round 6)")
     ap.add_argument("--no-train-step", action="store_true",
                     help="skip the `train_step` leg (BASELINE configs[2]: the captured SE-SSD training iteration with the reference loss)")
     ap.add_argument("--train-replays", type=int, default=20, help="timed replays of the captured training iteration")
@@ -161,6 +163,7 @@ def default_engine_factory(args, dev, model=None, count=None):
         e.fork_front = bool(args.fork)
         e.fork_active = bool(getattr(args, "fork_active", False))
         e.sparse_mt_candidates = bool(getattr(args, "sparse_mt", False))
+        e.allow_active_conv = not getattr(args, "no_active_conv", False)
         e.force_sparse = force
     return model, engines
 
@@ -699,7 +702,7 @@ def roofline_legs(args, out, eng, batch_of, cus=0):
     act = eng.active_tile_fractions() if hasattr(eng, "active_tile_fractions") else {}
     per = [(nm, lt[nm], 1, act.get(nm, 1.0)) for nm in names if nm in lt]
     if "conv_0+conv_1" in lt:
-        per.append(("conv_0+conv_1", lt["conv_0+conv_1"], 2, 1.0))
+        per.append(("conv_0+conv_1", lt["conv_0+conv_1"], 2, act.get("conv_0+conv_1", 1.0)))   # (round 6: may run over a tile list too)
     times = [p[1] for p in per]
     nlayers = sum(p[2] for p in per)
     assert nlayers == len(names)

@@ -51,7 +51,8 @@ typedef struct {
   const uint64_t* tile_mask;
   int32_t cout, h, w, mask_th;
   int32_t tile;   /* 0 / 2: 2x2-pixel tiles, value[cout]; 4: 4x4-pixel tiles (a transposed conv over 2x2 tiles of its input),
-                     value[4][cout] = the constant of each output parity class (py * 2 + px) */
+                     value[4][cout] = the constant of each output parity class (py * 2 + px); 6: 2x2-pixel tiles with such a
+                     value[4][cout] table (a 3x3 layer behind the transposed convs: its input is constant per parity class) */
   int32_t near_kind;           /* how near_mask's reader reaches this map: 0 = a 3x3 stride-1 layer on the SAME tile grid (reach:
                                   the 3x3 tiles around a listed tile); on a grid TWICE AS COARSE: 1 = it touches the map inside its
                                   listed tiles only (a residual), 2 = a 3x3 stride-2 layer over 2x2 tiles of its output (reach:

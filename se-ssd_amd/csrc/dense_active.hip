@@ -17,8 +17,12 @@
 //                         2  the same layer over a list of its own: the 2x2 tiles of its OUTPUT that hold a non-constant pixel
 //                         3  stride-2 transposed conv on the current map (rpn_v1.py:175-199) whose output also receives a map of
 //                            the resolution before the halving as a residual (:224): 2x2 tiles of its INPUT = 4x4 output blocks
-//                       rpn_v1.py:135-160 + 224 is {0, 0, 0, 2, 0, 0, 3}; the 1x1 trans layers take the list of the layer that
-//                       produced their input. Lists are ascending in (image, tile): deterministic, no atomics. One launch at batch
+//                         4  (round 6) no layer: the map becomes the OUTPUT of the step-3 transposed conv in front of it (twice the
+//                            resolution; non-constant pixels = the 4x4 blocks of that step's tiles), so that a following step 0 is
+//                            a 3x3 layer over the transposed conv's output -- conv_0 / conv_1 (rpn_v1.py:200-210), whose input is
+//                            constant PER OUTPUT PARITY CLASS outside those blocks, and so is its output outside its own tiles
+//                       rpn_v1.py:135-160 + 224 is {0, 0, 0, 2, 0, 0, 3} (+ {4, 0} for conv_0 / conv_1); the 1x1 trans layers take
+//                       the list of the layer that produced their input. Lists are ascending in (image, tile): deterministic, no atomics. One launch at batch
 //                       1; with more images a second launch numbers the lists (an image's base is the sum of the earlier images'
 //                       counts). (First version: byte maps walked by one workgroup -- 104 us; now 25 - 28 us, issue-bound.)
 //   fill_inactive_tiles the layers' constants into the tiles nobody computes, all layers in one launch (2x2-pixel tiles with one
@@ -42,7 +46,7 @@ namespace {
 constexpr int NT = 1024;
 constexpr int LPT = 8;    // site rows a thread fetches per round (all in flight together)
 constexpr int MAX_H = 256, MAX_W = 192;   // one image's pixel rows as 3 x 64-bit words in LDS; a thread pair per tile row
-constexpr int MAX_SLOTS = 7, MAX_STEPS = 8, MAX_FILL_JOBS = 10;
+constexpr int MAX_SLOTS = 8, MAX_STEPS = 10, MAX_FILL_JOBS = 12;
 constexpr int FILL_CG = 16;   // channels per fill block
 typedef unsigned long long u64;
 
@@ -274,6 +278,30 @@ __global__ __launch_bounds__(NT) void bev_tile_activity_kernel(ActArgs A) {
       ACT_LDS_BARRIER();
       have_layer = false;   // (s_m no longer holds a layer slot)
       ++slot;
+    } else if (A.kind[st] == 4) {
+      // ---- the map becomes the output of the transposed conv of the step before (a step 3: its tile rows are in s_m, one word
+      // each, TW <= 64; checked by the host): pixel (y, x) of the 2H x 2W map is non-constant iff tile (y >> 2, x >> 2) was
+      // computed. Nothing is emitted; the resolution doubles; a constant that depends on the output parity class is "a constant"
+      // for every 3x3 stride-1 layer that follows on 2x2 tiles (the period is one tile).
+      const int H2 = H << 1, W2 = W << 1;
+      u64 v0, v1, v2 = 0ull;
+      valid_bits(min(W2, 128), v0, v1);
+      if (W2 > 128) { u64 d; valid_bits(W2 - 128, v2, d); }
+      // the pair's mask words leave s_m through registers: nc and s_m are different arrays, but every thread reads before any writes
+      const int y = (int)threadIdx.x;
+      u64 m = 0ull;
+      if (y < H2) m = s_m[2 * (y >> 2)];
+      ACT_LDS_BARRIER();
+      if (y < H2) {
+        // every bit four times: bits 0 .. 15 -> word 0, 16 .. 31 -> word 1, 32 .. 47 -> word 2
+        nc[y][0] = double_bits((unsigned)double_bits((unsigned)(m & 0xFFFFull))) & v0;
+        nc[y][1] = double_bits((unsigned)double_bits((unsigned)((m >> 16) & 0xFFFFull))) & v1;
+        nc[y][2] = double_bits((unsigned)double_bits((unsigned)((m >> 32) & 0xFFFFull))) & v2;
+      }
+      ACT_LDS_BARRIER();
+      H = H2; W = W2;
+      zero_input = false;
+      have_layer = false; have_keep = false;
     } else {
       if (have_layer && threadIdx.x < 2 * (H >> 1)) s_keep[threadIdx.x] = s_m[threadIdx.x];   // (the thread's own words)
       have_keep = have_layer;
@@ -449,18 +477,26 @@ __global__ __launch_bounds__(256) void fill_inactive_tiles_kernel(FillJobs Q, in
   const size_t plane = (size_t)h * w;
   float* o = J.out + ((size_t)b * J.cout + (size_t)cg * FILL_CG) * plane + (size_t)(2 * ty) * w + 2 * tx;
   const int nco = min(FILL_CG, J.cout - cg * FILL_CG);
+  // J.tile == 3 (sessd_fill_tiles_job_t.tile = 6): one constant per output parity class, value[(py * 2 + px) * cout + co] -- the
+  // output of a 3x3 layer whose input is constant per parity class (conv_0 / conv_1 behind the transposed convs): a 2x2 tile is one
+  // period
+  const bool par = J.tile == 3;
   if (!on0 && !on1) {
     for (int cc = 0; cc < nco; ++cc, o += plane) {
-      const float c = J.value[cg * FILL_CG + cc];
-      *reinterpret_cast<float4*>(o) = make_float4(c, c, c, c);
-      *reinterpret_cast<float4*>(o + w) = make_float4(c, c, c, c);
+      const int co = cg * FILL_CG + cc;
+      const float c00 = J.value[co], c01 = par ? J.value[J.cout + co] : c00, c10 = par ? J.value[2 * J.cout + co] : c00,
+                  c11 = par ? J.value[3 * J.cout + co] : c00;
+      *reinterpret_cast<float4*>(o) = make_float4(c00, c01, c00, c01);
+      *reinterpret_cast<float4*>(o + w) = make_float4(c10, c11, c10, c11);
     }
   } else {
     float* q = on0 ? o + 2 : o;
     for (int cc = 0; cc < nco; ++cc, q += plane) {
-      const float c = J.value[cg * FILL_CG + cc];
-      *reinterpret_cast<float2*>(q) = make_float2(c, c);
-      *reinterpret_cast<float2*>(q + w) = make_float2(c, c);
+      const int co = cg * FILL_CG + cc;
+      const float c00 = J.value[co], c01 = par ? J.value[J.cout + co] : c00, c10 = par ? J.value[2 * J.cout + co] : c00,
+                  c11 = par ? J.value[3 * J.cout + co] : c00;
+      *reinterpret_cast<float2*>(q) = make_float2(c00, c01);
+      *reinterpret_cast<float2*>(q + w) = make_float2(c10, c11);
     }
   }
 }
@@ -505,6 +541,9 @@ int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_
       if (A.n_slots == MAX_SLOTS || cw / 2 > 64) return SESSD_EINVAL;
       A.slot_th[A.n_slots] = ch / 2; A.slot_tw[A.n_slots] = cw / 2;
       ++A.n_slots;
+    } else if (steps[s] == 4) {   // the output of the step-3 transposed conv in front: twice the resolution, no slot
+      if (s == 0 || steps[s - 1] != 3 || 2 * ch > MAX_H || 2 * cw > MAX_W || 2 * ch > NT) return SESSD_EINVAL;
+      ch *= 2; cw *= 2;
     } else if (steps[s] == 1 || steps[s] == 2) {
       ch /= 2; cw /= 2;
       if (steps[s] == 2) {   // the transition takes a slot of 2x2 tiles of ITS output
@@ -528,8 +567,8 @@ int sessd_bev_tile_activity(const int32_t* indices, const int32_t* n_dev, int n_
   return SESSD_OK;
 }
 
-// out[b][co][tile pixels] = value[co] for every tile of job j whose bit in tile_mask is 0, for up to 10 jobs (tile = 4: 4x4-pixel
-// tiles with one value per output parity class, value[(py * 2 + px) * cout + co]) (out (batch, cout, h, w),
+// out[b][co][tile pixels] = value[co] for every tile of job j whose bit in tile_mask is 0, for up to 12 jobs (tile = 4: 4x4-pixel
+// tiles with one value per output parity class, value[(py * 2 + px) * cout + co]; tile = 6: 2x2-pixel tiles with such a value table) (out (batch, cout, h, w),
 // value[cout], tile_mask (batch, mask_th, 2) words, cout, h, w, mask_th) in one launch.
 int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, int batch, hipStream_t stream) {
   if (!jobs || n_jobs < 1 || n_jobs > MAX_FILL_JOBS || batch < 1) return SESSD_EINVAL;
@@ -541,10 +580,10 @@ int sessd_fill_inactive_tiles(const sessd_fill_tiles_job_t* jobs, int n_jobs, in
     // (w % 4 == 0: a thread owns two adjacent 2x2 tiles, or one 4x4 tile = 16-byte aligned rows of four pixels)
     const int tile = S.tile == 4 ? 4 : 2;
     if (!S.out || !S.value || !S.tile_mask || S.cout < 1 || S.h < tile || S.w < 4 || (S.h % tile) || (S.w & 3) || S.mask_th < S.h / tile ||
-        S.w / tile > 128 || (S.tile != 0 && S.tile != 2 && S.tile != 4) || (S.near_mask && tile != 2))
+        S.w / tile > 128 || (S.tile != 0 && S.tile != 2 && S.tile != 4 && S.tile != 6) || (S.near_mask && tile != 2))
       return SESSD_EINVAL;
     Q.J[j] = S;
-    Q.J[j].tile = tile;
+    Q.J[j].tile = S.tile == 6 ? 3 : tile;   // (the kernel's codes: 4 = 4x4 blocks with parity constants, 3 = 2x2 tiles with parity constants, 2 = 2x2 tiles)
     Q.blk_off[j] = blk;
     blk += (tile == 4 ? sessd_divup((S.h / 4) * (S.w / 4), 256) : sessd_divup((S.h / 2) * (S.w / 4), 256)) * sessd_divup(S.cout, FILL_CG) * batch;
   }

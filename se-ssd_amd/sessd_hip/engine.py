@@ -68,7 +68,8 @@ def active_tile_constants(neck):
     constant map is constant. Entries 0-2 = bottom_up_block_0, 3-5 = bottom_up_block_1, 6 / 7 = trans_0 / trans_1 (1x1 layers over
     the constants of block 0 / block 1), 8 = (deconv_block_0 + the residual trans_0 map, deconv_block_1): (4, cout) each, one
     constant per output parity class (py, px) -- out(2y+py, 2x+px) sums the taps ky in K(py), kx in K(px), K(0) = {1},
-    K(1) = {0, 2}. tests/test_active_rule_cpu.py holds them to the modules applied to constant maps."""
+    K(1) = {0, 2}; 9 = (conv_0, conv_1) over those parity-class constants: (4, cout) each again.
+    tests/test_active_rule_cpu.py holds them to the modules applied to constant maps."""
     b0, b1 = neck.bottom_up_block_0, neck.bottom_up_block_1
     def step(seq, ci, bi, c):
         s_, t_ = fold_bn(seq[bi])
@@ -90,6 +91,19 @@ def active_tile_constants(neck):
         chain.append(c)
     chain += [step(neck.trans_0, 0, 1, chain[2]), step(neck.trans_1, 0, 1, chain[5])]
     chain.append((dstep(neck.deconv_block_0, chain[7]) + chain[6][None], dstep(neck.deconv_block_1, chain[7])))
+    def pstep(seq, cpar):
+        """a 3x3 stride-1 conv + BN + ReLU over a map that holds cpar[(py * 2 + px)] at pixels of parity (py, px): the output pixel
+        of parity (py, px) sees tap (ky, kx) on a pixel of parity ((py + ky - 1) & 1, (px + kx - 1) & 1) -- again one constant per
+        parity class (entry 9: conv_0 / conv_1 behind the transposed convs, rpn_v1.py:200-210, 226-227)"""
+        s_, t_ = fold_bn(seq[1])
+        w = seq[0].weight.detach().double().cpu()   # (cout, cin, 3, 3)
+        rows = []
+        for py in (0, 1):
+            for px in (0, 1):
+                acc = sum(w[:, :, ky, kx] @ cpar[((py + ky - 1) & 1) * 2 + ((px + kx - 1) & 1)] for ky in range(3) for kx in range(3))
+                rows.append(torch.relu(s_.double().cpu() * acc + t_.double().cpu()))
+        return torch.stack(rows)
+    chain.append((pstep(neck.conv_0, chain[8][0]), pstep(neck.conv_1, chain[8][1])))
     return chain
 
 
@@ -111,6 +125,7 @@ class DensePlan:
         chain = active_tile_constants(neck)
         self.act_const = [v.float().to(device).contiguous() for v in chain[:8]]
         self.act_const.append((chain[8][0].float().to(device).contiguous(), chain[8][1].float().to(device).contiguous()))
+        self.act_const.append((chain[9][0].float().to(device).contiguous(), chain[9][1].float().to(device).contiguous()))
         self.b1 = [cbr(b1, 0, 1), cbr(b1, 3, 4), cbr(b1, 6, 7)]
         self.trans_0 = cbr(neck.trans_0, 0, 1)
         self.trans_1 = cbr(neck.trans_1, 0, 1)
@@ -294,22 +309,28 @@ class InferenceEngine:
         # not constant (14 / 26 / 36 % of the tiles of block 0, 46 / 54 / 68 % of block 1's on a 20 k-point scan; a 1x1 layer is
         # computed where its input was) and the rest is filled with the layer's constant.
         # ACTIVE_SLOTS: layer id -> (layer name, layer, input buffer, output buffer); ACTIVE_MASK: id -> slot of the tile mask / list
-        # (sessd_bev_tile_activity steps {0, 0, 0, 2, 0, 0, 3}); ACTIVE_SK: ids on the LDS-tiled stream-K kernel (30, min_rounds) or,
+        # (sessd_bev_tile_activity steps {0, 0, 0, 2, 0, 0, 3, 4, 0}); ACTIVE_SK: ids on the LDS-tiled stream-K kernel (30, min_rounds) or,
         # for the 1x1 layers, on the direct kernel over the list (tile_cfg, 0); the others: Winograd. Id 8 = the two transposed
         # convs as one launch over 2x2 tiles of their input (direct kernel, (tile_cfg, 0); buffers: trans_1 in, mid0 / mid1 out).
         self.active_tiles = bool(active_tiles)
         self.active_cfg = {}   # id -> (stream-K shape, min_rounds) / (30, min_rounds), chosen by autotune(); empty = dense launches
         ok = self.active_tiles and H <= 256 and W <= 192 and H % 4 == 0 and W % 8 == 0
-        self.ta = ops.TileActivity(B, H, W, [0, 0, 0, 2, 0, 0, 3], dev) if ok else None
+        self.ta = ops.TileActivity(B, H, W, [0, 0, 0, 2, 0, 0, 3, 4, 0], dev) if ok else None
         self.ACTIVE_SLOTS = {0: ("b0.0", self.dn.b0[0], self.bev, self.t["a"]), 1: ("b0.1", self.dn.b0[1], self.t["a"], self.t["b"]),
                              2: ("b0.2", self.dn.b0[2], self.t["b"], self.t["x0"]), 3: ("b1.0", self.dn.b1[0], self.t["x0"], self.h["a"]),
                              4: ("b1.1", self.dn.b1[1], self.h["a"], self.h["b"]), 5: ("b1.2", self.dn.b1[2], self.h["b"], self.h["x1"]),
                              6: ("trans_0", self.dn.trans_0, self.t["x0"], self.t["tr0"]),
                              7: ("trans_1", self.dn.trans_1, self.h["x1"], self.h["tr1"]),
-                             8: ("deconv_0+deconv_1", (self.dn.deconv_0, self.dn.deconv_1), self.h["tr1"], (self.t["mid0"], self.t["mid1"]))}
-        self.ACTIVE_MASK = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 2, 7: 5, 8: 6}
+                             8: ("deconv_0+deconv_1", (self.dn.deconv_0, self.dn.deconv_1), self.h["tr1"], (self.t["mid0"], self.t["mid1"])),
+                             9: ("conv_0+conv_1", (self.dn.conv_0, self.dn.conv_1), (self.t["mid0"], self.t["mid1"]), (self.t["o0"], self.t["o1"]))}
+        self.ACTIVE_MASK = {0: 0, 1: 1, 2: 2, 3: 3, 4: 4, 5: 5, 6: 2, 7: 5, 8: 6, 9: 7}
         self.ACTIVE_SK = (3, 6, 7)
         self.ACTIVE_PAIR = 8
+        # Id 9 (round 6) = conv_0 and conv_1 (rpn_v1.py:200-210) over the 2x2 tiles of the transposed convs' OUTPUT that can differ from
+        # their per-parity-class constants (step program {.., 3, 4, 0}: 0.69 - 0.85 of the tiles of a 20 k-point scan): two Winograd list
+        # launches (one per branch, one list), the rest of o0 / o1 filled with the (4, cout) parity constants
+        self.ACTIVE_CONV = 9
+        self.allow_active_conv = True   # autotune() may put conv_0 / conv_1 on their tile list (bench.py --no-active-conv: A/B)
         self.near_fill = True   # fill only the tiles a list-driven reader can reach where that reader is the map's only one
         self.coarse_fill = True  # ... also where the readers run on a grid twice as coarse (x0, tr0) or on the map's own list (x1): round 5
         # minimum share lengths autotune() tries for a Winograd list launch: > 0 rounds of a stream-K share (units may be cut, partial
@@ -437,9 +458,11 @@ class InferenceEngine:
         outs, vals, slots, tiles, near, kinds = [], [], [], [], [], []
         ids = list(ids)
         for l in ids:
-            if l == self.ACTIVE_PAIR:
+            if l in (self.ACTIVE_PAIR, self.ACTIVE_CONV):
+                # one constant per output parity class: 4x4 blocks behind the transposed pair, 2x2 tiles behind conv_0 / conv_1
                 for o, v in zip(self.ACTIVE_SLOTS[l][3], self.dn.act_const[l]):
-                    outs.append(o); vals.append(v); slots.append(self.ACTIVE_MASK[l]); tiles.append(4); near.append(None); kinds.append(0)
+                    outs.append(o); vals.append(v); slots.append(self.ACTIVE_MASK[l]); tiles.append(4 if l == self.ACTIVE_PAIR else 6)
+                    near.append(None); kinds.append(0)
                 continue
             nr, kind = None, 0
             if self.near_fill:
@@ -510,12 +533,12 @@ class InferenceEngine:
         self.merge_branch_convs = other.merge_branch_convs
         self.sk_ws = torch.zeros_like(other.sk_ws) if other.sk_ws is not None else None
 
-    DEFAULT_ACTIVE_CFG = {0: (1, 4), 1: (0, 1), 2: (1, 2), 3: (30, 4), 4: (1, 2), 5: (0, 1), 6: (11, 0), 7: (30, 8), 8: (4, 0)}
+    DEFAULT_ACTIVE_CFG = {0: (1, 4), 1: (0, 1), 2: (1, 2), 3: (30, 4), 4: (1, 2), 5: (0, 1), 6: (11, 0), 7: (30, 8), 8: (4, 0), 9: (0, 8)}
 
     def force_active_tiles(self, active_cfg=None):
         """The configuration autotune() ends in on MI355X, WITHOUT timing anything: the neck's 3x3 stride-1 layers on the stream-K
         Winograd kernels, the stride-2 / 1x1 layers on the LDS-tiled stream-K kernel, and every layer of ACTIVE_SLOTS over its
-        tile list with the given (kernel, minimum share) choices (default: all nine). Allocates the stream-K workspace. Used by
+        tile list with the given (kernel, minimum share) choices (default: all ten). Allocates the stream-K workspace. Used by
         __graft_entry__.smoke() and the tests, so that what the driver smokes is the kind of configuration bench.py times."""
         if self.ta is None:
             raise RuntimeError("this engine has no tile-activity program (active_tiles=False or an unsupported BEV size)")
@@ -650,7 +673,7 @@ class InferenceEngine:
             return e0.elapsed_time(e1) / n
         L4, d = self.levels[-1], self.dn
         self.ta.run(L4["indices"], L4["n"], L4["cap"])
-        pick, gain, pair_dense_t = {}, 0.0, 0.0
+        pick, gain, pair_dense_t, special_dense = {}, 0.0, 0.0, {}
         t = self.t
         for l, (name, layer, x_in, x_out) in self.ACTIVE_SLOTS.items():
             best = (None, 1e30)
@@ -673,6 +696,38 @@ class InferenceEngine:
                         best = ((cfg, 0), tt)
                 pair_dense_t = dense_t
                 if best[1] < dense_t:
+                    pick[l] = best
+                    gain += dense_t - best[1]
+                continue
+            if l == self.ACTIVE_CONV and not self.allow_active_conv:
+                continue
+            if l == self.ACTIVE_CONV:
+                # conv_0 / conv_1 over ONE list (two launches) against what enqueue() runs otherwise: the two-set full-map launch, or
+                # the two layers' own launches
+                (p0, s0, t0_), (p1, s1, t1_) = layer
+                c01 = self.tile_cfg.get("conv_0")
+                if self.merge_branch_convs and c01 in (22, 23, 24) and self.tile_cfg.get("conv_1") == c01 and self._branch_sets(c01 - 22) is not None:
+                    sets = self._branch_sets(c01 - 22)
+                    dense_t = timed(lambda: ops.conv2d_winograd_sk_sets(t["mid"], sets["upk"], 2, 128, sets["scale"], sets["shift"], True, t["o"],
+                                                                        c01 - 22, self.sk_ws, self._wgs(c01 - 22)))
+                else:
+                    dense_t = self.tune_report.get("conv_0", (None, 0.0))[1] + self.tune_report.get("conv_1", (None, 0.0))[1]
+                for shape in (0, 1):
+                    if p0.upk_sk(shape) is None or p1.upk_sk(shape) is None:
+                        continue
+                    need = int(lib.sessd_conv3x3_winograd_sk_workspace_bytes(self.B, self.H, self.W, p0.cout, shape, 0))
+                    if self.sk_ws is None or self.sk_ws.numel() < need:
+                        self.sk_ws = torch.zeros(need, dtype=torch.uint8, device=self.dev)
+                    for mr in (4, 8, 16, -1):
+                        def both(shape=shape, mr=mr):
+                            for (pc_, sc_, sh_), xi, xo in ((layer[0], x_in[0], x_out[0]), (layer[1], x_in[1], x_out[1])):
+                                ops.conv2d_winograd_sk_active(xi, pc_.upk_sk(shape), pc_.cout, sc_, sh_, True, xo, shape, self.sk_ws,
+                                                              self.ta.tile_list[m], self.ta.n_list[m:m + 1], workgroups=self._wgs(shape), min_rounds=mr)
+                        tt = timed(both)
+                        if tt < best[1]:
+                            best = ((shape, mr), tt)
+                special_dense[l] = dense_t
+                if best[0] is not None and best[1] < dense_t:
                     pick[l] = best
                     gain += dense_t - best[1]
                 continue
@@ -718,11 +773,12 @@ class InferenceEngine:
         over = overhead(sl) if pick else 0.0
         # the layers whose outputs are read by full-map launches need the constant EVERYWHERE outside their lists (trans_0 / trans_1:
         # 0.4 - 0.7 of an 18 / 9 MB map, the transposed pair: two 18 MB maps): each must pay for its own share of the fill launch
-        for l in (self.ACTIVE_PAIR, 7, 6):
+        for l in (self.ACTIVE_CONV, self.ACTIVE_PAIR, 7, 6):
             if l in pick and len(pick) > 1:
                 rest = [q for q in sl if q != l]
                 over_wo = overhead(rest)
-                g = (self.tune_report.get(self.ACTIVE_SLOTS[l][0], (None, 0.0))[1] if l != self.ACTIVE_PAIR else pair_dense_t) - pick[l][1]
+                g = (special_dense[l] if l in special_dense else
+                     self.tune_report.get(self.ACTIVE_SLOTS[l][0], (None, 0.0))[1] if l != self.ACTIVE_PAIR else pair_dense_t) - pick[l][1]
                 if over - over_wo >= g:
                     del pick[l]
                     sl, over, gain = rest, over_wo, gain - g
@@ -737,7 +793,7 @@ class InferenceEngine:
         (the best positive candidate is not re-timed: 4 rounds), anything else leaves the autotune's choice. For A/B runs of
         the two-frames-in-flight rate, which autotune()'s per-launch timing cannot see."""
         for l, (shape, mr) in list(self.active_cfg.items()):
-            if l in self.ACTIVE_SK or l == self.ACTIVE_PAIR:
+            if l in self.ACTIVE_SK or l in (self.ACTIVE_PAIR, self.ACTIVE_CONV):   # (the conv_0 / conv_1 lists are long: their share rule is the autotune's)
                 continue
             if mode == "whole":
                 self.active_cfg[l] = (shape, -1)
@@ -910,7 +966,21 @@ class InferenceEngine:
             mid0 = self._conv(tr1, d.deconv_0, t["mid0"], residual=tr0, name="deconv_0")
             mid1 = self._conv(tr1, d.deconv_1, t["mid1"], name="deconv_1")
         c01 = self.tile_cfg.get("conv_0")
-        if self.merge_branch_convs and c01 in (22, 23, 24) and self.tile_cfg.get("conv_1") == c01 and self._tuning is None \
+        if self.ACTIVE_CONV in act:
+            # conv_0 / conv_1 over the tiles that can differ from the parity-class constants: one list, one launch per branch
+            shape, mr = self.active_cfg[self.ACTIVE_CONV]
+            mc = self.ACTIVE_MASK[self.ACTIVE_CONV]
+            if self._kmarks is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            for (pc, sc, sh), xin, xout in ((d.conv_0, mid0, t["o0"]), (d.conv_1, mid1, t["o1"])):
+                ops.conv2d_winograd_sk_active(xin, pc.upk_sk(shape), pc.cout, sc, sh, True, xout, shape, self.sk_ws, self.ta.tile_list[mc],
+                                              self.ta.n_list[mc:mc + 1], workgroups=self._wgs(shape), min_rounds=mr)
+            if self._kmarks is not None:
+                e1.record()
+                self._kmarks.append(("conv_0+conv_1", e0, e1))
+            o0, o1 = t["o0"], t["o1"]
+        elif self.merge_branch_convs and c01 in (22, 23, 24) and self.tile_cfg.get("conv_1") == c01 and self._tuning is None \
                 and self.sk_ws is not None and self._branch_sets(c01 - 22) is not None:
             sets = self._branch_sets(c01 - 22)
             if self._kmarks is not None:

@@ -1535,7 +1535,8 @@ class TileActivity:
     steps: 0 = a 3x3 stride-1 layer (takes the next slot), 1 = a 3x3 stride-2 layer computed everywhere (the map halves), 2 = a
     stride-2 layer that takes a slot itself (the 2x2 tiles of its OUTPUT that hold a non-constant pixel), 3 = a stride-2 transposed
     conv on the current map whose output also receives, as a residual, a map of the last layer slot before the halving (takes a
-    slot of 2x2 tiles of its INPUT = 4x4 blocks of its output; dims = the input map);
+    slot of 2x2 tiles of its INPUT = 4x4 blocks of its output; dims = the input map), 4 = no layer: the map becomes that transposed
+    conv's OUTPUT (twice the resolution), so that a following 0 is a 3x3 layer over it (conv_0 / conv_1);
     an int n means n stride-1 layers. Per slot s: dims[s] = (h, w) of the layer, tile_mask[s] (batch, H/2, 2) int64 -- bit tx of a
     row's 128 bits = tile (ty, tx) is computed; rows beyond h/2 unused --, tile_list[s] (batch * H/2 * W/2,) int32, n_list[s]."""
 
@@ -1547,6 +1548,8 @@ class TileActivity:
         for k in steps:
             if k in (0, 3):
                 self.dims.append((h, w))
+            elif k == 4:   # the map becomes the output of the transposed conv (step 3) in front: twice the resolution, no slot
+                h, w = 2 * h, 2 * w
             else:
                 h, w = h // 2, w // 2
                 if k == 2:
@@ -1576,8 +1579,9 @@ class TileActivity:
 
     def fill(self, outs, values, layers=None, tiles=None, near=None, near_kind=None):
         """outs[i] (batch, cout, h, w) <- values[i][cout] in the tiles slot layers[i] (default i) does not compute (one launch of up
-        to 10 jobs; several outputs may share a slot: a 1x1 layer is computed where its input was). tiles[i] = 4: the output of a
-        transposed conv over the slot's 2x2 INPUT tiles -- 4x4-pixel tiles, values[i] (4, cout) per output parity class.
+        to 12 jobs; several outputs may share a slot: a 1x1 layer is computed where its input was). tiles[i] = 4: the output of a
+        transposed conv over the slot's 2x2 INPUT tiles -- 4x4-pixel tiles, values[i] (4, cout) per output parity class; tiles[i] = 6:
+        2x2-pixel tiles with such a (4, cout) table (a 3x3 layer behind the transposed convs).
         near[i] = slot of the list-driven reader of outs[i], or None: only the tiles that reader can reach are filled.
         near_kind[i]: 0 (default) a 3x3 stride-1 layer on the same tile grid; on a grid twice as coarse: 1 = the reader touches
         the map inside its listed tiles only, 2 = a 3x3 stride-2 layer over 2x2 tiles of its output."""
@@ -1593,13 +1597,13 @@ class TileActivity:
                 _req(o, torch.float32, "out"); _req(v, torch.float32, "value")
                 up = 2 if t == 4 else 1
                 assert tuple(o.shape[2:]) == (up * self.dims[l][0], up * self.dims[l][1]) and o.shape[0] == self.batch
-                assert v.numel() == (4 if t == 4 else 1) * o.shape[1]
+                assert v.numel() == (4 if t in (4, 6) else 1) * o.shape[1]   # (4, 6: one value per output parity class)
                 arr[i].out, arr[i].value, arr[i].tile_mask, arr[i].cout = o.data_ptr(), v.data_ptr(), self.tile_mask[l].data_ptr(), o.shape[1]
                 arr[i].h, arr[i].w, arr[i].mask_th, arr[i].tile = o.shape[2], o.shape[3], self.H // 2, t
                 if near[i] is not None:
                     k = int(near_kind[i])
                     dn, dl = self.dims[near[i]], self.dims[l]
-                    assert t == 2 and k in (0, 1, 2) and (dn == dl if k == 0 else (2 * dn[0], 2 * dn[1]) == tuple(dl))
+                    assert t in (2, 6) and k in (0, 1, 2) and (dn == dl if k == 0 else (2 * dn[0], 2 * dn[1]) == tuple(dl))
                     arr[i].near_mask, arr[i].near_kind = self.tile_mask[near[i]].data_ptr(), k
             self._jobs = (key, arr)
         arr = self._jobs[1]

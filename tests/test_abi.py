@@ -62,11 +62,12 @@ def test_dense_entry_points_reject_bad_shapes_before_touching_the_device():
     ptr = ctypes.addressof(one)
     assert ska(None, ptr, 4) == -1 and ska(ptr, None, 4) == -1 and ska(ptr, ptr, 0) == -1 and ska(ptr, ptr, 4, hw=15) == -1
     assert ska(ptr, ptr, 4, hw=1024, batch=32, cin=16) == -1
-    # tile activity: a stride-2 step that takes a slot needs an output of even size; at most six slots
+    # tile activity: a stride-2 step that takes a slot needs an output of even size; at most eight slots; step 4 only behind a step 3
     steps = lambda *v: (ctypes.c_int32 * len(v))(*v)
     act = lambda st, h=200, w=176: lib.sessd_bev_tile_activity(ptr, ptr, 1, 1, h, w, st, len(st), ptr, ptr, ptr, 1, None, 0, None)
-    assert act(steps(2), h=202) == -1 and act(steps(0, 0, 0, 2, 0, 0, 0, 0)) == -1 and act(steps(4)) == -1 and act(steps(3), w=192) == -1
-    assert lib.sessd_fill_inactive_tiles(None, 11, 1, None) == -1
+    assert act(steps(2), h=202) == -1 and act(steps(0, 0, 0, 2, 0, 0, 0, 0, 0)) == -1 and act(steps(4)) == -1 and act(steps(0, 4)) == -1 and act(steps(3), w=192) == -1
+    assert act(steps(3, 4, 0), h=200, w=100) == -1   # the doubled map must fit the kernel's pixel rows
+    assert lib.sessd_fill_inactive_tiles(None, 13, 1, None) == -1
     # Winograd stream-K over weight sets: the batch must split evenly
     assert lib.sessd_conv3x3_winograd_sk_sets(None, 3, 2, 128, 8, 8, None, None, 128, None, None, 1, None, None, 0, 0, 8, None) == -1
     assert lib.sessd_conv3x3_winograd_sk_sets(None, 2, 2, 128, 7, 8, None, None, 128, None, None, 1, None, None, 0, 0, 8, None) == -1

@@ -11,11 +11,16 @@ import torch.nn.functional as F
 
 def masks(nc0, steps):
     """nc0 (h, w) bool: pixels that hold a site. Returns the slots' tile masks (2-D bool) in step order; the rule of
-    csrc/dense_active.hip (steps 0 / 1 / 2 / 3 as sessd_bev_tile_activity takes them)."""
+    csrc/dense_active.hip (steps 0 / 1 / 2 / 3 / 4 as sessd_bev_tile_activity takes them)."""
     nc = nc0.copy()
     per, zero_input, last_layer, keep = [], True, None, None
     for k in steps:
         h, w = nc.shape
+        if k == 4:
+            # the map becomes the output of the transposed conv in front (the last slot): non-constant = the 4x4 blocks of its tiles
+            nc = per[-1].repeat(4, 0).repeat(4, 1)
+            zero_input, last_layer, keep = False, None, None
+            continue
         if k == 3:
             q = np.pad(nc, ((0, 2), (0, 2)))
             tm = np.zeros((h // 2, w // 2), bool)
@@ -111,8 +116,9 @@ def test_what_the_rule_leaves_out_is_the_constant():
               torch.randn(C0, generator=g, dtype=torch.float64) * 0.3)
         db = (torch.randn(C1, C0, 3, 3, generator=g, dtype=torch.float64) / 5, 0.5 + torch.rand(C0, generator=g, dtype=torch.float64),
               torch.randn(C0, generator=g, dtype=torch.float64) * 0.3)
-        m = masks(nc0, [0, 0, 0, 2, 0, 0, 3])
-        assert len(m) == 7
+        m = masks(nc0, [0, 0, 0, 2, 0, 0, 3, 4, 0])
+        assert len(m) == 8 and m[7].shape == (H // 2, W // 2)
+        cv0, cv1 = _layer(g, C0, C0, 3), _layer(g, C0, C0, 3)   # conv_0 / conv_1 behind the transposed convs (rpn_v1.py:200-210)
         # the dense chain
         a = _cbr(x, b0[0]); b = _cbr(a, b0[1]); x0 = _cbr(b, b0[2])
         ha = _cbr(x0, b1[0], 2); hb = _cbr(ha, b1[1]); x1 = _cbr(hb, b1[2])
@@ -142,6 +148,21 @@ def test_what_the_rule_leaves_out_is_the_constant():
                     err = (y[0, :, py::2, px::2] - cv[py * 2 + px][:, None, None]).abs().amax(0)
                     o = out[py::2, px::2]
                     assert float(err[o].max() if o.any() else 0.0) < 1e-12, (trial, what, py, px)
+        # conv_0 / conv_1 over the transposed convs' outputs: outside the slot's 2x2 tiles the output is one constant per parity class
+        def _pconst(layer, cpar):
+            w, s_, t_ = layer
+            return torch.stack([torch.relu(s_ * sum(w[:, :, ky, kx] @ cpar[((py + ky - 1) & 1) * 2 + ((px + kx - 1) & 1)]
+                                                     for ky in range(3) for kx in range(3)) + t_) for py in (0, 1) for px in (0, 1)])
+        out2 = ~_up(m[7], 2)
+        for y, layer, cpar, what in ((_cbr(mid0, cv0), cv0, cda, "conv_0"), (_cbr(mid1, cv1), cv1, cdb, "conv_1")):
+            cv = _pconst(layer, cpar)
+            for py in (0, 1):
+                for px in (0, 1):
+                    err = (y[0, :, py::2, px::2] - cv[py * 2 + px][:, None, None]).abs().amax(0)
+                    o = out2[py::2, px::2]
+                    assert float(err[o].max() if o.any() else 0.0) < 1e-12, (trial, what, py, px)
+        if trial == 2:
+            assert float(out2.float().mean()) > 0.05
         if trial == 2:
             # the rule is not trivially "everything" (on a 96 x 112 map the border ring is a tenth of the tiles)
             assert skipped[0] > 0.9 and skipped[2] > 0.5 and skipped[5] > 0.1 and float(out.float().mean()) > 0.1, (skipped, float(out.float().mean()))
@@ -163,7 +184,7 @@ def test_the_engine_constants_are_this_chain():
             mod.running_var.copy_(0.5 + torch.rand(mod.num_features, generator=g))
     neck = model.neck.double().eval()
     chain = active_tile_constants(neck)
-    assert len(chain) == 9 and chain[8][0].shape == (4, 128)
+    assert len(chain) == 10 and chain[8][0].shape == (4, 128) and chain[9][0].shape == (4, 128)
     S = 12
     def on_constant(seq, ci, bi, c, pad=False):
         x = c[None, :, None, None].expand(1, -1, S, S).contiguous()
@@ -190,6 +211,17 @@ def test_the_engine_constants_are_this_chain():
             for px in (0, 1):
                 v = y[0, :, 6 + py, 6 + px] + (chain[6] if which == 0 else 0.0)
                 assert torch.allclose(chain[8][which][py * 2 + px], v, rtol=2e-6, atol=2e-6), (which, py, px)
+    # conv_0 / conv_1 on a map that holds the transposed convs' parity-class constants: the modules' own arithmetic, away from the border
+    for which, blk in ((0, neck.conv_0), (1, neck.conv_1)):
+        x = torch.zeros(1, 128, 2 * S, 2 * S, dtype=torch.float64)
+        for py in (0, 1):
+            for px in (0, 1):
+                x[0, :, py::2, px::2] = chain[8][which][py * 2 + px][:, None, None]
+        with torch.no_grad():
+            y = torch.relu(blk[1](blk[0](x)))
+        for py in (0, 1):
+            for px in (0, 1):
+                assert torch.allclose(chain[9][which][py * 2 + px], y[0, :, 6 + py, 6 + px], rtol=2e-6, atol=2e-6), (which, py, px)
 
 
 def test_the_gpu_tests_use_the_same_rule():
@@ -198,7 +230,8 @@ def test_the_gpu_tests_use_the_same_rule():
     import test_dense_active_gpu as G
     rng = np.random.RandomState(11)
     idx = G._sites(5, 2, 400)
-    for steps in (3, [0, 0, 0, 1, 0, 0], [0, 0, 0, 2, 0, 0], [2, 0], [0, 0, 0, 2, 0, 0, 3], [0, 1, 3], [2, 3], [0, 2, 3]):
+    for steps in (3, [0, 0, 0, 1, 0, 0], [0, 0, 0, 2, 0, 0], [2, 0], [0, 0, 0, 2, 0, 0, 3], [0, 1, 3], [2, 3], [0, 2, 3],
+                  [0, 0, 0, 2, 0, 0, 3, 4, 0], [2, 3, 4, 0]):
         want = G._masks_numpy(idx, 2, steps)
         st = [0] * steps if isinstance(steps, int) else steps
         for b in range(2):

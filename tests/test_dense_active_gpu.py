@@ -47,6 +47,10 @@ def _masks_numpy(idx, batch, steps):
         last_layer, keep = None, None
         for k in steps:
             h, w = nc.shape
+            if k == 4:   # the output of the transposed conv in front: the 4x4 blocks of its tiles, twice the resolution
+                nc = per[-1].reshape(h // 2, w // 2).repeat(4, 0).repeat(4, 1)
+                zero_input, last_layer, keep = False, None, None
+                continue
             p = np.pad(nc, 1)
             if k == 3:
                 q = np.pad(nc, ((0, 2), (0, 2)))
@@ -94,7 +98,8 @@ def _masks_numpy(idx, batch, steps):
 
 @pytest.mark.parametrize("batch,steps", [(1, 3), (3, 3), (1, [0, 0, 0, 1, 0, 0]), (2, [0, 0, 0, 1, 0, 0]), (1, [0, 0, 0, 2, 0, 0]),
                                          (3, [0, 0, 0, 2, 0, 0]), (2, [2, 0]), (1, [0, 0, 0, 2, 0, 0, 3]), (3, [0, 0, 0, 2, 0, 0, 3]),
-                                         (2, [0, 1, 3]), (1, [2, 3])])
+                                         (2, [0, 1, 3]), (1, [2, 3]), (1, [0, 0, 0, 2, 0, 0, 3, 4, 0]), (2, [0, 0, 0, 2, 0, 0, 3, 4, 0]),
+                                         (1, [2, 3, 4, 0])])
 def test_tile_masks_and_lists(dev, batch, steps):
     idx = _sites(1, batch, 1600 if isinstance(steps, int) else 500)
     ta = ops.TileActivity(batch, H, W, steps, dev)
@@ -114,13 +119,18 @@ def test_tile_masks_and_lists(dev, batch, steps):
             assert np.array_equal(tm[b], want[b][l]), (l, b)
         assert nl[l] == len(ref)
         assert np.array_equal(tl[l, :nl[l]], ref)     # ascending (image, tile): deterministic order
-    if ta.n_slots >= 3:
+    st = [0] * steps if isinstance(steps, int) else steps
+    if ta.n_slots >= 3 and st[:3] == [0, 0, 0]:
         assert 0.05 < nl[0] / (batch * (H // 2) * (W // 2)) < 0.6 and nl[0] < nl[1] < nl[2]
     if ta.n_slots == 5:
         assert ta.dims[3] == (H // 2, W // 2) and nl[3] < nl[4] <= batch * (H // 4) * (W // 4)
-    if ta.n_slots == 7:   # the transposed convs' slot: at least what the layer before them computed
+    if st == [2, 3, 4, 0]:   # stride-2 slot, the pair's slot, conv_0 / conv_1 behind the pair: back on the first resolution
+        assert ta.dims == [(H // 2, W // 2), (H // 2, W // 2), (H, W)] and 4 * nl[1] <= nl[2] <= batch * (H // 2) * (W // 2)
+    if ta.n_slots >= 7:   # the transposed convs' slot: at least what the layer before them computed
         assert ta.dims[6] == (H // 2, W // 2) and nl[5] <= nl[6] <= batch * (H // 4) * (W // 4)
-    if ta.n_slots >= 6:   # the stride-2 layer's own slot: fewer tiles than the layer after it computes
+    if ta.n_slots == 8:   # conv_0 / conv_1 behind them (steps 4, 0): back on the first resolution, at least the 4 tiles of every pair tile
+        assert ta.dims[7] == (H, W) and 4 * nl[6] <= nl[7] <= batch * (H // 2) * (W // 2)
+    if ta.n_slots >= 6 and st[:6] == [0, 0, 0, 2, 0, 0]:   # the stride-2 layer's own slot: fewer tiles than the layer after it computes
         assert ta.dims[3] == ta.dims[4] == (H // 2, W // 2) and nl[3] < nl[4] < nl[5] <= batch * (H // 4) * (W // 4)
 
 
@@ -405,6 +415,81 @@ def test_direct_kernels_over_tile_lists(dev, batch, cfg):
     frac = [float(ta.n_list[s]) / (batch * (ta.dims[s][0] // 2) * (ta.dims[s][1] // 2)) for s in range(3)]
     print("computed tile fractions", [round(f, 3) for f in frac])
     assert frac[0] < 0.6 and frac[2] < 1.0
+
+
+@pytest.mark.parametrize("batch,shape,min_rounds", [(1, 0, 8), (1, 1, 4), (2, 0, -1), (1, 1, -1)])
+def test_convs_behind_the_transposed_pair_over_their_tile_list(dev, batch, shape, min_rounds):
+    """rpn_v1.py:200-210 (conv_0 / conv_1) over the tile list of step program {.., 3, 4, 0} (round 6): the inputs are the transposed
+    convs' outputs, constant PER OUTPUT PARITY CLASS outside the 4x4 blocks of the pair's tiles; a 2x2-output tile of the conv is
+    computed iff its 4x4 patch touches such a block (or lies on the border ring), the rest of its output is filled with the layer's
+    own parity-class constants (sessd_fill_tiles_job_t.tile = 6). Computed pixels against the full-map launch of the same kernel
+    family, everything against torch float64 on the same input."""
+    C0, C1 = 128, 256
+    idx = _sites(71 + batch, batch, 400)
+    x = torch.zeros(batch, C0, H, W)
+    x[idx[:, 0], :, idx[:, 2], idx[:, 3]] = torch.randn(len(idx), C0, generator=torch.Generator().manual_seed(6))
+    x = x.to(dev)
+    g = torch.Generator().manual_seed(23)
+    def mk(ci, co, k):
+        return (torch.randn(co, ci, k, k, generator=g) / (k * ci ** 0.5), 0.5 + torch.rand(co, generator=g), torch.randn(co, generator=g) * 0.3)
+    l0, l1, tr0, tr1 = mk(C0, C0, 3), mk(C0, C1, 3), mk(C0, C0, 1), mk(C1, C1, 1)
+    dwa = (torch.randn(C1, C0, 3, 3, generator=g) / (3 * C1 ** 0.5), 0.5 + torch.rand(C0, generator=g), torch.randn(C0, generator=g) * 0.3)
+    dwb = (torch.randn(C1, C0, 3, 3, generator=g) / (3 * C1 ** 0.5), 0.5 + torch.rand(C0, generator=g), torch.randn(C0, generator=g) * 0.3)
+    cv0, cv1 = mk(C0, C0, 3), mk(C0, C0, 3)
+    def const(layer, c):
+        w_, sc_, sh_ = layer
+        return torch.relu(sc_.double() * (w_.double().sum((2, 3)) @ c) + sh_.double())
+    def dconst(layer, c):
+        w_, sc_, sh_ = layer
+        K = {0: [1], 1: [0, 2]}
+        return torch.stack([torch.relu(sc_.double() * (c @ sum(w_.double()[:, :, ky, kx] for ky in K[py] for kx in K[px])) + sh_.double())
+                            for py in (0, 1) for px in (0, 1)])
+    def pconst(layer, cpar):
+        w_, sc_, sh_ = layer
+        return torch.stack([torch.relu(sc_.double() * sum(w_.double()[:, :, ky, kx] @ cpar[((py + ky - 1) & 1) * 2 + ((px + kx - 1) & 1)]
+                                                             for ky in range(3) for kx in range(3)) + sh_.double()) for py in (0, 1) for px in (0, 1)])
+    c0 = const(l0, torch.zeros(C0, dtype=torch.float64)); c1 = const(l1, c0)
+    ct0, ct1 = const(tr0, c0), const(tr1, c1)
+    cda, cdb = dconst(dwa, ct1) + ct0[None], dconst(dwb, ct1)
+    cc0, cc1 = pconst(cv0, cda), pconst(cv1, cdb)
+    f32 = lambda v: v.float().to(dev).contiguous()
+    dv = lambda layer: (layer[1].to(dev), layer[2].to(dev))
+    ta = ops.TileActivity(batch, H, W, [0, 2, 3, 4, 0], dev)
+    assert ta.n_slots == 4 and ta.dims[3] == (H, W)
+    ta.run(torch.from_numpy(idx).to(dev), torch.tensor([len(idx)], dtype=torch.int32, device=dev), len(idx))
+    # the inputs of the stage through the dense kernels (their list forms are tested above)
+    p0, p1 = ops.pack_conv2d(l0[0].to(dev)), ops.pack_conv2d(l1[0].to(dev), 2)
+    x0 = ops.conv2d(x, p0, *dv(l0), True, None, None, 20)
+    x1 = ops.conv2d(x0, p1, *dv(l1), True)
+    pt0, pt1 = ops.pack_conv2d(tr0[0].to(dev)), ops.pack_conv2d(tr1[0].to(dev))
+    d_t0 = ops.conv2d(x0, pt0, *dv(tr0), True, None, None, 4)
+    d_t1 = ops.conv2d(x1, pt1, *dv(tr1), True, None, None, 4)
+    pa, pb = ops.pack_deconv2d_s2(dwa[0].to(dev)), ops.pack_deconv2d_s2(dwb[0].to(dev))
+    mid0, mid1 = torch.empty(batch, C0, H, W, device=dev), torch.empty(batch, C0, H, W, device=dev)
+    ops.deconv2d_s2_pair(d_t1, pa, pb, *dv(dwa), *dv(dwb), True, mid0, mid1, residual_a=d_t0, tile_cfg=4)
+    pc0, pc1 = ops.pack_conv2d(cv0[0].to(dev)), ops.pack_conv2d(cv1[0].to(dev))
+    ws = torch.zeros(int(ops.lib.sessd_conv3x3_winograd_sk_workspace_bytes(batch, H, W, C0, shape, 0)), dtype=torch.uint8, device=dev)
+    full0 = ops.conv2d(mid0, pc0, *dv(cv0), True, None, None, 22 + shape, workspace=ws)
+    full1 = ops.conv2d(mid1, pc1, *dv(cv1), True, None, None, 22 + shape, workspace=ws)
+    o0 = torch.full((batch, C0, H, W), float("nan"), device=dev)
+    o1 = torch.full((batch, C0, H, W), float("nan"), device=dev)
+    ta.fill([o0, o1], [f32(cc0), f32(cc1)], layers=[3, 3], tiles=[6, 6])
+    for pc, layer, xin, out in ((pc0, cv0, mid0, o0), (pc1, cv1, mid1, o1)):
+        ops.conv2d_winograd_sk_active(xin, pc.upk_sk(shape), C0, *dv(layer), True, out, shape, ws, ta.tile_list[3], ta.n_list[3:4],
+                                      min_rounds=min_rounds)
+    torch.cuda.synchronize()
+    tm = ta.mask_bool(3).to(dev).view(batch, 1, H // 2, W // 2).repeat_interleave(2, 2).repeat_interleave(2, 3)
+    for got, full, layer, xin, what in ((o0, full0, cv0, mid0, "conv_0"), (o1, full1, cv1, mid1, "conv_1")):
+        assert torch.isfinite(got).all(), "%s: a pixel neither filled nor computed" % what
+        ref = float(full.abs().max())
+        m = tm.expand_as(got)
+        assert float((got[m] - full[m]).abs().max()) <= 2e-6 * ref, "%s: a computed pixel differs from the full-map launch" % what
+        assert float((got - full).abs().max()) <= 1e-5 * ref, what       # filled pixels: the parity-class constants
+        _check_first_hand(got, _torch_cbr(xin, *layer), "%s over the transposed pair's output (list + parity fill) vs torch" % what)
+    frac = float(ta.n_list[3]) / (batch * (H // 2) * (W // 2))
+    pair = float(ta.n_list[2]) / (batch * (H // 4) * (W // 4))
+    print("computed tile fractions: pair %.3f, convs behind it %.3f" % (pair, frac))
+    assert pair < frac < 1.0
 
 
 @pytest.mark.parametrize("batch", [1, 2])

@@ -463,7 +463,7 @@ def test_frames_in_flight_on_cu_sets_equal_the_oracle(dev, model, state):
     ncu = torch.cuda.get_device_properties(dev).multi_processor_count // 2
     for e in engines:
         assert e.cu_budget == ncu and e._wgs(0) == ncu and e._wgs(1) == 2 * ncu and e._wgs(2) == ncu
-        assert sorted(e.active_cfg) == list(range(9)) and all(v[1] == -1 for l, v in e.active_cfg.items() if l in (0, 1, 2, 4, 5))
+        assert sorted(e.active_cfg) == list(range(10)) and all(v[1] == -1 for l, v in e.active_cfg.items() if l in (0, 1, 2, 4, 5))
     eager = []
     for i, f in enumerate(frames[:4]):
         with torch.cuda.stream(streams[i]):

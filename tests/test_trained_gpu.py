@@ -26,7 +26,7 @@ def test_training_lowers_the_loss_and_the_trained_engine_equals_the_oracle(dev):
     cmp = out["engine_vs_oracle_strict"]
     assert cmp["ok"] and cmp["frames"] == 12, cmp
     assert max(out["detected_box_sizes_max_m"]) < 20.0
-    assert len(out["active_tile_layers_of_the_engine"]) == 9
+    assert len(out["active_tile_layers_of_the_engine"]) == 10
     # both detection sets through the KITTI evaluation: the same AP
     for k, v in out["ap_abs_difference"].items():
         assert max(v) <= 0.1, (k, v, out["ap_engine"], out["ap_oracle"])
