@@ -16,9 +16,10 @@ timeout -k 5 600 python bench.py --weights $W --streams 1 --no-train-step > $O/b
 timeout -k 5 600 python bench.py --weights $W --streams 2 --cu-split none --no-train-step > $O/bench_two_plain_streams.json 2>$O/bench_two_plain_streams.err; echo "two plain streams rc $?"
 timeout -k 5 600 python bench.py --stress --no-train-step > $O/bench_stress_batch8.json 2>$O/bench_stress_batch8.err; echo "stress rc $?"
 timeout -k 5 600 python bench.py --random-weights --no-train-step > $O/bench_random_weights.json 2>$O/bench_random_weights.err; echo "random rc $?"
+timeout -k 5 600 python bench.py --weights $W --no-train-step --no-active-conv > $O/bench_4_in_flight_full_map_convs.json 2>$O/bench_4_in_flight_full_map_convs.err; echo "4 in flight, conv_0 / conv_1 as the full-map launch rc $?"
 python - <<'PY'
 import json
-for n in ("driver_command", "default_trains_itself", "4_in_flight", "1stream", "two_plain_streams", "stress_batch8", "random_weights"):
+for n in ("driver_command", "default_trains_itself", "4_in_flight", "4_in_flight_full_map_convs", "1stream", "two_plain_streams", "stress_batch8", "random_weights"):
     try:
         d = json.loads(open("gpurun_out/r6z/bench_%s.json" % n).read().strip().splitlines()[-1])
         c, r = d["config"], d.get("roofline") or {}
@@ -44,6 +45,27 @@ for cfg in 4inflight 1stream stress; do
   python $R/scripts/prof_summary.py $DB $F 60 > $O/trace_$cfg.txt; head -3 $O/trace_$cfg.txt | cut -c1-150
   rm -rf $O/p_$cfg
 done
+# counter passes of whole frames of the FIXED configuration (the same launches in every pass), CU-masked half and whole chip
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA"
+for mode in half whole; do
+  [ $mode = half ] && H="--cu-half" || H=""
+  files=""; i=0
+  for set in "$SQ1" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    D=$O/frame_pmc_${mode}_$i
+    rm -rf $D
+    timeout -k 5 300 rocprofv3 --kernel-trace --pmc $set -d $D -o p --output-format csv -- python $R/scripts/sparse_probe.py --frames 3 --fixed $H > $O/frame_pmc_${mode}_$i.log 2>&1
+    echo "frame pmc ($mode) pass $i rc $?"
+    f=$(find $D -name "*counter_collection.csv" | head -1)
+    files="$files $f"
+    [ $i = 1 ] && tr=$(find $D -name "*kernel_trace.csv" | head -1)
+  done
+  python $R/scripts/pmc_compact.py "WHOLE FRAME, batch 1, the engine on $mode chip, FIXED configuration (engine.force_active_tiles(), whole-unit list shares: scripts/sparse_probe.py --fixed), three separate --pmc passes over the same launches" $files --trace $tr --tail 400 > $O/frame_pmc_$mode.txt
+  grep "fixed configuration\|stages\|sites\|active_tile_fractions" $O/frame_pmc_${mode}_1.log | sed 's/^/# /' >> $O/frame_pmc_$mode.txt
+  for i in 1 2 3; do rm -rf $O/frame_pmc_${mode}_$i; done
+done
+python $R/scripts/r6_traffic_json.py $O/frame_pmc_half.txt $O/frame_pmc_whole.txt > $O/r6_wino_traffic.json; grep -n "times_algorithmic\|traffic_configuration" $O/r6_wino_traffic.json
+python $R/scripts/r6_mfma_flops_json.py $O/frame_pmc_half.txt $O/frame_pmc_whole.txt > $O/r6_mfma_flops_per_frame.json; grep -n "executed_gflop_per_frame" $O/r6_mfma_flops_per_frame.json
 rm -rf $O/p_train
 timeout -k 5 400 rocprofv3 --kernel-trace --stats -d $O/p_train -o tr -- python $R/scripts/train_step_bench.py --real-loss --replays-only 40 > $O/p_train.log 2>&1
 echo "train replay rc $?"; tail -1 $O/p_train.log | cut -c1-300

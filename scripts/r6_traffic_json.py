@@ -24,36 +24,64 @@ def table(path):
     return rows
 
 
-ALG_LIST_MB = 14.0     # a list launch: input + output of the computed tiles + packed U, average of the five
-ALG_PAIR_MB = 2 * (18.02 + 18.02) + 2 * 1.05   # conv_0 + conv_1: two 128 x 200 x 176 f32 maps in, two out, two packed U
+def fractions(path):
+    """the probe's `# active_tile_fractions {...}` line (scripts/sparse_probe.py)"""
+    import ast
+    for line in open(path):
+        if line.startswith("# active_tile_fractions"):
+            return ast.literal_eval(line.split("active_tile_fractions", 1)[1].strip())
+    return {}
+
+
+def algorithmic_mb(fr):
+    """input + output of the computed tiles + packed U per Winograd launch of the frame: 128 -> 128 @200x176 (18.02 MB maps, U 1.05 MB)
+    for block 0 and conv_0 / conv_1, 256 -> 256 @100x88 (9.01 MB maps, U 4.19 MB) for b1.1 / b1.2; full maps where a layer has no list"""
+    per = {}
+    for nm in ("b0.0", "b0.1", "b0.2"):
+        per[nm] = fr.get(nm, 1.0) * 36.04 + 1.05
+    for nm in ("b1.1", "b1.2"):
+        per[nm] = fr.get(nm, 1.0) * 18.02 + 4.19
+    per["conv_0"] = per["conv_1"] = fr.get("conv_0+conv_1", 1.0) * 36.04 + 1.05
+    return per
+
+
 half, whole = table(sys.argv[1]), table(sys.argv[2])
-out = {"kernel": "conv3x3s1_winograd_sk_kernel, batch 1, the frame's six launches: five over tile lists (whole-unit shares) and the full-map launch "
-                 "of conv_0 + conv_1 (two weight sets)",
+out = {"kernel": "conv3x3s1_winograd_sk_kernel, batch 1: the frame's seven 3x3 stride-1 layers (b0.0 b0.1 b0.2 b1.1 b1.2 over tile lists; conv_0 / conv_1 "
+                 "over THEIR list since round 6 -- two launches -- or as one full-map launch of two weight sets)",
        "fetch_correction": "x2 (gfx950 rocprofv3 tallies the 128-byte requests of 16-byte-per-lane reads at 64 B; MI355X_MICROARCH.md); WRITE_SIZE as reported",
        "source": "scripts/r6_traffic_json.py over %s and %s" % tuple(sys.argv[1:3])}
-for tag, T in (("cu_half_configuration", half), ("whole_chip_configuration", whole)):
-    lists = [(k, r) for k, r in T.items() if "winograd_sk_kernel" in k and k.endswith("true>") and r["fetch_mb"] is not None and r["write_mb"] is not None]
-    pair = [(k, r) for k, r in T.items() if "winograd_sk_kernel" in k and k.endswith("false>") and r["fetch_mb"] is not None and r["write_mb"] is not None]
+for tag, T, path in (("cu_half_configuration", half, sys.argv[1]), ("whole_chip_configuration", whole, sys.argv[2])):
+    fr = fractions(path)
+    alg = algorithmic_mb(fr)
+    wino = [(k, r) for k, r in T.items() if "winograd_sk_kernel" in k and r["fetch_mb"] is not None and r["write_mb"] is not None]
+    lists = [(k, r) for k, r in wino if k.endswith("true>")]
+    pair = [(k, r) for k, r in wino if k.endswith("false>")]
+    frames = T.get("fill_multi_kernel", {}).get("n", 1)
     n_l = sum(r["n"] for _, r in lists)
     lf = sum(r["fetch_mb"] * r["n"] for _, r in lists) / n_l
     lw = sum(r["write_mb"] * r["n"] for _, r in lists) / n_l
-    pk, pr = max(pair, key=lambda kr: kr[1]["n"])
-    fm = T.get("fill_multi_kernel", {})
-    fi = T.get("fill_inactive_tiles_kernel", {})
-    avg = (5 * (lf + lw) + (pr["fetch_mb"] + pr["write_mb"])) / 6.0
-    alg = (5 * ALG_LIST_MB + ALG_PAIR_MB) / 6.0
-    out[tag] = {"list_launch": {"fetch_mb_corrected": round(lf, 2), "write_mb": round(lw, 2), "times_algorithmic": round((lf + lw) / ALG_LIST_MB, 2),
-                                "kernels": [k for k, _ in lists]},
-                "full_map_pair_launch": {"kernel": pk, "fetch_mb_corrected": pr["fetch_mb"], "write_mb": pr["write_mb"], "us_profiled": pr["us"],
-                                         "mfma_per_launch": pr["mfma"], "times_algorithmic": round((pr["fetch_mb"] + pr["write_mb"]) / ALG_PAIR_MB, 2),
-                                         "write_at_least_the_two_output_maps_36_MB": bool(pr["write_mb"] >= 36.0)},
-                "calibration": {"fill_multi_kernel_write_mb": fm.get("write_mb"), "fill_multi_kernel_known_mb": 22.3,
-                                "fill_inactive_tiles_write_mb": fi.get("write_mb")},
-                "average_over_the_six_launches_mb": round(avg, 2), "algorithmic_mb_per_launch": round(alg, 2), "times_algorithmic": round(avg / alg, 2)}
+    launches = sum(r["n"] for _, r in wino) / float(frames)
+    total_mb = sum((r["fetch_mb"] + r["write_mb"]) * r["n"] for _, r in wino) / float(frames)
+    alg_total = sum(alg.values())
+    fm, fi = T.get("fill_multi_kernel", {}), T.get("fill_inactive_tiles_kernel", {})
+    cfg = {"active_tile_fractions": fr, "winograd_launches_per_frame": round(launches, 2),
+           "list_launch": {"fetch_mb_corrected": round(lf, 2), "write_mb": round(lw, 2), "per_frame": round(n_l / float(frames), 2),
+                           "kernels": sorted(k for k, _ in lists)},
+           "calibration": {"fill_multi_kernel_write_mb": fm.get("write_mb"), "fill_multi_kernel_known_mb": 22.3,
+                           "fill_inactive_tiles_write_mb": fi.get("write_mb")},
+           "winograd_mb_per_frame": round(total_mb, 2), "algorithmic_mb_per_frame": round(alg_total, 2),
+           "average_per_launch_mb": round(total_mb / launches, 2), "algorithmic_mb_per_launch": round(alg_total / launches, 2),
+           "times_algorithmic": round(total_mb / alg_total, 2)}
+    if pair:
+        pk, pr = max(pair, key=lambda kr: kr[1]["n"])
+        cfg["full_map_pair_launch"] = {"kernel": pk, "fetch_mb_corrected": pr["fetch_mb"], "write_mb": pr["write_mb"], "us_profiled": pr["us"],
+                                       "mfma_per_launch": pr["mfma"], "write_at_least_the_two_output_maps_36_MB": bool(pr["write_mb"] >= 36.0)}
+    out[tag] = cfg
 h = out["cu_half_configuration"]
-ok = h["full_map_pair_launch"]["write_at_least_the_two_output_maps_36_MB"] and abs((h["calibration"]["fill_multi_kernel_write_mb"] or 0) - 22.3) < 1.0
+ok = abs((h["calibration"]["fill_multi_kernel_write_mb"] or 0) - 22.3) < 1.0 and \
+    h.get("full_map_pair_launch", {}).get("write_at_least_the_two_output_maps_36_MB", True)
 use = h if ok else out["whole_chip_configuration"]
-out["traffic_bytes"] = int(use["average_over_the_six_launches_mb"] * 1e6)
+out["traffic_bytes"] = int(use["average_per_launch_mb"] * 1e6)
 out["algorithmic_bytes_per_launch"] = int(use["algorithmic_mb_per_launch"] * 1e6)
 out["traffic_configuration"] = "cu_half_configuration (the timed one; WRITE_SIZE calibration holds under the CU mask)" if ok else \
     "whole_chip_configuration (the CU-half table fails the WRITE_SIZE sanity bounds: not quoted)"

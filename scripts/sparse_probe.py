@@ -73,6 +73,7 @@ for i in range(a.frames):
         e.enqueue()
 torch.cuda.synchronize()
 print("sites", e.spmiddle_algorithmic_bytes())
+print("active_tile_fractions", {k: round(v, 4) for k, v in e.active_tile_fractions().items()})
 print("stages", e.stage_times(reps=5))
 if not a.fixed:
     print("tuning", {k: (v[0] & 255, v[0] >> 8, round(v[1] * 1e3, 1)) for k, v in e.tune_report.items() if k.startswith("sparse")})
