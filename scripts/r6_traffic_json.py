@@ -11,6 +11,14 @@ import re
 import sys
 
 
+def per_frame(T):
+    """launches per frame of every kernel: the tail window of a counter pass starts inside a frame, so kernels early in the frame
+    have one launch less than the others -- frames = the largest count among the once-per-frame kernels, per kernel round(n / frames)"""
+    once = [T[k]["n"] for k in ("ssfa_fuse_head_kernel<22, 32>", "bev_tile_activity_kernel", "chain_emit_kernel", "fill_multi_kernel") if k in T]
+    frames = max(once) if once else 1
+    return frames, {k: max(1, int(round(r["n"] / float(frames)))) for k, r in T.items()}
+
+
 def table(path):
     rows = {}
     for line in open(path):
@@ -56,16 +64,16 @@ for tag, T, path in (("cu_half_configuration", half, sys.argv[1]), ("whole_chip_
     wino = [(k, r) for k, r in T.items() if "winograd_sk_kernel" in k and r["fetch_mb"] is not None and r["write_mb"] is not None]
     lists = [(k, r) for k, r in wino if k.endswith("true>")]
     pair = [(k, r) for k, r in wino if k.endswith("false>")]
-    frames = T.get("fill_multi_kernel", {}).get("n", 1)
-    n_l = sum(r["n"] for _, r in lists)
-    lf = sum(r["fetch_mb"] * r["n"] for _, r in lists) / n_l
-    lw = sum(r["write_mb"] * r["n"] for _, r in lists) / n_l
-    launches = sum(r["n"] for _, r in wino) / float(frames)
-    total_mb = sum((r["fetch_mb"] + r["write_mb"]) * r["n"] for _, r in wino) / float(frames)
+    frames, lpf = per_frame(T)
+    n_l = sum(lpf[k] for k, _ in lists)
+    lf = sum(r["fetch_mb"] * lpf[k] for k, r in lists) / n_l
+    lw = sum(r["write_mb"] * lpf[k] for k, r in lists) / n_l
+    launches = float(sum(lpf[k] for k, _ in wino))
+    total_mb = sum((r["fetch_mb"] + r["write_mb"]) * lpf[k] for k, r in wino)
     alg_total = sum(alg.values())
     fm, fi = T.get("fill_multi_kernel", {}), T.get("fill_inactive_tiles_kernel", {})
     cfg = {"active_tile_fractions": fr, "winograd_launches_per_frame": round(launches, 2),
-           "list_launch": {"fetch_mb_corrected": round(lf, 2), "write_mb": round(lw, 2), "per_frame": round(n_l / float(frames), 2),
+           "list_launch": {"fetch_mb_corrected": round(lf, 2), "write_mb": round(lw, 2), "per_frame": n_l,
                            "kernels": sorted(k for k, _ in lists)},
            "calibration": {"fill_multi_kernel_write_mb": fm.get("write_mb"), "fill_multi_kernel_known_mb": 22.3,
                            "fill_inactive_tiles_write_mb": fi.get("write_mb")},
