@@ -11,23 +11,29 @@ max 16000 voxels, batch=1") through the whole path, input points already residen
 device (<= 100 boxes). Frames shard across ranks with no data-path collective (weak scaling: every rank runs K
 frames); value = total frames / max-over-ranks wall time. By default FOUR frames are in flight per GPU: four independent
 batch-1 engines, two on each HALF of the chip (CU-masked streams, hipExtStreamCreateWithCUMask: every engine owns a hardware
-queue, its kernels are confined to its half, its persistent stream-K launches are sized for 128 CUs) -- a batch-1 frame is 44
-dependent launches of which most cannot fill 256 CUs, and a frame on half the chip pays the per-launch latency chains once while
-its arithmetic takes twice as long: 1953 frames/s against 1557 for rounds 1 - 4's two plain streams sharing the whole chip
-(`--streams 2 --cu-split none`; `--streams 1` = strictly sequential frames on the whole chip). One JSON line on rank 0, with
+queue, its kernels are confined to its half, its persistent stream-K launches are sized for 128 CUs): 1925 - 1980 frames/s against
+1557 - 1630 for rounds 1 - 4's two plain streams sharing the whole chip (`--streams 2 --cu-split none`; `--streams 1` = strictly
+sequential frames on the whole chip). THE DETECTOR IS TRAINED FIRST (round 6): the `train_step` leg -- `--pretrain-iterations`
+captured SE-SSD iterations on fresh synthetic batches -- runs before anything else and its student's weights go into the timed
+engines (`--random-weights`: rounds 1 - 5's seeded random weights; `--weights FILE`: a saved state_dict). One JSON line on rank 0:
   parity        THE TIMED CONFIGURATION held to the oracle before the clock starts: the frames of the cpu_baseline sample go
                 through the very engines that are timed (autotuned tilings, stream-K workgroup counts, captured graphs) and
-                every detection is compared with the oracle's (oracle/compare.py: identical, or identical under the oracle's
-                own LISTED near-threshold NMS decisions). A mismatch prints the line with parity.ok = false and exits 3.
-  roofline      the dominant kernel (fused-Winograd f32-MFMA 3x3 conv 128->128 @200x176, 5 launches per frame + 2 of the
-                same FLOPs at 256->256 @100x88) against the dense f32 MFMA peak: EXECUTED matrix-core FLOPs / launch time
-                measured live with HIP events on the launching stream; `traffic` = rocprofv3 FETCH_SIZE/WRITE_SIZE (profiles/)
+                every detection is compared with the oracle's under oracle/compare.py's STRICT rule (trained weights: 2 mm / 2 mrad
+                absolute, scores 1e-3; identical, or identical under the oracle's own LISTED near-threshold NMS decisions; the
+                synthetic rule only with --random-weights). A mismatch prints the line with parity.ok = false and exits 3.
+                `config` carries the verdict as scalars: parity_ok / parity_matched / parity_frames / parity_rule.
+  roofline      the dominant kernel (fused-Winograd f32-MFMA 3x3 conv: the seven 3x3 stride-1 SSFA layers, all over tile lists)
+                against the WHOLE CHIP's dense f32 MFMA peak (157.3 TFLOP/s): EXECUTED matrix-core FLOPs / launch time measured
+                live with HIP events on the launching stream; frac_of_cu_set_peak = against the launch's own 128 CUs;
+                frac_chip_timed_region = executed GFLOP per step / ms_per_step / peak: what all frames in flight achieve together;
+                `traffic` = rocprofv3 FETCH_SIZE / WRITE_SIZE of a fixed configuration (profiles/r6_wino_traffic.json)
   roofline_spmiddle / stages_ms_eager   SURVEY 8(d)'s HBM figure for the sparse stage and per-stage times (informational)
-  value_sequential   the same engines, strictly one frame at a time (informational)
+  value_sequential   one engine on the whole chip, strictly one frame at a time (informational)
   host_io       PCIe-inclusive rate: pinned host points in, host detections out, pipelined (sessd_hip/runner.py) and the
                 strictly sequential latency mode (informational, never `value`)
   cpu_baseline  the CPU oracle pipeline (port of the reference path: the reference itself cannot run here) on a
                 bounded sample of the same frames, on this box's host cores.
+  train_step    BASELINE configs[2]: ms per replay of the captured SE-SSD training iteration (informational)
 `--stress` = BASELINE configs[4] (200k points, 64k voxels, batch 8), `--batch B` = B frames per step.
 """
 import argparse
@@ -250,6 +256,16 @@ def parity_gate(args, engines, streams, frames, sample):
                 try:
                     r = compare_detections(got, want, dbg, rule=rule)
                     rep["identical" if not r["flipped"] else "flipped_near_threshold"] += 1
+                    if not r["flipped"] and len(want["scores"]):
+                        # how far inside the tolerance the identical frames are (boxes: metres / radians, absolute; scores: relative)
+                        gb, wb = np.asarray(got["box3d_lidar"], np.float64).reshape(-1, 7), np.asarray(want["box3d_lidar"], np.float64).reshape(-1, 7)
+                        dyaw = np.abs(gb[:, 6] - wb[:, 6]) % (2 * np.pi)
+                        rep["max_centre_abs_diff_m"] = max(rep.get("max_centre_abs_diff_m", 0.0), float(np.abs(gb[:, :3] - wb[:, :3]).max()))
+                        rep["max_size_abs_diff_m"] = max(rep.get("max_size_abs_diff_m", 0.0), float(np.abs(gb[:, 3:6] - wb[:, 3:6]).max()))
+                        rep["max_yaw_abs_diff_rad"] = max(rep.get("max_yaw_abs_diff_rad", 0.0), float(np.minimum(dyaw, 2 * np.pi - dyaw).max()))
+                        ws_ = np.asarray(want["scores"], np.float64)
+                        rep["max_score_rel_diff"] = max(rep.get("max_score_rel_diff", 0.0),
+                                                        float((np.abs(np.asarray(got["scores"], np.float64) - ws_) / np.maximum(ws_, 1e-6)).max()))
                 except AssertionError as ex:
                     rep["mismatch"].append({"engine": ei, "frame": fi, "slot": slot, "why": str(ex)[:300]})
                 if bev is not None and ei == 0 and rep["bev_rel_err"] is None:
@@ -580,7 +596,8 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
             # the gate's verdict as SCALAR config keys: what the driver's record keeps
             out["config"].update(parity_ok=bool(parity["ok"]), parity_matched=int(parity["matched"]), parity_frames=int(parity["frames"]),
                                  parity_identical=int(parity["identical"]), parity_rule=parity["rule_set"],
-                                 parity_bev_rel_err=parity["bev_rel_err"])
+                                 parity_bev_rel_err=parity["bev_rel_err"], parity_max_centre_abs_diff_m=parity.get("max_centre_abs_diff_m"),
+                                 parity_max_score_rel_diff=parity.get("max_score_rel_diff"))
     if rank == 0 and on_gpu:
         # ---- the same engines strictly one frame at a time (informational; the driver's record then holds both figures)
         seq_eng, seq_st = eng, streams[0]
