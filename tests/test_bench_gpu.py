@@ -61,3 +61,29 @@ def test_two_ranks_each_hold_their_engines_to_the_oracle(streams):
     assert out["n_gpus"] == 2 and out["config"]["records_gathered"] == world * steps and out["config"]["rccl_ranks_seen"] == 2
     assert "cpu_baseline" not in out   # the baseline figure stays on the N = 1 line
     json.dumps(out)
+
+
+def test_two_ranks_train_first_and_gate_strictly():
+    """the driver's command at N > 1 (`bench.py --gpus N --steps K --warmup W`, no other flag): every rank trains the detector in its
+    own process BEFORE the process group exists (the captured iteration of a one-rank job: no SyncBN, one graph), then joins the
+    group, builds its engines on CU-masked streams, and gates them under the STRICT rule on a sample of its own frames"""
+    world, steps = 2, 8
+    argv = ["--gpus", str(world), "--steps", str(steps), "--warmup", "2", "--cpu-frames", "3", "--no-roofline", "--no-host-io", "--no-sequential",
+            "--pool", "4", "--spinup-seconds", "0.1", "--train-replays", "2"]
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, argv, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0, p.exitcode
+    out = res[0]
+    assert res[1] is None and "error" not in out and "exit" not in out, (res[1], out)
+    cfg, par = out["config"], out["parity"]
+    assert cfg["weights"] == "trained_in_process" and cfg["parity_rule"] == "strict" and cfg["parity_ok"], cfg
+    assert par["ranks"] == 2 and par["frames"] == 2 * 3 * 4 and par["matched"] == par["frames"], par
+    assert out["train_step"]["pretrain_iterations"] == 300 and out["train_step"]["sparse_overflow_flag"] == 0
+    assert cfg["frames_in_flight"] == 4 and cfg["cu_sets"] == 2 and cfg["records_gathered"] == world * steps and cfg["rccl_ranks_seen"] == 2
