@@ -4,7 +4,6 @@ Non-dict values (the box-coder object, a logging.Logger) survive untouched insid
 KeyError / AttributeError exactly like the reference's ConfigDict.__missing__."""
 import os.path as osp
 import sys
-from importlib import import_module
 
 
 class ConfigDict(dict):
@@ -40,68 +39,63 @@ class ConfigDict(dict):
         return {k: (v.to_dict() if isinstance(v, ConfigDict) else v) for k, v in self.items()}
 
 
-class Config(object):
-    @staticmethod
-    def fromfile(filename):
-        filename = osp.abspath(osp.expanduser(filename))
-        if not osp.isfile(filename):
-            raise FileNotFoundError('file "{}" does not exist'.format(filename))
-        if not filename.endswith(".py"):
-            raise IOError("Only py type is supported by this mirror")
-        module_name = osp.basename(filename)[:-3]
-        if "." in module_name:
-            raise ValueError("Dots are not allowed in config file path.")
-        config_dir = osp.dirname(filename)
-        sys.path.insert(0, config_dir)
-        try:
-            sys.modules.pop(module_name, None)
-            mod = import_module(module_name)
-        finally:
-            sys.path.pop(0)
-        cfg_dict = {name: value for name, value in mod.__dict__.items() if not name.startswith("__")}
-        return Config(cfg_dict, filename=filename)
+class Config:
+    """The reference's config object as far as this path uses it (reference surface: det3d/torchie/utils/config.py:59-160 --
+    `Config.fromfile(path)`, attribute and item access into the file's top-level names, `.filename`, `.text`, `len`, iteration,
+    `.get`). A config file is plain Python: it is executed with runpy and its public names become the tree."""
+
+    _OWN = ("_cfg_dict", "_filename", "_text")
 
     def __init__(self, cfg_dict=None, filename=None):
-        if cfg_dict is None:
-            cfg_dict = dict()
-        elif not isinstance(cfg_dict, dict):
+        if cfg_dict is not None and not isinstance(cfg_dict, dict):
             raise TypeError("cfg_dict must be a dict, but got {}".format(type(cfg_dict)))
-        super().__setattr__("_cfg_dict", ConfigDict(cfg_dict))
-        super().__setattr__("_filename", filename)
         text = ""
         if filename:
-            with open(filename, "r") as f:
-                text = f.read()
-        super().__setattr__("_text", text)
+            with open(filename) as fh:
+                text = fh.read()
+        for name, value in zip(self._OWN, (ConfigDict(cfg_dict or {}), filename, text)):
+            object.__setattr__(self, name, value)
 
-    @property
-    def filename(self):
-        return self._filename
+    @staticmethod
+    def fromfile(filename):
+        import runpy
+        path = osp.abspath(osp.expanduser(filename))
+        if not osp.isfile(path):
+            raise FileNotFoundError('file "{}" does not exist'.format(path))
+        if not path.endswith(".py"):
+            raise IOError("Only py type is supported by this mirror")
+        if "." in osp.basename(path)[:-3]:
+            raise ValueError("Dots are not allowed in config file path.")
+        sys.path.insert(0, osp.dirname(path))   # a config may import its neighbours
+        try:
+            names = runpy.run_path(path)
+        finally:
+            sys.path.pop(0)
+        return Config({k: v for k, v in names.items() if not k.startswith("__")}, filename=path)
 
-    @property
-    def text(self):
-        return self._text
+    filename = property(lambda self: self._filename)
+    text = property(lambda self: self._text)
 
-    def __repr__(self):
-        return "Config (path: {}): {}".format(self.filename, self._cfg_dict.__repr__())
-
-    def __len__(self):
-        return len(self._cfg_dict)
-
-    def __getattr__(self, name):
+    def __getattr__(self, name):          # (only reached for names that are not the object's own)
         return getattr(self._cfg_dict, name)
 
-    def __getitem__(self, name):
-        return self._cfg_dict.__getitem__(name)
-
     def __setattr__(self, name, value):
-        self._cfg_dict.__setattr__(name, value)
+        setattr(self._cfg_dict, name, value)
+
+    def __getitem__(self, name):
+        return self._cfg_dict[name]
 
     def __setitem__(self, name, value):
-        self._cfg_dict.__setitem__(name, value)
+        self._cfg_dict[name] = value
 
     def __iter__(self):
         return iter(self._cfg_dict)
 
+    def __len__(self):
+        return len(self._cfg_dict)
+
     def get(self, key, default=None):
         return self._cfg_dict.get(key, default)
+
+    def __repr__(self):
+        return "Config (path: {}): {!r}".format(self._filename, self._cfg_dict)
