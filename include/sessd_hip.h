@@ -517,10 +517,15 @@ int sessd_conv3x3_winograd_sk_sets(const float* in, int batch, int nsets, int ci
  *                               given as HOST steps (0 = stride-1 layer taking the next slot, 1 = stride-2 layer computed
  *                               everywhere, 2 = stride-2 layer that takes a slot itself -- the 2x2 tiles of ITS output with a
  *                               non-constant pixel, 3 = stride-2 transposed conv on the current map with a residual of the
- *                               resolution before the halving, a slot of 2x2 tiles of its INPUT: rpn_v1.py:135-160 + 224 is
- *                               {0, 0, 0, 2, 0, 0, 3}; <= 7 slots), from the (image, z, y, x) rows of the last sparse level
- *   sessd_fill_inactive_tiles   out[b][co][tile] = value[co] (the layer's constant, computed by the host from the folded weights)
- *                               in the tiles nobody computes, up to 10 layers per launch
+ *                               resolution before the halving, a slot of 2x2 tiles of its INPUT, 4 = no layer: the map
+ *                               becomes the OUTPUT of the step-3 transposed conv in front of it -- twice the resolution,
+ *                               non-constant in the 4x4 blocks of that step's tiles, constant PER OUTPUT PARITY CLASS elsewhere --
+ *                               so that a following 0 is a 3x3 layer behind the transposed convs: rpn_v1.py:135-160 + 224 is
+ *                               {0, 0, 0, 2, 0, 0, 3}, with conv_0 / conv_1 (:200-210) {.., 3, 4, 0}; <= 8 slots, <= 10 steps),
+ *                               from the (image, z, y, x) rows of the last sparse level
+ *   sessd_fill_inactive_tiles   out[b][co][tile] = value[co] (the layer's constant, computed by the host from the folded weights;
+ *                               one value per output parity class for job.tile = 4 / 6) in the tiles nobody computes, up to 12
+ *                               layers per launch
  *   sessd_conv3x3_winograd_sk_active   sessd_conv3x3_winograd_sk over the listed tiles only (same packed U, same workspace; the
  *                               shares of the round list are sized on the device, workgroups beyond rounds / min_rounds exit;
  *                               min_rounds = -k: whole-unit shares of at least k units, no unit cut, no partial sums in memory)
