@@ -47,5 +47,5 @@ for s in (0, 1):
         last = t
     tot = sum(acc.values())
     out["set%d" % s] = {k: round(100.0 * v / tot, 1) for k, v in sorted(acc.items(), key=lambda x: -x[1])}
-    out["set%d_us_per_frame_pair" % s] = round(tot / 1e3 / (nlast / 2.0), 1)
+    out["set%d_wall_us_per_frame_of_the_set" % s] = round(tot / 1e3 / (nlast / 2.0), 1)
 print(json.dumps(out, indent=1))
