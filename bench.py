@@ -81,6 +81,10 @@ def parse(argv=None):
     ap.add_argument("--no-active-tiles", action="store_true",
                     help="A/B: the first three SSFA layers over the whole BEV map (round 3) instead of only the tiles whose input is not "
                          "constant (csrc/dense_active.hip)")
+    ap.add_argument("--dense-token", action="store_true",
+                    help="EXPERIMENT: every engine's frame as two graphs (front: voxelizer + sparse stage + tile lists + fill; back: the dense "
+                         "convs + heads + predict) and ONE dense stage at a time per CU set -- a frame's back waits for the event the set's "
+                         "previous back recorded; the fronts run beside the other engines' backs")
     ap.add_argument("--no-active-conv", action="store_true",
                     help="A/B: conv_0 / conv_1 as the two-set full-map launch (rounds 3 - 5) instead of over their tile list (round 6)")
     ap.add_argument("--no-train-step", action="store_true",
@@ -450,12 +454,15 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
     per_engine = (args.warmup + args.steps + len(engines) - 1) // len(engines) * args.batch + args.batch
     for e in engines:
         e.attach_records(per_engine)
+    token = bool(getattr(args, "dense_token", False)) and on_gpu and not args.eager and len(engines) > 1
     if not args.eager:
         for e, st in zip(engines, streams):
             with _on(st):
-                e.capture()
+                e.capture(split=True) if token else e.capture()
         sync()
         log("graph captured")
+    n_sets = (parts if masked else 1)
+    tokens = [None] * n_sets     # per CU set: the event the last dense stage (back graph) of the set recorded
 
     # ---- CPU oracle sample (cpu_baseline) and the parity gate on the configuration that is about to be timed
     cpu_base, parity = None, None
@@ -487,11 +494,22 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
         log("parity (all ranks):", {k: v for k, v in parity.items() if k != "rule"})
 
     def step(i):
-        e, st = engines[i % len(engines)], streams[i % len(engines)]
+        k = i % len(engines)
+        e, st = engines[k], streams[k]
         with _on(st):
             e.set_points(batch_of(i))  # device-to-device staging into the engine's static input buffer
             if args.eager:
                 e.enqueue()
+            elif token:
+                # EXPERIMENT --dense-token: the front runs at once; the back waits until the set's previous back has finished
+                e.graph_front.replay()
+                cs = k % n_sets
+                if tokens[cs] is not None:
+                    st.wait_event(tokens[cs])
+                e.graph_back.replay()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                tokens[cs] = ev
             else:
                 e.replay()
 
@@ -562,7 +580,7 @@ def run_rank(args, rank=0, world=1, local_rank=0, backend="nccl", device=None, e
                                    % (args.batch, args.points, args.max_voxels, args.batch, 4 if args.stress else 1, wdesc),
                        "weights": weights_kind,
                        "launch": "eager" if args.eager else "hipGraph replay", "frames_per_rank": args.steps * args.batch,
-                       "frames_in_flight": len(engines), "streamk_workgroups": args.sk_workgroups,
+                       "frames_in_flight": len(engines), "streamk_workgroups": args.sk_workgroups, "dense_token": bool(token),
                        "cu_sets": (parts if masked else 0), "cus_per_set": (getattr(eng, "cu_budget", 0) if masked else 0),
                        "cu_layout": (cu_split if masked else "none"),
                        "cu_sets_note": cu_note,

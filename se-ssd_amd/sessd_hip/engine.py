@@ -810,10 +810,14 @@ class InferenceEngine:
         return {self.ACTIVE_SLOTS[l][0]: float(n[M[l]]) / (self.B * (self.ta.dims[M[l]][0] // 2) * (self.ta.dims[M[l]][1] // 2)) for l in act}
 
     # ------------------------------------------------------------------ the frame
-    def enqueue(self):
-        """Enqueue one batch on the current stream. No host synchronisation, no allocation."""
+    def enqueue(self, part=None):
+        """Enqueue one batch on the current stream. No host synchronisation, no allocation. part = "front": voxelizer, site chain,
+        sparse convs, tile lists and fill only; "back": the dense convs, the SSFA tail + heads and predict of a frame whose front has
+        run (capture(split=True) keeps them as two graphs: EXPERIMENT bench.py --dense-token); None: the whole frame."""
         s = torch.cuda.current_stream().cuda_stream
         B = self.B
+        if part == "back":
+            return self._enqueue_body(s, "back")
         if self.cu_budget and (self.fork_front or self.fork_active):
             # the side branches run on a plain stream of the engine's own: on the whole chip, outside the CU set the engine's stream is
             # confined to (and its launches are sized for). Both options were measured slower anyway (see __init__).
@@ -825,100 +829,103 @@ class InferenceEngine:
         ops.fill_multi([(self.zero_arena, 0), (self.arena, 0x7F7F7F7F), (self.bev, 0)])
         lib.sessd_set_external_clear(1)  # the arena fill above replaces the per-call scratch clears
         try:
-            return self._enqueue_body(s)
+            return self._enqueue_body(s, part)
         finally:
             lib.sessd_set_external_clear(0)
 
-    def _enqueue_body(self, s):
+    def _enqueue_body(self, s, part=None):
         B = self.B
-        if self.batched_voxelizer:
-            check(lib.sessd_voxelize_frames(self.points.data_ptr(), B, self.P_cap, 4, self.vrange.data_ptr(), self.vsize.data_ptr(),
-                                            self.grid.data_ptr(), self.max_points, self.max_voxels, self.hash0.keys.data_ptr(),
-                                            self.hash0.vals.data_ptr(), self.hash0.capacity, self.voxels.data_ptr(),
-                                            self.coors.data_ptr(), 4, self.nump.data_ptr(), self.vfeat.data_ptr(),
-                                            self.prefix.data_ptr(), self.vox_ws.data_ptr(), self.vox_ws.numel(), s), "voxelize_frames")
-        else:
-            for b in range(B):
-                check(lib.sessd_voxelize_frame(self.points[b].data_ptr(), self.P_cap, 4, self.vrange.data_ptr(),
-                                               self.vsize.data_ptr(), self.grid.data_ptr(), self.max_points, self.max_voxels,
-                                               b, self.hash0.keys.data_ptr(), self.hash0.vals.data_ptr(), self.hash0.capacity,
-                                               self.voxels.data_ptr(), self.coors.data_ptr(), 4, self.nump.data_ptr(),
-                                               self.vfeat.data_ptr(), self.prefix.data_ptr(), self.vox_ws.data_ptr(),
-                                               self.vox_ws.numel(), s), "voxelize_frame")
-        feat = self.vfeat
-        if self.sort_sites:
-            check(lib.sessd_sparse_renumber_sites(self.coors.data_ptr(), self._n(0), self.levels[0]["cap"], B,
-                                                  self._hash0_dims.data_ptr(), self.vfeat.data_ptr(), 4,
-                                                  self.hash0.keys.data_ptr(), self.hash0.vals.data_ptr(), self.hash0.capacity,
-                                                  self.coors_s.data_ptr(), self.vfeat_s.data_ptr(), self.renum_ws.data_ptr(),
-                                                  self.renum_ws.numel(), s), "sparse_renumber_sites")
-            feat = self.vfeat_s
-        self._mark("voxelize")
-        # ---- SpMiddleFHD (a4-a8): every level's sites and every rulebook first (4 launches), then the 14 convolutions
-        L0 = self.levels[0]
-        n_layers = len(self.sp.layers)
-        # layers that only need level-0 tables (the leading submanifold convs) and the jobs they use
-        lead = 0
-        while lead < n_layers and self.sp.layers[lead]["kind"] == "subm":
-            lead += 1
-        lead_jobs = 1 + max([self._job_of[i] for i in range(lead)] + [-1])
-        fork = self.fork_front and lead > 0 and self._tuning_sparse is None and self._marks is None
         forked_active = False
+        if part != "back":   # ---- the FRONT of a frame: voxelizer, site chain, the 14 sparse convs (+ the tile lists and the fill below)
+            if self.batched_voxelizer:
+                check(lib.sessd_voxelize_frames(self.points.data_ptr(), B, self.P_cap, 4, self.vrange.data_ptr(), self.vsize.data_ptr(),
+                                                self.grid.data_ptr(), self.max_points, self.max_voxels, self.hash0.keys.data_ptr(),
+                                                self.hash0.vals.data_ptr(), self.hash0.capacity, self.voxels.data_ptr(),
+                                                self.coors.data_ptr(), 4, self.nump.data_ptr(), self.vfeat.data_ptr(),
+                                                self.prefix.data_ptr(), self.vox_ws.data_ptr(), self.vox_ws.numel(), s), "voxelize_frames")
+            else:
+                for b in range(B):
+                    check(lib.sessd_voxelize_frame(self.points[b].data_ptr(), self.P_cap, 4, self.vrange.data_ptr(),
+                                                   self.vsize.data_ptr(), self.grid.data_ptr(), self.max_points, self.max_voxels,
+                                                   b, self.hash0.keys.data_ptr(), self.hash0.vals.data_ptr(), self.hash0.capacity,
+                                                   self.voxels.data_ptr(), self.coors.data_ptr(), 4, self.nump.data_ptr(),
+                                                   self.vfeat.data_ptr(), self.prefix.data_ptr(), self.vox_ws.data_ptr(),
+                                                   self.vox_ws.numel(), s), "voxelize_frame")
+            feat = self.vfeat
+            if self.sort_sites:
+                check(lib.sessd_sparse_renumber_sites(self.coors.data_ptr(), self._n(0), self.levels[0]["cap"], B,
+                                                      self._hash0_dims.data_ptr(), self.vfeat.data_ptr(), 4,
+                                                      self.hash0.keys.data_ptr(), self.hash0.vals.data_ptr(), self.hash0.capacity,
+                                                      self.coors_s.data_ptr(), self.vfeat_s.data_ptr(), self.renum_ws.data_ptr(),
+                                                      self.renum_ws.numel(), s), "sparse_renumber_sites")
+                feat = self.vfeat_s
+            self._mark("voxelize")
+            # ---- SpMiddleFHD (a4-a8): every level's sites and every rulebook first (4 launches), then the 14 convolutions
+            L0 = self.levels[0]
+            n_layers = len(self.sp.layers)
+            # layers that only need level-0 tables (the leading submanifold convs) and the jobs they use
+            lead = 0
+            while lead < n_layers and self.sp.layers[lead]["kind"] == "subm":
+                lead += 1
+            lead_jobs = 1 + max([self._job_of[i] for i in range(lead)] + [-1])
+            fork = self.fork_front and lead > 0 and self._tuning_sparse is None and self._marks is None
+            forked_active = False
 
-        def run_layers(lo, hi, feat, li, st):
-            for idx in range(lo, hi):
-                lay = self.sp.layers[idx]
-                last = idx == n_layers - 1
-                j = self._job_of[idx]
-                nbr, tm = self.chain.nbr[j], self.chain.tile_mask[j]
-                if lay["kind"] == "subm":
-                    L = self.levels[li]
-                    out = L["feat_a"] if feat is not L["feat_a"] else L["feat_b"]
-                    self._sconv(lay, feat, nbr, tm, li, out, st, idx=idx)
-                    feat = out
-                else:
-                    Lo = self.levels[li + 1]
-                    if last:
-                        self._sconv(lay, feat, nbr, tm, li + 1, None, st, dense=True, idx=idx)
+            def run_layers(lo, hi, feat, li, st):
+                for idx in range(lo, hi):
+                    lay = self.sp.layers[idx]
+                    last = idx == n_layers - 1
+                    j = self._job_of[idx]
+                    nbr, tm = self.chain.nbr[j], self.chain.tile_mask[j]
+                    if lay["kind"] == "subm":
+                        L = self.levels[li]
+                        out = L["feat_a"] if feat is not L["feat_a"] else L["feat_b"]
+                        self._sconv(lay, feat, nbr, tm, li, out, st, idx=idx)
+                        feat = out
                     else:
-                        self._sconv(lay, feat, nbr, tm, li + 1, Lo["feat_a"], st, idx=idx)
-                        feat = Lo["feat_a"]
-                    li += 1
-            return feat, li
+                        Lo = self.levels[li + 1]
+                        if last:
+                            self._sconv(lay, feat, nbr, tm, li + 1, None, st, dense=True, idx=idx)
+                        else:
+                            self._sconv(lay, feat, nbr, tm, li + 1, Lo["feat_a"], st, idx=idx)
+                            feat = Lo["feat_a"]
+                        li += 1
+                return feat, li
 
-        if fork:
-            main = torch.cuda.current_stream()
-            side = self.side_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                s2 = side.cuda_stream
-                self.chain.run_rulebooks(L0["indices"], self._n(0), L0["cap"], L0["hash"], 0, lead_jobs, stream=s2)
-                feat, li = run_layers(0, lead, feat, 0, s2)
-            self.chain.run_sites(L0["indices"], self._n(0), L0["cap"], self.err, clear=False, stream=s)
-            self.chain.run_rulebooks(L0["indices"], self._n(0), L0["cap"], L0["hash"], lead_jobs, len(self.chain.jobs), stream=s)
-            main.wait_stream(side)
-            feat, li = run_layers(lead, n_layers, feat, li, s)
-        else:
-            self.chain.run(L0["indices"], self._n(0), L0["cap"], L0["hash"], self.err, clear=False, stream=s)
-            # EXPERIMENT (off, measured slower): the tile lists and the fill depend on the last level's SITES only -- as a side branch
-            # beside the 14 sparse convs (which leave most of the chip idle) instead of in front of the dense stage
-            forked_active = self.fork_active and self._marks is None and self._kmarks is None and bool(self._active_layers())
-            if forked_active:
-                main, side = torch.cuda.current_stream(), self.side_stream
+            if fork:
+                main = torch.cuda.current_stream()
+                side = self.side_stream
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    L4 = self.levels[-1]
-                    self.ta.run(L4["indices"], L4["n"], L4["cap"])
-                    fj = self._fill_jobs(self._active_layers())
-                    self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4], near_kind=fj[5])
-            feat, li = run_layers(0, n_layers, feat, 0, s)
-            if forked_active:
+                    s2 = side.cuda_stream
+                    self.chain.run_rulebooks(L0["indices"], self._n(0), L0["cap"], L0["hash"], 0, lead_jobs, stream=s2)
+                    feat, li = run_layers(0, lead, feat, 0, s2)
+                self.chain.run_sites(L0["indices"], self._n(0), L0["cap"], self.err, clear=False, stream=s)
+                self.chain.run_rulebooks(L0["indices"], self._n(0), L0["cap"], L0["hash"], lead_jobs, len(self.chain.jobs), stream=s)
                 main.wait_stream(side)
-        self._mark("spmiddle")
+                feat, li = run_layers(lead, n_layers, feat, li, s)
+            else:
+                self.chain.run(L0["indices"], self._n(0), L0["cap"], L0["hash"], self.err, clear=False, stream=s)
+                # EXPERIMENT (off, measured slower): the tile lists and the fill depend on the last level's SITES only -- as a side branch
+                # beside the 14 sparse convs (which leave most of the chip idle) instead of in front of the dense stage
+                forked_active = self.fork_active and self._marks is None and self._kmarks is None and bool(self._active_layers())
+                if forked_active:
+                    main, side = torch.cuda.current_stream(), self.side_stream
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        L4 = self.levels[-1]
+                        self.ta.run(L4["indices"], L4["n"], L4["cap"])
+                        fj = self._fill_jobs(self._active_layers())
+                        self.ta.fill(fj[0], fj[1], layers=fj[2], tiles=fj[3], near=fj[4], near_kind=fj[5])
+                feat, li = run_layers(0, n_layers, feat, 0, s)
+                if forked_active:
+                    main.wait_stream(side)
+        if part != "back":
+            self._mark("spmiddle")
         # ---- SSFA (a9) rpn_v1.py:220-235
         t, h, d = self.t, self.h, self.dn
         act = self._active_layers()
-        if act and not forked_active:
+        if act and not forked_active and part != "back":
             L4 = self.levels[-1]
             if self._kmarks is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -929,6 +936,8 @@ class InferenceEngine:
             if self._kmarks is not None:
                 e1.record()
                 self._kmarks.append(("tile_activity+fill", e0, e1))
+        if part == "front":
+            return self.out
         x = self._conv(self.bev, d.b0[0], t["a"], name="b0.0", active=0 if 0 in act else None)
         x = self._conv(x, d.b0[1], t["b"], name="b0.1", active=1 if 1 in act else None)
         x0 = self._conv(x, d.b0[2], t["x0"], name="b0.2", active=2 if 2 in act else None)
@@ -1145,7 +1154,7 @@ class InferenceEngine:
                     useful_row_fraction=round(tot_use / tot_exe, 4))
 
     # ------------------------------------------------------------------ hipGraph
-    def capture(self, warmup=2):
+    def capture(self, warmup=2, split=False):
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -1154,6 +1163,17 @@ class InferenceEngine:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         ops.new_capture_epoch()
+        if split:
+            # EXPERIMENT (bench.py --dense-token): the frame as TWO graphs, so that the caller can order the dense stages of the engines
+            # that share a CU set (replay_front(); wait for the set's token; replay_back())
+            gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf):
+                self.enqueue("front")
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb, pool=gf.pool()):
+                self.enqueue("back")
+            self.graph, self.graph_front, self.graph_back = None, gf, gb
+            return gf, gb
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self.enqueue()
@@ -1161,6 +1181,10 @@ class InferenceEngine:
         return g
 
     def replay(self):
+        if self.graph is None and getattr(self, "graph_front", None) is not None:
+            self.graph_front.replay()
+            self.graph_back.replay()
+            return self.out
         self.graph.replay()
         return self.out
 
